@@ -1,0 +1,968 @@
+/*
+ * picsong_oracle.c -- CPU restatement (plain C99) of the PICSONG hot path:
+ *   pad -> level shift -> DWT 5/3 | 9/7(+quant) -> BPC-PaCo (2 passes, k=0) -> BitStreamBuilder
+ * and the exact inverse.
+ *
+ * TEST INFRASTRUCTURE ONLY (see picsong_oracle.h).  PARITY UNPINNED against the CUDA binary.
+ *
+ * All file:line citations are relative to /root/reference/CUDA_ImCod/.
+ *
+ * Floating point (9/7): the reference is built with nvcc -use_fast_math (CMakeLists.txt:9), so
+ * its results are not bit-reproducible.  This restatement fixes IEEE fp32 with the contraction
+ * nvcc applies by default to `b += (a+c)*w` (one fused multiply-add), true divisions, and no
+ * re-association.  Build with -ffp-contract=off so the compiler adds no contraction of its own.
+ */
+#include "picsong_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* geometry / ingest                                                                            */
+/* ------------------------------------------------------------------------------------------ */
+
+/* SupportFunctions/AuxiliarFunctions.cpp:22-26 -- ceil(v/64)*64 */
+int po_pad_dim(int v) { return ((v + PO_CB - 1) / PO_CB) * PO_CB; }
+
+/* IO/IOManager.ipp:72-112 -- pad right then bottom by edge-inclusive mirror:
+ * col W+j = col W-1-j (per row, :99-106); row H+r = row H-1-r of the already widened image
+ * (:107-110). */
+void po_pad_frame(const uint8_t *in, int W, int H, uint8_t *out, int AW, int AH)
+{
+    for (int y = 0; y < H; y++) {
+        memcpy(out + (size_t)y * AW, in + (size_t)y * W, (size_t)W);
+        for (int j = 0; j < AW - W; j++)
+            out[(size_t)y * AW + W + j] = in[(size_t)y * W + (W - 1 - j)];
+    }
+    for (int r = 0; r < AH - H; r++)
+        memcpy(out + (size_t)(H + r) * AW, out + (size_t)(H - 1 - r) * AW, (size_t)AW);
+}
+
+void po_crop_frame_u8(const uint8_t *in, int AW, int AH, uint8_t *out, int W, int H)
+{
+    (void)AH;
+    for (int y = 0; y < H; y++)
+        memcpy(out + (size_t)y * W, in + (size_t)y * AW, (size_t)W);
+}
+
+/* integer-only synthetic frame. */
+static int po_tri(int v, int p) { int m = v % (2 * p); int d = m - p; return d < 0 ? -d : d; }
+
+void po_gen_frame(uint8_t *out, int W, int H, uint32_t frame, uint32_t seed)
+{
+    uint32_t z = seed ^ (frame * 0x9E3779B9u);
+    for (int y = 0; y < H; y++) {
+        int by = po_tri(y, 384) * 255 / 384;
+        for (int x = 0; x < W; x++) {
+            z = 1664525u * z + 1013904223u;
+            int base = (po_tri(x, 512) * 255 / 512 + by) / 2;
+            int noise = (int)((z >> 24) & 15u) - 8;
+            int checker = 16 * (((x >> 5) ^ (y >> 5)) & 1);
+            int p = base + noise + checker;
+            out[(size_t)y * W + x] = (uint8_t)(p < 0 ? 0 : (p > 255 ? 255 : p));
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* level shift                                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Engines/CodingEngine.cu:581-588 -- out = (T)in - (1 << (bitDepth-1)) */
+void po_level_shift_fwd_i32(const uint8_t *in, int32_t *out, size_t n, int bit_depth)
+{
+    int off = 1 << (bit_depth - 1);
+    for (size_t i = 0; i < n; i++) out[i] = (int32_t)in[i] - off;
+}
+
+void po_level_shift_fwd_f32(const uint8_t *in, float *out, size_t n, int bit_depth)
+{
+    float off = (float)(1 << (bit_depth - 1));
+    for (size_t i = 0; i < n; i++) out[i] = (float)in[i] - off;
+}
+
+/* Engines/DecodingEngine.cu:720-729 -- max(min(x + offset, 255), 0) */
+void po_level_shift_inv_i32(int32_t *data, size_t n, int bit_depth)
+{
+    int off = 1 << (bit_depth - 1);
+    for (size_t i = 0; i < n; i++) {
+        int v = data[i] + off;
+        data[i] = v > 255 ? 255 : (v < 0 ? 0 : v);
+    }
+}
+
+/* Engines/DecodingEngine.cu:706-715 -- fmaxf(fminf(__float2int_rn(x + offset + 0.01f), 255), 0);
+ * __float2int_rn = round to nearest even -> rintf under the default rounding mode. */
+void po_level_shift_inv_f32(float *data, size_t n, int bit_depth)
+{
+    float off = (float)(1 << (bit_depth - 1));
+    for (size_t i = 0; i < n; i++) {
+        float t = data[i] + off;
+        t = t + 0.01f;
+        float r = rintf(t);
+        r = r > 255.0f ? 255.0f : r;
+        r = r < 0.0f ? 0.0f : r;
+        data[i] = r;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* DWT                                                                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Engines/CodingEngine.cu:170-177 -- extra = sum_{l=1}^{wl-1} (AW>>l)(AH>>l) */
+size_t po_dwt_extra(int AW, int AH, int wl)
+{
+    size_t e = 0;
+    for (int l = 1; l < wl; l++) e += (size_t)(AW >> l) * (size_t)(AH >> l);
+    return e;
+}
+
+/* DWT/DWTGenerator.cuh:168-179 -- quantisation steps, columns LL,HL,LH,HH, row = level */
+static const float PO_QSTEPS[10][4] = {
+    { 1.965908f, 1.0112865f, 1.0112865f, 0.52021784f },
+    { 4.1224113f, 1.9968134f, 1.9968134f, 0.96721643f },
+    { 8.416739f, 4.1833673f, 4.1833673f, 2.0792568f },
+    { 16.935543f, 8.534108f, 8.534108f, 4.3004827f },
+    { 33.924816f, 17.166693f, 17.166693f, 8.686718f },
+    { 67.87687f, 34.385098f, 34.385098f, 17.41882f },
+    { 135.76744f, 68.7964f, 68.7964f, 34.860676f },
+    { 271.5416f, 137.60588f, 137.60588f, 69.73287f },
+    { 543.0866f, 275.21814f, 275.21814f, 139.47136f },
+    { 1086.1624f, 550.43286f, 550.43286f, 278.94202f }
+};
+
+/* DWT/DWTGenerator.cuh:16-22 */
+#define PO_A1 (-1.586134342059924f)
+#define PO_A2 (-0.052980118572961f)
+#define PO_A3 (0.882911075530934f)
+#define PO_A4 (0.443506852043971f)
+#define PO_N1 (1.230174104914001f)
+#define PO_N2 (0.812893066f)
+
+/* One reversible 5/3 analysis of x[0], x[st], ..., x[(n-1)st] in place (interleaved s,d).
+ * Lifting: DWTGenerator.cu:72-76; order and boundary rule: vertical :137-157,
+ * horizontal :279-292 (lane 31 / last row re-use their own even sample = whole-sample
+ * symmetric extension; lane 0 / row 0 re-use d[0]). */
+static void po_53_fwd_1d(int32_t *x, size_t st, int n)
+{
+    for (int i = 1; i < n - 1; i += 2)
+        x[i * st] -= (x[(i - 1) * st] + x[(i + 1) * st]) >> 1;
+    x[(n - 1) * st] -= (x[(n - 2) * st] + x[(n - 2) * st]) >> 1;
+    x[0] += (x[st] + x[st] + 2) >> 2;
+    for (int i = 2; i < n; i += 2)
+        x[i * st] += (x[(i - 1) * st] + x[(i + 1) * st] + 2) >> 2;
+}
+
+/* DWTGenerator.cu:81-85 lifting; vertical :160-181, horizontal :295-308 */
+static void po_53_inv_1d(int32_t *x, size_t st, int n)
+{
+    x[0] -= (x[st] + x[st] + 2) >> 2;
+    for (int i = 2; i < n; i += 2)
+        x[i * st] -= (x[(i - 1) * st] + x[(i + 1) * st] + 2) >> 2;
+    for (int i = 1; i < n - 1; i += 2)
+        x[i * st] += (x[(i - 1) * st] + x[(i + 1) * st]) >> 1;
+    x[(n - 1) * st] += (x[(n - 2) * st] + x[(n - 2) * st]) >> 1;
+}
+
+/* 9/7 analysis, DWTGenerator.cu:91-104 lifting, vertical :184-227, horizontal :311-323.
+ * `*b += (a+c)*w` -> fmaf(a+c, w, b) (nvcc default -fmad=true); step four:
+ * b = (b + (a+c)*d) * N2 -> fmaf(a+c, d, b) * N2; finally odd *= N1. */
+static void po_97_fwd_1d(float *x, size_t st, int n)
+{
+    for (int i = 1; i < n - 1; i += 2)
+        x[i * st] = fmaf(x[(i - 1) * st] + x[(i + 1) * st], PO_A1, x[i * st]);
+    x[(n - 1) * st] = fmaf(x[(n - 2) * st] + x[(n - 2) * st], PO_A1, x[(n - 1) * st]);
+    x[0] = fmaf(x[st] + x[st], PO_A2, x[0]);
+    for (int i = 2; i < n; i += 2)
+        x[i * st] = fmaf(x[(i - 1) * st] + x[(i + 1) * st], PO_A2, x[i * st]);
+    for (int i = 1; i < n - 1; i += 2)
+        x[i * st] = fmaf(x[(i - 1) * st] + x[(i + 1) * st], PO_A3, x[i * st]);
+    x[(n - 1) * st] = fmaf(x[(n - 2) * st] + x[(n - 2) * st], PO_A3, x[(n - 1) * st]);
+    x[0] = fmaf(x[st] + x[st], PO_A4, x[0]) * PO_N2;
+    for (int i = 2; i < n; i += 2)
+        x[i * st] = fmaf(x[(i - 1) * st] + x[(i + 1) * st], PO_A4, x[i * st]) * PO_N2;
+    for (int i = 1; i < n; i += 2)
+        x[i * st] = x[i * st] * PO_N1;
+}
+
+/* 9/7 synthesis, DWTGenerator.cu:110-122 lifting, vertical :230-272, horizontal :326-339.
+ * odd /= N1; even = even/N2 - (a+c)*A4 ; odd -= (a+c)*A3 ; even -= (a+c)*A2 ; odd -= (a+c)*A1 */
+static void po_97_inv_1d(float *x, size_t st, int n)
+{
+    for (int i = 1; i < n; i += 2)
+        x[i * st] = x[i * st] / PO_N1;
+    x[0] = fmaf(-(x[st] + x[st]), PO_A4, x[0] / PO_N2);
+    for (int i = 2; i < n; i += 2)
+        x[i * st] = fmaf(-(x[(i - 1) * st] + x[(i + 1) * st]), PO_A4, x[i * st] / PO_N2);
+    for (int i = 1; i < n - 1; i += 2)
+        x[i * st] = fmaf(-(x[(i - 1) * st] + x[(i + 1) * st]), PO_A3, x[i * st]);
+    x[(n - 1) * st] = fmaf(-(x[(n - 2) * st] + x[(n - 2) * st]), PO_A3, x[(n - 1) * st]);
+    x[0] = fmaf(-(x[st] + x[st]), PO_A2, x[0]);
+    for (int i = 2; i < n; i += 2)
+        x[i * st] = fmaf(-(x[(i - 1) * st] + x[(i + 1) * st]), PO_A2, x[i * st]);
+    for (int i = 1; i < n - 1; i += 2)
+        x[i * st] = fmaf(-(x[(i - 1) * st] + x[(i + 1) * st]), PO_A1, x[i * st]);
+    x[(n - 1) * st] = fmaf(-(x[(n - 2) * st] + x[(n - 2) * st]), PO_A1, x[(n - 1) * st]);
+}
+
+/* Forward driver, DWTGenerator.cu:1268-1342 + placement :699-723 / :403-433.
+ * Level l reads `in` (l = 0, stride AW) or out + sum_{j<l} Wj*Hj (packed); vertical then
+ * horizontal lifting; LL -> out + sum_{j<=l} Wj*Hj packed (stride Wl/2), or out[0..] stride AW on
+ * the last level; HL/LH/HH -> Mallat positions in out, stride AW. */
+void po_dwt53_forward(const int32_t *in, int32_t *out, int AW, int AH, int wl)
+{
+    int W = AW, H = AH;
+    size_t off = 0;
+    int32_t *tmp = (int32_t *)malloc((size_t)AW * AH * sizeof(int32_t));
+    const int32_t *src = in;
+    for (int l = 0; l < wl; l++) {
+        int last = (l == wl - 1);
+        memcpy(tmp, src, (size_t)W * H * sizeof(int32_t));
+        for (int x = 0; x < W; x++) po_53_fwd_1d(tmp + x, (size_t)W, H);
+        for (int y = 0; y < H; y++) po_53_fwd_1d(tmp + (size_t)y * W, 1, W);
+        off += (size_t)W * H;
+        int32_t *ll = last ? out : out + off;
+        size_t llst = last ? (size_t)AW : (size_t)(W >> 1);
+        for (int y = 0; y < H; y += 2)
+            for (int x = 0; x < W; x += 2) {
+                size_t r = (size_t)(y >> 1), c = (size_t)(x >> 1);
+                ll[r * llst + c] = tmp[(size_t)y * W + x];
+                out[r * AW + c + (W >> 1)] = tmp[(size_t)y * W + x + 1];
+                out[(r + (H >> 1)) * AW + c] = tmp[(size_t)(y + 1) * W + x];
+                out[(r + (H >> 1)) * AW + c + (W >> 1)] = tmp[(size_t)(y + 1) * W + x + 1];
+            }
+        src = out + off;
+        W >>= 1; H >>= 1;
+    }
+    free(tmp);
+}
+
+/* Reverse driver, DWTGenerator.cu:1349-1424, reads :477-509, writes :556-691.
+ * Coarsest level first; level wl-1 takes LL from the Mallat array, finer levels take LL from the
+ * previous packed output; horizontal inverse then vertical inverse (:1116-1117); each level's
+ * output is packed at out + writeOffset; the full image ends at out + po_dwt_extra(). */
+void po_dwt53_inverse(const int32_t *in, int32_t *out, int AW, int AH, int wl)
+{
+    int W = AW >> (wl - 1), H = AH >> (wl - 1);
+    size_t read_off = 0, write_off = 0;
+    int32_t *tmp = (int32_t *)malloc((size_t)AW * AH * sizeof(int32_t));
+    for (int l = wl - 1; l >= 0; l--) {
+        int first = (l == wl - 1);
+        const int32_t *ll = first ? in : out + read_off;
+        size_t llst = first ? (size_t)AW : (size_t)(W >> 1);
+        for (int y = 0; y < H; y += 2)
+            for (int x = 0; x < W; x += 2) {
+                size_t r = (size_t)(y >> 1), c = (size_t)(x >> 1);
+                tmp[(size_t)y * W + x] = ll[r * llst + c];
+                tmp[(size_t)y * W + x + 1] = in[r * AW + c + (W >> 1)];
+                tmp[(size_t)(y + 1) * W + x] = in[(r + (H >> 1)) * AW + c];
+                tmp[(size_t)(y + 1) * W + x + 1] = in[(r + (H >> 1)) * AW + c + (W >> 1)];
+            }
+        for (int y = 0; y < H; y++) po_53_inv_1d(tmp + (size_t)y * W, 1, W);
+        for (int x = 0; x < W; x++) po_53_inv_1d(tmp + x, (size_t)W, H);
+        memcpy(out + write_off, tmp, (size_t)W * H * sizeof(int32_t));
+        read_off = write_off;
+        write_off += (size_t)W * H;
+        W <<= 1; H <<= 1;
+    }
+    free(tmp);
+}
+
+/* DWTGenerator.cu:405-419 -- quantisation on write: v * Q[l][sb] * qs (left to right);
+ * LL only on the last level with Q[wl-1][0]. */
+void po_dwt97_forward(const float *in, float *out, int AW, int AH, int wl, float qs)
+{
+    int W = AW, H = AH;
+    size_t off = 0;
+    float *tmp = (float *)malloc((size_t)AW * AH * sizeof(float));
+    const float *src = in;
+    for (int l = 0; l < wl; l++) {
+        int last = (l == wl - 1);
+        memcpy(tmp, src, (size_t)W * H * sizeof(float));
+        for (int x = 0; x < W; x++) po_97_fwd_1d(tmp + x, (size_t)W, H);
+        for (int y = 0; y < H; y++) po_97_fwd_1d(tmp + (size_t)y * W, 1, W);
+        off += (size_t)W * H;
+        float *ll = last ? out : out + off;
+        size_t llst = last ? (size_t)AW : (size_t)(W >> 1);
+        const float *q = PO_QSTEPS[l];
+        for (int y = 0; y < H; y += 2)
+            for (int x = 0; x < W; x += 2) {
+                size_t r = (size_t)(y >> 1), c = (size_t)(x >> 1);
+                float vll = tmp[(size_t)y * W + x];
+                ll[r * llst + c] = last ? (vll * q[0]) * qs : vll;
+                out[r * AW + c + (W >> 1)] = (tmp[(size_t)y * W + x + 1] * q[1]) * qs;
+                out[(r + (H >> 1)) * AW + c] = (tmp[(size_t)(y + 1) * W + x] * q[2]) * qs;
+                out[(r + (H >> 1)) * AW + c + (W >> 1)] =
+                    (tmp[(size_t)(y + 1) * W + x + 1] * q[3]) * qs;
+            }
+        src = out + off;
+        W >>= 1; H >>= 1;
+    }
+    free(tmp);
+}
+
+/* DWTGenerator.cu:513-553 -- de-quantisation on read:
+ * v == 0 -> 0 else ((|v| + 0.5) * sgn(v)) / Q[l][sb] / qs ; LL de-quantised only on the
+ * coarsest level (:531-542), finer levels read the float LL of the previous output (:546-553). */
+static float po_dequant(int32_t v, float q, float qs)
+{
+    if (v == 0) return 0.0f;
+    float m = fabsf((float)v) + 0.5f;
+    float s = (v < 0) ? -1.0f : 1.0f;
+    return ((m * s) / q) / qs;
+}
+
+void po_dwt97_inverse(const int32_t *in, float *out, int AW, int AH, int wl, float qs)
+{
+    int W = AW >> (wl - 1), H = AH >> (wl - 1);
+    size_t read_off = 0, write_off = 0;
+    float *tmp = (float *)malloc((size_t)AW * AH * sizeof(float));
+    for (int l = wl - 1; l >= 0; l--) {
+        int first = (l == wl - 1);
+        const float *q = PO_QSTEPS[l];
+        for (int y = 0; y < H; y += 2)
+            for (int x = 0; x < W; x += 2) {
+                size_t r = (size_t)(y >> 1), c = (size_t)(x >> 1);
+                tmp[(size_t)y * W + x] = first ? po_dequant(in[r * AW + c], q[0], qs)
+                                               : out[read_off + r * (size_t)(W >> 1) + c];
+                tmp[(size_t)y * W + x + 1] = po_dequant(in[r * AW + c + (W >> 1)], q[1], qs);
+                tmp[(size_t)(y + 1) * W + x] = po_dequant(in[(r + (H >> 1)) * AW + c], q[2], qs);
+                tmp[(size_t)(y + 1) * W + x + 1] =
+                    po_dequant(in[(r + (H >> 1)) * AW + c + (W >> 1)], q[3], qs);
+            }
+        for (int y = 0; y < H; y++) po_97_inv_1d(tmp + (size_t)y * W, 1, W);
+        for (int x = 0; x < W; x++) po_97_inv_1d(tmp + x, (size_t)W, H);
+        memcpy(out + write_off, tmp, (size_t)W * H * sizeof(float));
+        read_off = write_off;
+        write_off += (size_t)W * H;
+        W <<= 1; H <<= 1;
+    }
+    free(tmp);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* LUT loader                                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* IO/IOManager.ipp:363-386 + Engines/Engine.cu:190-210: 8 lines "KEY;int". */
+static int po_lut_header(const char *folder, po_lut *l)
+{
+    char path[1024];
+    snprintf(path, sizeof path, "%sheader.txt", folder);
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        snprintf(path, sizeof path, "%s/header.txt", folder);
+        f = fopen(path, "rb");
+    }
+    if (!f) return -1;
+    int v[8] = { 0 };
+    char line[256];
+    int n = 0;
+    while (n < 8 && fgets(line, sizeof line, f)) {
+        char *semi = strchr(line, ';');
+        if (!semi) continue;
+        v[n++] = atoi(semi + 1);
+    }
+    fclose(f);
+    if (n < 8) return -2;
+    l->n_bitplanes = v[0]; l->n_subbands = v[1]; l->ctx_ref = v[2]; l->ctx_sign = v[3];
+    l->ctx_sig = v[4]; l->precision = v[5]; l->n_files = v[6];
+    l->n_bp_files = v[7] > 32 ? 32 : v[7];
+    return 0;
+}
+
+/* One section of IO/IOManager.ipp:404-612 (ref :455-476, sig :478-510, sign :512-546).
+ * Lines "lvl sb bp : v0 .. v(C-1)".  On a group change (bp <= previous bp) the previous group's
+ * remaining planes are filled with 64 and the write index advances by nBp*C; the break test
+ * (lvl+1 > wl && sb > 0) comes after that.  Entries never written keep `fill`. */
+static int po_lut_section(const char *folder, const char *stem, int component, int C, int nBp,
+                          int wl, int32_t *T, int base)
+{
+    static const char *suffix[4] = { ".txt_", "R.txt_", "G.txt_", "B.txt_" };
+    char path[1024];
+    size_t fl = strlen(folder);
+    const char *sep = (fl && folder[fl - 1] != '/') ? "/" : "";
+    snprintf(path, sizeof path, "%s%s%s%s0", folder, sep, stem, suffix[component & 3]);
+    FILE *f = fopen(path, "rb");
+    if (!f) return -1;
+    int i = base, prev = -1, lvl, sb, bp, v[16];
+    for (;;) {
+        if (fscanf(f, "%d %d %d :", &lvl, &sb, &bp) != 3) break;
+        int ok = 1;
+        for (int c = 0; c < C; c++)
+            if (fscanf(f, "%d", &v[c]) != 1) { ok = 0; break; }
+        if (!ok) break;
+        if (bp <= prev) {
+            for (int z = 0; z < (nBp - prev - 1) * C; z++) T[i + prev * C + z + C] = 64;
+            i += nBp * C;
+        }
+        if ((lvl + 1) > wl && sb > 0) break;
+        prev = bp;
+        for (int c = 0; c < C; c++) T[i + bp * C + c] = v[c];
+    }
+    fclose(f);
+    return 0;
+}
+
+int po_lut_load(const char *folder, int component, int wl, int fill, po_lut *l)
+{
+    memset(l, 0, sizeof *l);
+    if (po_lut_header(folder, l)) return -1;
+    l->wl = wl;
+    int nBp = l->n_bitplanes, nS = l->n_subbands;
+    /* section sizes, IOManager.ipp:431-433 */
+    l->n_ref = nS * nBp * l->ctx_ref * wl + nBp * l->ctx_ref;
+    l->n_sig = nS * nBp * l->ctx_sig * wl + nBp * l->ctx_sig;
+    l->n_sign = nS * nBp * l->ctx_sign * wl + nBp * l->ctx_sign;
+    int total = l->n_ref + l->n_sig + l->n_sign;
+    /* generous tail: a group-change fill on the very last group may write one group past it */
+    l->table = (int32_t *)malloc(((size_t)total + (size_t)nBp * 16) * sizeof(int32_t));
+    if (!l->table) return -3;
+    for (int i = 0; i < total + nBp * 16; i++) l->table[i] = fill;
+    /* sections are loaded in order ref, sig, sign; a later section's group-change fill can spill
+     * into nothing (it stays inside its own section for the shipped files). */
+    if (po_lut_section(folder, "ref", component, l->ctx_ref, nBp, wl, l->table, 0)) return -4;
+    if (po_lut_section(folder, "sig", component, l->ctx_sig, nBp, wl, l->table, l->n_ref)) return -5;
+    if (po_lut_section(folder, "sign", component, l->ctx_sign, nBp, wl, l->table,
+                       l->n_ref + l->n_sig)) return -6;
+    return 0;
+}
+
+void po_lut_free(po_lut *l) { free(l->table); l->table = NULL; }
+
+/* ------------------------------------------------------------------------------------------ */
+/* BPC-PaCo, 2 coding passes, k = 0                                                             */
+/* ------------------------------------------------------------------------------------------ */
+
+/* BPC/BPCEngine.cu:143-170 */
+void po_find_subband(int x, int y, int AW, int AH, int wl, int *level, int *sb)
+{
+    for (int a = 1; a <= wl; a++) {
+        int cx = x >= (AW >> a), cy = y >= (AH >> a);
+        if (cx || cy) {
+            *level = a - 1;
+            *sb = cx ? (cy ? 2 : 0) : 1;
+            return;
+        }
+    }
+    *level = wl;
+    *sb = 0;
+}
+
+typedef struct {
+    uint32_t TD[32][128];        /* coefficient words, BPCEngine.cu:1969; layout SURVEY a6 */
+    uint32_t L[32], S[32];       /* interval lower / size, :1673-1675 */
+    int slot[32];                /* reserved codeword, relative to staging[1] */
+    uint32_t cw[32];             /* decoder: current codeword */
+    int count;                   /* codeStreamShared[warp], :1996 */
+    int ref_p[32], sig_p[32], sign_p[32];   /* LUT pointers per lane, :329-350 */
+    const po_lut *lut;
+    int lut_total;
+    int32_t *stage;              /* this codeblock's 4096 ints */
+} po_cb;
+
+static int po_lut_at(const po_cb *cb, int idx)
+{
+    /* raw index into [ref|sig|sign] exactly as the reference; clamped only to stay in memory */
+    if (idx < 0) idx = 0;
+    if (idx >= cb->lut_total) idx = cb->lut_total - 1;
+    return cb->lut->table[idx];
+}
+
+/* BPCEngine.cu:329-350 with s = 0 */
+static void po_lut_init(po_cb *cb, int t, int level, int sb, int msb)
+{
+    const po_lut *l = cb->lut;
+    int nS = l->n_subbands, nB = l->n_bitplanes;
+    cb->ref_p[t] = level * nS * nB * l->ctx_ref + sb * nB * l->ctx_ref + msb * l->ctx_ref;
+    cb->sig_p[t] = level * nS * nB * l->ctx_sig + sb * nB * l->ctx_sig + msb * l->ctx_sig + l->n_ref;
+    cb->sign_p[t] = level * nS * nB * l->ctx_sign + sb * nB * l->ctx_sign + msb * l->ctx_sign +
+                    l->n_ref + l->n_sig;
+}
+
+/* BPCEngine.cu:252-293 */
+static int po_sign_ctx_hv(int h, int v)
+{
+    if (h == 0) return v == 0 ? 0 : (v > 0 ? 2 : 3);
+    if (h > 0) return v == 0 ? 4 : (v > 0 ? 6 : 0);
+    return v == 0 ? 5 : (v > 0 ? 1 : 7);
+}
+
+/* BPCEngine.cu:296-308 */
+static int po_sign_ctx(uint32_t up, uint32_t left, uint32_t right, uint32_t bottom)
+{
+#define PO_CONTRIB(w) (((w) >> 31) == 0 ? 0 : (((w) & 1u) ? -1 : 1))
+    int h = PO_CONTRIB(left) + PO_CONTRIB(right);
+    int v = PO_CONTRIB(up) + PO_CONTRIB(bottom);
+#undef PO_CONTRIB
+    return po_sign_ctx_hv(h, v);
+}
+
+/* Grid view of the 32 lanes x 128 words: word at (row, col), col = 2*lane + side; outside the
+ * codeblock = 0 (BPCEngine.cu:465-484 for lanes 0/31, :785,831 for rows 0/63). */
+static uint32_t po_w(const po_cb *cb, int row, int col)
+{
+    if (row < 0 || row > 63 || col < 0 || col > 63) return 0;
+    return cb->TD[col >> 1][2 * row + (col & 1)];
+}
+
+/* One call site of arithmeticEncoder (BPCEngine.cu:371-399) executed in lock step by the lanes
+ * in `act`: lanes whose interval is exhausted reserve slots in ascending lane order
+ * (__activemask/__popc, :378-383), then every active lane codes its symbol. */
+static void po_enc_site(po_cb *cb, const uint8_t *act, const uint8_t *sym, const int *prob)
+{
+    int r = 0;
+    for (int t = 0; t < 32; t++)
+        if (act[t] && cb->S[t] == 0) {
+            cb->L[t] = 0;
+            cb->S[t] = 0xFFFFu;
+            int s = r + cb->count;
+            cb->slot[t] = s > 4094 ? 4094 : s;
+            r++;
+        }
+    if (r) { int c = cb->count + r; cb->count = c > 4095 ? 4095 : c; }
+    int prec = cb->lut->precision;
+    for (int t = 0; t < 32; t++)
+        if (act[t]) {
+            uint32_t a = ((cb->S[t] * (uint32_t)prob[t]) >> prec) + sym[t];
+            if (sym[t] == 0) cb->S[t] = a;
+            else { cb->S[t] -= a; cb->L[t] += a; }
+            if (cb->S[t] == 0) cb->stage[1 + cb->slot[t]] = (int32_t)cb->L[t];
+        }
+}
+
+/* arithmeticDecoder call site (BPCEngine.cu:405-442) */
+static void po_dec_site(po_cb *cb, const uint8_t *act, uint8_t *sym, const int *prob)
+{
+    int r = 0;
+    for (int t = 0; t < 32; t++)
+        if (act[t] && cb->S[t] == 0) {
+            cb->L[t] = 0;
+            cb->S[t] = 0xFFFFu;
+            int s = r + cb->count;
+            s = s > 4094 ? 4094 : s;
+            cb->cw[t] = (uint32_t)cb->stage[1 + s];
+            r++;
+        }
+    if (r) { int c = cb->count + r; cb->count = c > 4095 ? 4095 : c; }
+    int prec = cb->lut->precision;
+    for (int t = 0; t < 32; t++)
+        if (act[t]) {
+            uint32_t a = ((cb->S[t] * (uint32_t)prob[t]) >> prec) + 1u;
+            uint32_t a2 = cb->L[t] + a;
+            if (cb->cw[t] >= a2) { cb->S[t] -= a; cb->L[t] = a2; sym[t] = 1; }
+            else { cb->S[t] = a - 1u; sym[t] = 0; }
+        }
+}
+
+/* Significance propagation pass over one bit-plane: SPPEncoderLauncher BPCEngine.cu:770-843 /
+ * SPPEncoder :490-516 (encode), SPPDecoderLauncher + SPPDecoder :559-594 (decode).
+ * Row by row; all 32 lanes do their left column, then all 32 their right column; inside each of
+ * the two, the significance call site precedes the sign call site. */
+static void po_spp(po_cb *cb, int bp, int decode, uint32_t mask)
+{
+    uint8_t act[32], sym[32], act2[32], sym2[32];
+    int prob[32], prob2[32], sctx[32];
+    for (int i = 0; i < 64; i++)
+        for (int side = 0; side < 2; side++) {
+            for (int t = 0; t < 32; t++) {
+                int col = 2 * t + side;
+                uint32_t w = cb->TD[t][2 * i + side];
+                act[t] = (uint8_t)!(w >> 31);
+                act2[t] = 0;
+                if (!act[t]) continue;
+                uint32_t n1 = po_w(cb, i - 1, col - 1), n2 = po_w(cb, i - 1, col),
+                         n3 = po_w(cb, i - 1, col + 1), n4 = po_w(cb, i, col - 1),
+                         n5 = po_w(cb, i, col + 1), n6 = po_w(cb, i + 1, col - 1),
+                         n7 = po_w(cb, i + 1, col), n8 = po_w(cb, i + 1, col + 1);
+                /* computeContext :222-230 */
+                int ctx = (int)((n1 >> 31) + (n2 >> 31) + (n3 >> 31) + (n4 >> 31) + (n5 >> 31) +
+                                (n6 >> 31) + (n7 >> 31) + (n8 >> 31));
+                prob[t] = po_lut_at(cb, cb->sig_p[t] + ctx);
+                sym[t] = (uint8_t)((w >> (bp + 1)) & 1u);
+                sctx[t] = po_sign_ctx(n2, n4, n5, n7);
+            }
+            if (decode) po_dec_site(cb, act, sym, prob);
+            else po_enc_site(cb, act, sym, prob);
+            for (int t = 0; t < 32; t++) {
+                if (!act[t] || sym[t] != 1) continue;
+                uint32_t *w = &cb->TD[t][2 * i + side];
+                if (decode) *w |= mask;                       /* :577 */
+                *w |= (1u << 31);                             /* :507 / :579 */
+                *w |= ((uint32_t)bp << 24);                   /* :509 / :581 */
+                act2[t] = 1;
+                prob2[t] = po_lut_at(cb, cb->sign_p[t] + (sctx[t] >> 1));
+                sym2[t] = (uint8_t)((((*w) & 1u) == (uint32_t)(sctx[t] & 1)) ? 0 : 1);  /* :513 */
+            }
+            if (decode) {
+                po_dec_site(cb, act2, sym2, prob2);
+                for (int t = 0; t < 32; t++)
+                    if (act2[t]) {
+                        uint32_t s = ((sym2[t] & 1u) == (uint32_t)(sctx[t] & 1)) ? 0u : 1u;  /* :587 */
+                        cb->TD[t][2 * i + side] |= s;
+                    }
+            } else {
+                po_enc_site(cb, act2, sym2, prob2);
+            }
+        }
+}
+
+/* Magnitude refinement pass: MRPEncoderLauncher BPCEngine.cu:1249-1261 / MRPEncoder :726-736,
+ * MRPDecoder :743-762. */
+static void po_mrp(po_cb *cb, int bp, int decode, uint32_t mask)
+{
+    uint8_t act[32], sym[32];
+    int prob[32];
+    for (int i = 0; i < 64; i++)
+        for (int side = 0; side < 2; side++) {
+            for (int t = 0; t < 32; t++) {
+                uint32_t *w = &cb->TD[t][2 * i + side];
+                act[t] = (uint8_t)(((*w) >> 29) & 1u);
+                if (act[t]) {
+                    sym[t] = (uint8_t)(((*w) >> (bp + 1)) & 1u);
+                    prob[t] = po_lut_at(cb, cb->ref_p[t]);
+                } else if ((*w) >> 31) {
+                    *w |= (1u << 29);
+                }
+            }
+            if (decode) {
+                po_dec_site(cb, act, sym, prob);
+                for (int t = 0; t < 32; t++)
+                    if (act[t]) {
+                        uint32_t *w = &cb->TD[t][2 * i + side];
+                        *w &= ~mask;                                              /* :755 */
+                        *w |= (mask & ((((uint32_t)sym[t] << 1) + 1u) << bp));    /* :757 */
+                    }
+            } else {
+                po_enc_site(cb, act, sym, prob);
+            }
+        }
+}
+
+/* Encode BPCEngine.cu:1668-1721 (k = 0: consecutiveBitplanes = 0) */
+static void po_cb_encode(po_cb *cb, int msb)
+{
+    for (int t = 0; t < 32; t++) { cb->L[t] = 0; cb->S[t] = 0; cb->slot[t] = -1; }
+    for (int bp = msb; bp >= 0; bp--) {
+        po_spp(cb, bp, 0, 0);
+        po_mrp(cb, bp, 0, 0);
+        for (int t = 0; t < 32; t++) {        /* updateLUTPointers :353-358 */
+            cb->sig_p[t] -= cb->lut->ctx_sig;
+            cb->sign_p[t] -= cb->lut->ctx_sign;
+            cb->ref_p[t] -= cb->lut->ctx_ref;
+        }
+    }
+    /* flush :1719 -- every lane stores its L into its current slot */
+    for (int t = 0; t < 32; t++)
+        if (cb->slot[t] >= 0) cb->stage[1 + cb->slot[t]] = (int32_t)cb->L[t];
+}
+
+/* Decode BPCEngine.cu:1777-1837 */
+static void po_cb_decode(po_cb *cb, int msb)
+{
+    for (int t = 0; t < 32; t++) { cb->L[t] = 0; cb->S[t] = 0; cb->cw[t] = 0; }
+    uint32_t mask = 0x3u << msb;
+    if (msb == 0) mask &= 0x2u;
+    for (int bp = msb; bp >= 0; bp--) {
+        po_spp(cb, bp, 1, mask);
+        po_mrp(cb, bp, 1, mask);
+        mask >>= 1;
+        if (bp == 1) mask = 0x2u;
+        for (int t = 0; t < 32; t++) {
+            cb->sig_p[t] -= cb->lut->ctx_sig;
+            cb->sign_p[t] -= cb->lut->ctx_sign;
+            cb->ref_p[t] -= cb->lut->ctx_ref;
+        }
+    }
+}
+
+static int po_msb_of(const po_cb *cb)
+{
+    /* findMSB :176-192 -- 32 - ffs(brev(max)); 32 when every magnitude is 0 */
+    uint32_t m = 0;
+    for (int t = 0; t < 32; t++)
+        for (int i = 0; i < 128; i++) m |= cb->TD[t][i] >> 1;
+    if (m == 0) return 32;
+    int k = 31;
+    while (!((m >> k) & 1u)) k--;
+    return k;
+}
+
+/* after Encode: sizeArray + expansion fallback, kernelBPCCoder BPCEngine.cu:2002-2024 */
+static int po_cb_finish_encode(po_cb *cb)
+{
+    int size = cb->count + 1;
+    if (size == PO_CB_WORDS)      /* expansionFix :1905-1912 */
+        for (int t = 0; t < 32; t++)
+            for (int i = 0; i < 128; i++)
+                cb->stage[t * 128 + i] = (int32_t)(cb->TD[t][i] & 0xFFFFu);
+    return size;
+}
+
+void po_bpc_encode(const void *coeffs, int is_float, int AW, int AH, int wl, const po_lut *lut,
+                   int32_t *staging, int32_t *sizes)
+{
+    int ncx = AW / PO_CB, ncy = AH / PO_CB;
+    /* BPCEngine::deviceMemoryAllocator :2429-2441 -- staging memset to 0xFF */
+    memset(staging, 0xFF, (size_t)AW * AH * sizeof(int32_t));
+    po_cb *cb = (po_cb *)malloc(sizeof(po_cb));
+    cb->lut = lut;
+    cb->lut_total = lut->n_ref + lut->n_sig + lut->n_sign;
+    for (int cy = 0; cy < ncy; cy++)
+        for (int cx = 0; cx < ncx; cx++) {
+            int id = cy * ncx + cx;
+            cb->stage = staging + (size_t)id * PO_CB_WORDS;
+            int level[32], sb[32];
+            for (int t = 0; t < 32; t++) {
+                /* per-lane subband: x = lane's first column, y = top row (:1975-1990) */
+                po_find_subband(cx * 64 + 2 * t, cy * 64, AW, AH, wl, &level[t], &sb[t]);
+                for (int i = 0; i < 64; i++)
+                    for (int s = 0; s < 2; s++) {
+                        size_t idx = (size_t)(cy * 64 + i) * AW + (size_t)(cx * 64 + 2 * t + s);
+                        /* readCoefficients :41-63 -- (int) truncation, sign-magnitude word */
+                        int32_t v = is_float ? (int32_t)((const float *)coeffs)[idx]
+                                             : ((const int32_t *)coeffs)[idx];
+                        uint32_t neg = v < 0;
+                        uint32_t mag = (uint32_t)(v < 0 ? -(int64_t)v : (int64_t)v);
+                        cb->TD[t][2 * i + s] = (mag << 1) + neg;
+                    }
+            }
+            int msb = po_msb_of(cb);
+            cb->count = 0;
+            cb->stage[0] = msb;
+            if (msb != 32) {
+                for (int t = 0; t < 32; t++) po_lut_init(cb, t, level[t], sb[t], msb);
+                po_cb_encode(cb, msb);
+            }
+            sizes[id] = po_cb_finish_encode(cb);
+        }
+    free(cb);
+}
+
+int po_bpc_encode_block_uniform(const int32_t *block, int level, int sb, int wl, const po_lut *lut,
+                                int32_t *staging4096)
+{
+    (void)wl;
+    po_cb *cb = (po_cb *)malloc(sizeof(po_cb));
+    cb->lut = lut;
+    cb->lut_total = lut->n_ref + lut->n_sig + lut->n_sign;
+    cb->stage = staging4096;
+    memset(staging4096, 0xFF, PO_CB_WORDS * sizeof(int32_t));
+    for (int t = 0; t < 32; t++)
+        for (int i = 0; i < 64; i++)
+            for (int s = 0; s < 2; s++) {
+                int32_t v = block[i * 64 + 2 * t + s];
+                uint32_t neg = v < 0;
+                uint32_t mag = (uint32_t)(v < 0 ? -v : v);
+                cb->TD[t][2 * i + s] = (mag << 1) + neg;
+            }
+    int msb = po_msb_of(cb);
+    cb->count = 0;
+    cb->stage[0] = msb;
+    if (msb != 32) {
+        for (int t = 0; t < 32; t++) po_lut_init(cb, t, level, sb, msb);
+        po_cb_encode(cb, msb);
+    }
+    int size = po_cb_finish_encode(cb);
+    free(cb);
+    return size;
+}
+
+/* kernelBPCDecoder BPCEngine.cu:2126-2215, writeCoefficients :94-111, copyEntireCodeblock
+ * :1915-1922 */
+void po_bpc_decode(const int32_t *staging, const int32_t *sizes, int AW, int AH, int wl,
+                   const po_lut *lut, int32_t *coeffs)
+{
+    int ncx = AW / PO_CB, ncy = AH / PO_CB;
+    po_cb *cb = (po_cb *)malloc(sizeof(po_cb));
+    cb->lut = lut;
+    cb->lut_total = lut->n_ref + lut->n_sig + lut->n_sign;
+    for (int cy = 0; cy < ncy; cy++)
+        for (int cx = 0; cx < ncx; cx++) {
+            int id = cy * ncx + cx;
+            cb->stage = (int32_t *)(staging + (size_t)id * PO_CB_WORDS);
+            memset(cb->TD, 0, sizeof cb->TD);
+            cb->count = 0;
+            int msb = cb->stage[0];
+            if (sizes[id] == PO_CB_WORDS) {
+                for (int t = 0; t < 32; t++)
+                    for (int i = 0; i < 128; i++) cb->TD[t][i] = (uint32_t)cb->stage[t * 128 + i];
+            } else if (msb != 32) {
+                for (int t = 0; t < 32; t++) {
+                    int level, sb;
+                    po_find_subband(cx * 64 + 2 * t, cy * 64, AW, AH, wl, &level, &sb);
+                    po_lut_init(cb, t, level, sb, msb);
+                }
+                po_cb_decode(cb, msb);
+            }
+            for (int t = 0; t < 32; t++)
+                for (int i = 0; i < 64; i++)
+                    for (int s = 0; s < 2; s++) {
+                        uint32_t w = cb->TD[t][2 * i + s];
+                        int32_t v = (int32_t)((w & 0xFFFFFFu) >> 1);
+                        if (w & 1u) v = -v;
+                        coeffs[(size_t)(cy * 64 + i) * AW + (size_t)(cx * 64 + 2 * t + s)] = v;
+                    }
+        }
+    free(cb);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* BitStreamBuilder                                                                             */
+/* ------------------------------------------------------------------------------------------ */
+
+/* BitStreamBuilder/BitStreamBuilder.cpp:35-94 */
+void po_header_pack(const po_header *h, uint16_t o[PO_HDR_SHORTS])
+{
+    o[0] = (uint16_t)(h->n_samples & 0xFFFFu);
+    o[1] = (uint16_t)(h->n_samples >> 16);
+    o[2] = (uint16_t)((h->cp == 2 ? 0 : 1) | (h->cb_height << 1) | (h->cb_width << 8) |
+                      ((h->wl & 1) << 15));
+    o[3] = (uint16_t)(((h->wl & 7) >> 1) | (h->bit_depth << 3) | ((h->lossy ? 1 : 0) << 10) |
+                      ((h->qs_1e4 & 31) << 11));
+    o[4] = (uint16_t)((h->qs_1e4 >> 5) | ((h->components & 127) << 9));
+    o[5] = (uint16_t)((h->components >> 7) | ((h->is_rgb ? 1 : 0) << 7) | (h->height << 8));
+    o[6] = (uint16_t)((h->height >> 8) | (h->endianess << 8) | (h->bps << 9) |
+                      ((h->is_signed ? 1 : 0) << 14) | ((h->frames & 1) << 15));
+    o[7] = (uint16_t)((h->frames >> 1) & 0xFFFF);
+    o[8] = (uint16_t)h->k_1e3;
+}
+
+/* Engines/DecodingEngine.cu:567-585 */
+void po_header_unpack(const uint16_t e[PO_HDR_SHORTS], po_header *h)
+{
+    h->n_samples = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
+    h->cp = (e[2] & 1) ? 3 : 2;
+    h->cb_height = (e[2] >> 1) & 127;
+    h->cb_width = (e[2] >> 8) & 127;
+    h->wl = ((e[2] >> 15) & 1) | ((e[3] & 7) << 1);
+    h->bit_depth = (e[3] >> 3) & 127;
+    h->lossy = (e[3] >> 10) & 1;
+    h->qs_1e4 = ((e[3] >> 11) & 31) | ((e[4] & 511) << 5);
+    h->components = ((e[4] >> 9) & 127) | ((e[5] & 127) << 9);
+    h->is_rgb = (e[5] >> 7) & 1;
+    h->height = ((e[5] >> 8) & 255) | ((e[6] & 255) << 8);
+    h->endianess = (e[6] >> 8) & 1;
+    h->bps = (e[6] >> 9) & 31;
+    h->is_signed = (e[6] >> 14) & 1;
+    h->frames = ((e[6] >> 15) & 1) | ((int)e[7] << 1);
+    h->k_1e3 = e[8];
+}
+
+/* total shorts = sum(len) + 9 + 2 nCB - nCB + 1 (BitStreamBuilder.cu:300-305) */
+size_t po_bitstream_total(const int32_t *sizes, int n_cb)
+{
+    size_t s = 0;
+    for (int i = 0; i < n_cb; i++) s += (size_t)sizes[i];
+    return s + PO_HDR_SHORTS + (size_t)n_cb + 1;
+}
+
+/* createBitStream BitStreamBuilder.cpp:100-114; layout from buildBitStreamLUTBS
+ * BitStreamBuilder.cu:106-137 + binarySearchLUTBS :33-101: out[9+2cb] = staging[cb*4096] (MSB),
+ * out[10+2cb] = len, payload element j (1 <= j < len) of cb at 9 + 2 nCB + sum_{i<cb}(len_i-1) +
+ * (j-1); everything else (incl. one trailing short) stays 0xFFFF (memset :274). */
+size_t po_bitstream_pack(const int32_t *staging, const int32_t *sizes, int n_cb,
+                         const uint16_t *header, uint16_t *out)
+{
+    size_t total = po_bitstream_total(sizes, n_cb);
+    memset(out, 0xFF, total * sizeof(uint16_t));
+    if (header) memcpy(out, header, PO_HDR_SHORTS * sizeof(uint16_t));
+    size_t pos = PO_HDR_SHORTS + 2 * (size_t)n_cb;
+    for (int cb = 0; cb < n_cb; cb++) {
+        const int32_t *st = staging + (size_t)cb * PO_CB_WORDS;
+        out[PO_HDR_SHORTS + 2 * cb] = (uint16_t)st[0];
+        out[PO_HDR_SHORTS + 2 * cb + 1] = (uint16_t)sizes[cb];
+        for (int j = 1; j < sizes[cb]; j++) out[pos++] = (uint16_t)st[j];
+    }
+    return total;
+}
+
+/* createCodeStream BitStreamBuilder.cpp:119-153 + buildCodeStreamLUTBS BitStreamBuilder.cu:142-171 */
+void po_bitstream_unpack(const uint16_t *in, int n_cb, int32_t *staging, int32_t *sizes)
+{
+    memset(staging, 0xFF, (size_t)n_cb * PO_CB_WORDS * sizeof(int32_t));
+    size_t pos = PO_HDR_SHORTS + 2 * (size_t)n_cb;
+    for (int cb = 0; cb < n_cb; cb++) {
+        int32_t *st = staging + (size_t)cb * PO_CB_WORDS;
+        sizes[cb] = in[PO_HDR_SHORTS + 1 + 2 * cb];      /* retrieveSizeArray :119-129 */
+        st[0] = in[PO_HDR_SHORTS + 2 * cb];
+        for (int j = 1; j < sizes[cb]; j++) st[j] = in[pos++];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* whole frame                                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+size_t po_encode_frame(const uint8_t *frame, int W, int H, int wl, int lossy, float qs,
+                       const po_lut *lut, int iter, int frames, uint16_t *out)
+{
+    int AW = po_pad_dim(W), AH = po_pad_dim(H);
+    size_t P = (size_t)AW * AH, extra = po_dwt_extra(AW, AH, wl);
+    int n_cb = (AW / PO_CB) * (AH / PO_CB);
+    uint8_t *pad = (uint8_t *)malloc(P);
+    int32_t *staging = (int32_t *)malloc(P * sizeof(int32_t));
+    int32_t *sizes = (int32_t *)malloc((size_t)n_cb * sizeof(int32_t));
+    po_pad_frame(frame, W, H, pad, AW, AH);
+    if (!lossy) {
+        int32_t *a = (int32_t *)malloc(P * sizeof(int32_t));
+        int32_t *b = (int32_t *)malloc((P + extra) * sizeof(int32_t));
+        po_level_shift_fwd_i32(pad, a, P, 8);
+        po_dwt53_forward(a, b, AW, AH, wl);
+        po_bpc_encode(b, 0, AW, AH, wl, lut, staging, sizes);
+        free(a); free(b);
+    } else {
+        float *a = (float *)malloc(P * sizeof(float));
+        float *b = (float *)malloc((P + extra) * sizeof(float));
+        po_level_shift_fwd_f32(pad, a, P, 8);
+        po_dwt97_forward(a, b, AW, AH, wl, qs);
+        po_bpc_encode(b, 1, AW, AH, wl, lut, staging, sizes);
+        free(a); free(b);
+    }
+    uint16_t hdr[PO_HDR_SHORTS];
+    po_header h;
+    memset(&h, 0, sizeof h);
+    h.n_samples = (uint32_t)W * (uint32_t)H;
+    h.cp = 2; h.cb_height = 18; h.cb_width = 64; h.wl = wl; h.bit_depth = 8; h.lossy = lossy;
+    h.qs_1e4 = (int)(qs * 10000); h.components = 1; h.is_rgb = 0; h.height = H; h.endianess = 0;
+    h.bps = 8; h.is_signed = 0; h.frames = frames; h.k_1e3 = 0;
+    po_header_pack(&h, hdr);
+    size_t total = po_bitstream_pack(staging, sizes, n_cb, iter == 0 ? hdr : NULL, out);
+    free(pad); free(staging); free(sizes);
+    return total;
+}
+
+int po_decode_frame(const uint16_t *stream, int W, int H, int wl, int lossy, float qs,
+                    const po_lut *lut, uint8_t *frame_out)
+{
+    int AW = po_pad_dim(W), AH = po_pad_dim(H);
+    size_t P = (size_t)AW * AH, extra = po_dwt_extra(AW, AH, wl);
+    int n_cb = (AW / PO_CB) * (AH / PO_CB);
+    int32_t *staging = (int32_t *)malloc(P * sizeof(int32_t));
+    int32_t *sizes = (int32_t *)malloc((size_t)n_cb * sizeof(int32_t));
+    int32_t *coef = (int32_t *)malloc(P * sizeof(int32_t));
+    po_bitstream_unpack(stream, n_cb, staging, sizes);
+    po_bpc_decode(staging, sizes, AW, AH, wl, lut, coef);
+    if (!lossy) {
+        int32_t *img = (int32_t *)malloc((P + extra) * sizeof(int32_t));
+        po_dwt53_inverse(coef, img, AW, AH, wl);
+        po_level_shift_inv_i32(img + extra, P, 8);
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++)
+                frame_out[(size_t)y * W + x] = (uint8_t)img[extra + (size_t)y * AW + x];
+        free(img);
+    } else {
+        float *img = (float *)malloc((P + extra) * sizeof(float));
+        po_dwt97_inverse(coef, img, AW, AH, wl, qs);
+        po_level_shift_inv_f32(img + extra, P, 8);
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++)
+                frame_out[(size_t)y * W + x] = (uint8_t)img[extra + (size_t)y * AW + x];
+        free(img);
+    }
+    free(staging); free(sizes); free(coef);
+    return 0;
+}
