@@ -1,0 +1,454 @@
+// dwt_kernels.hpp -- one level of the 2-D lifting DWT for gfx950 (CDNA4), forward and inverse,
+// reversible 5/3 (int32) and irreversible 9/7 (fp32, quantisation gain fused into the write,
+// de-quantisation fused into the read).
+//
+// Replaces kernelDWTForward / kernelDWTForwardLossy / kernelDWTReverse / kernelDWTReverseLossy
+// (reference DWT/DWTGenerator.cu:753-812, 878-936, 1002-1124) and offsetImage
+// (Engines/CodingEngine.cu:581-588, fused into level 0 when the input is u8).  Arithmetic and
+// operation order per sample are those of the reference's lifting steps (:72-122, vertical
+// :137-272, horizontal :279-339, quantisation :405-419, de-quantisation :513-553), so the
+// coefficients are bit-identical to whole-image lifting with whole-sample symmetric extension.
+//
+// Design (not the reference's 64x18 register tile per 32-lane warp):
+//   * a wave64 owns a strip of 256 columns, 4 adjacent columns (16 B) per lane, and STREAMS down
+//     a band of rows: vertical lifting is a sliding window of 4 (9/7) / 2 (5/3) state registers
+//     per column, so every input row is loaded once per band, fully coalesced (1 KiB per wave);
+//   * horizontal lifting runs in registers; the two samples a lane needs from its neighbours come
+//     by DPP wave_shr:1 / wave_shl:1 (no LDS, no bank conflicts);
+//   * image borders use no special-case code: out-of-image rows / columns are loaded from their
+//     mirror position (whole-sample symmetric extension of the signal), after which interior
+//     lifting is exact; the first/last lane of a wave and the first rows of a band are overlap
+//     that is recomputed, never written (4 columns each side: 1.6 % re-read per strip);
+//   * subband writes are 8-byte vectors, contiguous across the wave per subband row.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace picsong {
+
+// DWT/DWTGenerator.cuh:16-22
+#define PS_A1 (-1.586134342059924f)
+#define PS_A2 (-0.052980118572961f)
+#define PS_A3 (0.882911075530934f)
+#define PS_A4 (0.443506852043971f)
+#define PS_N1 (1.230174104914001f)
+#define PS_N2 (0.812893066f)
+
+constexpr int kStripCols = 256;                 // columns held by one wave
+constexpr int kStripUseful = kStripCols - 8;    // lanes 1..62 write
+constexpr int kFwdBandRows = 32;                // output rows per band (forward)
+constexpr int kInvBandRows = 32;                // output rows per band (inverse)
+
+struct DwtFwdArgs {
+    const void *src;        // level input: T[ H x W ] (stride src_stride) or u8 at level 0
+    int src_stride;
+    int W, H;               // this level's dimensions
+    void *ll;               // LL destination (packed scratch or Mallat origin on the last level)
+    int ll_stride;
+    void *mallat;           // Mallat array origin (row stride AW)
+    int AW;
+    int level;              // 0 = finest (quantisation row)
+    int last;               // last level: LL gets quantised (lossy)
+    float qs;
+    float q[4];             // quantisation steps of this level: LL, HL, LH, HH
+};
+
+struct DwtInvArgs {
+    const int32_t *mallat;  // coded coefficients, int32, row stride AW
+    int AW;
+    const void *ll;         // LL source: Mallat (first == 1) or previous level's packed output (T)
+    int ll_stride;
+    int first;              // coarsest level: LL comes from `mallat` (and is de-quantised if lossy)
+    int W, H;               // this level's OUTPUT dimensions
+    void *dst;              // packed output T[H x W]
+    float qs;
+    float q[4];
+};
+
+__device__ __forceinline__ int reflect(int i, int n)
+{
+    // whole-sample symmetric extension: x[-k] = x[k], x[n-1+k] = x[n-1-k]
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+// subband-domain mirrors of the same extension (K = samples in the subband)
+__device__ __forceinline__ int reflect_s(int m, int K)
+{
+    if (m < 0) m = -m;
+    if (m >= K) m = 2 * K - 1 - m;
+    return m < 0 ? 0 : (m >= K ? K - 1 : m);
+}
+__device__ __forceinline__ int reflect_d(int m, int K)
+{
+    if (m < 0) m = -m - 1;
+    if (m >= K) m = 2 * K - 2 - m;
+    return m < 0 ? 0 : (m >= K ? K - 1 : m);
+}
+
+// bit casts between the 32-bit sample types and raw dwords (no pointer punning)
+__device__ __forceinline__ uint32_t as_u32(int v) { return (uint32_t)v; }
+__device__ __forceinline__ uint32_t as_u32(float v) { return __float_as_uint(v); }
+template <typename T> __device__ __forceinline__ T from_u32(uint32_t u);
+template <> __device__ __forceinline__ int from_u32<int>(uint32_t u) { return (int)u; }
+template <> __device__ __forceinline__ float from_u32<float>(uint32_t u) { return __uint_as_float(u); }
+
+template <typename T> __device__ __forceinline__ T dpp_prev(T v);
+template <typename T> __device__ __forceinline__ T dpp_next(T v);
+template <> __device__ __forceinline__ int dpp_prev<int>(int v)
+{ return (int)__builtin_amdgcn_update_dpp(0u, (uint32_t)v, 0x138, 0xf, 0xf, false); }
+template <> __device__ __forceinline__ int dpp_next<int>(int v)
+{ return (int)__builtin_amdgcn_update_dpp(0u, (uint32_t)v, 0x130, 0xf, 0xf, false); }
+template <> __device__ __forceinline__ float dpp_prev<float>(float v)
+{ return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x138, 0xf, 0xf, false)); }
+template <> __device__ __forceinline__ float dpp_next<float>(float v)
+{ return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x130, 0xf, 0xf, false)); }
+
+// ---- horizontal analysis of one row held as (e0,o0,e1,o1) per lane ----------------------------
+__device__ __forceinline__ void hfwd(int v[4])
+{   // DWTGenerator.cu:279-292, lifting :72-76
+    int en = dpp_next<int>(v[0]);
+    v[1] -= (v[0] + v[2]) >> 1;
+    v[3] -= (v[2] + en) >> 1;
+    int dp = dpp_prev<int>(v[3]);
+    v[0] += (dp + v[1] + 2) >> 2;
+    v[2] += (v[1] + v[3] + 2) >> 2;
+}
+__device__ __forceinline__ void hfwd(float v[4])
+{   // DWTGenerator.cu:311-323, lifting :91-104
+    float en = dpp_next<float>(v[0]);
+    v[1] = fmaf(v[0] + v[2], PS_A1, v[1]);
+    v[3] = fmaf(v[2] + en, PS_A1, v[3]);
+    float dp = dpp_prev<float>(v[3]);
+    v[0] = fmaf(v[1] + dp, PS_A2, v[0]);
+    v[2] = fmaf(v[3] + v[1], PS_A2, v[2]);
+    float sn = dpp_next<float>(v[0]);
+    v[1] = fmaf(v[0] + v[2], PS_A3, v[1]);
+    v[3] = fmaf(v[2] + sn, PS_A3, v[3]);
+    dp = dpp_prev<float>(v[3]);
+    v[0] = fmaf(v[1] + dp, PS_A4, v[0]) * PS_N2;
+    v[2] = fmaf(v[3] + v[1], PS_A4, v[2]) * PS_N2;
+    v[1] *= PS_N1;
+    v[3] *= PS_N1;
+}
+// ---- horizontal synthesis of one row held as (s0,d0,s1,d1) per lane ---------------------------
+__device__ __forceinline__ void hinv(int v[4])
+{   // DWTGenerator.cu:295-308, lifting :81-85
+    int dp = dpp_prev<int>(v[3]);
+    v[0] -= (v[1] + dp + 2) >> 2;
+    v[2] -= (v[3] + v[1] + 2) >> 2;
+    int sn = dpp_next<int>(v[0]);
+    v[1] += (v[0] + v[2]) >> 1;
+    v[3] += (v[2] + sn) >> 1;
+}
+__device__ __forceinline__ void hinv(float v[4])
+{   // DWTGenerator.cu:326-339, lifting :110-122
+    v[1] = v[1] / PS_N1;
+    v[3] = v[3] / PS_N1;
+    float dp = dpp_prev<float>(v[3]);
+    v[0] = fmaf(-(v[1] + dp), PS_A4, v[0] / PS_N2);
+    v[2] = fmaf(-(v[3] + v[1]), PS_A4, v[2] / PS_N2);
+    float sn = dpp_next<float>(v[0]);
+    v[1] = fmaf(-(v[0] + v[2]), PS_A3, v[1]);
+    v[3] = fmaf(-(v[2] + sn), PS_A3, v[3]);
+    dp = dpp_prev<float>(v[3]);
+    v[0] = fmaf(-(v[1] + dp), PS_A2, v[0]);
+    v[2] = fmaf(-(v[3] + v[1]), PS_A2, v[2]);
+    sn = dpp_next<float>(v[0]);
+    v[1] = fmaf(-(v[0] + v[2]), PS_A1, v[1]);
+    v[3] = fmaf(-(v[2] + sn), PS_A1, v[3]);
+}
+
+// ---- forward --------------------------------------------------------------------------------
+template <typename T, bool U8IN>
+__device__ __forceinline__ void load_row4(const DwtFwdArgs &a, int y, int c0, bool vec, T v[4])
+{
+    const int ry = reflect(y, a.H);
+    if (U8IN) {
+        const uint8_t *p = (const uint8_t *)a.src + (size_t)ry * (size_t)a.src_stride;
+        // offsetImage Engines/CodingEngine.cu:581-588 fused: (T)u8 - 128
+        if (vec) {
+            uint32_t w = *reinterpret_cast<const uint32_t *>(p + c0);
+            v[0] = (T)(int)(w & 0xFFu) - (T)128; v[1] = (T)(int)((w >> 8) & 0xFFu) - (T)128;
+            v[2] = (T)(int)((w >> 16) & 0xFFu) - (T)128; v[3] = (T)(int)(w >> 24) - (T)128;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = (T)(int)p[reflect(c0 + k, a.W)] - (T)128;
+        }
+    } else {
+        const T *p = (const T *)a.src + (size_t)ry * (size_t)a.src_stride;
+        if (vec) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(p + c0);
+            v[0] = from_u32<T>(w.x); v[1] = from_u32<T>(w.y); v[2] = from_u32<T>(w.z); v[3] = from_u32<T>(w.w);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = p[reflect(c0 + k, a.W)];
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store2(T *p, T x, T y, bool vec, bool two)
+{
+    if (vec) {
+        uint2 w;
+        w.x = as_u32(x);
+        w.y = as_u32(y);
+        *reinterpret_cast<uint2 *>(p) = w;
+    } else { p[0] = x; if (two) p[1] = y; }
+}
+
+// writeSubbands DWTGenerator.cu:403-433 + placement :719-723.  Lrow/Hrow: vertically low / high
+// rows after horizontal analysis (s0,d0,s1,d1): s -> LL / LH, d -> HL / HH.
+template <typename T, bool LOSSY>
+__device__ __forceinline__ void emit_pair(const DwtFwdArgs &a, int m, int pc, bool wr, bool vst,
+                                          T Lr[4], T Hr[4])
+{
+    hfwd(Lr);
+    hfwd(Hr);
+    if (!wr || m < 0 || m >= (a.H >> 1)) return;
+    T ll0 = Lr[0], ll1 = Lr[2], hl0 = Lr[1], hl1 = Lr[3];
+    T lh0 = Hr[0], lh1 = Hr[2], hh0 = Hr[1], hh1 = Hr[3];
+    if (LOSSY) {
+        if (a.last) { ll0 = (T)(((float)ll0 * a.q[0]) * a.qs); ll1 = (T)(((float)ll1 * a.q[0]) * a.qs); }
+        hl0 = (T)(((float)hl0 * a.q[1]) * a.qs); hl1 = (T)(((float)hl1 * a.q[1]) * a.qs);
+        lh0 = (T)(((float)lh0 * a.q[2]) * a.qs); lh1 = (T)(((float)lh1 * a.q[2]) * a.qs);
+        hh0 = (T)(((float)hh0 * a.q[3]) * a.qs); hh1 = (T)(((float)hh1 * a.q[3]) * a.qs);
+    }
+    const int hW = a.W >> 1, hH = a.H >> 1;
+    const bool two = pc + 1 < hW;
+    T *mal = (T *)a.mallat;
+    store2((T *)a.ll + (size_t)m * (size_t)a.ll_stride + pc, ll0, ll1, vst, two);
+    store2(mal + (size_t)m * (size_t)a.AW + hW + pc, hl0, hl1, vst, two);
+    store2(mal + (size_t)(m + hH) * (size_t)a.AW + pc, lh0, lh1, vst, two);
+    store2(mal + (size_t)(m + hH) * (size_t)a.AW + hW + pc, hh0, hh1, vst, two);
+}
+
+// grid.x = ceil(strips / 4), grid.y = bands; block = 256 threads = 4 waves = 4 adjacent strips
+template <typename T, bool LOSSY, bool U8IN>
+__global__ __launch_bounds__(256) void dwt_fwd_kernel(DwtFwdArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int strip = blockIdx.x * 4 + wave;
+    if (strip * kStripUseful >= a.W) return;               // whole wave idle (no cross-lane use)
+    const int c0 = strip * kStripUseful - 4 + 4 * lane;    // first of the lane's 4 columns
+    const int m0 = blockIdx.y * (kFwdBandRows / 2);
+    int m1 = m0 + kFwdBandRows / 2;
+    if (m1 > (a.H >> 1)) m1 = a.H >> 1;
+    const bool inside = c0 >= 0 && c0 + 3 < a.W;
+    const bool vld = inside && (a.src_stride & 3) == 0;
+    const bool wr = lane >= 1 && lane <= 62 && c0 >= 0 && c0 < a.W;
+    const bool vst = ((a.W >> 1) & 1) == 0 && (a.ll_stride & 1) == 0;
+    const int pc = c0 >> 1;
+
+    if constexpr (!LOSSY) {
+        // vertical 5/3, DWTGenerator.cu:137-157: d[m] = x[2m+1] - ((x[2m]+x[2m+2])>>1);
+        // s[m] = x[2m] + ((d[m-1]+d[m]+2)>>2)
+        T xe[4], xo[4], xn[4], dp[4];
+        load_row4<T, U8IN>(a, 2 * m0 - 2, c0, vld, xe);
+        load_row4<T, U8IN>(a, 2 * m0 - 1, c0, vld, xo);
+        load_row4<T, U8IN>(a, 2 * m0, c0, vld, xn);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { dp[k] = xo[k] - ((xe[k] + xn[k]) >> 1); xe[k] = xn[k]; }
+        for (int m = m0; m < m1; m++) {
+            load_row4<T, U8IN>(a, 2 * m + 1, c0, vld, xo);
+            load_row4<T, U8IN>(a, 2 * m + 2, c0, vld, xn);
+            T Lr[4], Hr[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                T d = xo[k] - ((xe[k] + xn[k]) >> 1);
+                Lr[k] = xe[k] + ((dp[k] + d + 2) >> 2);
+                Hr[k] = d;
+                dp[k] = d; xe[k] = xn[k];
+            }
+            emit_pair<T, LOSSY>(a, m, pc, wr, vst, Lr, Hr);
+        }
+    } else {
+        // vertical 9/7, DWTGenerator.cu:184-227, streamed: at step j the pair j-1 completes
+        T xe[4], xo[4], xn[4], d1p[4], s1p[4], d2p[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { d1p[k] = s1p[k] = d2p[k] = (T)0; }
+        load_row4<T, U8IN>(a, 2 * m0 - 4, c0, vld, xe);
+        for (int j = m0 - 2; j <= m1; j++) {
+            load_row4<T, U8IN>(a, 2 * j + 1, c0, vld, xo);
+            load_row4<T, U8IN>(a, 2 * j + 2, c0, vld, xn);
+            T Lr[4], Hr[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float d1 = fmaf((float)xe[k] + (float)xn[k], PS_A1, (float)xo[k]);
+                float s1 = fmaf((float)d1p[k] + d1, PS_A2, (float)xe[k]);
+                float d2 = fmaf((float)s1p[k] + s1, PS_A3, (float)d1p[k]);
+                float s2 = fmaf((float)d2p[k] + d2, PS_A4, (float)s1p[k]);
+                Lr[k] = (T)(s2 * PS_N2);
+                Hr[k] = (T)(d2 * PS_N1);
+                d1p[k] = (T)d1; s1p[k] = (T)s1; d2p[k] = (T)d2; xe[k] = xn[k];
+            }
+            if (j - 1 >= m0) emit_pair<T, LOSSY>(a, j - 1, pc, wr, vst, Lr, Hr);
+        }
+    }
+}
+
+// ---- inverse --------------------------------------------------------------------------------
+// readSubbands* DWTGenerator.cu:477-553: de-quantisation (|v| + 0.5) * sgn(v) / Q / qs, 0 -> 0
+__device__ __forceinline__ float dequant(int32_t v, float q, float qs)
+{
+    if (v == 0) return 0.0f;
+    float m = fabsf((float)v) + 0.5f;
+    float s = v < 0 ? -1.0f : 1.0f;
+    return ((m * s) / q) / qs;
+}
+
+// one subband row pair-segment: s-type values for pair columns pc, pc+1 and d-type likewise
+template <typename T, bool LOSSY>
+__device__ __forceinline__ void load_sub4(const DwtInvArgs &a, int row_s_or_d, bool high_row,
+                                          int pc, bool vec, T v[4])
+{
+    // row index already reflected by the caller.  low row: s = LL, d = HL; high row: s = LH, d = HH
+    const int hW = a.W >> 1, hH = a.H >> 1;
+    const int32_t *mrow = a.mallat + (size_t)(row_s_or_d + (high_row ? hH : 0)) * (size_t)a.AW;
+    int cs0 = pc, cs1 = pc + 1, cd0 = pc, cd1 = pc + 1;
+    if (!vec) {
+        cs0 = reflect_s(pc, hW); cs1 = reflect_s(pc + 1, hW);
+        cd0 = reflect_d(pc, hW); cd1 = reflect_d(pc + 1, hW);
+    }
+    int32_t d0 = mrow[hW + cd0], d1 = mrow[hW + cd1];
+    const float qd = high_row ? a.q[3] : a.q[1];
+    if (LOSSY) { v[1] = (T)dequant(d0, qd, a.qs); v[3] = (T)dequant(d1, qd, a.qs); }
+    else { v[1] = (T)d0; v[3] = (T)d1; }
+    if (high_row || a.first) {
+        int32_t s0 = mrow[cs0], s1 = mrow[cs1];
+        const float qsb = high_row ? a.q[2] : a.q[0];
+        if (LOSSY) { v[0] = (T)dequant(s0, qsb, a.qs); v[2] = (T)dequant(s1, qsb, a.qs); }
+        else { v[0] = (T)s0; v[2] = (T)s1; }
+    } else {
+        const T *lrow = (const T *)a.ll + (size_t)row_s_or_d * (size_t)a.ll_stride;
+        v[0] = lrow[cs0]; v[2] = lrow[cs1];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void store_row4(const DwtInvArgs &a, int y, int c0, bool vec, const T v[4])
+{
+    T *p = (T *)a.dst + (size_t)y * (size_t)a.W + c0;
+    if (vec) {
+        uint4 w;
+        w.x = as_u32(v[0]); w.y = as_u32(v[1]); w.z = as_u32(v[2]); w.w = as_u32(v[3]);
+        *reinterpret_cast<uint4 *>(p) = w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (c0 + k < a.W) p[k] = v[k];
+    }
+}
+
+template <typename T, bool LOSSY>
+__global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int strip = blockIdx.x * 4 + wave;
+    if (strip * kStripUseful >= a.W) return;
+    const int c0 = strip * kStripUseful - 4 + 4 * lane;
+    const int pc = c0 >> 1;                                  // arithmetic shift: -4 -> -2
+    const int hW = a.W >> 1, hH = a.H >> 1;
+    const int m0 = blockIdx.y * (kInvBandRows / 2);
+    int m1 = m0 + kInvBandRows / 2;
+    if (m1 > hH) m1 = hH;
+    const bool inside = pc >= 0 && pc + 1 < hW;
+    const bool wr = lane >= 1 && lane <= 62 && c0 >= 0 && c0 < a.W;
+    const bool vst = (a.W & 3) == 0;
+
+    if constexpr (!LOSSY) {
+        // vertical 5/3 synthesis, DWTGenerator.cu:160-181, streamed: at step j pair j-1 completes
+        T Hp[4], sp[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { Hp[k] = sp[k] = 0; }
+        for (int j = m0 - 1; j <= m1; j++) {
+            T Lr[4], Hr[4];
+            load_sub4<T, LOSSY>(a, reflect_s(j, hH), false, pc, inside, Lr);
+            load_sub4<T, LOSSY>(a, reflect_d(j, hH), true, pc, inside, Hr);
+            hinv(Lr);
+            hinv(Hr);
+            T ev[4], od[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                T s = Lr[k] - ((Hp[k] + Hr[k] + 2) >> 2);
+                ev[k] = sp[k];
+                od[k] = Hp[k] + ((sp[k] + s) >> 1);
+                sp[k] = s; Hp[k] = Hr[k];
+            }
+            if (j - 1 >= m0 && wr) {
+                store_row4<T>(a, 2 * (j - 1), c0, vst, ev);
+                store_row4<T>(a, 2 * (j - 1) + 1, c0, vst, od);
+            }
+        }
+    } else {
+        // vertical 9/7 synthesis, DWTGenerator.cu:230-272, streamed: at step j pair j-2 completes
+        T ddp[4], s1p[4], d1p[4], s0p[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { ddp[k] = s1p[k] = d1p[k] = s0p[k] = (T)0; }
+        for (int j = m0 - 2; j <= m1 + 1; j++) {
+            T Lr[4], Hr[4];
+            load_sub4<T, LOSSY>(a, reflect_s(j, hH), false, pc, inside, Lr);
+            load_sub4<T, LOSSY>(a, reflect_d(j, hH), true, pc, inside, Hr);
+            hinv(Lr);
+            hinv(Hr);
+            T ev[4], od[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float dd = (float)Hr[k] / PS_N1;
+                float s1 = fmaf(-((float)ddp[k] + dd), PS_A4, (float)Lr[k] / PS_N2);
+                float d1 = fmaf(-((float)s1p[k] + s1), PS_A3, (float)ddp[k]);      // d1[j-1]
+                float s0 = fmaf(-((float)d1p[k] + d1), PS_A2, (float)s1p[k]);      // s0[j-1]
+                float xo = fmaf(-((float)s0p[k] + s0), PS_A1, (float)d1p[k]);      // x[2(j-2)+1]
+                ev[k] = s0p[k];
+                od[k] = (T)xo;
+                ddp[k] = (T)dd; s1p[k] = (T)s1; d1p[k] = (T)d1; s0p[k] = (T)s0;
+            }
+            if (j - 2 >= m0 && wr) {
+                store_row4<T>(a, 2 * (j - 2), c0, vst, ev);
+                store_row4<T>(a, 2 * (j - 2) + 1, c0, vst, od);
+            }
+        }
+    }
+}
+
+// ---- level shift kernels (used when the stages are called one by one) -------------------------
+// offsetImage Engines/CodingEngine.cu:581-588
+template <typename T>
+__global__ __launch_bounds__(256) void level_shift_fwd_kernel(const uint8_t *in, T *out, size_t n4, int off)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t w = reinterpret_cast<const uint32_t *>(in)[i];
+        T v[4] = { (T)(int)(w & 0xFFu) - (T)off, (T)(int)((w >> 8) & 0xFFu) - (T)off,
+                   (T)(int)((w >> 16) & 0xFFu) - (T)off, (T)(int)(w >> 24) - (T)off };
+        uint4 o;
+        o.x = as_u32(v[0]); o.y = as_u32(v[1]); o.z = as_u32(v[2]); o.w = as_u32(v[3]);
+        reinterpret_cast<uint4 *>(out)[i] = o;
+    }
+}
+// removeOffsetAndApplyMaxMin / ...Lossy, Engines/DecodingEngine.cu:706-729
+__global__ __launch_bounds__(256) void level_shift_inv_i32_kernel(int32_t *d, size_t n, int off)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        int v = d[i] + off;
+        d[i] = v > 255 ? 255 : (v < 0 ? 0 : v);
+    }
+}
+__global__ __launch_bounds__(256) void level_shift_inv_f32_kernel(float *d, size_t n, float off)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float t = d[i] + off;
+        t = t + 0.01f;
+        float r = rintf(t);                      // __float2int_rn
+        r = r > 255.0f ? 255.0f : r;
+        d[i] = r < 0.0f ? 0.0f : r;
+    }
+}
+// final image (T, row stride AW, after the inverse level shift) -> u8 crop-free copy
+template <typename T>
+__global__ __launch_bounds__(256) void to_u8_kernel(const T *in, uint8_t *out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (uint8_t)(int)in[i];
+}
+
+}  // namespace picsong

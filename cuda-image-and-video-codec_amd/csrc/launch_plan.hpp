@@ -1,0 +1,90 @@
+// launch_plan.hpp -- host-side launch geometry for the per-level DWT kernels (pure host code,
+// shared by the C-ABI implementation and by the CPU wave-emulator tests so both walk the levels
+// the same way).  Level order and scratch offsets follow DWTEngine::DWTForward / DWTReverse
+// (reference DWT/DWTGenerator.cu:1268-1424).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <vector>
+
+#include "dwt_kernels.hpp"
+
+namespace picsong {
+
+// DWT/DWTGenerator.cuh:168-179 -- quantisation steps, columns LL,HL,LH,HH, row = level
+static const float kQSteps[10][4] = {
+    { 1.965908f, 1.0112865f, 1.0112865f, 0.52021784f },
+    { 4.1224113f, 1.9968134f, 1.9968134f, 0.96721643f },
+    { 8.416739f, 4.1833673f, 4.1833673f, 2.0792568f },
+    { 16.935543f, 8.534108f, 8.534108f, 4.3004827f },
+    { 33.924816f, 17.166693f, 17.166693f, 8.686718f },
+    { 67.87687f, 34.385098f, 34.385098f, 17.41882f },
+    { 135.76744f, 68.7964f, 68.7964f, 34.860676f },
+    { 271.5416f, 137.60588f, 137.60588f, 69.73287f },
+    { 543.0866f, 275.21814f, 275.21814f, 139.47136f },
+    { 1086.1624f, 550.43286f, 550.43286f, 278.94202f }
+};
+
+struct FwdLaunch { DwtFwdArgs a; unsigned gx, gy; bool u8; };
+struct InvLaunch { DwtInvArgs a; unsigned gx, gy; };
+
+inline std::vector<FwdLaunch> plan_dwt_forward(const void *d_in, bool u8in, void *d_out, int aw, int ah,
+                                               int wl, float qs)
+{
+    std::vector<FwdLaunch> v;
+    int W = aw, H = ah;
+    size_t off = 0;
+    const char *src = (const char *)d_in;
+    int src_stride = aw;
+    for (int l = 0; l < wl; l++) {
+        const bool last = (l == wl - 1);
+        off += (size_t)W * (size_t)H;
+        FwdLaunch f;
+        DwtFwdArgs &a = f.a;
+        a.src = src; a.src_stride = src_stride; a.W = W; a.H = H;
+        a.ll = last ? d_out : (void *)((char *)d_out + off * 4);
+        a.ll_stride = last ? aw : (W >> 1);
+        a.mallat = d_out; a.AW = aw; a.level = l; a.last = last ? 1 : 0; a.qs = qs;
+        for (int k = 0; k < 4; k++) a.q[k] = kQSteps[l][k];
+        const int strips = (W + kStripUseful - 1) / kStripUseful;
+        f.gx = (unsigned)((strips + 3) / 4);
+        f.gy = (unsigned)(((H >> 1) + kFwdBandRows / 2 - 1) / (kFwdBandRows / 2));
+        f.u8 = u8in && l == 0;
+        v.push_back(f);
+        src = (const char *)d_out + off * 4;
+        src_stride = W >> 1;
+        W >>= 1; H >>= 1;
+    }
+    return v;
+}
+
+inline std::vector<InvLaunch> plan_dwt_inverse(const int32_t *d_in, void *d_out, int aw, int ah, int wl,
+                                               float qs)
+{
+    std::vector<InvLaunch> v;
+    int W = aw >> (wl - 1), H = ah >> (wl - 1);
+    size_t read_off = 0, write_off = 0;
+    for (int l = wl - 1; l >= 0; l--) {
+        const bool first = (l == wl - 1);
+        InvLaunch f;
+        DwtInvArgs &a = f.a;
+        a.mallat = d_in; a.AW = aw;
+        a.ll = first ? (const void *)d_in : (const void *)((const char *)d_out + read_off * 4);
+        a.ll_stride = first ? aw : (W >> 1);
+        a.first = first ? 1 : 0;
+        a.W = W; a.H = H;
+        a.dst = (char *)d_out + write_off * 4;
+        a.qs = qs;
+        for (int k = 0; k < 4; k++) a.q[k] = kQSteps[l][k];
+        const int strips = (W + kStripUseful - 1) / kStripUseful;
+        f.gx = (unsigned)((strips + 3) / 4);
+        f.gy = (unsigned)(((H >> 1) + kInvBandRows / 2 - 1) / (kInvBandRows / 2));
+        v.push_back(f);
+        read_off = write_off;
+        write_off += (size_t)W * (size_t)H;
+        W <<= 1; H <<= 1;
+    }
+    return v;
+}
+
+}  // namespace picsong

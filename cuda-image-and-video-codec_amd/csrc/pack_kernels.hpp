@@ -1,0 +1,85 @@
+// pack_kernels.hpp -- BitStreamBuilder ("CR" compaction) for gfx950: per-codeblock lengths ->
+// exclusive offsets -> dense uint16 codestream, and the inverse.
+//
+// Replaces cub::DeviceScan::InclusiveSum + binarySearchLUTBSB + buildBitStreamLUTBS /
+// buildCodeStreamLUTBS (reference BitStreamBuilder/BitStreamBuilder.cu:33-171,198-229,290-323).
+// The stream layout is the reference's; the method is not: the reference launches
+// one thread per staged value and binary-searches the prefix array through a 256-entry index;
+// here one workgroup owns one codeblock, so both sides of the copy are contiguous bursts and no
+// search exists.  The scan is a single-workgroup wave scan (nCB <= 65,536).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace picsong {
+
+struct HeaderArg { uint16_t h[9]; int has; };
+
+// offsets[cb] = sum_{i<cb} (sizes[i] - 1); *total = 9 + 2n + sum(sizes - 1) + 1
+// (BitStreamBuilder.cu:300-305).  One block of 1024 threads.
+__global__ __launch_bounds__(1024) void scan_sizes_kernel(const int32_t *sizes, int n, int32_t *offsets,
+                                                          int32_t *total)
+{
+    __shared__ int32_t s_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = (n + 1023) / 1024;
+    const int b = tid * chunk, e = b + chunk < n ? b + chunk : n;
+    int32_t sum = 0;
+    for (int i = b; i < e; i++) sum += sizes[i] - 1;
+    int32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int32_t o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int32_t base = 0;
+    for (int w = 0; w < wave; w++) base += s_wave[w];
+    int32_t run = base + inc - sum;
+    for (int i = b; i < e; i++) { offsets[i] = run; run += sizes[i] - 1; }
+    if (tid == 1023) *total = 9 + 2 * n + (base + inc) + 1;
+}
+
+// one workgroup per codeblock (buildBitStreamLUTBS BitStreamBuilder.cu:106-137 layout)
+__global__ __launch_bounds__(256) void pack_kernel(const int32_t *staging, const int32_t *sizes,
+                                                   const int32_t *offsets, const int32_t *total, int n,
+                                                   HeaderArg hdr, uint16_t *out)
+{
+    const int cb = blockIdx.x, tid = threadIdx.x;
+    const int32_t *st = staging + (size_t)cb * 4096u;
+    const int len = sizes[cb];
+    uint16_t *dst = out + 9 + 2 * (size_t)n + (size_t)offsets[cb];
+    for (int j = 1 + tid; j < len; j += 256) dst[j - 1] = (uint16_t)st[j];
+    if (tid == 0) {
+        out[9 + 2 * cb] = (uint16_t)st[0];
+        out[9 + 2 * cb + 1] = (uint16_t)len;
+    }
+    if (cb == 0) {
+        // deviceMemoryAllocator BitStreamBuilder.cu:270-279: 0xFFFF everywhere not written,
+        // header copied only when iter == 0; one trailing short stays 0xFFFF
+        if (tid < 9) out[tid] = hdr.has ? hdr.h[tid] : (uint16_t)0xFFFFu;
+        if (tid == 9) out[*total - 1] = (uint16_t)0xFFFFu;
+    }
+}
+
+// retrieveSizeArray BitStreamBuilder.cpp:119-129 on the device
+__global__ __launch_bounds__(256) void read_sizes_kernel(const uint16_t *stream, int n, int32_t *sizes)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sizes[i] = stream[10 + 2 * i];
+}
+
+// buildCodeStreamLUTBS BitStreamBuilder.cu:142-171 layout
+__global__ __launch_bounds__(256) void unpack_kernel(const uint16_t *stream, const int32_t *sizes,
+                                                     const int32_t *offsets, int n, int32_t *staging)
+{
+    const int cb = blockIdx.x, tid = threadIdx.x;
+    int32_t *st = staging + (size_t)cb * 4096u;
+    const int len = sizes[cb];
+    const uint16_t *src = stream + 9 + 2 * (size_t)n + (size_t)offsets[cb];
+    for (int j = 1 + tid; j < len; j += 256) st[j] = (int32_t)src[j - 1];
+    if (tid == 0) st[0] = (int32_t)stream[9 + 2 * cb];
+}
+
+}  // namespace picsong

@@ -1,0 +1,574 @@
+// picsong_hip.hip -- C-ABI implementation (include/picsong_hip.h): host launch logic for the
+// gfx950 kernels in dwt_kernels.hpp / bpc_kernels.hpp / pack_kernels.hpp.
+// No CPU fallback exists: without a GPU every device entry point returns PICSONG_ERR_NODEVICE.
+#include "../../include/picsong_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bpc_kernels.hpp"
+#include "dwt_kernels.hpp"
+#include "launch_plan.hpp"
+#include "pack_kernels.hpp"
+
+using namespace picsong;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(PICSONG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+
+}  // namespace
+
+struct picsong_ctx {
+    picsong_params p;
+    int device;
+    int aw, ah, ncb;
+    size_t P, extra;
+    // LUT
+    picsong_lut_info li;
+    int32_t *d_lut;
+    bool has_lut;
+    // small scratch
+    int32_t *d_offsets;   // nCB
+    int32_t *d_total;     // 1
+    int *d_flag;          // 1
+    int32_t *h_pinned;    // [0] total, [1] flag
+    // frame pipeline workspace (lazy)
+    void *d_coef;         // T[P + extra]
+    int32_t *d_staging;   // int32[P]
+    int32_t *d_sizes;     // int32[nCB]
+    int32_t *d_coef_i;    // int32[P] (decode)
+    // stage profiling (HIP events on the launch stream)
+    std::vector<hipEvent_t> *prof_ev;   // 4 per frame
+    int prof_cap, prof_n;
+};
+
+extern "C" {
+
+const char *picsong_last_error(void) { return g_err; }
+const char *picsong_version(void) { return "picsong-mi355x 0.1 (gfx950)"; }
+
+int picsong_pad_dim(int v) { return ((v + PICSONG_CB - 1) / PICSONG_CB) * PICSONG_CB; }
+
+size_t picsong_dwt_extra(int aw, int ah, int wl)
+{
+    size_t e = 0;
+    for (int l = 1; l < wl; l++) e += (size_t)(aw >> l) * (size_t)(ah >> l);
+    return e;
+}
+
+size_t picsong_max_stream_shorts(int aw, int ah)
+{
+    size_t ncb = (size_t)(aw / PICSONG_CB) * (size_t)(ah / PICSONG_CB);
+    return PICSONG_HDR_SHORTS + 2 * ncb + (size_t)aw * (size_t)ah + 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// header
+// ---------------------------------------------------------------------------------------------
+int picsong_header_pack(const picsong_params *p, uint16_t o[PICSONG_HDR_SHORTS])
+{
+    if (!p || !o) return fail(PICSONG_ERR_ARG, "header_pack: null argument");
+    const uint32_t n = (uint32_t)p->width * (uint32_t)p->height * (uint32_t)p->components;
+    const int qs4 = (int)(p->qs * 10000), k3 = (int)(p->k * 1000);
+    o[0] = (uint16_t)(n & 0xFFFFu);
+    o[1] = (uint16_t)(n >> 16);
+    o[2] = (uint16_t)((p->cp == 2 ? 0 : 1) | (p->cb_height << 1) | (p->cb_width << 8) | ((p->wl & 1) << 15));
+    o[3] = (uint16_t)(((p->wl & 7) >> 1) | (p->bit_depth << 3) | ((p->lossy ? 1 : 0) << 10) | ((qs4 & 31) << 11));
+    o[4] = (uint16_t)((qs4 >> 5) | ((p->components & 127) << 9));
+    o[5] = (uint16_t)((p->components >> 7) | (0 << 7) | (p->height << 8));
+    o[6] = (uint16_t)((p->height >> 8) | (0 << 8) | (p->bit_depth << 9) | (0 << 14) | ((p->frames & 1) << 15));
+    o[7] = (uint16_t)((p->frames >> 1) & 0xFFFF);
+    o[8] = (uint16_t)k3;
+    return PICSONG_OK;
+}
+
+int picsong_header_unpack(const uint16_t e[PICSONG_HDR_SHORTS], picsong_params *p)
+{
+    if (!p || !e) return fail(PICSONG_ERR_ARG, "header_unpack: null argument");
+    memset(p, 0, sizeof *p);
+    const uint32_t n = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
+    p->cp = (e[2] & 1) ? 3 : 2;
+    p->cb_height = (e[2] >> 1) & 127;
+    p->cb_width = (e[2] >> 8) & 127;
+    p->wl = ((e[2] >> 15) & 1) | ((e[3] & 7) << 1);
+    p->bit_depth = (e[3] >> 3) & 127;
+    p->lossy = (e[3] >> 10) & 1;
+    p->qs = (float)((((e[3] >> 11) & 31) | ((e[4] & 511) << 5)) / 10000.0);   // DecodingEngine.cu:161
+    p->components = ((e[4] >> 9) & 127) | ((e[5] & 127) << 9);
+    p->height = ((e[5] >> 8) & 255) | ((e[6] & 255) << 8);
+    p->frames = ((e[6] >> 15) & 1) | ((int)e[7] << 1);
+    p->k = (float)(e[8] / 1000.0);
+    if (p->height <= 0 || p->components <= 0) return fail(PICSONG_ERR_ARG, "header_unpack: bad header");
+    p->width = (int)(n / (uint32_t)p->height / (uint32_t)p->components);       // DecodingEngine.cu:146
+    return PICSONG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LUT text parser
+// ---------------------------------------------------------------------------------------------
+static int lut_section(const std::string &folder, const char *stem, int component, int C, int nBp,
+                       int wl, int32_t *T, int base, size_t cap)
+{
+    static const char *suffix[4] = { ".txt_", "R.txt_", "G.txt_", "B.txt_" };
+    std::string path = folder + stem + suffix[component & 3] + "0";
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return fail(PICSONG_ERR_IO, "cannot open LUT file %s", path.c_str());
+    int i = base, prev = -1, lvl, sb, bp, v[16];
+    for (;;) {
+        if (fscanf(f, "%d %d %d :", &lvl, &sb, &bp) != 3) break;
+        bool ok = true;
+        for (int c = 0; c < C; c++)
+            if (fscanf(f, "%d", &v[c]) != 1) { ok = false; break; }
+        if (!ok) break;
+        if (bp <= prev) {
+            // remaining planes of the previous group get the 7-bit mid value (IOManager.ipp:459)
+            for (int z = 0; z < (nBp - prev - 1) * C; z++) {
+                size_t at = (size_t)(i + prev * C + z + C);
+                if (at < cap) T[at] = 64;
+            }
+            i += nBp * C;
+        }
+        if ((lvl + 1) > wl && sb > 0) break;
+        prev = bp;
+        for (int c = 0; c < C; c++) {
+            size_t at = (size_t)(i + bp * C + c);
+            if (at < cap) T[at] = v[c];
+        }
+    }
+    fclose(f);
+    return PICSONG_OK;
+}
+
+int picsong_lut_load(const char *folder_c, int component, int wl, int fill, picsong_lut_info *info,
+                     int32_t *table, size_t cap)
+{
+    if (!folder_c || !info) return fail(PICSONG_ERR_ARG, "lut_load: null argument");
+    if (wl < 1 || wl > 10) return fail(PICSONG_ERR_ARG, "lut_load: wl %d out of range", wl);
+    std::string folder(folder_c);
+    if (!folder.empty() && folder.back() != '/') folder += '/';
+    FILE *f = fopen((folder + "header.txt").c_str(), "rb");
+    if (!f) return fail(PICSONG_ERR_IO, "cannot open %sheader.txt", folder.c_str());
+    int v[8], n = 0;
+    char line[256];
+    while (n < 8 && fgets(line, sizeof line, f)) {
+        const char *semi = strchr(line, ';');
+        if (semi) v[n++] = atoi(semi + 1);
+    }
+    fclose(f);
+    if (n < 8) return fail(PICSONG_ERR_IO, "%sheader.txt: expected 8 KEY;value lines", folder.c_str());
+    info->n_bitplanes = v[0]; info->n_subbands = v[1]; info->ctx_ref = v[2]; info->ctx_sign = v[3];
+    info->ctx_sig = v[4]; info->precision = v[5]; info->n_files = v[6];
+    info->n_bp_files = v[7] > 32 ? 32 : v[7];
+    const int nBp = v[0], nS = v[1];
+    info->n_ref = nS * nBp * info->ctx_ref * wl + nBp * info->ctx_ref;
+    info->n_sig = nS * nBp * info->ctx_sig * wl + nBp * info->ctx_sig;
+    info->n_sign = nS * nBp * info->ctx_sign * wl + nBp * info->ctx_sign;
+    if (!table) return PICSONG_OK;
+    const size_t total = (size_t)info->n_ref + info->n_sig + info->n_sign;
+    if (cap < total) return fail(PICSONG_ERR_ARG, "lut_load: table capacity %zu < %zu", cap, total);
+    if (info->ctx_ref > 16 || info->ctx_sig > 16 || info->ctx_sign > 16)
+        return fail(PICSONG_ERR_ARG, "lut_load: context counts above 16 are not supported");
+    for (size_t i = 0; i < total; i++) table[i] = fill;
+    int rc;
+    if ((rc = lut_section(folder, "ref", component, info->ctx_ref, nBp, wl, table, 0, total))) return rc;
+    if ((rc = lut_section(folder, "sig", component, info->ctx_sig, nBp, wl, table, info->n_ref, total))) return rc;
+    if ((rc = lut_section(folder, "sign", component, info->ctx_sign, nBp, wl, table,
+                          info->n_ref + info->n_sig, total))) return rc;
+    return PICSONG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+int picsong_ctx_create(const picsong_params *p, int device, picsong_ctx **out)
+{
+    if (!p || !out) return fail(PICSONG_ERR_ARG, "ctx_create: null argument");
+    *out = nullptr;
+    // Launcher.cu:132 validation + header limits
+    if (p->width <= 0 || p->height <= 0) return fail(PICSONG_ERR_ARG, "xSize/ySize must be positive");
+    if (p->wl < 1 || p->wl > 7) return fail(PICSONG_ERR_ARG, "wl %d outside 1..7", p->wl);
+    if (p->cp != 2) return fail(PICSONG_ERR_ARG, "only -cp 2 is implemented (got %d)", p->cp);
+    if (p->k != 0.0f) return fail(PICSONG_ERR_ARG, "only -k 0 is implemented");
+    if (p->lossy && !(p->qs > 0.0f && p->qs <= 1.0f)) return fail(PICSONG_ERR_ARG, "qs %g outside (0,1]", p->qs);
+    if (p->bit_depth != 8) return fail(PICSONG_ERR_ARG, "only 8-bit samples are implemented");
+    if (p->components != 1) return fail(PICSONG_ERR_ARG, "only 1 component is implemented");
+    const int aw = picsong_pad_dim(p->width), ah = picsong_pad_dim(p->height);
+    if ((aw >> (p->wl - 1)) < 8 || (ah >> (p->wl - 1)) < 8 || ((aw >> (p->wl - 1)) & 1) || ((ah >> (p->wl - 1)) & 1))
+        return fail(PICSONG_ERR_ARG, "image %dx%d too small for %d wavelet levels", aw, ah, p->wl);
+    if ((size_t)aw * (size_t)ah >= ((size_t)1 << 30)) return fail(PICSONG_ERR_ARG, "frame too large");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(PICSONG_ERR_NODEVICE, "no HIP device: this library has no CPU path");
+    if (device < 0 || device >= ndev) return fail(PICSONG_ERR_ARG, "device %d of %d", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    picsong_ctx *c = new picsong_ctx();
+    memset(c, 0, sizeof *c);
+    c->p = *p;
+    c->device = device;
+    c->aw = aw; c->ah = ah;
+    c->ncb = (aw / PICSONG_CB) * (ah / PICSONG_CB);
+    c->P = (size_t)aw * (size_t)ah;
+    c->extra = picsong_dwt_extra(aw, ah, p->wl);
+    hipError_t e = hipMalloc(&c->d_offsets, sizeof(int32_t) * (size_t)c->ncb);
+    if (e == hipSuccess) e = hipMalloc(&c->d_total, sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&c->d_flag, sizeof(int));
+    if (e == hipSuccess) e = hipHostMalloc(&c->h_pinned, 2 * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemset(c->d_flag, 0, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->d_total, 0, sizeof(int32_t));
+    if (e != hipSuccess) {
+        picsong_ctx_destroy(c);
+        return fail(PICSONG_ERR_HIP, "ctx_create: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return PICSONG_OK;
+}
+
+void picsong_ctx_destroy(picsong_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_lut) (void)hipFree(c->d_lut);
+    if (c->d_offsets) (void)hipFree(c->d_offsets);
+    if (c->d_total) (void)hipFree(c->d_total);
+    if (c->d_flag) (void)hipFree(c->d_flag);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->d_coef) (void)hipFree(c->d_coef);
+    if (c->d_staging) (void)hipFree(c->d_staging);
+    if (c->d_sizes) (void)hipFree(c->d_sizes);
+    if (c->d_coef_i) (void)hipFree(c->d_coef_i);
+    if (c->prof_ev) {
+        for (hipEvent_t e : *c->prof_ev) (void)hipEventDestroy(e);
+        delete c->prof_ev;
+    }
+    delete c;
+}
+
+int picsong_ctx_set_lut(picsong_ctx *c, const picsong_lut_info *info, const int32_t *host_table)
+{
+    if (!c || !info || !host_table) return fail(PICSONG_ERR_ARG, "set_lut: null argument");
+    // the context formation of BPCEngine.cu:222-308 is fixed to 9 / 4 / 1 contexts
+    if (info->ctx_sig != 9 || info->ctx_sign != 4 || info->ctx_ref != 1)
+        return fail(PICSONG_ERR_ARG, "LUT contexts must be 9/4/1 (sig/sign/ref), got %d/%d/%d", info->ctx_sig,
+                    info->ctx_sign, info->ctx_ref);
+    if (info->precision < 1 || info->precision > 8) return fail(PICSONG_ERR_ARG, "LUT precision %d", info->precision);
+    const size_t total = (size_t)info->n_ref + info->n_sig + info->n_sign;
+    for (size_t i = 0; i < total; i++)
+        if (host_table[i] < 0 || host_table[i] > 255)
+            return fail(PICSONG_ERR_ARG, "LUT entry %zu = %d outside 0..255", i, host_table[i]);
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->d_lut) { (void)hipFree(c->d_lut); c->d_lut = nullptr; }
+    HIP_TRY(hipMalloc(&c->d_lut, total * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(c->d_lut, host_table, total * sizeof(int32_t), hipMemcpyHostToDevice));
+    c->li = *info;
+    c->has_lut = true;
+    return PICSONG_OK;
+}
+
+int picsong_ctx_padded_dims(const picsong_ctx *c, int *aw, int *ah, int *ncb)
+{
+    if (!c) return fail(PICSONG_ERR_ARG, "null ctx");
+    if (aw) *aw = c->aw;
+    if (ah) *ah = c->ah;
+    if (ncb) *ncb = c->ncb;
+    return PICSONG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// level shift
+// ---------------------------------------------------------------------------------------------
+int picsong_level_shift_fwd(picsong_ctx *c, const uint8_t *d_in, void *d_out, void *stream)
+{
+    if (!c || !d_in || !d_out) return fail(PICSONG_ERR_ARG, "level_shift_fwd: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n4 = c->P / 4;
+    const int off = 1 << (c->p.bit_depth - 1);
+    const int grid = (int)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+    if (c->p.lossy) level_shift_fwd_kernel<float><<<grid, 256, 0, s>>>(d_in, (float *)d_out, n4, off);
+    else level_shift_fwd_kernel<int32_t><<<grid, 256, 0, s>>>(d_in, (int32_t *)d_out, n4, off);
+    HIP_TRY(hipGetLastError());
+    return PICSONG_OK;
+}
+
+int picsong_level_shift_inv(picsong_ctx *c, void *d_data, void *stream)
+{
+    if (!c || !d_data) return fail(PICSONG_ERR_ARG, "level_shift_inv: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int off = 1 << (c->p.bit_depth - 1);
+    const int grid = (int)((c->P + 255) / 256 > 8192 ? 8192 : (c->P + 255) / 256);
+    if (c->p.lossy) level_shift_inv_f32_kernel<<<grid, 256, 0, s>>>((float *)d_data, c->P, (float)off);
+    else level_shift_inv_i32_kernel<<<grid, 256, 0, s>>>((int32_t *)d_data, c->P, off);
+    HIP_TRY(hipGetLastError());
+    return PICSONG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// DWT
+// ---------------------------------------------------------------------------------------------
+static int dwt_forward_impl(picsong_ctx *c, const void *d_in, bool u8in, void *d_out, hipStream_t s)
+{
+    for (const FwdLaunch &f : plan_dwt_forward(d_in, u8in, d_out, c->aw, c->ah, c->p.wl, c->p.qs)) {
+        dim3 grid(f.gx, f.gy);
+        if (c->p.lossy) {
+            if (f.u8) dwt_fwd_kernel<float, true, true><<<grid, 256, 0, s>>>(f.a);
+            else dwt_fwd_kernel<float, true, false><<<grid, 256, 0, s>>>(f.a);
+        } else {
+            if (f.u8) dwt_fwd_kernel<int, false, true><<<grid, 256, 0, s>>>(f.a);
+            else dwt_fwd_kernel<int, false, false><<<grid, 256, 0, s>>>(f.a);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    return PICSONG_OK;
+}
+
+int picsong_dwt_forward(picsong_ctx *c, const void *d_in, void *d_out, void *stream)
+{
+    if (!c || !d_in || !d_out) return fail(PICSONG_ERR_ARG, "dwt_forward: null argument");
+    return dwt_forward_impl(c, d_in, false, d_out, (hipStream_t)stream);
+}
+
+int picsong_dwt_forward_u8(picsong_ctx *c, const uint8_t *d_in, void *d_out, void *stream)
+{
+    if (!c || !d_in || !d_out) return fail(PICSONG_ERR_ARG, "dwt_forward_u8: null argument");
+    return dwt_forward_impl(c, d_in, true, d_out, (hipStream_t)stream);
+}
+
+int picsong_dwt_inverse(picsong_ctx *c, const int32_t *d_in, void *d_out, void *stream)
+{
+    if (!c || !d_in || !d_out) return fail(PICSONG_ERR_ARG, "dwt_inverse: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    for (const InvLaunch &f : plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs)) {
+        dim3 grid(f.gx, f.gy);
+        if (c->p.lossy) dwt_inv_kernel<float, true><<<grid, 256, 0, s>>>(f.a);
+        else dwt_inv_kernel<int, false><<<grid, 256, 0, s>>>(f.a);
+        HIP_TRY(hipGetLastError());
+    }
+    return PICSONG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BPC
+// ---------------------------------------------------------------------------------------------
+static int bpc_args(picsong_ctx *c, BpcArgs &a)
+{
+    if (!c->has_lut) return fail(PICSONG_ERR_ARG, "no LUT loaded: call picsong_ctx_set_lut first");
+    memset(&a, 0, sizeof a);
+    a.AW = c->aw; a.AH = c->ah; a.wl = c->p.wl; a.nCB = c->ncb; a.ncx = c->aw / PICSONG_CB;
+    a.lut = c->d_lut;
+    a.g.nBp = c->li.n_bitplanes; a.g.nSub = c->li.n_subbands; a.g.cRef = c->li.ctx_ref;
+    a.g.cSign = c->li.ctx_sign; a.g.cSig = c->li.ctx_sig; a.g.prec = c->li.precision;
+    a.g.nRef = c->li.n_ref; a.g.nSig = c->li.n_sig; a.g.nSign = c->li.n_sign;
+    a.range_flag = c->d_flag;
+    return PICSONG_OK;
+}
+
+static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_staging, int32_t *d_sizes,
+                           bool memset_staging, hipStream_t s)
+{
+    BpcArgs a;
+    int rc = bpc_args(c, a);
+    if (rc) return rc;
+    a.coeffs_in = d_coeffs; a.is_float = c->p.lossy ? 1 : 0;
+    a.staging = d_staging; a.sizes = d_sizes;
+    // BPCEngine::deviceMemoryAllocator BPCEngine.cu:2429-2441.  Slots beyond a codeblock's length
+    // are never read downstream, so the fused frame path skips this 4*AW*AH-byte fill.
+    if (memset_staging) HIP_TRY(hipMemsetAsync(d_staging, 0xFF, c->P * sizeof(int32_t), s));
+    bpc_kernel<false><<<(unsigned)((c->ncb + 1) / 2), 64, 0, s>>>(a);
+    HIP_TRY(hipGetLastError());
+    return PICSONG_OK;
+}
+
+int picsong_bpc_encode(picsong_ctx *c, const void *d_coeffs, int32_t *d_staging, int32_t *d_sizes, void *stream)
+{
+    if (!c || !d_coeffs || !d_staging || !d_sizes) return fail(PICSONG_ERR_ARG, "bpc_encode: null argument");
+    return bpc_encode_impl(c, d_coeffs, d_staging, d_sizes, true, (hipStream_t)stream);
+}
+
+int picsong_bpc_decode(picsong_ctx *c, const int32_t *d_staging, const int32_t *d_sizes, int32_t *d_coeffs,
+                       void *stream)
+{
+    if (!c || !d_coeffs || !d_staging || !d_sizes) return fail(PICSONG_ERR_ARG, "bpc_decode: null argument");
+    BpcArgs a;
+    int rc = bpc_args(c, a);
+    if (rc) return rc;
+    a.coeffs_out = d_coeffs;
+    a.staging = const_cast<int32_t *>(d_staging);
+    a.sizes = const_cast<int32_t *>(d_sizes);
+    bpc_kernel<true><<<(unsigned)((c->ncb + 1) / 2), 64, 0, (hipStream_t)stream>>>(a);
+    HIP_TRY(hipGetLastError());
+    return PICSONG_OK;
+}
+
+int picsong_range_flag(picsong_ctx *c, void *stream, int *h_flag)
+{
+    if (!c || !h_flag) return fail(PICSONG_ERR_ARG, "range_flag: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(&c->h_pinned[1], c->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *h_flag = c->h_pinned[1];
+    return PICSONG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BitStreamBuilder
+// ---------------------------------------------------------------------------------------------
+int picsong_last_total(picsong_ctx *c, void *stream, int *h_total)
+{
+    if (!c || !h_total) return fail(PICSONG_ERR_ARG, "last_total: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(&c->h_pinned[0], c->d_total, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *h_total = c->h_pinned[0];
+    return PICSONG_OK;
+}
+
+int picsong_bitstream_pack(picsong_ctx *c, const int32_t *d_staging, const int32_t *d_sizes,
+                           const uint16_t *h_header, uint16_t *d_stream, int *h_total, void *stream)
+{
+    if (!c || !d_staging || !d_sizes || !d_stream) return fail(PICSONG_ERR_ARG, "bitstream_pack: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    HeaderArg h;
+    memset(&h, 0, sizeof h);
+    if (h_header) { memcpy(h.h, h_header, sizeof h.h); h.has = 1; }
+    scan_sizes_kernel<<<1, 1024, 0, s>>>(d_sizes, c->ncb, c->d_offsets, c->d_total);
+    HIP_TRY(hipGetLastError());
+    pack_kernel<<<(unsigned)c->ncb, 256, 0, s>>>(d_staging, d_sizes, c->d_offsets, c->d_total, c->ncb, h, d_stream);
+    HIP_TRY(hipGetLastError());
+    if (h_total) return picsong_last_total(c, stream, h_total);
+    return PICSONG_OK;
+}
+
+int picsong_bitstream_unpack(picsong_ctx *c, const uint16_t *d_stream, int32_t *d_staging, int32_t *d_sizes,
+                             void *stream)
+{
+    if (!c || !d_staging || !d_sizes || !d_stream) return fail(PICSONG_ERR_ARG, "bitstream_unpack: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    // BSEngine::deviceMemoryAllocator BitStreamBuilder.cu:281-284
+    HIP_TRY(hipMemsetAsync(d_staging, 0xFF, c->P * sizeof(int32_t), s));
+    read_sizes_kernel<<<(unsigned)((c->ncb + 255) / 256), 256, 0, s>>>(d_stream, c->ncb, d_sizes);
+    HIP_TRY(hipGetLastError());
+    scan_sizes_kernel<<<1, 1024, 0, s>>>(d_sizes, c->ncb, c->d_offsets, c->d_total);
+    HIP_TRY(hipGetLastError());
+    unpack_kernel<<<(unsigned)c->ncb, 256, 0, s>>>(d_stream, d_sizes, c->d_offsets, c->ncb, d_staging);
+    HIP_TRY(hipGetLastError());
+    return PICSONG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// whole frame
+// ---------------------------------------------------------------------------------------------
+static int ensure_workspace(picsong_ctx *c, bool decode)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->d_coef) HIP_TRY(hipMalloc(&c->d_coef, (c->P + c->extra) * 4));
+    if (!c->d_staging) HIP_TRY(hipMalloc(&c->d_staging, c->P * sizeof(int32_t)));
+    if (!c->d_sizes) HIP_TRY(hipMalloc(&c->d_sizes, (size_t)c->ncb * sizeof(int32_t)));
+    if (decode && !c->d_coef_i) HIP_TRY(hipMalloc(&c->d_coef_i, c->P * sizeof(int32_t)));
+    return PICSONG_OK;
+}
+
+int picsong_profile_begin(picsong_ctx *c, int capacity)
+{
+    if (!c || capacity < 0) return fail(PICSONG_ERR_ARG, "profile_begin: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->prof_ev) c->prof_ev = new std::vector<hipEvent_t>();
+    while ((int)c->prof_ev->size() < 4 * capacity) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        c->prof_ev->push_back(e);
+    }
+    c->prof_cap = capacity;
+    c->prof_n = 0;
+    return PICSONG_OK;
+}
+
+int picsong_profile_read(picsong_ctx *c, int *n_frames, float *ms, int cap)
+{
+    if (!c || !n_frames || !ms) return fail(PICSONG_ERR_ARG, "profile_read: null argument");
+    const int n = c->prof_n < cap ? c->prof_n : cap;
+    for (int f = 0; f < n; f++) {
+        hipEvent_t *e = c->prof_ev->data() + 4 * f;
+        HIP_TRY(hipEventSynchronize(e[3]));
+        for (int k = 0; k < 3; k++) HIP_TRY(hipEventElapsedTime(&ms[3 * f + k], e[k], e[k + 1]));
+    }
+    *n_frames = n;
+    return PICSONG_OK;
+}
+
+int picsong_encode_frame(picsong_ctx *c, const uint8_t *d_frame, int iter, uint16_t *d_stream, void *stream)
+{
+    if (!c || !d_frame || !d_stream) return fail(PICSONG_ERR_ARG, "encode_frame: null argument");
+    int rc = ensure_workspace(c, false);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t *ev = nullptr;
+    if (c->prof_cap > 0 && c->prof_n < c->prof_cap) ev = c->prof_ev->data() + 4 * (c->prof_n++);
+    if (ev) HIP_TRY(hipEventRecord(ev[0], s));
+    if ((rc = dwt_forward_impl(c, d_frame, true, c->d_coef, s))) return rc;
+    if (ev) HIP_TRY(hipEventRecord(ev[1], s));
+    if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, s))) return rc;
+    if (ev) HIP_TRY(hipEventRecord(ev[2], s));
+    uint16_t hdr[PICSONG_HDR_SHORTS];
+    if (iter == 0) picsong_header_pack(&c->p, hdr);
+    rc = picsong_bitstream_pack(c, c->d_staging, c->d_sizes, iter == 0 ? hdr : nullptr, d_stream, nullptr, stream);
+    if (ev) HIP_TRY(hipEventRecord(ev[3], s));
+    return rc;
+}
+
+int picsong_decode_frame(picsong_ctx *c, const uint16_t *d_stream, uint8_t *d_frame_out, void *stream)
+{
+    if (!c || !d_frame_out || !d_stream) return fail(PICSONG_ERR_ARG, "decode_frame: null argument");
+    int rc = ensure_workspace(c, true);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = picsong_bitstream_unpack(c, d_stream, c->d_staging, c->d_sizes, stream))) return rc;
+    if ((rc = picsong_bpc_decode(c, c->d_staging, c->d_sizes, c->d_coef_i, stream))) return rc;
+    if ((rc = picsong_dwt_inverse(c, c->d_coef_i, c->d_coef, stream))) return rc;
+    void *img = (char *)c->d_coef + c->extra * 4;
+    if ((rc = picsong_level_shift_inv(c, img, stream))) return rc;
+    const int grid = (int)((c->P + 255) / 256 > 8192 ? 8192 : (c->P + 255) / 256);
+    if (c->p.lossy) to_u8_kernel<float><<<grid, 256, 0, s>>>((const float *)img, d_frame_out, c->P);
+    else to_u8_kernel<int32_t><<<grid, 256, 0, s>>>((const int32_t *)img, d_frame_out, c->P);
+    HIP_TRY(hipGetLastError());
+    return PICSONG_OK;
+}
+
+int picsong_pad_frame_host(const uint8_t *in, int w, int h, uint8_t *out, int aw, int ah)
+{
+    if (!in || !out || w <= 0 || h <= 0 || aw < w || ah < h) return fail(PICSONG_ERR_ARG, "pad_frame: bad argument");
+    for (int y = 0; y < h; y++) {
+        memcpy(out + (size_t)y * aw, in + (size_t)y * w, (size_t)w);
+        for (int j = 0; j < aw - w; j++) out[(size_t)y * aw + w + j] = in[(size_t)y * w + (w - 1 - j)];
+    }
+    for (int r = 0; r < ah - h; r++) memcpy(out + (size_t)(h + r) * aw, out + (size_t)(h - 1 - r) * aw, (size_t)aw);
+    return PICSONG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+/*
+ * picsong_hip.h -- C ABI of the MI355X-native PICSONG hot path
+ *                  (level shift -> DWT 5/3 | 9/7 -> BPC-PaCo -> BitStreamBuilder, and inverse).
+ *
+ * The reference (13Karl/CUDA-Image-and-Video-codec) exposes no FFI; the seam this library replaces
+ * is the C++ facade layer its engines call with device pointers and a stream.
+ * Each entry point cites the reference interface it stands in for (paths relative to
+ * CUDA_ImCod/).  Conventions:
+ *   - plain C linkage, POD arguments, caller-owned device memory, no torch / C++ types;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - every function returns PICSONG_OK (0) or a negative error code; nothing calls exit()
+ *     (the reference prints and exits, SupportFunctions/AuxiliarFunctions.cpp:39-56);
+ *     picsong_last_error() returns a thread-local message for the last failure;
+ *   - stage functions are asynchronous on `stream` unless their name ends in _sync or they
+ *     return a host value (documented per function);
+ *   - a context is thread-safe for concurrent use only with distinct workspaces/streams, as the
+ *     reference's facades are (one set of scratch buffers per worker, CodingEngine.cu:157-197).
+ */
+#ifndef PICSONG_HIP_H
+#define PICSONG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PICSONG_OK 0
+#define PICSONG_ERR_ARG (-1)        /* invalid argument / validity limit of SURVEY A.9 */
+#define PICSONG_ERR_HIP (-2)        /* a HIP runtime call failed */
+#define PICSONG_ERR_IO (-3)         /* LUT folder / file problem */
+#define PICSONG_ERR_NOMEM (-4)
+#define PICSONG_ERR_RANGE (-5)      /* a codeblock exceeded the supported magnitude range */
+#define PICSONG_ERR_NODEVICE (-6)   /* no usable GPU: the product has no CPU fallback */
+
+#define PICSONG_CB 64               /* codeblock edge, BPC/BPCEngine.cuh:29-36 */
+#define PICSONG_CB_WORDS 4096       /* staging ints per codeblock */
+#define PICSONG_HDR_SHORTS 9        /* global header, BitStreamBuilder.cpp:54-93 */
+
+/* Coding parameters == the flag globals of Launcher.cu:8-29 that reach the hot path. */
+typedef struct picsong_params {
+    int width, height;      /* -xSize / -ySize (unpadded) */
+    int wl;                 /* -wl, 1..7 (header limit) */
+    int cp;                 /* -cp, only 2 is implemented */
+    int lossy;              /* -type: 0 = 5/3 reversible, 1 = 9/7 + quantisation */
+    float qs;               /* -qs */
+    float k;                /* -k, only 0 is implemented */
+    int cb_width, cb_height;/* -cbWidth / -cbHeight: header-only */
+    int bit_depth;          /* -bps (8) */
+    int frames;             /* -frames (header only) */
+    int components;         /* 1 */
+} picsong_params;
+
+/* LUT geometry == header.txt (Engines/Engine.cu:190-210) + section sizes
+ * (IO/IOManager.ipp:431-433). */
+typedef struct picsong_lut_info {
+    int n_bitplanes, n_subbands, ctx_ref, ctx_sign, ctx_sig, precision, n_files, n_bp_files;
+    int n_ref, n_sig, n_sign;       /* section sizes in ints; table = [ref | sig | sign] */
+} picsong_lut_info;
+
+typedef struct picsong_ctx picsong_ctx;
+
+const char *picsong_last_error(void);
+const char *picsong_version(void);
+
+/* ---- geometry (SupportFunctions/AuxiliarFunctions.cpp:22-26, CodingEngine.cu:170-177) ---- */
+int    picsong_pad_dim(int v);
+size_t picsong_dwt_extra(int aw, int ah, int wl);
+/* upper bound of one frame's codestream in shorts: 9 + 2 nCB + AW*AH + 1 */
+size_t picsong_max_stream_shorts(int aw, int ah);
+
+/* ---- header (BitStreamBuilder::setExtraInformation BitStreamBuilder.cpp:35-94 <->
+ *      DecodingEngine::getExtraInformation Engines/DecodingEngine.cu:567-585), host only ---- */
+int picsong_header_pack(const picsong_params *p, uint16_t out[PICSONG_HDR_SHORTS]);
+int picsong_header_unpack(const uint16_t in[PICSONG_HDR_SHORTS], picsong_params *p);
+
+/* ---- LUT text parser (IOManager::loadLUTHeaders IO/IOManager.ipp:363-386 +
+ *      IOManager::loadLUTUpgraded :404-612), host only.  component 1/2/3 = R/G/B files,
+ *      0 = un-suffixed.  `fill` = value of entries the reference never writes (de-facto 0,
+ *      SURVEY fact 5).  table may be NULL to query info->n_* first. ---- */
+int picsong_lut_load(const char *folder, int component, int wl, int fill,
+                     picsong_lut_info *info, int32_t *table, size_t table_capacity);
+
+/* ---- context: replaces `new DWT<T,Y>(...)` / `new BPCCuda<T>(...)` + Engine::initLUT's
+ *      cudaMalloc/cudaMemcpy of the table (Engines/Engine.cu:111-136).  Owns only the LUT copy
+ *      and a small internal workspace (scan scratch, flags, the frame pipeline's buffers when
+ *      picsong_encode_frame/picsong_decode_frame are used). ---- */
+int  picsong_ctx_create(const picsong_params *p, int device, picsong_ctx **out);
+void picsong_ctx_destroy(picsong_ctx *ctx);
+int  picsong_ctx_set_lut(picsong_ctx *ctx, const picsong_lut_info *info, const int32_t *host_table);
+int  picsong_ctx_padded_dims(const picsong_ctx *ctx, int *aw, int *ah, int *n_codeblocks);
+
+/* ---- level shift: offsetImage<T> Engines/CodingEngine.cu:581-588 and
+ *      removeOffsetAndApplyMaxMin(/Lossy) Engines/DecodingEngine.cu:706-729.
+ *      T = int32 (lossless ctx) or float (lossy ctx); n = AW*AH. ---- */
+int picsong_level_shift_fwd(picsong_ctx *ctx, const uint8_t *d_in, void *d_out, void *stream);
+int picsong_level_shift_inv(picsong_ctx *ctx, void *d_data, void *stream);
+
+/* ---- DWT: DWT<T,Y>::DWTEncode(T* in, T* out, stream) / DWTDecode(int* in, T* out, stream)
+ *      (DWT/DWTGenerator.hpp:27-29, DWT/DWTGenerator.cu:1268-1424).  Same buffer contract:
+ *      d_out has AW*AH + picsong_dwt_extra() elements; forward leaves the Mallat-layout
+ *      coefficients (row stride AW) in d_out[0 .. AW*AH); inverse leaves the image at
+ *      d_out + picsong_dwt_extra().  Quantisation / de-quantisation fused for lossy. ---- */
+int picsong_dwt_forward(picsong_ctx *ctx, const void *d_in, void *d_out, void *stream);
+int picsong_dwt_inverse(picsong_ctx *ctx, const int32_t *d_in, void *d_out, void *stream);
+/* level-0 u8 ingest with the level shift fused (the reference's deprecated DWTEncodeChar,
+ * DWT/DWTGenerator.cu:1141-1261, is the model); results identical to shift + forward. */
+int picsong_dwt_forward_u8(picsong_ctx *ctx, const uint8_t *d_in, void *d_out, void *stream);
+
+/* ---- BPC: BPCEngine<T>::kernelLauncher(CODE|DECODE) BPC/BPCEngine.cu:2307-2424 preceded by
+ *      deviceMemoryAllocator's 0xFF memset (:2429-2441).  d_coeffs: Mallat T[AW*AH];
+ *      d_staging: int32[AW*AH] (4096 per codeblock: [0] = MSB, [1..len) codewords);
+ *      d_sizes: int32[nCB]. ---- */
+int picsong_bpc_encode(picsong_ctx *ctx, const void *d_coeffs, int32_t *d_staging,
+                       int32_t *d_sizes, void *stream);
+int picsong_bpc_decode(picsong_ctx *ctx, const int32_t *d_staging, const int32_t *d_sizes,
+                       int32_t *d_coeffs, void *stream);
+
+/* ---- BitStreamBuilder: createBitStream BitStreamBuilder.cpp:100-114 (CUB InclusiveSum +
+ *      index LUT + buildBitStreamLUTBS BitStreamBuilder.cu:106-137,290-323) and createCodeStream
+ *      BitStreamBuilder.cpp:134-153.  h_header NULL == iter != 0 (header shorts stay 0xFFFF).
+ *      pack: *h_total (host) receives the stream length in shorts after an internal stream
+ *      synchronisation, exactly like HTotalBSSize[0]; pass NULL to stay asynchronous and read
+ *      the length later with picsong_last_total(). ---- */
+int picsong_bitstream_pack(picsong_ctx *ctx, const int32_t *d_staging, const int32_t *d_sizes,
+                           const uint16_t *h_header, uint16_t *d_stream, int *h_total,
+                           void *stream);
+int picsong_bitstream_unpack(picsong_ctx *ctx, const uint16_t *d_stream, int32_t *d_staging,
+                             int32_t *d_sizes, void *stream);
+/* synchronises `stream` and returns the total (shorts) of the most recent pack on this ctx */
+int picsong_last_total(picsong_ctx *ctx, void *stream, int *h_total);
+
+/* ---- whole frame: the grey call sequences of CodingEngine::runImage/runVideo
+ *      (Engines/CodingEngine.cu:634-674,819-872) and DecodingEngine::runImage
+ *      (Engines/DecodingEngine.cu:770-794).  d_frame: padded u8[AW*AH] (caller pads as
+ *      IOManager::loadFrameCAdaptedSizes does, or uses picsong_pad_frame_host).  iter == 0
+ *      writes the populated header.  Asynchronous; length via picsong_last_total(). ---- */
+int picsong_encode_frame(picsong_ctx *ctx, const uint8_t *d_frame, int iter, uint16_t *d_stream,
+                         void *stream);
+int picsong_decode_frame(picsong_ctx *ctx, const uint16_t *d_stream, uint8_t *d_frame_out,
+                         void *stream);
+/* host helper: IOManager::loadFrameCAdaptedSizes' mirror padding (IO/IOManager.ipp:72-112) */
+int picsong_pad_frame_host(const uint8_t *in, int w, int h, uint8_t *out, int aw, int ah);
+
+/* ---- measurement: per-stage durations of picsong_encode_frame, taken with HIP events recorded
+ *      on the launch stream (the reference accumulates host chrono time around its BPC kernel,
+ *      BPC/BPCEngine.cu:2318-2422, "BPC acum time").  profile_begin(capacity) arms a ring of event
+ *      sets; every later encode_frame records into the next set without synchronising;
+ *      profile_read synchronises the last set and returns, per recorded frame, 3 floats:
+ *      {dwt_ms (all levels), bpc_ms (bpc_kernel), pack_ms (scan + pack)}.  capacity 0 disarms. ---- */
+int picsong_profile_begin(picsong_ctx *ctx, int capacity);
+int picsong_profile_read(picsong_ctx *ctx, int *n_frames, float *ms, int ms_capacity_frames);
+
+/* ---- diagnostics: nonzero if any codeblock of the last bpc call on ctx had MSB > 15 (outside
+ *      the LUT's 15 bit-planes); synchronises `stream`. ---- */
+int picsong_range_flag(picsong_ctx *ctx, void *stream, int *h_flag);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

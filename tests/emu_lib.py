@@ -1,0 +1,104 @@
+"""ctypes binding of the CPU wave emulator build of the product kernels (tests/hipemu).
+TEST INFRASTRUCTURE ONLY -- lets `-m "not gpu"` tests run the real kernel sources on the CPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "hipemu")
+SO_PATH = os.path.join(EMU_DIR, "_build", "libpicsong_emu.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-C", EMU_DIR, "-s"])
+        _lib = C.CDLL(SO_PATH)
+        _lib.emu_pack.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _geo(lut):
+    g = lut.geometry()
+    return np.array([g["n_bitplanes"], g["n_subbands"], g["ctx_ref"], g["ctx_sign"], g["ctx_sig"],
+                     g["precision"], g["n_ref"], g["n_sig"], g["n_sign"]], np.int32)
+
+
+def dwt_forward(x, wl, lossy, qs=1.0, extra=0):
+    """x: (AH, AW) uint8 (fused level shift) / int32 / float32."""
+    AH, AW = x.shape
+    x = np.ascontiguousarray(x)
+    out = np.zeros(AW * AH + extra, np.float32 if lossy else np.int32)
+    lib().emu_dwt_forward(_p(x), int(x.dtype == np.uint8), _p(out), AW, AH, wl, int(lossy),
+                          C.c_float(qs))
+    return out
+
+
+def dwt_inverse(coef, wl, lossy, qs=1.0, extra=0):
+    AH, AW = coef.shape
+    coef = np.ascontiguousarray(coef, np.int32)
+    out = np.zeros(AW * AH + extra, np.float32 if lossy else np.int32)
+    lib().emu_dwt_inverse(_p(coef), _p(out), AW, AH, wl, int(lossy), C.c_float(qs))
+    return out
+
+
+def level_shift_inv(x):
+    x = np.ascontiguousarray(x).copy()
+    lib().emu_level_shift_inv(_p(x), C.c_size_t(x.size), int(x.dtype == np.float32))
+    return x
+
+
+def level_shift_fwd(u8, lossy):
+    u8 = np.ascontiguousarray(u8)
+    out = np.empty(u8.shape, np.float32 if lossy else np.int32)
+    lib().emu_level_shift_fwd(_p(u8), _p(out), C.c_size_t(u8.size), int(lossy))
+    return out
+
+
+def bpc_encode(coef, wl, lut):
+    AH, AW = coef.shape
+    coef = np.ascontiguousarray(coef)
+    staging = np.empty(AW * AH, np.int32)
+    sizes = np.empty((AW // 64) * (AH // 64), np.int32)
+    flag = np.zeros(1, np.int32)
+    tab = np.ascontiguousarray(lut.table, np.int32)
+    geo = _geo(lut)
+    lib().emu_bpc_encode(_p(coef), int(coef.dtype == np.float32), AW, AH, wl, _p(tab), _p(geo),
+                         _p(staging), _p(sizes), _p(flag))
+    return staging, sizes, int(flag[0])
+
+
+def bpc_decode(staging, sizes, AW, AH, wl, lut):
+    staging = np.ascontiguousarray(staging, np.int32)
+    sizes = np.ascontiguousarray(sizes, np.int32)
+    coef = np.empty((AH, AW), np.int32)
+    flag = np.zeros(1, np.int32)
+    tab = np.ascontiguousarray(lut.table, np.int32)
+    geo = _geo(lut)
+    lib().emu_bpc_decode(_p(staging), _p(sizes), AW, AH, wl, _p(tab), _p(geo), _p(coef), _p(flag))
+    return coef
+
+
+def pack(staging, sizes, header=None):
+    staging = np.ascontiguousarray(staging, np.int32)
+    sizes = np.ascontiguousarray(sizes, np.int32)
+    n = sizes.size
+    out = np.zeros(9 + 2 * n + int(sizes.sum()) + 1, np.uint16)
+    hp = _p(np.ascontiguousarray(header, np.uint16)) if header is not None else None
+    total = lib().emu_pack(_p(staging), _p(sizes), n, hp, _p(out))
+    return out[:total].copy()
+
+
+def unpack(stream, n_cb):
+    stream = np.ascontiguousarray(stream, np.uint16)
+    staging = np.empty(n_cb * 4096, np.int32)
+    sizes = np.empty(n_cb, np.int32)
+    lib().emu_unpack(_p(stream), n_cb, _p(staging), _p(sizes))
+    return staging, sizes

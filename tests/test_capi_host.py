@@ -1,0 +1,93 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol include/picsong_hip.h
+declares, its host-side functions (header, LUT parser, padding, geometry) agree with the oracle,
+and device entry points fail loudly (no CPU fallback) when no GPU is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import picsong_amd as pa
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = pa.load()
+    hdr = open(os.path.join(ROOT, "include", "picsong_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(picsong_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/picsong_hip.h but not exported"
+    assert sorted(pa.EXPORTS) == declared
+
+
+def test_geometry_helpers(oracle):
+    for v in (1, 63, 64, 65, 2160, 4320, 7680):
+        assert pa.pad_dim(v) == oracle.pad_dim(v)
+    for aw, ah, wl in ((512, 512, 3), (3840, 2176, 5), (7680, 4352, 6), (16384, 16384, 5)):
+        assert pa.dwt_extra(aw, ah, wl) == oracle.dwt_extra(aw, ah, wl)
+    assert pa.load().picsong_max_stream_shorts(128, 64) == 9 + 2 * 2 + 128 * 64 + 1
+
+
+def test_header_matches_oracle(oracle):
+    p = pa.make_params(3840, 2160, wl=5, lossy=True, qs=0.5, frames=256)
+    s = pa.header_pack(p)
+    ref = oracle.header_pack(n_samples=3840 * 2160, cp=2, cb_height=18, cb_width=64, wl=5, bit_depth=8,
+                             lossy=1, qs_1e4=5000, components=1, is_rgb=0, height=2160, endianess=0,
+                             bps=8, is_signed=0, frames=256, k_1e3=0)
+    assert np.array_equal(s, ref)
+    q = pa.header_unpack(s)
+    assert (q.width, q.height, q.wl, q.lossy, q.cp, q.frames) == (3840, 2160, 5, 1, 2, 256)
+    assert abs(q.qs - 0.5) < 1e-6 and q.cb_width == 64 and q.cb_height == 18
+
+
+@pytest.mark.parametrize("folder,wl", [("n1_lossless", 3), ("n1_lossless", 5), ("n1_lossy", 6)])
+def test_lut_parser_matches_oracle(oracle, folder, wl):
+    path = os.path.join(oracle.LUT_DIR, folder)
+    info, table = pa.lut_load(path, wl, component=1, fill=0)
+    ref = oracle.Lut(path, wl, 1, 0)
+    assert (info.n_ref, info.n_sig, info.n_sign) == (ref.c.n_ref, ref.c.n_sig, ref.c.n_sign)
+    assert (info.ctx_sig, info.ctx_sign, info.ctx_ref, info.precision) == (9, 4, 1, 7)
+    assert np.array_equal(table, ref.table)
+
+
+def test_lut_missing_folder_reports_error():
+    info = pa.LutInfo()
+    rc = pa.load().picsong_lut_load(b"/nonexistent/", 1, 5, 0, C.byref(info), None, 0)
+    assert rc == -3 and b"header.txt" in pa.load().picsong_last_error()
+
+
+def test_pad_frame_host_matches_oracle(oracle):
+    img = oracle.gen_frame(100, 70)
+    out = np.empty((128, 128), np.uint8)
+    rc = pa.load().picsong_pad_frame_host(img.ctypes.data_as(C.c_void_p), 100, 70,
+                                          out.ctypes.data_as(C.c_void_p), 128, 128)
+    assert rc == 0 and np.array_equal(out, oracle.pad_frame(img))
+
+
+def test_invalid_parameters_are_rejected_without_exit():
+    L = pa.load()
+    h = C.c_void_p()
+    for kw in (dict(wl=0), dict(wl=8), dict(width=0)):
+        p = pa.make_params(kw.get("width", 512), 512, wl=kw.get("wl", 3))
+        assert L.picsong_ctx_create(C.byref(p), 0, C.byref(h)) == -1
+    p = pa.make_params(512, 512, wl=3)
+    p.cp = 3
+    assert L.picsong_ctx_create(C.byref(p), 0, C.byref(h)) == -1
+    p = pa.make_params(64, 64, wl=5)
+    assert L.picsong_ctx_create(C.byref(p), 0, C.byref(h)) == -1        # too small for 5 levels
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = pa.load()
+    h = C.c_void_p()
+    p = pa.make_params(512, 512, wl=3)
+    assert L.picsong_ctx_create(C.byref(p), 0, C.byref(h)) == -6       # PICSONG_ERR_NODEVICE
+    assert b"no CPU path" in L.picsong_last_error()
+    with pytest.raises(RuntimeError):
+        pa.Codec(512, 512, wl=3)

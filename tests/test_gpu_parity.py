@@ -1,0 +1,216 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle, bit-exact for integer work and
+for the fp32 9/7 path (explicit fmaf on both sides, contraction off), plus size-independent
+properties at BASELINE.json's full sizes."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    if not t.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU: the HIP path has no CPU fallback")
+    return t
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import picsong_amd
+    picsong_amd.load()          # raises if the extension is missing
+    return picsong_amd
+
+
+def _lutdir(oracle, lossy):
+    return os.path.join(oracle.LUT_DIR, "n1_lossy" if lossy else "n1_lossless")
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("W,H,wl,lossy,qs", [
+    (512, 512, 3, False, 1.0),        # BASELINE config 1 geometry
+    (320, 192, 3, False, 1.0),
+    (1000, 300, 4, False, 1.0),       # ragged -> padded 1024x320
+    (512, 512, 3, True, 0.5),
+    (832, 192, 4, True, 1.0),         # (AW >> 3)/2 odd: scalar store paths
+])
+def test_stage_by_stage_parity(oracle, pa, torch, W, H, wl, lossy, qs):
+    img = oracle.pad_frame(oracle.gen_frame(W, H, 1))
+    AH, AW = img.shape
+    lut = oracle.lut_for(lossy, wl)
+    c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=_lutdir(oracle, lossy))
+    assert (c.aw, c.ah) == (AW, AH)
+    d_img = _dev(torch, img)
+    # level shift
+    x_ref = oracle.level_shift_fwd(img, lossy)
+    x = c.level_shift_fwd(d_img)
+    assert np.array_equal(x.cpu().numpy().reshape(AH, AW), x_ref)
+    # DWT forward (separate shift and fused u8 ingest)
+    f_ref = oracle.dwt_forward(x_ref, wl, qs)
+    P = AW * AH
+    view = np.uint32 if lossy else np.int32
+    for src in (x, d_img):
+        f = c.dwt_forward(src).cpu().numpy()
+        assert np.array_equal(f[:P].view(view), f_ref[:P].view(view))
+    coef_ref = f_ref[:P].reshape(AH, AW)
+    # BPC encode: staging + sizes
+    st_ref, sz_ref = oracle.bpc_encode(coef_ref, wl, lut)
+    st, sz = c.bpc_encode(_dev(torch, f_ref[:P]))
+    assert c.range_flag() == 0
+    assert np.array_equal(sz.cpu().numpy(), sz_ref)
+    assert np.array_equal(st.cpu().numpy(), st_ref)
+    # pack
+    hdr = pa.header_pack(c.params)
+    s_ref = oracle.bitstream_pack(st_ref, sz_ref, hdr)
+    s = c.bitstream_pack(st, sz, hdr).cpu().numpy().view(np.uint16)
+    assert np.array_equal(s, s_ref)
+    s2 = c.bitstream_pack(st, sz, None).cpu().numpy().view(np.uint16)
+    assert (s2[:9] == 0xFFFF).all() and np.array_equal(s2[9:], s_ref[9:])
+    # unpack
+    st2, sz2 = c.bitstream_unpack(_dev(torch, s_ref.view(np.int16)))
+    assert np.array_equal(sz2.cpu().numpy(), sz_ref) and np.array_equal(st2.cpu().numpy(), st_ref)
+    # BPC decode
+    ci = np.trunc(coef_ref).astype(np.int32)
+    dec = c.bpc_decode(st2, sz2).cpu().numpy().reshape(AH, AW)
+    assert np.array_equal(dec, ci)
+    # DWT inverse + inverse level shift
+    inv_ref, extra = oracle.dwt_inverse(ci, wl, lossy, qs)
+    inv = c.dwt_inverse(_dev(torch, ci))
+    assert np.array_equal(inv.cpu().numpy()[extra:].view(view), inv_ref[extra:].view(view))
+    pix_ref = oracle.level_shift_inv(inv_ref[extra:])
+    pix = c.level_shift_inv(inv[extra:].clone()).cpu().numpy()
+    assert np.array_equal(pix.view(view), pix_ref.view(view))
+    c.close()
+
+
+@pytest.mark.parametrize("W,H,wl,lossy,qs", [(512, 512, 3, False, 1.0), (700, 500, 4, False, 1.0),
+                                             (512, 512, 5, True, 0.5), (640, 384, 3, True, 1.0)])
+def test_frame_codestream_identical_to_oracle(oracle, pa, torch, W, H, wl, lossy, qs):
+    img = oracle.gen_frame(W, H, 2)
+    lut = oracle.lut_for(lossy, wl)
+    ref = oracle.encode_frame(img, wl, lossy, qs, lut, 0, 0)
+    c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=_lutdir(oracle, lossy))
+    got = c.encode_frame(_dev(torch, oracle.pad_frame(img)), 0).cpu().numpy().view(np.uint16)
+    assert np.array_equal(got, ref)
+    dec = c.decode_frame(_dev(torch, ref.view(np.int16))).cpu().numpy()[:H, :W]
+    assert np.array_equal(dec, oracle.decode_frame(ref, W, H, wl, lossy, qs, lut))
+    if not lossy:
+        assert np.array_equal(dec, img)
+    else:
+        mse = np.mean((dec.astype(np.float64) - img) ** 2)
+        assert 10 * np.log10(255 ** 2 / mse) > 40.0        # oracle and HIP are bit-identical; sanity
+    c.close()
+
+
+@pytest.mark.parametrize("name", ["zeros", "c255", "random", "impulse"])
+def test_edge_inputs_roundtrip_and_oracle_parity(oracle, pa, torch, name):
+    W, H, wl = 256, 192, 2
+    rng = np.random.default_rng(9)
+    img = {"zeros": np.zeros((H, W), np.uint8), "c255": np.full((H, W), 255, np.uint8),
+           "random": rng.integers(0, 256, (H, W), dtype=np.uint8), "impulse": np.zeros((H, W), np.uint8)}[name]
+    if name == "impulse":
+        img[100, 77] = 255
+    lut = oracle.lut_for(False, wl)
+    ref = oracle.encode_frame(img, wl, False, 1.0, lut)
+    c = pa.Codec(W, H, wl=wl, lut_folder=_lutdir(oracle, False))
+    got = c.encode_frame(_dev(torch, oracle.pad_frame(img))).cpu().numpy().view(np.uint16)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(c.decode_frame(_dev(torch, got.view(np.int16))).cpu().numpy()[:H, :W], img)
+    c.close()
+
+
+def test_raw_fallback_and_mixed_blocks(oracle, pa, torch):
+    rng = np.random.default_rng(4)
+    coef = np.zeros((64, 256), np.int32)
+    coef[:, 0:64] = rng.integers(-30000, 30000, (64, 64))
+    coef[:, 128:192] = rng.integers(-1, 2, (64, 64))
+    coef[:, 192:256] = (rng.standard_normal((64, 64)) * 600).astype(np.int32)
+    lut = oracle.lut_for(False, 1)
+    st_ref, sz_ref = oracle.bpc_encode(coef, 1, lut)
+    c = pa.Codec(256, 64, wl=1, lut_folder=_lutdir(oracle, False))
+    st, sz = c.bpc_encode(_dev(torch, coef))
+    assert np.array_equal(sz.cpu().numpy(), sz_ref) and np.array_equal(st.cpu().numpy(), st_ref)
+    assert np.array_equal(c.bpc_decode(st, sz).cpu().numpy().reshape(64, 256), coef)
+    c.close()
+
+
+def test_wl6_lut_holes_behaviour(oracle, pa, torch):
+    """BASELINE config 3 geometry in miniature (wl = 6, lossy): the three never-written LUT groups
+    (zero-filled) drive level-5 LH/HH and LL codeblocks into the raw fallback; HIP == oracle."""
+    W, H, wl, qs = 2048, 2048, 6, 0.5
+    img = oracle.gen_frame(W, H, 0)
+    lut = oracle.lut_for(True, wl)
+    ref = oracle.encode_frame(img, wl, True, qs, lut)
+    c = pa.Codec(W, H, wl=wl, lossy=True, qs=qs, lut_folder=_lutdir(oracle, True))
+    got = c.encode_frame(_dev(torch, img)).cpu().numpy().view(np.uint16)
+    assert np.array_equal(got, ref)
+    dec = c.decode_frame(_dev(torch, got.view(np.int16))).cpu().numpy()
+    assert np.array_equal(dec, oracle.decode_frame(ref, W, H, wl, True, qs, lut))
+    c.close()
+
+
+def test_missing_lut_is_an_error(pa, torch):
+    c = pa.Codec(256, 256, wl=2)
+    with pytest.raises(pa.PicsongError):
+        c.bpc_encode(torch.zeros(256 * 256, dtype=torch.int32, device="cuda"))
+    c.close()
+
+
+# ---- full BASELINE sizes: size-independent properties (the oracle would take minutes) ----------
+def _gen_device(torch, oracle, W, H, f=0):
+    return _dev(torch, oracle.pad_frame(oracle.gen_frame(W, H, f)))
+
+
+@pytest.mark.parametrize("W,H,wl", [(3840, 2160, 5), (7680, 4320, 5)])
+def test_full_size_lossless_roundtrip(oracle, pa, torch, W, H, wl):
+    """configs[1] (4K) and the headline 8K lossless workload: encode -> decode is the identity."""
+    c = pa.Codec(W, H, wl=wl, lut_folder=_lutdir(oracle, False))
+    frame = _gen_device(torch, oracle, W, H)
+    s = c.encode_frame(frame)
+    assert c.range_flag() == 0
+    sn = s.cpu().numpy().view(np.uint16)
+    ncb = c.ncb
+    assert sn[-1] == 0xFFFF
+    assert sn.size == 9 + 2 * ncb + int((sn[10:10 + 2 * ncb:2].astype(np.int64) - 1).sum()) + 1
+    hp = pa.header_unpack(sn[:9])
+    assert (hp.width, hp.height, hp.wl, hp.lossy) == (W, H, wl, 0)
+    dec = c.decode_frame(s)
+    assert torch.equal(dec, frame.view(c.ah, c.aw))
+    # determinism: a second encode of the same frame gives the same bytes
+    s2 = c.encode_frame(frame)
+    assert zlib.crc32(s2.cpu().numpy().tobytes()) == zlib.crc32(sn.tobytes())
+    c.close()
+
+
+def test_full_size_8k_lossy_psnr(oracle, pa, torch):
+    """configs[2]: 8K, 9/7, qs = 0.5, wl = 6.  Stated tolerance: PSNR >= 40 dB on the synthetic
+    frame (the oracle gives 49.6 dB at 512^2 with these settings; HIP is bit-identical to it)."""
+    W, H, wl, qs = 7680, 4320, 6, 0.5
+    c = pa.Codec(W, H, wl=wl, lossy=True, qs=qs, lut_folder=_lutdir(oracle, True))
+    frame = _gen_device(torch, oracle, W, H)
+    s = c.encode_frame(frame)
+    dec = c.decode_frame(s)
+    a = dec[:H, :W].float()
+    b = frame.view(c.ah, c.aw)[:H, :W].float()
+    mse = torch.mean((a - b) ** 2).item()
+    assert 10 * np.log10(255 ** 2 / mse) >= 40.0
+    assert s.numel() * 2 < W * H           # it compresses
+    c.close()
+
+
+def test_dwt_linearity_full_size(pa, torch, oracle):
+    """5/3 without rounding effects: DWT(2^k * x) of a smooth input scales exactly for the
+    constant image; and DWT of constant c has LL = c, all detail = 0 at 8K."""
+    W, H, wl = 7680, 4352, 5
+    c = pa.Codec(W, H, wl=wl)
+    x = torch.full((H * W,), 37, dtype=torch.int32, device="cuda")
+    f = c.dwt_forward(x)[:H * W].view(H, W)
+    assert (f[:H >> wl, :W >> wl] == 37).all()
+    assert (f[H >> wl:, :] == 0).all() and (f[:, W >> wl:] == 0).all()
+    c.close()
