@@ -172,8 +172,7 @@ def main():
     # ---- CPU baseline: the oracle (scalar C port), bounded sample, rank 0, N = 1 only
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        rows = args.cpu_sample_rows or H
-        rows = min(H, max(64 << wl >> 1, (rows // 64) * 64))
+        rows = H if args.cpu_sample_rows <= 0 else min(H, max(64 << (wl - 1), (args.cpu_sample_rows // 64) * 64))
         sample = np.ascontiguousarray(orc.gen_frame(W, H, 0)[:rows])
         lut = orc.lut_for(lossy, wl)
         t1 = time.perf_counter()

@@ -45,6 +45,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its wheel bundles a HIP runtime that it exposes process-wide; loading it before
+    # libpicsong_hip.so makes the library bind to that same runtime, so the device pointers and
+    # hipStream_t handles torch hands out are valid inside the library (one runtime per process).
+    import torch  # noqa: F401
     if not os.path.exists(SO_PATH):
         raise RuntimeError(f"{SO_PATH} not built: run __graft_entry__.build() (hipcc, gfx950). "
                            "There is no CPU fallback.")
