@@ -489,4 +489,302 @@ __global__ __launch_bounds__(64) void bpc_kernel(BpcArgs a)
     }
 }
 
+
+// =============================================================================================
+// Encoder, second formulation: contexts without neighbour exchange.
+//
+// The encoder knows every coefficient, so the significance state a coefficient SEES when the
+// lock-step scan reaches it is a pure function of the data: a neighbour is significant if it
+// became significant in an earlier plane (mask A), or in this plane (mask N = cur & ~A) AND it is
+// visited before the coefficient.  With the reference's scan order (row by row; all left columns,
+// then all right columns -- SPPEncoderLauncher BPCEngine.cu:770-843):
+//     row above      : already visited            -> A | N
+//     same row       : left coeff sees odd columns not yet visited  -> A
+//                      right coeff sees even columns already visited -> A | N
+//     row below      : not yet visited            -> A
+// So per plane the 8-neighbour count (computeContext :222-230) of all 64 rows of a column is a
+// carry-save addition of eight 64-bit row masks (4 result bit-planes n0..n3), and the sign context
+// (computeSignContext :252-308) is a handful of mask operations giving its three bits c0..c2.
+// The per-coefficient work shrinks to bit extraction + the arithmetic coder call; the two
+// neighbour columns are fetched ONCE per plane by DPP instead of twice per row; rows in which no
+// lane of the wave has anything to code are skipped by a wave-uniform row mask.
+// Codeword slot order is untouched: call sites are still visited in the lock-step order.
+// =============================================================================================
+
+struct U64 { uint32_t lo, hi; };
+__device__ __forceinline__ U64 u_and(U64 a, U64 b) { return U64{ a.lo & b.lo, a.hi & b.hi }; }
+__device__ __forceinline__ U64 u_or(U64 a, U64 b) { return U64{ a.lo | b.lo, a.hi | b.hi }; }
+__device__ __forceinline__ U64 u_xor(U64 a, U64 b) { return U64{ a.lo ^ b.lo, a.hi ^ b.hi }; }
+__device__ __forceinline__ U64 u_andn(U64 a, U64 b) { return U64{ a.lo & ~b.lo, a.hi & ~b.hi }; }   // a & ~b
+__device__ __forceinline__ U64 u_up(U64 a) { return U64{ a.lo << 1, (a.hi << 1) | (a.lo >> 31) }; }    // row i-1 -> bit i
+__device__ __forceinline__ U64 u_dn(U64 a) { return U64{ (a.lo >> 1) | (a.hi << 31), a.hi >> 1 }; }    // row i+1 -> bit i
+__device__ __forceinline__ U64 u_prev(U64 a, uint32_t t) { return U64{ from_prev32(a.lo, t), from_prev32(a.hi, t) }; }
+__device__ __forceinline__ U64 u_next(U64 a, uint32_t t) { return U64{ from_next32(a.lo, t), from_next32(a.hi, t) }; }
+__device__ __forceinline__ void full_add(U64 a, U64 b, U64 c, U64 &s, U64 &cy)
+{
+    U64 x = u_xor(a, b);
+    s = u_xor(x, c);
+    cy = u_or(u_and(a, b), u_and(c, x));
+}
+__device__ __forceinline__ void half_add(U64 a, U64 b, U64 &s, U64 &cy) { s = u_xor(a, b); cy = u_and(a, b); }
+
+// per-column, per-plane bit-sliced side information
+struct ColPlane {
+    U64 n0, n1, n2, n3;     // significance context (0..8), bit-sliced over the 64 rows
+    U64 c1, c2;             // sign context bits 1, 2 (LUT index = c >> 1)
+    U64 s2;                 // sign symbol = sign bit ^ context bit 0
+};
+
+// x1..x3: row above (post-pass state), x4,x5: same row, x6..x8: row below (pre-pass state);
+// sign neighbours: (us,ug) up, (ds,dg) down, (ls,lg) left, (rs,rg) right -- visible-significance
+// and sign masks, already shifted onto the coefficient's row.
+__device__ __forceinline__ ColPlane make_col(U64 x1, U64 x2, U64 x3, U64 x4, U64 x5, U64 x6, U64 x7, U64 x8,
+                                             U64 us, U64 ug, U64 ds, U64 dg, U64 ls, U64 lg, U64 rs, U64 rg,
+                                             U64 self_sgn)
+{
+    ColPlane r;
+    U64 s1, c1, s2, c2, s3, c3, c4, t1, d1, d2;
+    full_add(x1, x2, x3, s1, c1);
+    full_add(x4, x5, x6, s2, c2);
+    half_add(x7, x8, s3, c3);
+    full_add(s1, s2, s3, r.n0, c4);
+    full_add(c1, c2, c3, t1, d1);
+    half_add(t1, c4, r.n1, d2);
+    half_add(d1, d2, r.n2, r.n3);
+    // contributions: +1 significant & positive, -1 significant & negative (BPCEngine.cu:302-305)
+    U64 pu = u_andn(us, ug), nu = u_and(us, ug), pd = u_andn(ds, dg), nd = u_and(ds, dg);
+    U64 pl = u_andn(ls, lg), nl = u_and(ls, lg), pr = u_andn(rs, rg), nr = u_and(rs, rg);
+    U64 hp = u_andn(u_or(pl, pr), u_or(nl, nr)), hn = u_andn(u_or(nl, nr), u_or(pl, pr));
+    U64 vp = u_andn(u_or(pu, pd), u_or(nu, nd)), vn = u_andn(u_or(nu, nd), u_or(pu, pd));
+    // context table :258-290: h0: v0 0, v+ 2, v- 3 | h+: v0 4, v+ 6, v- 0 | h-: v0 5, v+ 1, v- 7
+    U64 hz = U64{ ~(hp.lo | hn.lo), ~(hp.hi | hn.hi) }, vz = U64{ ~(vp.lo | vn.lo), ~(vp.hi | vn.hi) };
+    U64 same = u_or(u_and(hp, vp), u_and(hn, vn));
+    U64 c0 = u_or(hn, u_andn(vn, hp));
+    r.c1 = u_or(u_and(hz, u_or(vp, vn)), same);
+    r.c2 = u_or(u_and(u_or(hp, hn), vz), same);
+    r.s2 = u_xor(self_sgn, c0);
+    return r;
+}
+
+__device__ __forceinline__ uint32_t wave_or32(uint32_t v)
+{
+    v |= __shfl_xor(v, 32);
+    v |= __shfl_xor(v, 16);
+    v |= __shfl_xor(v, 8);
+    v |= __shfl_xor(v, 4);
+    v |= __shfl_xor(v, 2);
+    v |= __shfl_xor(v, 1);
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+// arithmeticEncoder BPCEngine.cu:371-399, one call site, codeword stored straight to the staging
+__device__ __forceinline__ void enc_site(Coder &c, bool active, uint32_t sym, uint32_t p, uint32_t prec,
+                                         uint32_t lane, int32_t *st)
+{
+    bool need = active && c.S == 0u;
+    uint64_t m = __builtin_amdgcn_ballot_w64(need);
+    if (m != 0ull) reserve(c, need, lane, m);
+    uint32_t a = (__umul24(c.S, p) >> prec) + sym;
+    uint32_t S1 = sym ? c.S - a : a;
+    uint32_t L1 = c.L + (sym ? a : 0u);
+    if (active) {
+        c.S = S1; c.L = L1;
+        if (S1 == 0u) st[1u + c.slot] = (int32_t)L1;
+    }
+}
+
+__device__ __forceinline__ void enc_spp_coeff(Coder &c, uint32_t ii, uint32_t V, uint32_t B, const ColPlane &cp,
+                                              int hw, const PlaneLut &pl, uint32_t prec, uint32_t lane, int32_t *st)
+{
+    const bool visit = (V >> ii) & 1u;
+    const uint32_t sym = (B >> ii) & 1u;
+    const uint32_t n0 = hw ? cp.n0.hi : cp.n0.lo, n1 = hw ? cp.n1.hi : cp.n1.lo;
+    const uint32_t n2 = hw ? cp.n2.hi : cp.n2.lo, n3 = hw ? cp.n3.hi : cp.n3.lo;
+    const uint32_t ctx = ((n0 >> ii) & 1u) | (((n1 >> ii) & 1u) << 1) | (((n2 >> ii) & 1u) << 2);
+    uint32_t p = __builtin_amdgcn_perm(pl.sig1, pl.sig0, ctx | 0x0C0C0C00u);
+    p = ((n3 >> ii) & 1u) ? pl.sig8 : p;
+    enc_site(c, visit, sym, p, prec, lane, st);
+    const bool became = visit && sym;
+    if (__builtin_amdgcn_ballot_w64(became) != 0ull) {
+        const uint32_t c1 = hw ? cp.c1.hi : cp.c1.lo, c2 = hw ? cp.c2.hi : cp.c2.lo, s2 = hw ? cp.s2.hi : cp.s2.lo;
+        const uint32_t idx = ((c1 >> ii) & 1u) | (((c2 >> ii) & 1u) << 1);
+        const uint32_t p2 = (pl.sign >> (8u * idx)) & 0xFFu;
+        enc_site(c, became, (s2 >> ii) & 1u, p2, prec, lane, st);
+    }
+}
+
+// One wave64 per workgroup, two codeblocks (lanes 0-31 / 32-63), no LDS.
+__global__ __launch_bounds__(64) void bpc_encode_kernel(BpcArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
+    const int cb = 2 * (int)blockIdx.x + (int)half;
+    const bool valid = cb < a.nCB;
+    const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
+    const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
+    int32_t *st = a.staging + (size_t)(valid ? cb : 0) * 4096u;
+    const int lut_total = a.g.nRef + a.g.nSig + a.g.nSign;
+    const uint32_t prec = (uint32_t)a.g.prec;
+
+    uint32_t PLlo[kMaxPlanes], PLhi[kMaxPlanes], PRlo[kMaxPlanes], PRhi[kMaxPlanes];
+#pragma unroll
+    for (int k = 0; k < kMaxPlanes; k++) { PLlo[k] = PLhi[k] = PRlo[k] = PRhi[k] = 0u; }
+    U64 sgL = { 0u, 0u }, sgR = { 0u, 0u };
+
+    // ---- findMSB (BPCEngine.cu:176-192)
+    uint32_t ormag = 0u;
+    if (valid) {
+        for (int i = 0; i < 64; i++) {
+            int32_t v0, v1;
+            size_t idx = cbase + (size_t)i * (size_t)a.AW;
+            if (a.is_float) {
+                float2 f = *reinterpret_cast<const float2 *>((const float *)a.coeffs_in + idx);
+                v0 = (int32_t)f.x; v1 = (int32_t)f.y;
+            } else {
+                int2 q = *reinterpret_cast<const int2 *>((const int32_t *)a.coeffs_in + idx);
+                v0 = q.x; v1 = q.y;
+            }
+            ormag |= (uint32_t)(v0 < 0 ? -v0 : v0) | (uint32_t)(v1 < 0 ? -v1 : v1);
+        }
+    }
+    ormag = half_or(ormag);
+    int msb = ormag ? 31 - __builtin_clz(ormag) : 32;
+    if (valid && msb != 32 && msb > kMaxPlanes - 1) { *a.range_flag = 1; msb = kMaxPlanes - 1; }
+    const bool coded = valid && msb != 32;
+
+    int np = coded ? msb + 1 : 0;
+    { int o = __shfl_xor(np, 32); np = np > o ? np : o; }
+
+    // ---- transpose: plane (msb - k) of row i -> bit i of P[k]; only the planes some block needs
+    if (coded) {
+        const uint32_t up = (uint32_t)(kMaxPlanes - 1 - msb);
+#pragma unroll
+        for (int hw = 0; hw < 2; hw++) {
+            for (int ii = 0; ii < 32; ii++) {
+                int32_t v0, v1;
+                size_t idx = cbase + (size_t)(hw * 32 + ii) * (size_t)a.AW;
+                if (a.is_float) {
+                    float2 f = *reinterpret_cast<const float2 *>((const float *)a.coeffs_in + idx);
+                    v0 = (int32_t)f.x; v1 = (int32_t)f.y;
+                } else {
+                    int2 q = *reinterpret_cast<const int2 *>((const int32_t *)a.coeffs_in + idx);
+                    v0 = q.x; v1 = q.y;
+                }
+                uint32_t m0 = ((uint32_t)(v0 < 0 ? -v0 : v0) << up) & 0xFFFFu;
+                uint32_t m1 = ((uint32_t)(v1 < 0 ? -v1 : v1) << up) & 0xFFFFu;
+                uint32_t n0 = v0 < 0, n1 = v1 < 0;
+                if (hw == 0) { sgL.lo |= n0 << ii; sgR.lo |= n1 << ii; }
+                else         { sgL.hi |= n0 << ii; sgR.hi |= n1 << ii; }
+#pragma unroll
+                for (int k = 0; k < kMaxPlanes; k++) {
+                    if (k < np) {
+                        uint32_t b0 = (m0 >> (kMaxPlanes - 1 - k)) & 1u;
+                        uint32_t b1 = (m1 >> (kMaxPlanes - 1 - k)) & 1u;
+                        if (hw == 0) { PLlo[k] |= b0 << ii; PRlo[k] |= b1 << ii; }
+                        else         { PLhi[k] |= b0 << ii; PRhi[k] |= b1 << ii; }
+                    }
+                }
+            }
+        }
+    }
+
+    int level, sb;
+    find_subband(cbx * 64 + 2 * (int)t, cby * 64, a.AW, a.AH, a.wl, level, sb);
+    const int grp = level * a.g.nSub + sb;
+
+    Coder c = { 0u, 0u, 0u, 0u, 0u };
+    U64 AL = { 0u, 0u }, AR = { 0u, 0u };                 // significant before the current plane
+    const U64 sgPL = u_prev(sgR, t), sgNL = u_next(sgL, t);     // neighbour sign columns
+
+    for (int p = 0; p < np; p++) {
+        const int bp = msb - p;
+        const bool act = coded && bp >= 0;
+
+        PlaneLut pl = { 0u, 0u, 0u, 0u, 0u };
+        if (act) {
+            int ri = (grp * a.g.nBp + bp) * a.g.cRef;
+            int si = (grp * a.g.nBp + bp) * a.g.cSig + a.g.nRef;
+            int gi = (grp * a.g.nBp + bp) * a.g.cSign + a.g.nRef + a.g.nSig;
+            pl.ref = lut_at(a.lut, ri, lut_total);
+            pl.sig0 = lut_at(a.lut, si + 0, lut_total) | (lut_at(a.lut, si + 1, lut_total) << 8) |
+                      (lut_at(a.lut, si + 2, lut_total) << 16) | (lut_at(a.lut, si + 3, lut_total) << 24);
+            pl.sig1 = lut_at(a.lut, si + 4, lut_total) | (lut_at(a.lut, si + 5, lut_total) << 8) |
+                      (lut_at(a.lut, si + 6, lut_total) << 16) | (lut_at(a.lut, si + 7, lut_total) << 24);
+            pl.sig8 = lut_at(a.lut, si + 8, lut_total);
+            pl.sign = lut_at(a.lut, gi + 0, lut_total) | (lut_at(a.lut, gi + 1, lut_total) << 8) |
+                      (lut_at(a.lut, gi + 2, lut_total) << 16) | (lut_at(a.lut, gi + 3, lut_total) << 24);
+        }
+
+        const U64 BL = { PLlo[0], PLhi[0] }, BR = { PRlo[0], PRhi[0] };
+        const U64 NL = u_andn(BL, AL), NR = u_andn(BR, AR);          // become significant in this plane
+        const U64 AL2 = u_or(AL, NL), AR2 = u_or(AR, NR);            // state after this plane's SPP
+        const U64 APL = u_prev(AR, t), APL2 = u_prev(AR2, t);        // lane-1's right column
+        const U64 ANL = u_next(AL, t), ANL2 = u_next(AL2, t);        // lane+1's left column
+
+        const ColPlane cpL = make_col(u_up(APL2), u_up(AL2), u_up(AR2), APL, AR, u_dn(APL), u_dn(AL), u_dn(AR),
+                                      u_up(AL2), u_up(sgL), u_dn(AL), u_dn(sgL), APL, sgPL, AR, sgR, sgL);
+        const ColPlane cpR = make_col(u_up(AL2), u_up(AR2), u_up(ANL2), AL2, ANL2, u_dn(AL), u_dn(AR), u_dn(ANL),
+                                      u_up(AR2), u_up(sgR), u_dn(AR), u_dn(sgR), AL2, sgL, ANL2, sgNL, sgR);
+
+        // ---- significance propagation pass: rows where some lane still has an insignificant coeff
+        const U64 VL = act ? U64{ ~AL.lo, ~AL.hi } : U64{ 0u, 0u };
+        const U64 VR = act ? U64{ ~AR.lo, ~AR.hi } : U64{ 0u, 0u };
+#pragma unroll
+        for (int hw = 0; hw < 2; hw++) {
+            const uint32_t vl = hw ? VL.hi : VL.lo, vr = hw ? VR.hi : VR.lo;
+            const uint32_t bl = hw ? BL.hi : BL.lo, br = hw ? BR.hi : BR.lo;
+            uint32_t rows = wave_or32(vl | vr);
+            while (rows) {
+                const uint32_t ii = (uint32_t)__builtin_ctz(rows);
+                rows &= rows - 1u;
+                enc_spp_coeff(c, ii, vl, bl, cpL, hw, pl, prec, lane, st);
+                enc_spp_coeff(c, ii, vr, br, cpR, hw, pl, prec, lane, st);
+            }
+        }
+        // ---- magnitude refinement pass: coefficients significant before this plane
+#pragma unroll
+        for (int hw = 0; hw < 2; hw++) {
+            const uint32_t ml = act ? (hw ? AL.hi : AL.lo) : 0u, mr = act ? (hw ? AR.hi : AR.lo) : 0u;
+            const uint32_t bl = hw ? BL.hi : BL.lo, br = hw ? BR.hi : BR.lo;
+            uint32_t rows = wave_or32(ml | mr);
+            while (rows) {
+                const uint32_t ii = (uint32_t)__builtin_ctz(rows);
+                rows &= rows - 1u;
+                const bool aL = (ml >> ii) & 1u, aR = (mr >> ii) & 1u;
+                if (__builtin_amdgcn_ballot_w64(aL) != 0ull) enc_site(c, aL, (bl >> ii) & 1u, pl.ref, prec, lane, st);
+                if (__builtin_amdgcn_ballot_w64(aR) != 0ull) enc_site(c, aR, (br >> ii) & 1u, pl.ref, prec, lane, st);
+            }
+        }
+        AL = AL2; AR = AR2;
+#pragma unroll
+        for (int k = 0; k < kMaxPlanes - 1; k++) {
+            PLlo[k] = PLlo[k + 1]; PLhi[k] = PLhi[k + 1];
+            PRlo[k] = PRlo[k + 1]; PRhi[k] = PRhi[k + 1];
+        }
+    }
+
+    // flush (Encode BPCEngine.cu:1719) + sizeArray (:2010) + MSB slot (:1998)
+    if (coded) st[1u + c.slot] = (int32_t)c.L;
+    const uint32_t size = c.count + 1u;
+    if (valid && t == 0u) { a.sizes[cb] = (int32_t)size; st[0] = msb; }
+    // expansionFix :1905-1912 overwrites the whole block and must land after every codeword store
+    // of the block (they come from other lanes): drain the wave's stores first.
+    __syncthreads();
+    if (valid && size == 4096u) {
+        for (int i = 0; i < 64; i++) {
+            int32_t v0, v1;
+            size_t idx = cbase + (size_t)i * (size_t)a.AW;
+            if (a.is_float) {
+                float2 f = *reinterpret_cast<const float2 *>((const float *)a.coeffs_in + idx);
+                v0 = (int32_t)f.x; v1 = (int32_t)f.y;
+            } else {
+                int2 q = *reinterpret_cast<const int2 *>((const int32_t *)a.coeffs_in + idx);
+                v0 = q.x; v1 = q.y;
+            }
+            uint32_t w0 = (((uint32_t)(v0 < 0 ? -v0 : v0) << 1) + (uint32_t)(v0 < 0)) & 0xFFFFu;
+            uint32_t w1 = (((uint32_t)(v1 < 0 ? -v1 : v1) << 1) + (uint32_t)(v1 < 0)) & 0xFFFFu;
+            *reinterpret_cast<int2 *>(st + t * 128u + 2u * (uint32_t)i) = make_int2((int)w0, (int)w1);
+        }
+    }
+}
+
 }  // namespace picsong

@@ -400,7 +400,7 @@ static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_stag
     // BPCEngine::deviceMemoryAllocator BPCEngine.cu:2429-2441.  Slots beyond a codeblock's length
     // are never read downstream, so the fused frame path skips this 4*AW*AH-byte fill.
     if (memset_staging) HIP_TRY(hipMemsetAsync(d_staging, 0xFF, c->P * sizeof(int32_t), s));
-    bpc_kernel<false><<<(unsigned)((c->ncb + 1) / 2), 64, 0, s>>>(a);
+    bpc_encode_kernel<<<(unsigned)((c->ncb + 1) / 2), 64, 0, s>>>(a);
     HIP_TRY(hipGetLastError());
     return PICSONG_OK;
 }

@@ -66,7 +66,7 @@ void emu_bpc_encode(const void *coeffs, int is_float, int aw, int ah, int wl, co
     BpcArgs a = mk(aw, ah, wl, lut, geo, staging, sizes, flag);
     a.coeffs_in = coeffs; a.is_float = is_float;
     memset(staging, 0xFF, (size_t)aw * ah * 4);
-    emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_kernel<false>(a); });
+    emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_encode_kernel(a); });
 }
 
 void emu_bpc_decode(const int32_t *staging, const int32_t *sizes, int aw, int ah, int wl, const int32_t *lut,

@@ -64,10 +64,15 @@ static void resolve(Op op, unsigned wave_id, uint64_t /*unused*/)
     if (op == OP_BALLOT)
         for (unsigned i = 0; i < 64; i++)
             if (alive(i) && g.lanes[base + i].in) ballot |= 1ull << i;
+    uint64_t first = 0;
+    if (op == OP_READFIRST)
+        for (unsigned i = 0; i < 64; i++)
+            if (alive(i)) { first = g.lanes[base + i].in; break; }
     for (unsigned i = 0; i < 64; i++) {
         if (!alive(i)) continue;
         Lane &l = g.lanes[base + i];
         switch (op) {
+        case OP_READFIRST: l.out = first; break;
         case OP_DPP_SHR: l.out = (i >= 1 && alive(i - 1)) ? g.lanes[base + i - 1].in : l.out; break;
         case OP_DPP_SHL: l.out = (i + 1 < 64 && alive(i + 1)) ? g.lanes[base + i + 1].in : l.out; break;
         case OP_BALLOT: l.out = ballot; break;

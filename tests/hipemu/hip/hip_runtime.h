@@ -68,7 +68,7 @@ extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 namespace emu {
 
-enum Op { OP_DPP_SHR, OP_DPP_SHL, OP_BALLOT, OP_SHFL_XOR, OP_SHFL_UP };
+enum Op { OP_DPP_SHR, OP_DPP_SHL, OP_BALLOT, OP_SHFL_XOR, OP_SHFL_UP, OP_READFIRST };
 
 // generic wave collective: park (in, aux), last arriver resolves all lanes of the wave
 uint64_t collective(Op op, uint64_t in, unsigned aux, uint64_t old);
@@ -137,6 +137,12 @@ template <typename T> static inline T __shfl_up(T v, unsigned d)
     memcpy(&r, &o, sizeof r);
     return r;
 }
+static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v)
+{
+    return (unsigned)emu::collective(emu::OP_READFIRST, v, 0, 0);
+}
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+static inline void __builtin_amdgcn_s_waitcnt(int) {}
 static inline void __syncthreads() { emu::barrier(); }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
