@@ -528,41 +528,50 @@ __device__ __forceinline__ void full_add(U64 a, U64 b, U64 c, U64 &s, U64 &cy)
 }
 __device__ __forceinline__ void half_add(U64 a, U64 b, U64 &s, U64 &cy) { s = u_xor(a, b); cy = u_and(a, b); }
 
-// per-column, per-plane bit-sliced side information
-struct ColPlane {
-    U64 n0, n1, n2, n3;     // significance context (0..8), bit-sliced over the 64 rows
-    U64 c1, c2;             // sign context bits 1, 2 (LUT index = c >> 1)
-    U64 s2;                 // sign symbol = sign bit ^ context bit 0
+// per-column side information for the 32 rows of one half-pass, bit-sliced
+struct ColHalf {
+    uint32_t n0, n1, n2, n3;    // significance context (0..8)
+    uint32_t c1, c2;            // sign context bits 1, 2 (LUT index = c >> 1)
+    uint32_t s2;                // sign symbol = sign bit ^ context bit 0
 };
+__device__ __forceinline__ void fa32(uint32_t a, uint32_t b, uint32_t c, uint32_t &s, uint32_t &cy)
+{
+    uint32_t x = a ^ b;
+    s = x ^ c;
+    cy = (a & b) | (c & x);
+}
+__device__ __forceinline__ uint32_t w_of(U64 a, int hw) { return hw ? a.hi : a.lo; }
+__device__ __forceinline__ uint32_t up_of(U64 a, int hw) { return hw ? ((a.hi << 1) | (a.lo >> 31)) : (a.lo << 1); }
+__device__ __forceinline__ uint32_t dn_of(U64 a, int hw) { return hw ? (a.hi >> 1) : ((a.lo >> 1) | (a.hi << 31)); }
 
 // x1..x3: row above (post-pass state), x4,x5: same row, x6..x8: row below (pre-pass state);
 // sign neighbours: (us,ug) up, (ds,dg) down, (ls,lg) left, (rs,rg) right -- visible-significance
 // and sign masks, already shifted onto the coefficient's row.
-__device__ __forceinline__ ColPlane make_col(U64 x1, U64 x2, U64 x3, U64 x4, U64 x5, U64 x6, U64 x7, U64 x8,
-                                             U64 us, U64 ug, U64 ds, U64 dg, U64 ls, U64 lg, U64 rs, U64 rg,
-                                             U64 self_sgn)
+__device__ __forceinline__ ColHalf make_col(uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4, uint32_t x5,
+                                            uint32_t x6, uint32_t x7, uint32_t x8, uint32_t us, uint32_t ug,
+                                            uint32_t ds, uint32_t dg, uint32_t ls, uint32_t lg, uint32_t rs,
+                                            uint32_t rg, uint32_t self_sgn)
 {
-    ColPlane r;
-    U64 s1, c1, s2, c2, s3, c3, c4, t1, d1, d2;
-    full_add(x1, x2, x3, s1, c1);
-    full_add(x4, x5, x6, s2, c2);
-    half_add(x7, x8, s3, c3);
-    full_add(s1, s2, s3, r.n0, c4);
-    full_add(c1, c2, c3, t1, d1);
-    half_add(t1, c4, r.n1, d2);
-    half_add(d1, d2, r.n2, r.n3);
+    ColHalf r;
+    uint32_t s1, c1, s2, c2, s3, c3, c4, t1, d1, d2;
+    fa32(x1, x2, x3, s1, c1);
+    fa32(x4, x5, x6, s2, c2);
+    s3 = x7 ^ x8; c3 = x7 & x8;
+    fa32(s1, s2, s3, r.n0, c4);
+    fa32(c1, c2, c3, t1, d1);
+    r.n1 = t1 ^ c4; d2 = t1 & c4;
+    r.n2 = d1 ^ d2; r.n3 = d1 & d2;
     // contributions: +1 significant & positive, -1 significant & negative (BPCEngine.cu:302-305)
-    U64 pu = u_andn(us, ug), nu = u_and(us, ug), pd = u_andn(ds, dg), nd = u_and(ds, dg);
-    U64 pl = u_andn(ls, lg), nl = u_and(ls, lg), pr = u_andn(rs, rg), nr = u_and(rs, rg);
-    U64 hp = u_andn(u_or(pl, pr), u_or(nl, nr)), hn = u_andn(u_or(nl, nr), u_or(pl, pr));
-    U64 vp = u_andn(u_or(pu, pd), u_or(nu, nd)), vn = u_andn(u_or(nu, nd), u_or(pu, pd));
+    uint32_t pu = us & ~ug, nu = us & ug, pd = ds & ~dg, nd = ds & dg;
+    uint32_t pl = ls & ~lg, nl = ls & lg, pr = rs & ~rg, nr = rs & rg;
+    uint32_t hp = (pl | pr) & ~(nl | nr), hn = (nl | nr) & ~(pl | pr);
+    uint32_t vp = (pu | pd) & ~(nu | nd), vn = (nu | nd) & ~(pu | pd);
     // context table :258-290: h0: v0 0, v+ 2, v- 3 | h+: v0 4, v+ 6, v- 0 | h-: v0 5, v+ 1, v- 7
-    U64 hz = U64{ ~(hp.lo | hn.lo), ~(hp.hi | hn.hi) }, vz = U64{ ~(vp.lo | vn.lo), ~(vp.hi | vn.hi) };
-    U64 same = u_or(u_and(hp, vp), u_and(hn, vn));
-    U64 c0 = u_or(hn, u_andn(vn, hp));
-    r.c1 = u_or(u_and(hz, u_or(vp, vn)), same);
-    r.c2 = u_or(u_and(u_or(hp, hn), vz), same);
-    r.s2 = u_xor(self_sgn, c0);
+    uint32_t same = (hp & vp) | (hn & vn);
+    uint32_t c0 = hn | (vn & ~hp);
+    r.c1 = (~(hp | hn) & (vp | vn)) | same;
+    r.c2 = ((hp | hn) & ~(vp | vn)) | same;
+    r.s2 = self_sgn ^ c0;
     return r;
 }
 
@@ -593,28 +602,28 @@ __device__ __forceinline__ void enc_site(Coder &c, bool active, uint32_t sym, ui
     }
 }
 
-__device__ __forceinline__ void enc_spp_coeff(Coder &c, uint32_t ii, uint32_t V, uint32_t B, const ColPlane &cp,
-                                              int hw, const PlaneLut &pl, uint32_t prec, uint32_t lane, int32_t *st)
+__device__ __forceinline__ void enc_spp_coeff(Coder &c, uint32_t ii, uint32_t V, uint32_t B, const ColHalf &cp,
+                                              const PlaneLut &pl, uint32_t prec, uint32_t lane, int32_t *st)
 {
     const bool visit = (V >> ii) & 1u;
     const uint32_t sym = (B >> ii) & 1u;
-    const uint32_t n0 = hw ? cp.n0.hi : cp.n0.lo, n1 = hw ? cp.n1.hi : cp.n1.lo;
-    const uint32_t n2 = hw ? cp.n2.hi : cp.n2.lo, n3 = hw ? cp.n3.hi : cp.n3.lo;
-    const uint32_t ctx = ((n0 >> ii) & 1u) | (((n1 >> ii) & 1u) << 1) | (((n2 >> ii) & 1u) << 2);
+    const uint32_t ctx = ((cp.n0 >> ii) & 1u) | (((cp.n1 >> ii) & 1u) << 1) | (((cp.n2 >> ii) & 1u) << 2);
     uint32_t p = __builtin_amdgcn_perm(pl.sig1, pl.sig0, ctx | 0x0C0C0C00u);
-    p = ((n3 >> ii) & 1u) ? pl.sig8 : p;
+    p = ((cp.n3 >> ii) & 1u) ? pl.sig8 : p;
     enc_site(c, visit, sym, p, prec, lane, st);
     const bool became = visit && sym;
     if (__builtin_amdgcn_ballot_w64(became) != 0ull) {
-        const uint32_t c1 = hw ? cp.c1.hi : cp.c1.lo, c2 = hw ? cp.c2.hi : cp.c2.lo, s2 = hw ? cp.s2.hi : cp.s2.lo;
-        const uint32_t idx = ((c1 >> ii) & 1u) | (((c2 >> ii) & 1u) << 1);
+        const uint32_t idx = ((cp.c1 >> ii) & 1u) | (((cp.c2 >> ii) & 1u) << 1);
         const uint32_t p2 = (pl.sign >> (8u * idx)) & 0xFFu;
-        enc_site(c, became, (s2 >> ii) & 1u, p2, prec, lane, st);
+        enc_site(c, became, (cp.s2 >> ii) & 1u, p2, prec, lane, st);
     }
 }
 
 // One wave64 per workgroup, two codeblocks (lanes 0-31 / 32-63), no LDS.
-__global__ __launch_bounds__(64) void bpc_encode_kernel(BpcArgs a)
+#ifndef PICSONG_BPC_ENC_WAVES
+#define PICSONG_BPC_ENC_WAVES 4        // waves per SIMD the register allocator must leave room for
+#endif
+__global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(BpcArgs a)
 {
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
     const int cb = 2 * (int)blockIdx.x + (int)half;
@@ -653,6 +662,7 @@ __global__ __launch_bounds__(64) void bpc_encode_kernel(BpcArgs a)
 
     int np = coded ? msb + 1 : 0;
     { int o = __shfl_xor(np, 32); np = np > o ? np : o; }
+    np = (int)__builtin_amdgcn_readfirstlane((uint32_t)np);      // wave-uniform: keep it scalar
 
     // ---- transpose: plane (msb - k) of row i -> bit i of P[k]; only the planes some block needs
     if (coded) {
@@ -720,24 +730,26 @@ __global__ __launch_bounds__(64) void bpc_encode_kernel(BpcArgs a)
         const U64 APL = u_prev(AR, t), APL2 = u_prev(AR2, t);        // lane-1's right column
         const U64 ANL = u_next(AL, t), ANL2 = u_next(AL2, t);        // lane+1's left column
 
-        const ColPlane cpL = make_col(u_up(APL2), u_up(AL2), u_up(AR2), APL, AR, u_dn(APL), u_dn(AL), u_dn(AR),
-                                      u_up(AL2), u_up(sgL), u_dn(AL), u_dn(sgL), APL, sgPL, AR, sgR, sgL);
-        const ColPlane cpR = make_col(u_up(AL2), u_up(AR2), u_up(ANL2), AL2, ANL2, u_dn(AL), u_dn(AR), u_dn(ANL),
-                                      u_up(AR2), u_up(sgR), u_dn(AR), u_dn(sgR), AL2, sgL, ANL2, sgNL, sgR);
-
-        // ---- significance propagation pass: rows where some lane still has an insignificant coeff
-        const U64 VL = act ? U64{ ~AL.lo, ~AL.hi } : U64{ 0u, 0u };
-        const U64 VR = act ? U64{ ~AR.lo, ~AR.hi } : U64{ 0u, 0u };
+        // ---- significance propagation pass, 32 rows at a time; only rows where some lane of the
+        // wave still has an insignificant coefficient
 #pragma unroll
         for (int hw = 0; hw < 2; hw++) {
-            const uint32_t vl = hw ? VL.hi : VL.lo, vr = hw ? VR.hi : VR.lo;
-            const uint32_t bl = hw ? BL.hi : BL.lo, br = hw ? BR.hi : BR.lo;
+            const ColHalf cpL = make_col(up_of(APL2, hw), up_of(AL2, hw), up_of(AR2, hw), w_of(APL, hw), w_of(AR, hw),
+                                         dn_of(APL, hw), dn_of(AL, hw), dn_of(AR, hw),
+                                         up_of(AL2, hw), up_of(sgL, hw), dn_of(AL, hw), dn_of(sgL, hw),
+                                         w_of(APL, hw), w_of(sgPL, hw), w_of(AR, hw), w_of(sgR, hw), w_of(sgL, hw));
+            const ColHalf cpR = make_col(up_of(AL2, hw), up_of(AR2, hw), up_of(ANL2, hw), w_of(AL2, hw), w_of(ANL2, hw),
+                                         dn_of(AL, hw), dn_of(AR, hw), dn_of(ANL, hw),
+                                         up_of(AR2, hw), up_of(sgR, hw), dn_of(AR, hw), dn_of(sgR, hw),
+                                         w_of(AL2, hw), w_of(sgL, hw), w_of(ANL2, hw), w_of(sgNL, hw), w_of(sgR, hw));
+            const uint32_t vl = act ? ~w_of(AL, hw) : 0u, vr = act ? ~w_of(AR, hw) : 0u;
+            const uint32_t bl = w_of(BL, hw), br = w_of(BR, hw);
             uint32_t rows = wave_or32(vl | vr);
             while (rows) {
                 const uint32_t ii = (uint32_t)__builtin_ctz(rows);
                 rows &= rows - 1u;
-                enc_spp_coeff(c, ii, vl, bl, cpL, hw, pl, prec, lane, st);
-                enc_spp_coeff(c, ii, vr, br, cpR, hw, pl, prec, lane, st);
+                enc_spp_coeff(c, ii, vl, bl, cpL, pl, prec, lane, st);
+                enc_spp_coeff(c, ii, vr, br, cpR, pl, prec, lane, st);
             }
         }
         // ---- magnitude refinement pass: coefficients significant before this plane

@@ -10,7 +10,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SO_PATH = os.path.join(PKG, "csrc", "libpicsong_hip.so")
+SO_PATH = os.environ.get("PICSONG_SO", os.path.join(PKG, "csrc", "libpicsong_hip.so"))
 
 PICSONG_OK = 0
 
