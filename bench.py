@@ -69,6 +69,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import picsong_amd as pa
+    import picsong_dist as pdist
     import oracle_lib as orc          # checker + cpu_baseline only
 
     W, H, wl, lossy, qs = WORKLOADS[args.workload]
@@ -84,23 +85,15 @@ def main():
     if world > 1 and rank == 0:
         gather_bufs = [torch.empty(codec.max_stream_shorts(), dtype=torch.int16, device="cuda")
                        for _ in range(world - 1)]
-    len_all = torch.zeros(world, dtype=torch.int32, device="cuda")
-    len_mine = torch.zeros(1, dtype=torch.int32, device="cuda")
+    dev = torch.device("cuda", local_rank)
 
     def step(it):
         codec.encode_frame_async(frame, out, 0 if it == 0 else 1)
         if world > 1:
-            # the only exchange of the frame-sharded path: lengths, then payload gatherv to rank 0
+            # the only exchange of the frame-sharded path (picsong_dist.gather_round, covered by the
+            # gloo tests): lengths all-gathered, then payload gatherv to rank 0 over RCCL
             total = codec.last_total()
-            len_mine[0] = total
-            dist.all_gather_into_tensor(len_all, len_mine)
-            lens = len_all.tolist()
-            if rank == 0:
-                reqs = [dist.irecv(gather_bufs[r - 1][:lens[r]], src=r) for r in range(1, world)]
-                for q in reqs:
-                    q.wait()
-            else:
-                dist.send(out[:total], dst=0)
+            pdist.gather_round(out[:total], rank, world, dev, recv_bufs=gather_bufs)
 
     def sync_all():
         if world > 1:

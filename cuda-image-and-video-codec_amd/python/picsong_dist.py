@@ -1,0 +1,84 @@
+"""Frame-sharded video encode across the GPUs of one node: one process per GPU
+(torch.distributed, backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+Frames of a video are fully independent units: rank r encodes frames
+r, r + N, r + 2N, ...; the only exchange is, per round of N frames, an all-gather of the codestream
+lengths followed by a gatherv of the payloads to the writer rank (point-to-point sends into rank 0:
+on MI355X each peer has its own xGMI link to the root, the payload is a few MB, so no ring is
+needed).  Only frame 0 carries the populated 9-short header (BitStreamBuilder.cu:277-278: iter == 0),
+so the rank that owns frame 0 encodes it with iter = 0 and every other frame with iter != 0.
+The `_SIZE` sidecar order is frame order (IOManager.ipp:176-190).
+
+The encoder is injected (`encode_fn(frame_index, iter) -> 1-D int16/uint16 tensor`), so the
+distribution logic is testable without a GPU.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_frames(n_frames, rank, world):
+    """Frame indices owned by `rank` (round-robin, f mod N)."""
+    return list(range(rank, n_frames, world))
+
+
+def owner_of(frame, world):
+    return frame % world
+
+
+def gather_round(local_stream, rank, world, device, recv_bufs=None, group=None):
+    """One exchange step.  `local_stream`: this rank's codestream for the round (1-D int16 tensor on
+    `device`) or None if the rank has no frame in this round.  Returns on rank 0 the list of
+    per-rank streams (None for ranks without a frame), elsewhere None."""
+    n = 0 if local_stream is None else int(local_stream.numel())
+    mine = torch.tensor([n], dtype=torch.int32, device=device)
+    lens = torch.zeros(world, dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(lens, mine, group=group)
+    lens = lens.tolist()
+    if rank == 0:
+        out = [local_stream if n else None]
+        reqs = []
+        for r in range(1, world):
+            if lens[r] == 0:
+                out.append(None)
+                continue
+            if recv_bufs is not None:
+                buf = recv_bufs[r - 1][:lens[r]]
+            else:
+                buf = torch.empty(lens[r], dtype=torch.int16, device=device)
+            out.append(buf)
+            reqs.append(dist.irecv(buf, src=r, group=group))
+        for q in reqs:
+            q.wait()
+        return out
+    if n:
+        dist.send(local_stream, dst=0, group=group)
+    return None
+
+
+def encode_video_distributed(n_frames, encode_fn, rank, world, device, on_frame=None, group=None):
+    """Encode `n_frames` frames sharded f mod world; rank 0 receives every codestream in frame
+    order and hands it to `on_frame(frame_index, stream_tensor)`.  Returns the per-frame lengths
+    (shorts) on rank 0, None elsewhere."""
+    sizes = []
+    rounds = (n_frames + world - 1) // world
+    for rd in range(rounds):
+        f = rd * world + rank
+        local = None
+        if f < n_frames:
+            local = encode_fn(f, 0 if f == 0 else 1)
+        got = gather_round(local, rank, world, device, group=group)
+        if rank == 0:
+            for r, s in enumerate(got):
+                fr = rd * world + r
+                if fr >= n_frames:
+                    continue
+                assert s is not None, f"missing stream for frame {fr}"
+                sizes.append(int(s.numel()))
+                if on_frame is not None:
+                    on_frame(fr, s)
+    return sizes if rank == 0 else None
+
+
+def size_sidecar(sizes):
+    """`<o>_SIZE` contents: decimal lengths in shorts, comma-separated, no trailing newline."""
+    return ",".join(str(int(s)) for s in sizes)

@@ -1,0 +1,82 @@
+"""N > 1 path on CPU: world_size-2 (and 3) gloo processes run the frame-sharding + gatherv logic of
+picsong_dist with the oracle standing in for the GPU encoder, and the assembled video codestream
+must equal the single-process result frame by frame (header only on frame 0, _SIZE in frame order)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+W, H, WL, NF = 128, 64, 1, 5
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(ROOT, "cuda-image-and-video-codec_amd", "python"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as orc
+    import picsong_dist as pd
+    lut = orc.lut_for(False, WL)
+    encoded = []
+
+    def encode_fn(f, it):
+        encoded.append(f)
+        s = orc.encode_frame(orc.gen_frame(W, H, f), WL, False, 1.0, lut, it, NF)
+        return torch.from_numpy(s.view(np.int16).copy())
+
+    chunks = {}
+    sizes = pd.encode_video_distributed(NF, encode_fn, rank, world, torch.device("cpu"),
+                                        on_frame=lambda f, s: chunks.__setitem__(f, s.numpy().view(np.uint16).copy()))
+    assert encoded == pd.shard_frames(NF, rank, world)
+    if rank == 0:
+        assert sorted(chunks) == list(range(NF))
+        np.save(os.path.join(outdir, "video.npy"), np.concatenate([chunks[f] for f in range(NF)]))
+        with open(os.path.join(outdir, "video_SIZE"), "w") as fh:
+            fh.write(pd.size_sidecar(sizes))
+    else:
+        assert sizes is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_frame_sharding_gather_matches_single_process(oracle, tmp_path, world):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    lut = oracle.lut_for(False, WL)
+    ref = [oracle.encode_frame(oracle.gen_frame(W, H, f), WL, False, 1.0, lut, 0 if f == 0 else 1, NF)
+           for f in range(NF)]
+    got = np.load(os.path.join(tmp_path, "video.npy"))
+    assert np.array_equal(got, np.concatenate(ref))
+    sizes = open(os.path.join(tmp_path, "video_SIZE")).read()
+    assert sizes == ",".join(str(r.size) for r in ref) and not sizes.endswith("\n")
+    # only frame 0 carries the populated header; the others have 0xFFFF there
+    assert (ref[1][:9] == 0xFFFF).all() and not (ref[0][:9] == 0xFFFF).all()
+    # every frame decodes back to its input
+    for f in (0, NF - 1):
+        assert np.array_equal(oracle.decode_frame(ref[f], W, H, WL, False, 1.0, lut), oracle.gen_frame(W, H, f))
+
+
+def test_shard_helpers():
+    sys.path.insert(0, os.path.join(ROOT, "cuda-image-and-video-codec_amd", "python"))
+    import picsong_dist as pd
+    assert pd.shard_frames(10, 1, 4) == [1, 5, 9]
+    assert pd.shard_frames(3, 3, 4) == []
+    assert [pd.owner_of(f, 8) for f in (0, 7, 8, 255)] == [0, 7, 0, 7]
+    assert pd.size_sidecar([12, 3456, 7]) == "12,3456,7"
