@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="8k_lossless", choices=sorted(WORKLOADS))
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams (each with its own context) the frames of consecutive steps alternate on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=0,
                     help="rows of the frame the CPU baseline encodes (0 = whole frame)")
@@ -74,13 +76,18 @@ def main():
 
     W, H, wl, lossy, qs = WORKLOADS[args.workload]
     lut_dir = os.path.join(orc.LUT_DIR, "n1_lossy" if lossy else "n1_lossless")
-    codec = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=lut_dir, device=local_rank)
+    nstreams = max(1, args.streams)
+    codecs = [pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=lut_dir, device=local_rank)
+              for _ in range(nstreams)]
+    streams = [torch.cuda.Stream(device=local_rank) for _ in range(nstreams)]
+    codec = codecs[0]
     AW, AH, nCB, P = codec.aw, codec.ah, codec.ncb, codec.P
 
     # synthetic frames (SURVEY 8d generator), one distinct frame per rank, resident in HBM
     frame_np = orc.pad_frame(orc.gen_frame(W, H, rank))
     frame = torch.from_numpy(frame_np).cuda()
-    out = torch.empty(codec.max_stream_shorts(), dtype=torch.int16, device="cuda")
+    outs = [torch.empty(codec.max_stream_shorts(), dtype=torch.int16, device="cuda") for _ in range(nstreams)]
+    out = outs[0]
     gather_bufs = None
     if world > 1 and rank == 0:
         gather_bufs = [torch.empty(codec.max_stream_shorts(), dtype=torch.int16, device="cuda")
@@ -88,12 +95,16 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     def step(it):
-        codec.encode_frame_async(frame, out, 0 if it == 0 else 1)
-        if world > 1:
-            # the only exchange of the frame-sharded path (picsong_dist.gather_round, covered by the
-            # gloo tests): lengths all-gathered, then payload gatherv to rank 0 over RCCL
-            total = codec.last_total()
-            pdist.gather_round(out[:total], rank, world, dev, recv_bufs=gather_bufs)
+        # consecutive frames alternate over the streams: frame i's BPC tail overlaps frame i+1's
+        # DWT/BPC head (each stream has its own context = its own workspace)
+        k = it % nstreams
+        with torch.cuda.stream(streams[k]):
+            codecs[k].encode_frame_async(frame, outs[k], 0 if it == 0 else 1)
+            if world > 1:
+                # the only exchange of the frame-sharded path (picsong_dist.gather_round, covered by
+                # the gloo tests): lengths all-gathered, then payload gatherv to rank 0 over RCCL
+                total = codecs[k].last_total()
+                pdist.gather_round(outs[k][:total], rank, world, dev, recv_bufs=gather_bufs)
 
     def sync_all():
         if world > 1:
@@ -103,14 +114,16 @@ def main():
     for i in range(args.warmup):
         step(i)
     sync_all()
-    codec.profile_begin(args.steps)
+    for c in codecs:
+        c.profile_begin(args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(1 + i)
     sync_all()
     dt = time.perf_counter() - t0
-    stage_ms = codec.profile_read(args.steps)
-    codec.profile_begin(0)
+    stage_ms = np.concatenate([c.profile_read(args.steps) for c in codecs], axis=0)
+    for c in codecs:
+        c.profile_begin(0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -188,7 +201,8 @@ def main():
         "config": {"workload": f"{W}x{H} greyscale u8 frame (padded {AW}x{AH}), "
                                f"-type {int(lossy)} {'9/7 qs=%g' % qs if lossy else '5/3 lossless'}, "
                                f"wl={wl}, cp=2, k=0, LUT {'n1_lossy' if lossy else 'n1_lossless'}, "
-                               f"1 frame/step/GPU, frames sharded over {world} GPU(s)",
+                               f"1 frame/step/GPU, frames sharded over {world} GPU(s), "
+                               f"{nstreams} HIP stream(s) per GPU",
                    "codeblocks": nCB, "stream_shorts": int(total_shorts),
                    "bits_per_pixel": round(total_shorts * 16 / (W * H), 4)},
         "roundtrip_ok": roundtrip_ok, "range_flag": flag,

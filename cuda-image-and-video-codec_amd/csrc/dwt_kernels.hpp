@@ -34,9 +34,18 @@ namespace picsong {
 #define PS_N1 (1.230174104914001f)
 #define PS_N2 (0.812893066f)
 
+#ifndef PICSONG_DWT_EDGE_LANES
+#define PICSONG_DWT_EDGE_LANES 1
+#endif
 constexpr int kStripCols = 256;                 // columns held by one wave
-constexpr int kStripUseful = kStripCols - 8;    // lanes 1..62 write
-constexpr int kFwdBandRows = 32;                // output rows per band (forward)
+constexpr int kEdgeLanes = PICSONG_DWT_EDGE_LANES;          // recomputed, never-written lanes per side (>= 1)
+constexpr int kStripUseful = kStripCols - 8 * kEdgeLanes;   // lanes kEdgeLanes .. 63-kEdgeLanes write
+#ifndef PICSONG_DWT_UNROLL
+#define PICSONG_DWT_UNROLL 4
+#endif
+// Output rows per band are a template parameter (BAND = 4, 8, 16 or 32): big levels want tall bands
+// (less vertical halo), small levels want many short waves (a level with 18 tall waves is bound by
+// one wave's serial instruction time, not by memory).  Row pairs fetched ahead = min(4, BAND/2).
 constexpr int kInvBandRows = 32;                // output rows per band (inverse)
 
 struct DwtFwdArgs {
@@ -160,31 +169,55 @@ __device__ __forceinline__ void hinv(float v[4])
 }
 
 // ---- forward --------------------------------------------------------------------------------
+// A row segment as it comes from memory (conversion deferred so that many loads can be in flight):
+// u8 input: one dword = 4 samples; T input: four dwords.
+template <bool U8IN> struct RawRow;
+template <> struct RawRow<true> { uint32_t w; };
+template <> struct RawRow<false> { uint32_t w[4]; };
+
+template <typename T, bool U8IN>
+__device__ __forceinline__ RawRow<U8IN> load_raw(const DwtFwdArgs &a, int y, int c0, bool vec)
+{
+    RawRow<U8IN> r;
+    const int ry = reflect(y, a.H);
+    if constexpr (U8IN) {
+        const uint8_t *p = (const uint8_t *)a.src + (size_t)ry * (size_t)a.src_stride;
+        if (vec) {
+            r.w = *reinterpret_cast<const uint32_t *>(p + c0);
+        } else {
+            r.w = (uint32_t)p[reflect(c0, a.W)] | ((uint32_t)p[reflect(c0 + 1, a.W)] << 8) |
+                  ((uint32_t)p[reflect(c0 + 2, a.W)] << 16) | ((uint32_t)p[reflect(c0 + 3, a.W)] << 24);
+        }
+    } else {
+        const uint32_t *p = (const uint32_t *)a.src + (size_t)ry * (size_t)a.src_stride;
+        if (vec) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(p + c0);
+            r.w[0] = q.x; r.w[1] = q.y; r.w[2] = q.z; r.w[3] = q.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) r.w[k] = p[reflect(c0 + k, a.W)];
+        }
+    }
+    return r;
+}
+
+template <typename T, bool U8IN>
+__device__ __forceinline__ void unpack_row(const RawRow<U8IN> &r, T v[4])
+{
+    if constexpr (U8IN) {
+        // offsetImage Engines/CodingEngine.cu:581-588 fused: (T)u8 - 128
+        v[0] = (T)(int)(r.w & 0xFFu) - (T)128; v[1] = (T)(int)((r.w >> 8) & 0xFFu) - (T)128;
+        v[2] = (T)(int)((r.w >> 16) & 0xFFu) - (T)128; v[3] = (T)(int)(r.w >> 24) - (T)128;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = from_u32<T>(r.w[k]);
+    }
+}
+
 template <typename T, bool U8IN>
 __device__ __forceinline__ void load_row4(const DwtFwdArgs &a, int y, int c0, bool vec, T v[4])
 {
-    const int ry = reflect(y, a.H);
-    if (U8IN) {
-        const uint8_t *p = (const uint8_t *)a.src + (size_t)ry * (size_t)a.src_stride;
-        // offsetImage Engines/CodingEngine.cu:581-588 fused: (T)u8 - 128
-        if (vec) {
-            uint32_t w = *reinterpret_cast<const uint32_t *>(p + c0);
-            v[0] = (T)(int)(w & 0xFFu) - (T)128; v[1] = (T)(int)((w >> 8) & 0xFFu) - (T)128;
-            v[2] = (T)(int)((w >> 16) & 0xFFu) - (T)128; v[3] = (T)(int)(w >> 24) - (T)128;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = (T)(int)p[reflect(c0 + k, a.W)] - (T)128;
-        }
-    } else {
-        const T *p = (const T *)a.src + (size_t)ry * (size_t)a.src_stride;
-        if (vec) {
-            const uint4 w = *reinterpret_cast<const uint4 *>(p + c0);
-            v[0] = from_u32<T>(w.x); v[1] = from_u32<T>(w.y); v[2] = from_u32<T>(w.z); v[3] = from_u32<T>(w.w);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = p[reflect(c0 + k, a.W)];
-        }
-    }
+    unpack_row<T, U8IN>(load_raw<T, U8IN>(a, y, c0, vec), v);
 }
 
 template <typename T>
@@ -225,65 +258,105 @@ __device__ __forceinline__ void emit_pair(const DwtFwdArgs &a, int m, int pc, bo
 }
 
 // grid.x = ceil(strips / 4), grid.y = bands; block = 256 threads = 4 waves = 4 adjacent strips
-template <typename T, bool LOSSY, bool U8IN>
+template <typename T, bool LOSSY, bool U8IN, int BAND>
 __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwtFwdArgs a)
 {
+    constexpr int kFwdBandRows = BAND;
+    constexpr int kFwdChunk = BAND / 2 < 4 ? BAND / 2 : 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int strip = blockIdx.x * 4 + wave;
     if (strip * kStripUseful >= a.W) return;               // whole wave idle (no cross-lane use)
-    const int c0 = strip * kStripUseful - 4 + 4 * lane;    // first of the lane's 4 columns
+    const int c0 = strip * kStripUseful - 4 * kEdgeLanes + 4 * lane;    // first of the lane's 4 columns
     const int m0 = blockIdx.y * (kFwdBandRows / 2);
     int m1 = m0 + kFwdBandRows / 2;
     if (m1 > (a.H >> 1)) m1 = a.H >> 1;
     const bool inside = c0 >= 0 && c0 + 3 < a.W;
     const bool vld = inside && (a.src_stride & 3) == 0;
-    const bool wr = lane >= 1 && lane <= 62 && c0 >= 0 && c0 < a.W;
+    const bool wr = lane >= kEdgeLanes && lane <= 63 - kEdgeLanes && c0 >= 0 && c0 < a.W;
     const bool vst = ((a.W >> 1) & 1) == 0 && (a.ll_stride & 1) == 0;
     const int pc = c0 >> 1;
 
+    // Rows are fetched a chunk (kFwdChunk row pairs) at a time into raw registers, double-buffered:
+    // chunk c+1's loads are issued BEFORE chunk c's subband stores.  vmcnt counts loads and stores
+    // in one in-order queue, so loads issued after stores could only be waited for by draining
+    // those stores too; issued first, the wait is a counted vmcnt that leaves the stores in flight.
     if constexpr (!LOSSY) {
         // vertical 5/3, DWTGenerator.cu:137-157: d[m] = x[2m+1] - ((x[2m]+x[2m+2])>>1);
         // s[m] = x[2m] + ((d[m-1]+d[m]+2)>>2)
+        constexpr int NCH = (kFwdBandRows / 2 + kFwdChunk - 1) / kFwdChunk;
         T xe[4], xo[4], xn[4], dp[4];
-        load_row4<T, U8IN>(a, 2 * m0 - 2, c0, vld, xe);
-        load_row4<T, U8IN>(a, 2 * m0 - 1, c0, vld, xo);
-        load_row4<T, U8IN>(a, 2 * m0, c0, vld, xn);
+        RawRow<U8IN> raw[2][2 * kFwdChunk];
+        const RawRow<U8IN> r0 = load_raw<T, U8IN>(a, 2 * m0 - 2, c0, vld);
+        const RawRow<U8IN> r1 = load_raw<T, U8IN>(a, 2 * m0 - 1, c0, vld);
+        const RawRow<U8IN> r2 = load_raw<T, U8IN>(a, 2 * m0, c0, vld);
+#pragma unroll
+        for (int r = 0; r < 2 * kFwdChunk; r++) raw[0][r] = load_raw<T, U8IN>(a, 2 * m0 + 1 + r, c0, vld);
+        unpack_row<T, U8IN>(r0, xe);
+        unpack_row<T, U8IN>(r1, xo);
+        unpack_row<T, U8IN>(r2, xn);
 #pragma unroll
         for (int k = 0; k < 4; k++) { dp[k] = xo[k] - ((xe[k] + xn[k]) >> 1); xe[k] = xn[k]; }
-        for (int m = m0; m < m1; m++) {
-            load_row4<T, U8IN>(a, 2 * m + 1, c0, vld, xo);
-            load_row4<T, U8IN>(a, 2 * m + 2, c0, vld, xn);
-            T Lr[4], Hr[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                T d = xo[k] - ((xe[k] + xn[k]) >> 1);
-                Lr[k] = xe[k] + ((dp[k] + d + 2) >> 2);
-                Hr[k] = d;
-                dp[k] = d; xe[k] = xn[k];
+        for (int c = 0; c < NCH; c++) {
+            const int mc = m0 + c * kFwdChunk;
+            if (c + 1 < NCH) {
+#pragma unroll
+                for (int r = 0; r < 2 * kFwdChunk; r++)
+                    raw[(c + 1) & 1][r] = load_raw<T, U8IN>(a, 2 * (mc + kFwdChunk) + 1 + r, c0, vld);
             }
-            emit_pair<T, LOSSY>(a, m, pc, wr, vst, Lr, Hr);
+#pragma unroll
+            for (int q = 0; q < kFwdChunk; q++) {
+                const int m = mc + q;
+                unpack_row<T, U8IN>(raw[c & 1][2 * q], xo);
+                unpack_row<T, U8IN>(raw[c & 1][2 * q + 1], xn);
+                T Lr[4], Hr[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    T d = xo[k] - ((xe[k] + xn[k]) >> 1);
+                    Lr[k] = xe[k] + ((dp[k] + d + 2) >> 2);
+                    Hr[k] = d;
+                    dp[k] = d; xe[k] = xn[k];
+                }
+                emit_pair<T, LOSSY>(a, m, pc, wr && m < m1, vst, Lr, Hr);
+            }
         }
     } else {
         // vertical 9/7, DWTGenerator.cu:184-227, streamed: at step j the pair j-1 completes
+        constexpr int NCH = (kFwdBandRows / 2 + 3 + kFwdChunk - 1) / kFwdChunk;
         T xe[4], xo[4], xn[4], d1p[4], s1p[4], d2p[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) { d1p[k] = s1p[k] = d2p[k] = (T)0; }
-        load_row4<T, U8IN>(a, 2 * m0 - 4, c0, vld, xe);
-        for (int j = m0 - 2; j <= m1; j++) {
-            load_row4<T, U8IN>(a, 2 * j + 1, c0, vld, xo);
-            load_row4<T, U8IN>(a, 2 * j + 2, c0, vld, xn);
-            T Lr[4], Hr[4];
+        RawRow<U8IN> raw[2][2 * kFwdChunk];
+        const RawRow<U8IN> r0 = load_raw<T, U8IN>(a, 2 * m0 - 4, c0, vld);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                float d1 = fmaf((float)xe[k] + (float)xn[k], PS_A1, (float)xo[k]);
-                float s1 = fmaf((float)d1p[k] + d1, PS_A2, (float)xe[k]);
-                float d2 = fmaf((float)s1p[k] + s1, PS_A3, (float)d1p[k]);
-                float s2 = fmaf((float)d2p[k] + d2, PS_A4, (float)s1p[k]);
-                Lr[k] = (T)(s2 * PS_N2);
-                Hr[k] = (T)(d2 * PS_N1);
-                d1p[k] = (T)d1; s1p[k] = (T)s1; d2p[k] = (T)d2; xe[k] = xn[k];
+        for (int r = 0; r < 2 * kFwdChunk; r++) raw[0][r] = load_raw<T, U8IN>(a, 2 * (m0 - 2) + 1 + r, c0, vld);
+        unpack_row<T, U8IN>(r0, xe);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const int jc = m0 - 2 + c * kFwdChunk;
+            if (c + 1 < NCH) {
+#pragma unroll
+                for (int r = 0; r < 2 * kFwdChunk; r++)
+                    raw[(c + 1) & 1][r] = load_raw<T, U8IN>(a, 2 * (jc + kFwdChunk) + 1 + r, c0, vld);
             }
-            if (j - 1 >= m0) emit_pair<T, LOSSY>(a, j - 1, pc, wr, vst, Lr, Hr);
+#pragma unroll
+            for (int q = 0; q < kFwdChunk; q++) {
+                const int j = jc + q;
+                unpack_row<T, U8IN>(raw[c & 1][2 * q], xo);
+                unpack_row<T, U8IN>(raw[c & 1][2 * q + 1], xn);
+                T Lr[4], Hr[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float d1 = fmaf((float)xe[k] + (float)xn[k], PS_A1, (float)xo[k]);
+                    float s1 = fmaf((float)d1p[k] + d1, PS_A2, (float)xe[k]);
+                    float d2 = fmaf((float)s1p[k] + s1, PS_A3, (float)d1p[k]);
+                    float s2 = fmaf((float)d2p[k] + d2, PS_A4, (float)s1p[k]);
+                    Lr[k] = (T)(s2 * PS_N2);
+                    Hr[k] = (T)(d2 * PS_N1);
+                    d1p[k] = (T)d1; s1p[k] = (T)s1; d2p[k] = (T)d2; xe[k] = xn[k];
+                }
+                emit_pair<T, LOSSY>(a, j - 1, pc, wr && j - 1 >= m0 && j <= m1, vst, Lr, Hr);
+            }
         }
     }
 }
@@ -346,14 +419,14 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int strip = blockIdx.x * 4 + wave;
     if (strip * kStripUseful >= a.W) return;
-    const int c0 = strip * kStripUseful - 4 + 4 * lane;
+    const int c0 = strip * kStripUseful - 4 * kEdgeLanes + 4 * lane;
     const int pc = c0 >> 1;                                  // arithmetic shift: -4 -> -2
     const int hW = a.W >> 1, hH = a.H >> 1;
     const int m0 = blockIdx.y * (kInvBandRows / 2);
     int m1 = m0 + kInvBandRows / 2;
     if (m1 > hH) m1 = hH;
     const bool inside = pc >= 0 && pc + 1 < hW;
-    const bool wr = lane >= 1 && lane <= 62 && c0 >= 0 && c0 < a.W;
+    const bool wr = lane >= kEdgeLanes && lane <= 63 - kEdgeLanes && c0 >= 0 && c0 < a.W;
     const bool vst = (a.W & 3) == 0;
 
     if constexpr (!LOSSY) {
@@ -361,6 +434,7 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
         T Hp[4], sp[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) { Hp[k] = sp[k] = 0; }
+#pragma unroll PICSONG_DWT_UNROLL
         for (int j = m0 - 1; j <= m1; j++) {
             T Lr[4], Hr[4];
             load_sub4<T, LOSSY>(a, reflect_s(j, hH), false, pc, inside, Lr);
@@ -385,6 +459,7 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
         T ddp[4], s1p[4], d1p[4], s0p[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) { ddp[k] = s1p[k] = d1p[k] = s0p[k] = (T)0; }
+#pragma unroll PICSONG_DWT_UNROLL
         for (int j = m0 - 2; j <= m1 + 1; j++) {
             T Lr[4], Hr[4];
             load_sub4<T, LOSSY>(a, reflect_s(j, hH), false, pc, inside, Lr);

@@ -5,6 +5,7 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <vector>
 
 #include "dwt_kernels.hpp"
@@ -25,8 +26,27 @@ static const float kQSteps[10][4] = {
     { 1086.1624f, 550.43286f, 550.43286f, 278.94202f }
 };
 
-struct FwdLaunch { DwtFwdArgs a; unsigned gx, gy; bool u8; };
+struct FwdLaunch { DwtFwdArgs a; unsigned gx, gy; bool u8; int band; };
 struct InvLaunch { DwtInvArgs a; unsigned gx, gy; };
+
+// Band height per level: big levels want taller bands (less vertical halo re-read), small levels
+// want many short waves (a level with a handful of tall waves is bound by one wave's serial
+// instruction time, not by memory); PICSONG_DWT_BANDS="16,8,4,..." overrides per level.
+inline int fwd_band_rows(int level, int strips, int H)
+{
+    if (const char *e = getenv("PICSONG_DWT_BANDS")) {
+        int l = 0;
+        for (const char *p = e; *p; l++) {
+            int v = atoi(p);
+            if (l == level && (v == 4 || v == 8 || v == 16 || v == 32)) return v;
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+        }
+    }
+    // measured on MI355X (8K: 16,8,4,4,4 best; 4K: 8,8,4,4,4): by level size in samples
+    const long n = (long)H * (long)strips * kStripUseful;
+    return n >= (16L << 20) ? 16 : (n >= (4L << 20) ? 8 : 4);
+}
 
 inline std::vector<FwdLaunch> plan_dwt_forward(const void *d_in, bool u8in, void *d_out, int aw, int ah,
                                                int wl, float qs)
@@ -47,8 +67,9 @@ inline std::vector<FwdLaunch> plan_dwt_forward(const void *d_in, bool u8in, void
         a.mallat = d_out; a.AW = aw; a.level = l; a.last = last ? 1 : 0; a.qs = qs;
         for (int k = 0; k < 4; k++) a.q[k] = kQSteps[l][k];
         const int strips = (W + kStripUseful - 1) / kStripUseful;
+        f.band = fwd_band_rows(l, strips, H);
         f.gx = (unsigned)((strips + 3) / 4);
-        f.gy = (unsigned)(((H >> 1) + kFwdBandRows / 2 - 1) / (kFwdBandRows / 2));
+        f.gy = (unsigned)(((H >> 1) + f.band / 2 - 1) / (f.band / 2));
         f.u8 = u8in && l == 0;
         v.push_back(f);
         src = (const char *)d_out + off * 4;

@@ -68,6 +68,19 @@ struct picsong_ctx {
     int prof_cap, prof_n;
 };
 
+template <int BAND>
+static void launch_fwd(const picsong_ctx *c, const FwdLaunch &f, hipStream_t s)
+{
+    dim3 grid(f.gx, f.gy);
+    if (c->p.lossy) {
+        if (f.u8) dwt_fwd_kernel<float, true, true, BAND><<<grid, 256, 0, s>>>(f.a);
+        else dwt_fwd_kernel<float, true, false, BAND><<<grid, 256, 0, s>>>(f.a);
+    } else {
+        if (f.u8) dwt_fwd_kernel<int, false, true, BAND><<<grid, 256, 0, s>>>(f.a);
+        else dwt_fwd_kernel<int, false, false, BAND><<<grid, 256, 0, s>>>(f.a);
+    }
+}
+
 extern "C" {
 
 const char *picsong_last_error(void) { return g_err; }
@@ -335,13 +348,11 @@ int picsong_level_shift_inv(picsong_ctx *c, void *d_data, void *stream)
 static int dwt_forward_impl(picsong_ctx *c, const void *d_in, bool u8in, void *d_out, hipStream_t s)
 {
     for (const FwdLaunch &f : plan_dwt_forward(d_in, u8in, d_out, c->aw, c->ah, c->p.wl, c->p.qs)) {
-        dim3 grid(f.gx, f.gy);
-        if (c->p.lossy) {
-            if (f.u8) dwt_fwd_kernel<float, true, true><<<grid, 256, 0, s>>>(f.a);
-            else dwt_fwd_kernel<float, true, false><<<grid, 256, 0, s>>>(f.a);
-        } else {
-            if (f.u8) dwt_fwd_kernel<int, false, true><<<grid, 256, 0, s>>>(f.a);
-            else dwt_fwd_kernel<int, false, false><<<grid, 256, 0, s>>>(f.a);
+        switch (f.band) {
+        case 32: launch_fwd<32>(c, f, s); break;
+        case 16: launch_fwd<16>(c, f, s); break;
+        case 8: launch_fwd<8>(c, f, s); break;
+        default: launch_fwd<4>(c, f, s); break;
         }
         HIP_TRY(hipGetLastError());
     }

@@ -10,18 +10,28 @@
 
 using namespace picsong;
 
+template <int BAND> static void emu_fwd(const FwdLaunch &f, int lossy)
+{
+    DwtFwdArgs a = f.a;
+    if (lossy) {
+        if (f.u8) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_fwd_kernel<float, true, true, BAND>(a); });
+        else emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_fwd_kernel<float, true, false, BAND>(a); });
+    } else {
+        if (f.u8) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_fwd_kernel<int, false, true, BAND>(a); });
+        else emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_fwd_kernel<int, false, false, BAND>(a); });
+    }
+}
+
 extern "C" {
 
 void emu_dwt_forward(const void *in, int u8in, void *out, int aw, int ah, int wl, int lossy, float qs)
 {
     for (const FwdLaunch &f : plan_dwt_forward(in, u8in != 0, out, aw, ah, wl, qs)) {
-        DwtFwdArgs a = f.a;
-        if (lossy) {
-            if (f.u8) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_fwd_kernel<float, true, true>(a); });
-            else emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_fwd_kernel<float, true, false>(a); });
-        } else {
-            if (f.u8) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_fwd_kernel<int, false, true>(a); });
-            else emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_fwd_kernel<int, false, false>(a); });
+        switch (f.band) {
+        case 32: emu_fwd<32>(f, lossy); break;
+        case 16: emu_fwd<16>(f, lossy); break;
+        case 8: emu_fwd<8>(f, lossy); break;
+        default: emu_fwd<4>(f, lossy); break;
         }
     }
 }
