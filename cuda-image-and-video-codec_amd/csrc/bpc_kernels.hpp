@@ -561,6 +561,9 @@ __device__ __forceinline__ ColHalf make_col(uint32_t x1, uint32_t x2, uint32_t x
     fa32(c1, c2, c3, t1, d1);
     r.n1 = t1 ^ c4; d2 = t1 & c4;
     r.n2 = d1 ^ d2; r.n3 = d1 & d2;
+    r.n1 = __builtin_amdgcn_alignbit(r.n1, r.n1, 31u);      // rotate left by 1 (see enc_spp_coeff)
+    r.n2 = __builtin_amdgcn_alignbit(r.n2, r.n2, 30u);      // rotate left by 2
+    r.n3 = __builtin_amdgcn_alignbit(r.n3, r.n3, 30u);      // rotate left by 2
     // contributions: +1 significant & positive, -1 significant & negative (BPCEngine.cu:302-305)
     uint32_t pu = us & ~ug, nu = us & ug, pd = ds & ~dg, nd = ds & dg;
     uint32_t pl = ls & ~lg, nl = ls & lg, pr = rs & ~rg, nr = rs & rg;
@@ -571,6 +574,8 @@ __device__ __forceinline__ ColHalf make_col(uint32_t x1, uint32_t x2, uint32_t x
     uint32_t c0 = hn | (vn & ~hp);
     r.c1 = (~(hp | hn) & (vp | vn)) | same;
     r.c2 = ((hp | hn) & ~(vp | vn)) | same;
+    r.c1 = __builtin_amdgcn_alignbit(r.c1, r.c1, 29u);      // rotate left by 3
+    r.c2 = __builtin_amdgcn_alignbit(r.c2, r.c2, 28u);      // rotate left by 4
     r.s2 = self_sgn ^ c0;
     return r;
 }
@@ -586,40 +591,74 @@ __device__ __forceinline__ uint32_t wave_or32(uint32_t v)
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-// arithmeticEncoder BPCEngine.cu:371-399, one call site, codeword stored straight to the staging
-__device__ __forceinline__ void enc_site(Coder &c, bool active, uint32_t sym, uint32_t p, uint32_t prec,
-                                         uint32_t lane, int32_t *st)
+// Slot reservation for the encoder: m = ballot of the lanes that need a codeword.
+// lower_mask / upper_mask are per-lane constants (all ones in lanes 0-31 / 32-63).  The lower
+// half's ballot word is masked per lane and handed to v_mbcnt_lo as a VGPR, so lanes 32-63 start
+// their rank at their own counter; v_mbcnt_hi then adds the upper half's rank (0 in lanes 0-31).
+// `count` is a VGPR that is uniform across each half; v_bcnt adds the half's population to it.
+__device__ __forceinline__ void reserve_enc(Coder &c, bool need, uint64_t m, uint32_t lower_mask, uint32_t upper_mask)
 {
-    bool need = active && c.S == 0u;
-    uint64_t m = __builtin_amdgcn_ballot_w64(need);
-    if (m != 0ull) reserve(c, need, lane, m);
-    uint32_t a = (__umul24(c.S, p) >> prec) + sym;
-    uint32_t S1 = sym ? c.S - a : a;
-    uint32_t L1 = c.L + (sym ? a : 0u);
-    if (active) {
-        c.S = S1; c.L = L1;
-        if (S1 == 0u) st[1u + c.slot] = (int32_t)L1;
+    const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
+    const uint32_t vlo = mlo & lower_mask;                 // lower half's needs, 0 in the upper lanes
+    const uint32_t vhalf = (mhi & upper_mask) | vlo;       // this lane's half's needs
+    uint32_t s = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(vlo, c.count));
+    s = s > 4094u ? 4094u : s;
+    c.L = need ? 0u : c.L;
+    c.S = need ? 0xFFFFu : c.S;
+    c.slot = need ? s : c.slot;
+    const uint32_t n = (uint32_t)__builtin_popcount(vhalf) + c.count;
+    c.count = n > 4095u ? 4095u : n;
+}
+
+// arithmeticEncoder BPCEngine.cu:371-399, one call site; `inact` = 1 for lanes that sit this call
+// site out.  VALU instructions are what this kernel is bound by (SALU issues beside them), so:
+// the need-ballot is ONE compare ((S | inact) == 0), the state update runs inside an exec-masked
+// region (no selects for idle lanes), and the interval update uses 24-bit mads:
+//   a = ((S*p) >> prec) + sym;  S' = sym ? S - a : a = a + sym*(S - 2a);  L' = L + sym*a.
+__device__ __forceinline__ void enc_site(Coder &c, uint32_t inact, uint32_t sym, uint32_t p, uint32_t prec,
+                                         uint32_t lower_mask, uint32_t upper_mask, int32_t *st)
+{
+    const bool need = (c.S | inact) == 0u;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(need);
+    if (m != 0ull) reserve_enc(c, need, m, lower_mask, upper_mask);
+    if (inact == 0u) {
+        const uint32_t a = (__umul24(c.S, p) >> prec) + sym;
+        const int32_t t = (int32_t)(c.S - a) - (int32_t)a;                  // S - 2a, |t| < 2^17
+        c.S = (uint32_t)(__mul24((int32_t)sym, t) + (int32_t)a);
+        c.L = __umul24(sym, a) + c.L;
+        if (c.S == 0u) st[1u + c.slot] = (int32_t)c.L;
     }
 }
 
-__device__ __forceinline__ void enc_spp_coeff(Coder &c, uint32_t ii, uint32_t V, uint32_t B, const ColHalf &cp,
-                                              const PlaneLut &pl, uint32_t prec, uint32_t lane, int32_t *st)
+// Context masks are kept pre-rotated (n1 by 1, n2 and n3 by 2 bits; sign bits c1 by 3, c2 by 4) so
+// that one rotate-right by the row index drops each bit where the consumer wants it.
+__device__ __forceinline__ uint32_t rotr32(uint32_t v, uint32_t sh) { return __builtin_amdgcn_alignbit(v, v, sh); }
+__device__ __forceinline__ uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+
+// A: significant-before mask of the column's 32 rows (all ones for an idle half): a set bit = skip.
+__device__ __forceinline__ void enc_spp_coeff(Coder &c, uint32_t ii, uint32_t A, uint32_t B, const ColHalf &cp,
+                                              const PlaneLut &pl, uint32_t prec, uint32_t lower_mask,
+                                              uint32_t upper_mask, int32_t *st)
 {
-    const bool visit = (V >> ii) & 1u;
+    const uint32_t inact = (A >> ii) & 1u;
     const uint32_t sym = (B >> ii) & 1u;
-    const uint32_t ctx = ((cp.n0 >> ii) & 1u) | (((cp.n1 >> ii) & 1u) << 1) | (((cp.n2 >> ii) & 1u) << 2);
-    uint32_t p = __builtin_amdgcn_perm(pl.sig1, pl.sig0, ctx | 0x0C0C0C00u);
-    p = ((cp.n3 >> ii) & 1u) ? pl.sig8 : p;
-    enc_site(c, visit, sym, p, prec, lane, st);
-    const bool became = visit && sym;
-    if (__builtin_amdgcn_ballot_w64(became) != 0ull) {
-        const uint32_t idx = ((cp.c1 >> ii) & 1u) | (((cp.c2 >> ii) & 1u) << 1);
-        const uint32_t p2 = (pl.sign >> (8u * idx)) & 0xFFu;
-        enc_site(c, became, (cp.s2 >> ii) & 1u, p2, prec, lane, st);
+    // byte selector of v_perm: bits 0..2 = context 0..7, other selector bytes = 0x0C (constant 0)
+    uint32_t sel = (rotr32(cp.n0, ii) & 1u) | 0x0C0C0C00u;
+    sel = bfi32(2u, rotr32(cp.n1, ii), sel);
+    sel = bfi32(4u, rotr32(cp.n2, ii), sel);
+    const uint32_t p07 = __builtin_amdgcn_perm(pl.sig1, pl.sig0, sel);
+    // context 8 (n3 set => n0 = n1 = n2 = 0): a second byte select takes p8 (byte 4) instead of p07
+    const uint32_t p = __builtin_amdgcn_perm(pl.sig8, p07, (rotr32(cp.n3, ii) & 4u) | 0x0C0C0C00u);
+    enc_site(c, inact, sym, p, prec, lower_mask, upper_mask, st);
+    const uint32_t inact2 = inact | (sym ^ 1u);
+    if (__builtin_amdgcn_ballot_w64(inact2 == 0u) != 0ull) {
+        // bit offset of the sign probability inside pl.sign = 8 * (c >> 1)
+        const uint32_t off = (rotr32(cp.c2, ii) & 16u) | (rotr32(cp.c1, ii) & 8u);
+        const uint32_t p2 = (pl.sign >> off) & 0xFFu;
+        enc_site(c, inact2, (cp.s2 >> ii) & 1u, p2, prec, lower_mask, upper_mask, st);
     }
 }
 
-// One wave64 per workgroup, two codeblocks (lanes 0-31 / 32-63), no LDS.
 #ifndef PICSONG_BPC_ENC_WAVES
 #define PICSONG_BPC_ENC_WAVES 4        // waves per SIMD the register allocator must leave room for
 #endif
@@ -702,6 +741,7 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
     const int grp = level * a.g.nSub + sb;
 
     Coder c = { 0u, 0u, 0u, 0u, 0u };
+    const uint32_t upper_mask = half ? 0xFFFFFFFFu : 0u, lower_mask = ~upper_mask;
     U64 AL = { 0u, 0u }, AR = { 0u, 0u };                 // significant before the current plane
     const U64 sgPL = u_prev(sgR, t), sgNL = u_next(sgL, t);     // neighbour sign columns
 
@@ -742,14 +782,14 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
                                          dn_of(AL, hw), dn_of(AR, hw), dn_of(ANL, hw),
                                          up_of(AR2, hw), up_of(sgR, hw), dn_of(AR, hw), dn_of(sgR, hw),
                                          w_of(AL2, hw), w_of(sgL, hw), w_of(ANL2, hw), w_of(sgNL, hw), w_of(sgR, hw));
-            const uint32_t vl = act ? ~w_of(AL, hw) : 0u, vr = act ? ~w_of(AR, hw) : 0u;
+            const uint32_t al = act ? w_of(AL, hw) : 0xFFFFFFFFu, ar = act ? w_of(AR, hw) : 0xFFFFFFFFu;
             const uint32_t bl = w_of(BL, hw), br = w_of(BR, hw);
-            uint32_t rows = wave_or32(vl | vr);
+            uint32_t rows = wave_or32(~(al & ar));
             while (rows) {
                 const uint32_t ii = (uint32_t)__builtin_ctz(rows);
                 rows &= rows - 1u;
-                enc_spp_coeff(c, ii, vl, bl, cpL, pl, prec, lane, st);
-                enc_spp_coeff(c, ii, vr, br, cpR, pl, prec, lane, st);
+                enc_spp_coeff(c, ii, al, bl, cpL, pl, prec, lower_mask, upper_mask, st);
+                enc_spp_coeff(c, ii, ar, br, cpR, pl, prec, lower_mask, upper_mask, st);
             }
         }
         // ---- magnitude refinement pass: coefficients significant before this plane
@@ -761,9 +801,9 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
             while (rows) {
                 const uint32_t ii = (uint32_t)__builtin_ctz(rows);
                 rows &= rows - 1u;
-                const bool aL = (ml >> ii) & 1u, aR = (mr >> ii) & 1u;
-                if (__builtin_amdgcn_ballot_w64(aL) != 0ull) enc_site(c, aL, (bl >> ii) & 1u, pl.ref, prec, lane, st);
-                if (__builtin_amdgcn_ballot_w64(aR) != 0ull) enc_site(c, aR, (br >> ii) & 1u, pl.ref, prec, lane, st);
+                const uint32_t iL = ((ml >> ii) & 1u) ^ 1u, iR = ((mr >> ii) & 1u) ^ 1u;
+                if (__builtin_amdgcn_ballot_w64(iL == 0u) != 0ull) enc_site(c, iL, (bl >> ii) & 1u, pl.ref, prec, lower_mask, upper_mask, st);
+                if (__builtin_amdgcn_ballot_w64(iR == 0u) != 0ull) enc_site(c, iR, (br >> ii) & 1u, pl.ref, prec, lower_mask, upper_mask, st);
             }
         }
         AL = AL2; AR = AR2;
