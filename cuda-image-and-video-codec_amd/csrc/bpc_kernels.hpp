@@ -36,6 +36,7 @@ struct BpcArgs {
     int32_t *coeffs_out;           // decoder: Mallat int32[AW*AH]
     int is_float;                  // encoder input is float (truncated toward zero on load)
     int AW, AH, wl, nCB, ncx;
+    int cb_base;                   // first codeblock of this launch (intra-frame striping), nCB = end
     const int32_t *lut;
     LutGeo g;
     int32_t *staging;              // int32[nCB*4096]
@@ -665,11 +666,11 @@ __device__ __forceinline__ void enc_spp_coeff(Coder &c, uint32_t ii, uint32_t A,
 __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(BpcArgs a)
 {
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
-    const int cb = 2 * (int)blockIdx.x + (int)half;
+    const int cb = a.cb_base + 2 * (int)blockIdx.x + (int)half;
     const bool valid = cb < a.nCB;
     const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
     const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
-    int32_t *st = a.staging + (size_t)(valid ? cb : 0) * 4096u;
+    int32_t *st = a.staging + (size_t)(valid ? cb : a.cb_base) * 4096u;
     const int lut_total = a.g.nRef + a.g.nSig + a.g.nSign;
     const uint32_t prec = (uint32_t)a.g.prec;
 

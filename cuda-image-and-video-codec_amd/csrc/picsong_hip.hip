@@ -401,17 +401,20 @@ static int bpc_args(picsong_ctx *c, BpcArgs &a)
 }
 
 static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_staging, int32_t *d_sizes,
-                           bool memset_staging, hipStream_t s)
+                           bool memset_staging, hipStream_t s, int cb_begin = 0, int cb_count = -1)
 {
     BpcArgs a;
     int rc = bpc_args(c, a);
     if (rc) return rc;
+    if (cb_count < 0) cb_count = c->ncb - cb_begin;
+    a.cb_base = cb_begin;
+    a.nCB = cb_begin + cb_count;
     a.coeffs_in = d_coeffs; a.is_float = c->p.lossy ? 1 : 0;
     a.staging = d_staging; a.sizes = d_sizes;
     // BPCEngine::deviceMemoryAllocator BPCEngine.cu:2429-2441.  Slots beyond a codeblock's length
     // are never read downstream, so the fused frame path skips this 4*AW*AH-byte fill.
     if (memset_staging) HIP_TRY(hipMemsetAsync(d_staging, 0xFF, c->P * sizeof(int32_t), s));
-    bpc_encode_kernel<<<(unsigned)((c->ncb + 1) / 2), 64, 0, s>>>(a);
+    bpc_encode_kernel<<<(unsigned)((cb_count + 1) / 2), 64, 0, s>>>(a);
     HIP_TRY(hipGetLastError());
     return PICSONG_OK;
 }
@@ -460,18 +463,25 @@ int picsong_last_total(picsong_ctx *c, void *stream, int *h_total)
     return PICSONG_OK;
 }
 
+static int pack_range(picsong_ctx *c, const int32_t *d_staging, const int32_t *d_sizes, int n,
+                      const uint16_t *h_header, uint16_t *d_stream, hipStream_t s)
+{
+    HeaderArg h;
+    memset(&h, 0, sizeof h);
+    if (h_header) { memcpy(h.h, h_header, sizeof h.h); h.has = 1; }
+    scan_sizes_kernel<<<1, 1024, 0, s>>>(d_sizes, n, c->d_offsets, c->d_total);
+    HIP_TRY(hipGetLastError());
+    pack_kernel<<<(unsigned)n, 256, 0, s>>>(d_staging, d_sizes, c->d_offsets, c->d_total, n, h, d_stream);
+    HIP_TRY(hipGetLastError());
+    return PICSONG_OK;
+}
+
 int picsong_bitstream_pack(picsong_ctx *c, const int32_t *d_staging, const int32_t *d_sizes,
                            const uint16_t *h_header, uint16_t *d_stream, int *h_total, void *stream)
 {
     if (!c || !d_staging || !d_sizes || !d_stream) return fail(PICSONG_ERR_ARG, "bitstream_pack: null argument");
-    hipStream_t s = (hipStream_t)stream;
-    HeaderArg h;
-    memset(&h, 0, sizeof h);
-    if (h_header) { memcpy(h.h, h_header, sizeof h.h); h.has = 1; }
-    scan_sizes_kernel<<<1, 1024, 0, s>>>(d_sizes, c->ncb, c->d_offsets, c->d_total);
-    HIP_TRY(hipGetLastError());
-    pack_kernel<<<(unsigned)c->ncb, 256, 0, s>>>(d_staging, d_sizes, c->d_offsets, c->d_total, c->ncb, h, d_stream);
-    HIP_TRY(hipGetLastError());
+    int rc = pack_range(c, d_staging, d_sizes, c->ncb, h_header, d_stream, (hipStream_t)stream);
+    if (rc) return rc;
     if (h_total) return picsong_last_total(c, stream, h_total);
     return PICSONG_OK;
 }
@@ -569,6 +579,22 @@ int picsong_decode_frame(picsong_ctx *c, const uint16_t *d_stream, uint8_t *d_fr
     else to_u8_kernel<int32_t><<<grid, 256, 0, s>>>((const int32_t *)img, d_frame_out, c->P);
     HIP_TRY(hipGetLastError());
     return PICSONG_OK;
+}
+
+int picsong_encode_frame_stripe(picsong_ctx *c, const uint8_t *d_frame, int cb_begin, int cb_count,
+                                uint16_t *d_stream, void *stream)
+{
+    if (!c || !d_frame || !d_stream) return fail(PICSONG_ERR_ARG, "encode_frame_stripe: null argument");
+    if (cb_begin < 0 || cb_count <= 0 || cb_begin + cb_count > c->ncb)
+        return fail(PICSONG_ERR_ARG, "encode_frame_stripe: codeblocks [%d, %d) outside [0, %d)", cb_begin,
+                    cb_begin + cb_count, c->ncb);
+    int rc = ensure_workspace(c, false);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = dwt_forward_impl(c, d_frame, true, c->d_coef, s))) return rc;
+    if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, s, cb_begin, cb_count))) return rc;
+    return pack_range(c, c->d_staging + (size_t)cb_begin * PICSONG_CB_WORDS, c->d_sizes + cb_begin, cb_count, nullptr,
+                      d_stream, s);
 }
 
 int picsong_pad_frame_host(const uint8_t *in, int w, int h, uint8_t *out, int aw, int ah)

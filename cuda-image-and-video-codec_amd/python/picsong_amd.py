@@ -35,6 +35,7 @@ EXPORTS = [
     "picsong_dwt_forward_u8", "picsong_bpc_encode", "picsong_bpc_decode", "picsong_bitstream_pack",
     "picsong_bitstream_unpack", "picsong_last_total", "picsong_encode_frame", "picsong_decode_frame",
     "picsong_pad_frame_host", "picsong_range_flag", "picsong_profile_begin", "picsong_profile_read",
+    "picsong_encode_frame_stripe",
 ]
 
 _lib = None
@@ -81,6 +82,7 @@ def load():
     L.picsong_last_total.argtypes = [vp, vp, C.POINTER(i)]
     L.picsong_encode_frame.argtypes = [vp, vp, i, vp, vp]
     L.picsong_decode_frame.argtypes = [vp, vp, vp, vp]
+    L.picsong_encode_frame_stripe.argtypes = [vp, vp, i, i, vp, vp]
     L.picsong_pad_frame_host.argtypes = [vp, i, i, vp, i, i]
     L.picsong_range_flag.argtypes = [vp, vp, C.POINTER(i)]
     L.picsong_profile_begin.argtypes = [vp, i]
@@ -268,6 +270,13 @@ class Codec:
     def encode_frame(self, frame_u8_padded, iter_=0):
         out = self.torch.empty(self.max_stream_shorts(), dtype=self.torch.int16, device=self.dev)
         self.encode_frame_async(frame_u8_padded, out, iter_)
+        return out[:self.last_total()]
+
+    def encode_frame_stripe(self, frame_u8_padded, cb_begin, cb_count):
+        """Mini-stream (9 x 0xFFFF | pairs | payload | 0xFFFF) of codeblocks [cb_begin, +cb_count)."""
+        out = self.torch.empty(9 + 2 * cb_count + cb_count * 4096 + 1, dtype=self.torch.int16, device=self.dev)
+        _check(self.L.picsong_encode_frame_stripe(self.h, self._p(frame_u8_padded), cb_begin, cb_count,
+                                                  self._p(out), self._stream()))
         return out[:self.last_total()]
 
     def decode_frame(self, stream):

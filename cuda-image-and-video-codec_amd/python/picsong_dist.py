@@ -82,3 +82,38 @@ def encode_video_distributed(n_frames, encode_fn, rank, world, device, on_frame=
 def size_sidecar(sizes):
     """`<o>_SIZE` contents: decimal lengths in shorts, comma-separated, no trailing newline."""
     return ",".join(str(int(s)) for s in sizes)
+
+
+# ---- intra-frame sharding (BASELINE config 5): stripes of codeblocks of ONE frame ---------------
+def stripe_ranges(n_cb, world):
+    """Contiguous codeblock ranges [(begin, count)] per rank, sizes differing by at most 1."""
+    q, r = divmod(n_cb, world)
+    out, b = [], 0
+    for k in range(world):
+        n = q + (1 if k < r else 0)
+        out.append((b, n))
+        b += n
+    return out
+
+
+def splice_stripes(header9, mini_streams, counts):
+    """Root side: 1-GPU codestream from the per-rank mini-streams (each 9 x 0xFFFF | count pairs |
+    payload | 0xFFFF): header + all pair tables + all payloads + one trailing 0xFFFF."""
+    pairs = [m[9:9 + 2 * n] for m, n in zip(mini_streams, counts)]
+    payloads = [m[9 + 2 * n:-1] for m, n in zip(mini_streams, counts)]
+    tail = mini_streams[0][-1:]
+    return torch.cat([header9] + pairs + payloads + [tail])
+
+
+def encode_frame_striped(n_cb, encode_stripe_fn, header9, rank, world, device, group=None):
+    """Every rank codes its stripe (`encode_stripe_fn(begin, count) -> mini-stream tensor`); rank 0
+    returns the spliced full codestream, other ranks None.  One gatherv = the only exchange."""
+    ranges = stripe_ranges(n_cb, world)
+    b, n = ranges[rank]
+    local = encode_stripe_fn(b, n) if n > 0 else None
+    got = gather_round(local, rank, world, device, group=group)
+    if rank != 0:
+        return None
+    minis = [g for g, (_, cnt) in zip(got, ranges) if cnt > 0]
+    counts = [cnt for _, cnt in ranges if cnt > 0]
+    return splice_stripes(header9, minis, counts)

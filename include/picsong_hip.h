@@ -140,6 +140,16 @@ int picsong_encode_frame(picsong_ctx *ctx, const uint8_t *d_frame, int iter, uin
                          void *stream);
 int picsong_decode_frame(picsong_ctx *ctx, const uint16_t *d_stream, uint8_t *d_frame_out,
                          void *stream);
+/* ---- intra-frame sharding (BASELINE config 5): codeblocks are independent
+ *      (correctCBBorders zeroes outside neighbours, BPC/BPCEngine.cu:465-484), so a rank can code
+ *      the stripe [cb_begin, cb_begin + cb_count) of the frame's raster-ordered codeblocks.  The
+ *      stripe leaves as a self-describing mini-stream with the normal layout for cb_count blocks:
+ *      9 x 0xFFFF | cb_count x (MSB, len) | payload | 0xFFFF.  The writer rank splices: header(9) +
+ *      all pair tables in stripe order + all payloads in stripe order + 0xFFFF == the 1-GPU
+ *      stream.  The DWT is computed for the whole frame on every rank (it needs all rows).
+ *      Asynchronous; length via picsong_last_total(). ---- */
+int picsong_encode_frame_stripe(picsong_ctx *ctx, const uint8_t *d_frame, int cb_begin, int cb_count,
+                                uint16_t *d_stream, void *stream);
 /* host helper: IOManager::loadFrameCAdaptedSizes' mirror padding (IO/IOManager.ipp:72-112) */
 int picsong_pad_frame_host(const uint8_t *in, int w, int h, uint8_t *out, int aw, int ah);
 

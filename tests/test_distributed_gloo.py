@@ -80,3 +80,53 @@ def test_shard_helpers():
     assert pd.shard_frames(3, 3, 4) == []
     assert [pd.owner_of(f, 8) for f in (0, 7, 8, 255)] == [0, 7, 0, 7]
     assert pd.size_sidecar([12, 3456, 7]) == "12,3456,7"
+
+
+# ---- intra-frame sharding (BASELINE config 5 in miniature) -------------------------------------
+SW, SH, SWL = 256, 192, 2          # 4 x 3 = 12 codeblocks
+
+
+def _stripe_worker(rank, world, port, outdir):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(ROOT, "cuda-image-and-video-codec_amd", "python"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as orc
+    import picsong_dist as pd
+    lut = orc.lut_for(False, SWL)
+    img = orc.pad_frame(orc.gen_frame(SW, SH, 9))
+    coef = orc.dwt_forward(orc.level_shift_fwd(img, False), SWL)[:SW * SH].reshape(SH, SW)
+    staging, sizes = orc.bpc_encode(coef, SWL, lut)          # every rank has the whole frame's DWT
+
+    def encode_stripe(b, n):                                  # oracle stand-in for encode_frame_stripe
+        mini = orc.bitstream_pack(staging[b * 4096:(b + n) * 4096], sizes[b:b + n], None)
+        return torch.from_numpy(mini.view(np.int16).copy())
+
+    hdr = orc.header_pack(n_samples=SW * SH, cp=2, cb_height=18, cb_width=64, wl=SWL, bit_depth=8, lossy=0,
+                          qs_1e4=10000, components=1, is_rgb=0, height=SH, endianess=0, bps=8, is_signed=0,
+                          frames=0, k_1e3=0)
+    full = pd.encode_frame_striped(sizes.size, encode_stripe, torch.from_numpy(hdr.view(np.int16).copy()), rank,
+                                   world, torch.device("cpu"))
+    if rank == 0:
+        np.save(os.path.join(outdir, "striped.npy"), full.numpy().view(np.uint16))
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_codeblock_stripes_splice_to_single_gpu_stream(oracle, tmp_path, world):
+    port = _free_port()
+    mp.spawn(_stripe_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    ref = oracle.encode_frame(oracle.gen_frame(SW, SH, 9), SWL, False, 1.0, oracle.lut_for(False, SWL), 0, 0)
+    assert np.array_equal(np.load(os.path.join(tmp_path, "striped.npy")), ref)
+
+
+def test_stripe_ranges():
+    sys.path.insert(0, os.path.join(ROOT, "cuda-image-and-video-codec_amd", "python"))
+    import picsong_dist as pd
+    assert pd.stripe_ranges(12, 5) == [(0, 3), (3, 3), (6, 2), (8, 2), (10, 2)]
+    assert pd.stripe_ranges(3, 4) == [(0, 1), (1, 1), (2, 1), (3, 0)]
+    assert sum(n for _, n in pd.stripe_ranges(65536, 8)) == 65536

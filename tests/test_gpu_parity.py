@@ -214,3 +214,45 @@ def test_dwt_linearity_full_size(pa, torch, oracle):
     assert (f[:H >> wl, :W >> wl] == 37).all()
     assert (f[H >> wl:, :] == 0).all() and (f[:, W >> wl:] == 0).all()
     c.close()
+
+
+def test_codeblock_stripes_equal_full_frame(oracle, pa, torch):
+    """Intra-frame sharding on one GPU: the frame coded as 3 uneven stripes and spliced by
+    picsong_dist.splice_stripes is byte-identical to the whole-frame codestream."""
+    import picsong_dist as pd
+    W, H, wl = 640, 448, 3
+    img = oracle.gen_frame(W, H, 4)
+    c = pa.Codec(W, H, wl=wl, lut_folder=_lutdir(oracle, False))
+    frame = _dev(torch, oracle.pad_frame(img))
+    full = c.encode_frame(frame, 0)
+    ranges = pd.stripe_ranges(c.ncb, 3)
+    minis = [c.encode_frame_stripe(frame, b, n).clone() for b, n in ranges]
+    hdr = torch.from_numpy(pa.header_pack(c.params).view(np.int16).copy()).cuda()
+    spliced = pd.splice_stripes(hdr, minis, [n for _, n in ranges])
+    assert torch.equal(spliced, full)
+    ref = oracle.encode_frame(img, wl, False, 1.0, oracle.lut_for(False, wl))
+    assert np.array_equal(spliced.cpu().numpy().view(np.uint16), ref)
+    with pytest.raises(pa.PicsongError):
+        c.encode_frame_stripe(frame, c.ncb - 1, 2)
+    c.close()
+
+
+def test_config5_16k_single_frame_roundtrip(oracle, pa, torch):
+    """BASELINE config 5 geometry on one GPU: 16384 x 16384, -type 0, wl 5, 65,536 codeblocks."""
+    W = H = 16384
+    c = pa.Codec(W, H, wl=5, lut_folder=_lutdir(oracle, False))
+    assert c.ncb == 65536
+    tile = torch.from_numpy(oracle.gen_frame(2048, 2048, 1)).cuda()
+    frame = tile.repeat(8, 8).contiguous()
+    frame[5000:5064, 7000:7064] = torch.randint(0, 256, (64, 64), dtype=torch.uint8, device="cuda")
+    s = c.encode_frame(frame)
+    assert c.range_flag() == 0
+    dec = c.decode_frame(s)
+    assert torch.equal(dec, frame)
+    # two stripes of the same frame splice to the same bytes
+    import picsong_dist as pd
+    ranges = pd.stripe_ranges(c.ncb, 2)
+    minis = [c.encode_frame_stripe(frame, b, n).clone() for b, n in ranges]
+    hdr = torch.from_numpy(pa.header_pack(c.params).view(np.int16).copy()).cuda()
+    assert torch.equal(pd.splice_stripes(hdr, minis, [n for _, n in ranges]), s)
+    c.close()
