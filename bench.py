@@ -34,6 +34,43 @@ WORKLOADS = {
 }
 
 
+def host_cores():
+    """CPU cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def pmc_traffic(workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_hbm.csv:
+    FETCH_SIZE and WRITE_SIZE collected in separate runs of this command with --streams 1, unit
+    1024 B; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note -- calibrated on the DWT
+    kernels' known read bytes).  None when no summary for this workload is committed."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01_final_pmc_hbm.csv")
+    if workload != "8k_lossless" or not os.path.exists(path):
+        return None, None
+    bpc = dwt = 0.0
+    frames = None
+    rows = list(csv.DictReader(open(path)))
+    for r in rows:
+        if "bpc_encode_kernel" in r["Kernel_Name"]:
+            frames = int(r["Dispatches"])
+    for r in rows:
+        mult = 2.0 if r["Counter_Name"] == "FETCH_SIZE" else 1.0
+        b = float(r["MeanValue"]) * 1024.0 * mult
+        if "bpc_encode_kernel" in r["Kernel_Name"]:
+            bpc += b
+        elif "dwt_fwd_kernel" in r["Kernel_Name"] and frames:
+            dwt += b * int(r["Dispatches"]) / frames       # all levels of one frame
+    return (int(bpc) if bpc else None), (int(dwt) if dwt else None)
+
+
 def dwt_bytes(P, wl, s0):
     """P*(s0+4) + 8*P*sum_{l=1}^{wl-1} 4^-l."""
     return P * (s0 + 4) + 8 * P * sum(4.0 ** -l for l in range(1, wl))
@@ -132,6 +169,16 @@ def main():
     total_shorts = codec.last_total()
     flag = codec.range_flag()
 
+    # ---- the same frames on ONE stream, nothing else on the GPU: per-stage kernel time in isolation
+    iso_n = min(args.steps, 10)
+    torch.cuda.synchronize()
+    codec.profile_begin(iso_n)
+    for i in range(iso_n):
+        codec.encode_frame_async(frame, out, 1)
+    torch.cuda.synchronize()
+    iso_ms = codec.profile_read(iso_n).mean(axis=0)
+    codec.profile_begin(0)
+
     # ---- correctness outside the timed region: decode(encode(x)) == x
     stream0 = codec.encode_frame(frame, 0)
     dec = codec.decode_frame(stream0)
@@ -162,9 +209,10 @@ def main():
     dwt_ms, bpc_ms, pack_ms = [float(x) for x in stage_ms.mean(axis=0)]
     bpc_gbs = bpc_bytes / (bpc_ms * 1e-3) / 1e9
     dwt_b = dwt_bytes(P, wl, 1)
-    roofline = {"kernel": "bpc_kernel<false> (BPC-PaCo encode)", "bound": "hbm",
+    bpc_traffic, dwt_traffic = pmc_traffic(args.workload)
+    roofline = {"kernel": "bpc_encode_kernel (BPC-PaCo encode)", "bound": "hbm",
                 "achieved": round(bpc_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(bpc_gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(bpc_gbs / HBM_PEAK_GBS, 5), "traffic": bpc_traffic,
                 "algorithmic_bytes_per_launch": bpc_bytes, "avg_launch_ms": round(bpc_ms, 4),
                 "codeblocks_per_s": round(nCB / (bpc_ms * 1e-3), 1),
                 "note": "BPC is integer/latency-bound, not HBM-bound (SURVEY 8d): codeblocks/s is "
@@ -172,25 +220,65 @@ def main():
     roofline_dwt = {"kernel": "dwt_fwd_kernel (all levels, u8 ingest fused)", "bound": "hbm",
                     "achieved": round(dwt_b / (dwt_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(dwt_b / (dwt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "traffic": None, "algorithmic_bytes_per_launch": int(dwt_b),
-                    "avg_launch_ms": round(dwt_ms, 4)}
+                    "traffic": dwt_traffic, "algorithmic_bytes_per_launch": int(dwt_b),
+                    "avg_launch_ms": round(dwt_ms, 4),
+                    "note": "5 launches (one per level) counted as one; durations are HIP-event times "
+                            "inside the timed region, where frames of the other stream(s) share the GPU"}
 
-    # ---- CPU baseline: the oracle (scalar C port), bounded sample, rank 0, N = 1 only
+    # ---- CPU baseline: the oracle (C port, OpenMP over codeblocks / DWT rows+columns) on the
+    # box's host cores, rank 0, N = 1 only.  Same stage boundaries as the GPU step (level shift +
+    # DWT, BPC, pack) on preallocated, warmed buffers; file I/O and padding excluded.
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        rows = H if args.cpu_sample_rows <= 0 else min(H, max(64 << (wl - 1), (args.cpu_sample_rows // 64) * 64))
-        sample = np.ascontiguousarray(orc.gen_frame(W, H, 0)[:rows])
+        import ctypes as C
+        L = orc.lib()
         lut = orc.lut_for(lossy, wl)
+        rows = AH if args.cpu_sample_rows <= 0 else min(AH, max(64 << (wl - 1), (args.cpu_sample_rows // 64) * 64))
+        pad = np.ascontiguousarray(frame_np[:rows]) if rank == 0 else None
+        Pc = AW * rows
+        ncb_c = (AW // 64) * (rows // 64)
+        extra_c = orc.dwt_extra(AW, rows, wl)
+        ftype = np.float32 if lossy else np.int32
+        shifted = np.zeros(Pc, ftype)
+        coef = np.zeros(Pc + extra_c, ftype)
+        staging = np.zeros(Pc, np.int32)
+        sizes_c = np.zeros(ncb_c, np.int32)
+        out_c = np.zeros(9 + 2 * ncb_c + Pc + 1, np.uint16)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+
+        def cpu_encode():
+            if lossy:
+                L.po_level_shift_fwd_f32(vp(pad), vp(shifted), Pc, 8)
+                L.po_dwt97_forward(vp(shifted), vp(coef), AW, rows, wl, C.c_float(qs))
+            else:
+                L.po_level_shift_fwd_i32(vp(pad), vp(shifted), Pc, 8)
+                L.po_dwt53_forward(vp(shifted), vp(coef), AW, rows, wl)
+            L.po_bpc_encode(vp(coef), int(lossy), AW, rows, wl, C.byref(lut.c), vp(staging), vp(sizes_c))
+            return L.po_bitstream_pack(vp(staging), vp(sizes_c), ncb_c, None, vp(out_c))
+
+        nthr = min(orc.max_threads(), host_cores())
+        orc.set_threads(nthr)
+        cpu_encode()                                   # warm-up (page faults, thread pool)
+        reps, t1 = 0, time.perf_counter()
+        while True:
+            total_c = cpu_encode()
+            reps += 1
+            if time.perf_counter() - t1 > 8.0 or reps >= 64:
+                break
+        mt = (time.perf_counter() - t1) / reps
+        orc.set_threads(1)
         t1 = time.perf_counter()
-        ref_stream = orc.encode_frame(sample, wl, lossy, qs, lut, 0, 0)
-        cdt = time.perf_counter() - t1
-        cpu = {"value": round(W * rows / cdt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-               "sample": f"1 frame {W}x{rows} of the workload, full encode (pad+shift+DWT+BPC+pack), "
-                         f"oracle/picsong_oracle.c -O3, {cdt:.1f} s",
-               "host_cpu_count": os.cpu_count()}
-        if rows == H:
+        cpu_encode()
+        st_ = time.perf_counter() - t1
+        cpu = {"value": round(W * min(H, rows) / mt / 1e6, 2), "unit": "Mpixels/s", "cores": nthr, "kind": "port",
+               "sample": f"{reps} x 1 frame {W}x{min(H, rows)} of the workload, level shift + DWT + BPC + pack on "
+                         f"warmed buffers, oracle/picsong_oracle.c -O3 -fopenmp, {nthr} threads, {mt * reps:.1f} s",
+               "single_thread_value": round(W * min(H, rows) / st_ / 1e6, 3), "host_cpu_count": os.cpu_count(),
+               "host_cpu_quota": host_cores()}
+        if rows == AH:
+            ref_stream = out_c[:total_c]
             cpu["codestream_matches_gpu"] = bool(np.array_equal(
-                ref_stream, stream0.cpu().numpy().view(np.uint16)))
+                ref_stream[9:], stream0.cpu().numpy().view(np.uint16)[9:]))
 
     line = {
         "metric": "Mpixels/s encode (DWT+BPC) 8K P5 lossless; round-trip bit-exact"
@@ -207,6 +295,8 @@ def main():
                    "bits_per_pixel": round(total_shorts * 16 / (W * H), 4)},
         "roundtrip_ok": roundtrip_ok, "range_flag": flag,
         "stage_ms": {"dwt": round(dwt_ms, 4), "bpc": round(bpc_ms, 4), "pack": round(pack_ms, 4)},
+        "stage_ms_single_stream": {"dwt": round(float(iso_ms[0]), 4), "bpc": round(float(iso_ms[1]), 4),
+                                   "pack": round(float(iso_ms[2]), 4)},
         "roofline": roofline, "roofline_dwt": roofline_dwt, "cpu_baseline": cpu,
     }
     if psnr is not None:

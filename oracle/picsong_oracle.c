@@ -18,6 +18,23 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* Threads used by the parallel loops (codeblocks, DWT rows / columns); 1 = scalar port.
+ * Only the CPU-baseline leg of bench.py raises it; results do not depend on it. */
+static int po_threads = 1;
+void po_set_threads(int n) { po_threads = n < 1 ? 1 : n; }
+int po_get_threads(void) { return po_threads; }
+int po_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_num_procs();
+#else
+    return 1;
+#endif
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* geometry / ingest                                                                            */
@@ -221,11 +238,14 @@ void po_dwt53_forward(const int32_t *in, int32_t *out, int AW, int AH, int wl)
     for (int l = 0; l < wl; l++) {
         int last = (l == wl - 1);
         memcpy(tmp, src, (size_t)W * H * sizeof(int32_t));
+        _Pragma("omp parallel for num_threads(po_threads) schedule(static)")
         for (int x = 0; x < W; x++) po_53_fwd_1d(tmp + x, (size_t)W, H);
+        _Pragma("omp parallel for num_threads(po_threads) schedule(static)")
         for (int y = 0; y < H; y++) po_53_fwd_1d(tmp + (size_t)y * W, 1, W);
         off += (size_t)W * H;
         int32_t *ll = last ? out : out + off;
         size_t llst = last ? (size_t)AW : (size_t)(W >> 1);
+        _Pragma("omp parallel for num_threads(po_threads) schedule(static)")
         for (int y = 0; y < H; y += 2)
             for (int x = 0; x < W; x += 2) {
                 size_t r = (size_t)(y >> 1), c = (size_t)(x >> 1);
@@ -253,6 +273,7 @@ void po_dwt53_inverse(const int32_t *in, int32_t *out, int AW, int AH, int wl)
         int first = (l == wl - 1);
         const int32_t *ll = first ? in : out + read_off;
         size_t llst = first ? (size_t)AW : (size_t)(W >> 1);
+        _Pragma("omp parallel for num_threads(po_threads) schedule(static)")
         for (int y = 0; y < H; y += 2)
             for (int x = 0; x < W; x += 2) {
                 size_t r = (size_t)(y >> 1), c = (size_t)(x >> 1);
@@ -261,7 +282,9 @@ void po_dwt53_inverse(const int32_t *in, int32_t *out, int AW, int AH, int wl)
                 tmp[(size_t)(y + 1) * W + x] = in[(r + (H >> 1)) * AW + c];
                 tmp[(size_t)(y + 1) * W + x + 1] = in[(r + (H >> 1)) * AW + c + (W >> 1)];
             }
+        _Pragma("omp parallel for num_threads(po_threads) schedule(static)")
         for (int y = 0; y < H; y++) po_53_inv_1d(tmp + (size_t)y * W, 1, W);
+        _Pragma("omp parallel for num_threads(po_threads) schedule(static)")
         for (int x = 0; x < W; x++) po_53_inv_1d(tmp + x, (size_t)W, H);
         memcpy(out + write_off, tmp, (size_t)W * H * sizeof(int32_t));
         read_off = write_off;
@@ -282,12 +305,15 @@ void po_dwt97_forward(const float *in, float *out, int AW, int AH, int wl, float
     for (int l = 0; l < wl; l++) {
         int last = (l == wl - 1);
         memcpy(tmp, src, (size_t)W * H * sizeof(float));
+        _Pragma("omp parallel for num_threads(po_threads) schedule(static)")
         for (int x = 0; x < W; x++) po_97_fwd_1d(tmp + x, (size_t)W, H);
+        _Pragma("omp parallel for num_threads(po_threads) schedule(static)")
         for (int y = 0; y < H; y++) po_97_fwd_1d(tmp + (size_t)y * W, 1, W);
         off += (size_t)W * H;
         float *ll = last ? out : out + off;
         size_t llst = last ? (size_t)AW : (size_t)(W >> 1);
         const float *q = PO_QSTEPS[l];
+        _Pragma("omp parallel for num_threads(po_threads) schedule(static)")
         for (int y = 0; y < H; y += 2)
             for (int x = 0; x < W; x += 2) {
                 size_t r = (size_t)(y >> 1), c = (size_t)(x >> 1);
@@ -323,6 +349,7 @@ void po_dwt97_inverse(const int32_t *in, float *out, int AW, int AH, int wl, flo
     for (int l = wl - 1; l >= 0; l--) {
         int first = (l == wl - 1);
         const float *q = PO_QSTEPS[l];
+        _Pragma("omp parallel for num_threads(po_threads) schedule(static)")
         for (int y = 0; y < H; y += 2)
             for (int x = 0; x < W; x += 2) {
                 size_t r = (size_t)(y >> 1), c = (size_t)(x >> 1);
@@ -333,7 +360,9 @@ void po_dwt97_inverse(const int32_t *in, float *out, int AW, int AH, int wl, flo
                 tmp[(size_t)(y + 1) * W + x + 1] =
                     po_dequant(in[(r + (H >> 1)) * AW + c + (W >> 1)], q[3], qs);
             }
+        _Pragma("omp parallel for num_threads(po_threads) schedule(static)")
         for (int y = 0; y < H; y++) po_97_inv_1d(tmp + (size_t)y * W, 1, W);
+        _Pragma("omp parallel for num_threads(po_threads) schedule(static)")
         for (int x = 0; x < W; x++) po_97_inv_1d(tmp + x, (size_t)W, H);
         memcpy(out + write_off, tmp, (size_t)W * H * sizeof(float));
         read_off = write_off;
@@ -708,12 +737,14 @@ void po_bpc_encode(const void *coeffs, int is_float, int AW, int AH, int wl, con
     int ncx = AW / PO_CB, ncy = AH / PO_CB;
     /* BPCEngine::deviceMemoryAllocator :2429-2441 -- staging memset to 0xFF */
     memset(staging, 0xFF, (size_t)AW * AH * sizeof(int32_t));
+    _Pragma("omp parallel num_threads(po_threads)")
+    {
     po_cb *cb = (po_cb *)malloc(sizeof(po_cb));
     cb->lut = lut;
     cb->lut_total = lut->n_ref + lut->n_sig + lut->n_sign;
-    for (int cy = 0; cy < ncy; cy++)
-        for (int cx = 0; cx < ncx; cx++) {
-            int id = cy * ncx + cx;
+    _Pragma("omp for schedule(dynamic, 4)")
+    for (int id = 0; id < ncx * ncy; id++) {
+            int cy = id / ncx, cx = id % ncx;
             cb->stage = staging + (size_t)id * PO_CB_WORDS;
             int level[32], sb[32];
             for (int t = 0; t < 32; t++) {
@@ -738,8 +769,9 @@ void po_bpc_encode(const void *coeffs, int is_float, int AW, int AH, int wl, con
                 po_cb_encode(cb, msb);
             }
             sizes[id] = po_cb_finish_encode(cb);
-        }
+    }
     free(cb);
+    }
 }
 
 int po_bpc_encode_block_uniform(const int32_t *block, int level, int sb, int wl, const po_lut *lut,

@@ -62,6 +62,11 @@ typedef struct po_header {
     int k_1e3;            /* floor(k*1000) */
 } po_header;
 
+/* ---- threading of the CPU-baseline leg (OpenMP over codeblocks / DWT rows+columns); default 1 */
+void po_set_threads(int n);
+int  po_get_threads(void);
+int  po_max_threads(void);
+
 /* ---- geometry / ingest (IO/IOManager.ipp:72-112, SupportFunctions/AuxiliarFunctions.cpp:22-26) */
 int  po_pad_dim(int v);
 void po_pad_frame(const uint8_t *in, int W, int H, uint8_t *out, int AW, int AH);

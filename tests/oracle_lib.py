@@ -83,12 +83,23 @@ def lib():
     L.po_encode_frame.argtypes = [vp, i32, i32, i32, i32, f32, C.POINTER(PoLut), i32, i32, vp]
     L.po_decode_frame.restype = i32
     L.po_decode_frame.argtypes = [vp, i32, i32, i32, i32, f32, C.POINTER(PoLut), vp]
+    L.po_set_threads.argtypes = [i32]
+    L.po_get_threads.restype = i32
+    L.po_max_threads.restype = i32
     _lib = L
     return L
 
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def set_threads(n):
+    lib().po_set_threads(int(n))
+
+
+def max_threads():
+    return lib().po_max_threads()
 
 
 class Lut:
