@@ -13,11 +13,12 @@
 //     visit is bit-field extraction (v_alignbit / v_bfe / v_bcnt) on those masks instead of 128
 //     live 32-bit coefficient words per lane, and the "current plane" is always register 0: the
 //     plane registers rotate once per plane, so no register is indexed dynamically.
-//   * neighbour columns arrive by DPP wave_shr:1 / wave_shl:1 once per half-row, not by
-//     three LDS-crossbar shuffles per coefficient.
+//   * neighbour columns arrive by DPP wave_shr:1 / wave_shl:1 -- once per plane in the encoder,
+//     in the decoder only after a lane actually changed state -- not by three LDS-crossbar
+//     shuffles per coefficient.
 //   * codeword slot reservation is a 64-bit ballot split per 32-lane half + v_mbcnt; the per-half
 //     counter lives in a VGPR that is uniform across the half.
-//   * encoder codewords are staged as u16 in LDS and leave the CU as one coalesced burst.
+//   * rows in which no lane of the wave has anything to code are skipped (wave-uniform row mask).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -127,369 +128,8 @@ struct Coder {
     uint32_t count;     // per-half codeword counter (codeStreamShared), uniform across the half
 };
 
-// Slot reservation for the lanes in `need` (their interval is exhausted): ascending lane order
-// inside each 32-lane half (__activemask/__popc, BPCEngine.cu:378-383).  Called in wave-uniform
-// control flow only.
-__device__ __forceinline__ void reserve(Coder &c, bool need, uint32_t lane, uint64_t m)
-{
-    uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
-    uint32_t rank = lane < 32u ? __builtin_amdgcn_mbcnt_lo(mlo, 0u) : __builtin_amdgcn_mbcnt_hi(mhi, 0u);
-    uint32_t pc = (uint32_t)__builtin_popcount(lane < 32u ? mlo : mhi);
-    uint32_t s = rank + c.count;
-    s = s > 4094u ? 4094u : s;
-    if (need) { c.L = 0u; c.S = 0xFFFFu; c.slot = s; }
-    uint32_t n = c.count + pc;
-    c.count = n > 4095u ? 4095u : n;
-}
-
-template <bool DEC>
-__device__ __forceinline__ uint32_t code_site(Coder &c, bool active, uint32_t sym, uint32_t p,
-                                              uint32_t prec, uint32_t lane, uint16_t *s_cw,
-                                              const int32_t *stage)
-{
-    bool need = active && c.S == 0u;
-    uint64_t m = __builtin_amdgcn_ballot_w64(need);
-    if (m != 0ull) {
-        reserve(c, need, lane, m);
-        if constexpr (DEC) {
-            if (need) c.cw = (uint32_t)stage[1u + c.slot];
-        }
-    }
-    if (active) {
-        if constexpr (!DEC) {
-            uint32_t a = ((c.S * p) >> prec) + sym;
-            if (sym) { c.S -= a; c.L += a; } else { c.S = a; }
-            if (c.S == 0u) s_cw[1u + c.slot] = (uint16_t)c.L;
-        } else {
-            uint32_t a = ((c.S * p) >> prec) + 1u;
-            uint32_t a2 = c.L + a;
-            if (c.cw >= a2) { c.S -= a; c.L = a2; sym = 1u; } else { c.S = a - 1u; sym = 0u; }
-        }
-    }
-    return sym;
-}
-
 // significance probabilities for contexts 0..8 packed as bytes: w0 = ctx 0-3, w1 = ctx 4-7, p8.
 struct PlaneLut { uint32_t sig0, sig1, sig8, sign, ref; };
-
-__device__ __forceinline__ uint32_t sig_prob(const PlaneLut &pl, uint32_t ctx)
-{
-    uint32_t b = __builtin_amdgcn_perm(pl.sig1, pl.sig0, ctx | 0x0C0C0C00u);
-    return ctx >= 8u ? pl.sig8 : b;
-}
-
-// One coefficient of the significance propagation pass (SPPEncoder BPCEngine.cu:490-516 /
-// SPPDecoder :559-594).  wo/wl/wr: W-form significance of the own / left / right column;
-// so/sl/sr: W-form sign masks.  cur: the current plane's 32 rows (X-form dword of this half-pass).
-template <bool DEC>
-__device__ __forceinline__ void spp_coeff(Coder &c, bool half_active, uint32_t ii, M64 &wo,
-                                          const M64 &wl, const M64 &wr, M64 &so, const M64 &sl,
-                                          const M64 &sr, uint32_t &cur, const PlaneLut &pl,
-                                          uint32_t prec, uint32_t lane, uint16_t *s_cw,
-                                          const int32_t *stage)
-{
-    uint32_t to = triple(wo, ii), tl = triple(wl, ii), tr = triple(wr, ii);
-    bool visit = half_active && !((to >> 1) & 1u);
-    // computeContext BPCEngine.cu:222-230 -- own column contributes rows i-1, i+1 (row i is the
-    // coefficient itself, not significant when visited), neighbours rows i-1, i, i+1.
-    uint32_t ctx = (uint32_t)__builtin_popcount(to) + (uint32_t)__builtin_popcount(tl) +
-                   (uint32_t)__builtin_popcount(tr);
-    uint32_t sym = DEC ? 0u : ((cur >> ii) & 1u);
-    sym = code_site<DEC>(c, visit, sym, sig_prob(pl, ctx), prec, lane, s_cw, stage);
-    bool became = visit && sym;
-    if (__builtin_amdgcn_ballot_w64(became) != 0ull) {
-        uint32_t xo = triple(so, ii), xl = triple(sl, ii), xr = triple(sr, ii);
-        // computeSignContext BPCEngine.cu:296-308: 0 if not significant, -1 if sign bit set, else +1
-        int up = (to & 1u) ? ((xo & 1u) ? -1 : 1) : 0;
-        int dn = (to & 4u) ? ((xo & 4u) ? -1 : 1) : 0;
-        int lf = (tl & 2u) ? ((xl & 2u) ? -1 : 1) : 0;
-        int rt = (tr & 2u) ? ((xr & 2u) ? -1 : 1) : 0;
-        uint32_t sc = sign_ctx(lf + rt, up + dn);
-        uint32_t p2 = (pl.sign >> (8u * (sc >> 1))) & 0xFFu;
-        uint32_t s2 = DEC ? 0u : (((xo >> 1) & 1u) ^ (sc & 1u));      // :513
-        s2 = code_site<DEC>(c, became, s2, p2, prec, lane, s_cw, stage);
-        if constexpr (DEC) {
-            if (became) w_set(so, ii, s2 ^ (sc & 1u));                 // :587-589
-        }
-    }
-    if (became) {
-        w_set(wo, ii, 1u);
-        if constexpr (DEC) cur |= 1u << ii;
-    }
-}
-
-template <bool DEC>
-__device__ __forceinline__ void mrp_coeff(Coder &c, bool half_active, uint32_t ii, uint32_t ref,
-                                          uint32_t &cur, const PlaneLut &pl, uint32_t prec,
-                                          uint32_t lane, uint16_t *s_cw, const int32_t *stage)
-{
-    bool act = half_active && ((ref >> ii) & 1u);
-    if (__builtin_amdgcn_ballot_w64(act) == 0ull) return;
-    uint32_t sym = DEC ? 0u : ((cur >> ii) & 1u);
-    sym = code_site<DEC>(c, act, sym, pl.ref, prec, lane, s_cw, stage);
-    if constexpr (DEC) {
-        if (act && sym) cur |= 1u << ii;
-    }
-}
-
-// One wave64 per workgroup; codeblocks 2*blockIdx.x (lanes 0-31) and 2*blockIdx.x+1 (32-63).
-template <bool DEC>
-__global__ __launch_bounds__(64) void bpc_kernel(BpcArgs a)
-{
-    __shared__ uint16_t s_cw_all[2][4096];
-
-    const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
-    const int cb = 2 * (int)blockIdx.x + (int)half;
-    const bool valid = cb < a.nCB;
-    const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
-    const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
-    uint16_t *s_cw = s_cw_all[half];
-    const int32_t *stage_r = a.staging + (size_t)(valid ? cb : 0) * 4096u;
-    const int lut_total = a.g.nRef + a.g.nSig + a.g.nSign;
-    const uint32_t prec = (uint32_t)a.g.prec;
-
-    // bit-planes, relative: index 0 = the plane being coded
-    uint32_t PLlo[kMaxPlanes], PLhi[kMaxPlanes], PRlo[kMaxPlanes], PRhi[kMaxPlanes];
-#pragma unroll
-    for (int k = 0; k < kMaxPlanes; k++) { PLlo[k] = PLhi[k] = PRlo[k] = PRhi[k] = 0u; }
-    M64 sgnL = { 0u, 0u }, sgnR = { 0u, 0u };
-    int msb = 32;
-    int32_t sz = 0;
-
-    if constexpr (!DEC) {
-        // ---- findMSB (BPCEngine.cu:176-192): OR of magnitudes over the codeblock
-        uint32_t ormag = 0u;
-        if (valid) {
-            for (int i = 0; i < 64; i++) {
-                int32_t v0, v1;
-                size_t idx = cbase + (size_t)i * (size_t)a.AW;
-                if (a.is_float) {
-                    float2 f = *reinterpret_cast<const float2 *>((const float *)a.coeffs_in + idx);
-                    v0 = (int32_t)f.x; v1 = (int32_t)f.y;          // readCoefficients :49,:55
-                } else {
-                    int2 q = *reinterpret_cast<const int2 *>((const int32_t *)a.coeffs_in + idx);
-                    v0 = q.x; v1 = q.y;
-                }
-                ormag |= (uint32_t)(v0 < 0 ? -v0 : v0) | (uint32_t)(v1 < 0 ? -v1 : v1);
-            }
-        }
-        ormag = half_or(ormag);
-        msb = ormag ? 31 - __builtin_clz(ormag) : 32;
-        if (valid && msb != 32 && msb > kMaxPlanes - 1) {
-            *a.range_flag = 1;
-            msb = kMaxPlanes - 1;
-        }
-        // ---- transpose: plane (msb - k) of row i -> bit i of P[k]
-        if (valid && msb != 32) {
-            const uint32_t up = (uint32_t)(kMaxPlanes - 1 - msb);
-#pragma unroll
-            for (int hw = 0; hw < 2; hw++) {
-                for (int ii = 0; ii < 32; ii++) {
-                    int32_t v0, v1;
-                    size_t idx = cbase + (size_t)(hw * 32 + ii) * (size_t)a.AW;
-                    if (a.is_float) {
-                        float2 f = *reinterpret_cast<const float2 *>((const float *)a.coeffs_in + idx);
-                        v0 = (int32_t)f.x; v1 = (int32_t)f.y;
-                    } else {
-                        int2 q = *reinterpret_cast<const int2 *>((const int32_t *)a.coeffs_in + idx);
-                        v0 = q.x; v1 = q.y;
-                    }
-                    uint32_t m0 = ((uint32_t)(v0 < 0 ? -v0 : v0) << up) & 0xFFFFu;
-                    uint32_t m1 = ((uint32_t)(v1 < 0 ? -v1 : v1) << up) & 0xFFFFu;
-                    uint32_t n0 = v0 < 0, n1 = v1 < 0;
-                    if (hw == 0) { sgnL.lo |= n0 << ii; sgnR.lo |= n1 << ii; }
-                    else         { sgnL.hi |= n0 << ii; sgnR.hi |= n1 << ii; }
-#pragma unroll
-                    for (int k = 0; k < kMaxPlanes; k++) {
-                        uint32_t b0 = (m0 >> (kMaxPlanes - 1 - k)) & 1u;
-                        uint32_t b1 = (m1 >> (kMaxPlanes - 1 - k)) & 1u;
-                        if (hw == 0) { PLlo[k] |= b0 << ii; PRlo[k] |= b1 << ii; }
-                        else         { PLhi[k] |= b0 << ii; PRhi[k] |= b1 << ii; }
-                    }
-                }
-            }
-        }
-    } else {
-        if (valid) { msb = stage_r[0]; sz = a.sizes[cb]; }
-        if (valid && sz != 4096 && msb != 32 && msb > kMaxPlanes - 1) {
-            *a.range_flag = 1;
-            msb = kMaxPlanes - 1;
-        }
-    }
-
-    const bool coded = valid && msb != 32 && (!DEC || sz != 4096);
-
-    // per-lane subband -> LUT row (BPCEngine.cu:1975,1990: x of the lane, y of the top row)
-    int level, sb;
-    find_subband(cbx * 64 + 2 * (int)t, cby * 64, a.AW, a.AH, a.wl, level, sb);
-    const int grp = level * a.g.nSub + sb;
-
-    Coder c = { 0u, 0u, 0u, 0u, 0u };
-    M64 sigL = { 0u, 0u }, sigR = { 0u, 0u }, refL = { 0u, 0u }, refR = { 0u, 0u };
-
-    // number of planes this wave walks = max over its two codeblocks
-    int np = coded ? msb + 1 : 0;
-    {
-        int o = __shfl_xor(np, 32);
-        np = np > o ? np : o;
-    }
-
-    // encoder: neighbour sign columns are static
-    M64 psgnR = { from_prev32(sgnR.lo, t), from_prev32(sgnR.hi, t) };
-    M64 nsgnL = { from_next32(sgnL.lo, t), from_next32(sgnL.hi, t) };
-
-    for (int p = 0; p < np; p++) {
-        const int bp = msb - p;
-        const bool act = coded && bp >= 0;
-
-        if constexpr (DEC) {
-            // make room: plane registers move up so that after the last plane index k = plane k
-            if (act && p > 0) {
-#pragma unroll
-                for (int k = kMaxPlanes - 1; k > 0; k--) {
-                    PLlo[k] = PLlo[k - 1]; PLhi[k] = PLhi[k - 1];
-                    PRlo[k] = PRlo[k - 1]; PRhi[k] = PRhi[k - 1];
-                }
-                PLlo[0] = PLhi[0] = PRlo[0] = PRhi[0] = 0u;
-            }
-        }
-
-        // initializeLUTPointers / updateLUTPointers (BPCEngine.cu:329-358): row (level, sb, bp)
-        PlaneLut pl = { 0u, 0u, 0u, 0u, 0u };
-        if (act) {
-            int ri = (grp * a.g.nBp + bp) * a.g.cRef;
-            int si = (grp * a.g.nBp + bp) * a.g.cSig + a.g.nRef;
-            int gi = (grp * a.g.nBp + bp) * a.g.cSign + a.g.nRef + a.g.nSig;
-            pl.ref = lut_at(a.lut, ri, lut_total);
-            pl.sig0 = lut_at(a.lut, si + 0, lut_total) | (lut_at(a.lut, si + 1, lut_total) << 8) |
-                      (lut_at(a.lut, si + 2, lut_total) << 16) | (lut_at(a.lut, si + 3, lut_total) << 24);
-            pl.sig1 = lut_at(a.lut, si + 4, lut_total) | (lut_at(a.lut, si + 5, lut_total) << 8) |
-                      (lut_at(a.lut, si + 6, lut_total) << 16) | (lut_at(a.lut, si + 7, lut_total) << 24);
-            pl.sig8 = lut_at(a.lut, si + 8, lut_total);
-            pl.sign = lut_at(a.lut, gi + 0, lut_total) | (lut_at(a.lut, gi + 1, lut_total) << 8) |
-                      (lut_at(a.lut, gi + 2, lut_total) << 16) | (lut_at(a.lut, gi + 3, lut_total) << 24);
-        }
-
-        // ---- significance propagation pass (SPPEncoderLauncher BPCEngine.cu:770-843)
-#pragma unroll
-        for (int hw = 0; hw < 2; hw++) {
-            M64 wL = to_w(sigL, hw), wR = to_w(sigR, hw);
-            M64 sL = to_w(sgnL, hw), sR = to_w(sgnR, hw);
-            M64 wPR = { from_prev32(wR.lo, t), from_prev32(wR.hi, t) };    // lane-1's right column
-            M64 wNL = { from_next32(wL.lo, t), from_next32(wL.hi, t) };    // lane+1's left column
-            M64 sPR, sNL;
-            if constexpr (DEC) {
-                sPR = M64{ from_prev32(sR.lo, t), from_prev32(sR.hi, t) };
-                sNL = M64{ from_next32(sL.lo, t), from_next32(sL.hi, t) };
-            } else {
-                sPR = to_w(psgnR, hw);
-                sNL = to_w(nsgnL, hw);
-            }
-            uint32_t curL = hw ? PLhi[0] : PLlo[0], curR = hw ? PRhi[0] : PRlo[0];
-            for (uint32_t ii = 0; ii < 32u; ii++) {
-                // all lanes: left column, neighbours = lane-1's right column | own right column
-                spp_coeff<DEC>(c, act, ii, wL, wPR, wR, sL, sPR, sR, curL, pl, prec, lane, s_cw, stage_r);
-                // lane+1's left column as it is after this row's left phase (:791, shfl_down)
-                wNL.lo = from_next32(wL.lo, t); wNL.hi = from_next32(wL.hi, t);
-                if constexpr (DEC) { sNL.lo = from_next32(sL.lo, t); sNL.hi = from_next32(sL.hi, t); }
-                // all lanes: right column, neighbours = own left column | lane+1's left column
-                spp_coeff<DEC>(c, act, ii, wR, wL, wNL, sR, sL, sNL, curR, pl, prec, lane, s_cw, stage_r);
-                // lane-1's right column as it is after this row's right phase (:804, shfl_up)
-                wPR.lo = from_prev32(wR.lo, t); wPR.hi = from_prev32(wR.hi, t);
-                if constexpr (DEC) { sPR.lo = from_prev32(sR.lo, t); sPR.hi = from_prev32(sR.hi, t); }
-            }
-            // fold the 32 rows of this half-pass back
-            if (hw == 0) { sigL.lo = w_rows(wL); sigR.lo = w_rows(wR); }
-            else         { sigL.hi = w_rows(wL); sigR.hi = w_rows(wR); }
-            if constexpr (DEC) {
-                if (hw == 0) { sgnL.lo = w_rows(sL); sgnR.lo = w_rows(sR); PLlo[0] = curL; PRlo[0] = curR; }
-                else         { sgnL.hi = w_rows(sL); sgnR.hi = w_rows(sR); PLhi[0] = curL; PRhi[0] = curR; }
-            }
-        }
-
-        // ---- magnitude refinement pass (MRPEncoderLauncher BPCEngine.cu:1249-1261): coefficients
-        // significant before this plane (bit 29); afterwards every significant one is eligible.
-#pragma unroll
-        for (int hw = 0; hw < 2; hw++) {
-            uint32_t curL = hw ? PLhi[0] : PLlo[0], curR = hw ? PRhi[0] : PRlo[0];
-            const uint32_t rL = hw ? refL.hi : refL.lo, rR = hw ? refR.hi : refR.lo;
-            for (uint32_t ii = 0; ii < 32u; ii++) {
-                mrp_coeff<DEC>(c, act, ii, rL, curL, pl, prec, lane, s_cw, stage_r);
-                mrp_coeff<DEC>(c, act, ii, rR, curR, pl, prec, lane, s_cw, stage_r);
-            }
-            if constexpr (DEC) {
-                if (hw == 0) { PLlo[0] = curL; PRlo[0] = curR; } else { PLhi[0] = curL; PRhi[0] = curR; }
-            }
-        }
-        refL = sigL; refR = sigR;
-
-        if constexpr (!DEC) {
-            // next plane becomes index 0
-#pragma unroll
-            for (int k = 0; k < kMaxPlanes - 1; k++) {
-                PLlo[k] = PLlo[k + 1]; PLhi[k] = PLhi[k + 1];
-                PRlo[k] = PRlo[k + 1]; PRhi[k] = PRhi[k + 1];
-            }
-        }
-    }
-
-    if constexpr (!DEC) {
-        // flush (Encode BPCEngine.cu:1719): every lane stores its L into its current slot
-        if (coded) s_cw[1u + c.slot] = (uint16_t)c.L;
-        __syncthreads();
-        if (valid) {
-            int32_t *st = a.staging + (size_t)cb * 4096u;
-            const uint32_t size = c.count + 1u;                       // :2010
-            if (t == 0u) { a.sizes[cb] = (int32_t)size; st[0] = msb; }     // :1998
-            if (size == 4096u) {
-                // expansionFix :1905-1912 -- raw 16-bit sign-magnitude words at [lane*128 + 2i(+1)]
-                for (int i = 0; i < 64; i++) {
-                    int32_t v0, v1;
-                    size_t idx = cbase + (size_t)i * (size_t)a.AW;
-                    if (a.is_float) {
-                        float2 f = *reinterpret_cast<const float2 *>((const float *)a.coeffs_in + idx);
-                        v0 = (int32_t)f.x; v1 = (int32_t)f.y;
-                    } else {
-                        int2 q = *reinterpret_cast<const int2 *>((const int32_t *)a.coeffs_in + idx);
-                        v0 = q.x; v1 = q.y;
-                    }
-                    uint32_t w0 = (((uint32_t)(v0 < 0 ? -v0 : v0) << 1) + (uint32_t)(v0 < 0)) & 0xFFFFu;
-                    uint32_t w1 = (((uint32_t)(v1 < 0 ? -v1 : v1) << 1) + (uint32_t)(v1 < 0)) & 0xFFFFu;
-                    *reinterpret_cast<int2 *>(st + t * 128u + 2u * (uint32_t)i) = make_int2((int)w0, (int)w1);
-                }
-            } else {
-                for (uint32_t j = 1u + t; j < size; j += 32u) st[j] = (int32_t)s_cw[j];
-            }
-        }
-    } else {
-        if (valid) {
-            // writeCoefficients BPCEngine.cu:94-111 / copyEntireCodeblock :1915-1922
-            for (int i = 0; i < 64; i++) {
-                int32_t v0, v1;
-                if (sz == 4096) {
-                    int2 w = *reinterpret_cast<const int2 *>(stage_r + t * 128u + 2u * (uint32_t)i);
-                    v0 = (int32_t)(((uint32_t)w.x & 0xFFFFFFu) >> 1); if (w.x & 1) v0 = -v0;
-                    v1 = (int32_t)(((uint32_t)w.y & 0xFFFFFFu) >> 1); if (w.y & 1) v1 = -v1;
-                } else {
-                    const uint32_t ii = (uint32_t)i & 31u;
-                    uint32_t m0 = 0u, m1 = 0u;
-#pragma unroll
-                    for (int k = 0; k < kMaxPlanes; k++) {
-                        uint32_t l = i < 32 ? PLlo[k] : PLhi[k], r = i < 32 ? PRlo[k] : PRhi[k];
-                        m0 |= ((l >> ii) & 1u) << k;
-                        m1 |= ((r >> ii) & 1u) << k;
-                    }
-                    uint32_t s0 = ((i < 32 ? sgnL.lo : sgnL.hi) >> ii) & 1u;
-                    uint32_t s1 = ((i < 32 ? sgnR.lo : sgnR.hi) >> ii) & 1u;
-                    v0 = s0 ? -(int32_t)m0 : (int32_t)m0;
-                    v1 = s1 ? -(int32_t)m1 : (int32_t)m1;
-                }
-                *reinterpret_cast<int2 *>(a.coeffs_out + cbase + (size_t)i * (size_t)a.AW) = make_int2(v0, v1);
-            }
-        }
-    }
-}
-
 
 // =============================================================================================
 // Encoder, second formulation: contexts without neighbour exchange.
@@ -836,6 +476,228 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
             uint32_t w0 = (((uint32_t)(v0 < 0 ? -v0 : v0) << 1) + (uint32_t)(v0 < 0)) & 0xFFFFu;
             uint32_t w1 = (((uint32_t)(v1 < 0 ? -v1 : v1) << 1) + (uint32_t)(v1 < 0)) & 0xFFFFu;
             *reinterpret_cast<int2 *>(st + t * 128u + 2u * (uint32_t)i) = make_int2((int)w0, (int)w1);
+        }
+    }
+}
+
+
+// =============================================================================================
+// Decoder (kernelBPCDecoder BPCEngine.cu:2126-2215, Decode :1777-1837, SPPDecoder :559-594,
+// MRPDecoder :743-762, arithmeticDecoder :405-442, writeCoefficients :94-111,
+// copyEntireCodeblock :1915-1922).  Significance is only known as symbols decode, so the
+// decoder keeps LIVE row masks in W-form (row i of the current 32-row half-pass at bit ii+1, the
+// rows above / below at bits ii / ii+2) and refreshes its copies of the two neighbour columns by
+// DPP only after some lane became significant in the phase before.  Decoded planes rotate upward
+// so that plane register k ends up holding plane k; all planes are decoded (k = 0), so the
+// mid-point approximation bits of the reference (:577,:755-757) never reach the output.
+// =============================================================================================
+
+// arithmeticDecoder BPCEngine.cu:405-442, one call site
+__device__ __forceinline__ uint32_t dec_site(Coder &c, uint32_t inact, uint32_t p, uint32_t prec,
+                                             uint32_t lower_mask, uint32_t upper_mask, const int32_t *stage)
+{
+    const bool need = (c.S | inact) == 0u;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(need);
+    if (m != 0ull) {
+        reserve_enc(c, need, m, lower_mask, upper_mask);
+        if (need) c.cw = (uint32_t)stage[1u + c.slot];
+    }
+    uint32_t sym = 0u;
+    if (inact == 0u) {
+        const uint32_t a = (__umul24(c.S, p) >> prec) + 1u;
+        const uint32_t a2 = c.L + a;
+        const bool ge = c.cw >= a2;
+        c.S = ge ? c.S - a : a - 1u;
+        c.L = ge ? a2 : c.L;
+        sym = ge ? 1u : 0u;
+    }
+    return sym;
+}
+
+// One coefficient of the decoder's significance propagation pass; returns 1 in lanes whose
+// coefficient became significant.  wo/wl/wr: W-form significance of the own / left / right column,
+// so/sl/sr: W-form signs; cur: the plane's 32 rows being decoded (X-form dword).
+__device__ __forceinline__ uint32_t dec_spp_coeff(Coder &c, uint32_t idle, uint32_t ii, M64 &wo, const M64 &wl,
+                                                  const M64 &wr, M64 &so, const M64 &sl, const M64 &sr,
+                                                  uint32_t &cur, const PlaneLut &pl, uint32_t prec,
+                                                  uint32_t lower_mask, uint32_t upper_mask, const int32_t *stage)
+{
+    const uint32_t to = triple(wo, ii), tl = triple(wl, ii), tr = triple(wr, ii);
+    const uint32_t inact = idle | ((to >> 1) & 1u);
+    // computeContext BPCEngine.cu:222-230 -- the coefficient's own bit is 0 whenever it is visited
+    const uint32_t ctx = (uint32_t)__builtin_popcount(to) + (uint32_t)__builtin_popcount(tl) +
+                         (uint32_t)__builtin_popcount(tr);
+    const uint32_t p07 = __builtin_amdgcn_perm(pl.sig1, pl.sig0, ctx | 0x0C0C0C00u);
+    const uint32_t sym = dec_site(c, inact, ctx >= 8u ? pl.sig8 : p07, prec, lower_mask, upper_mask, stage);
+    if (__builtin_amdgcn_ballot_w64(sym != 0u) != 0ull) {
+        const uint32_t xo = triple(so, ii), xl = triple(sl, ii), xr = triple(sr, ii);
+        // computeSignContext BPCEngine.cu:296-308: 0 if not significant, -1 if sign bit set, else +1
+        const int up = (to & 1u) ? ((xo & 1u) ? -1 : 1) : 0;
+        const int dn = (to & 4u) ? ((xo & 4u) ? -1 : 1) : 0;
+        const int lf = (tl & 2u) ? ((xl & 2u) ? -1 : 1) : 0;
+        const int rt = (tr & 2u) ? ((xr & 2u) ? -1 : 1) : 0;
+        const uint32_t sc = sign_ctx(lf + rt, up + dn);
+        const uint32_t p2 = (pl.sign >> (8u * (sc >> 1))) & 0xFFu;
+        const uint32_t s2 = dec_site(c, sym ^ 1u, p2, prec, lower_mask, upper_mask, stage);
+        if (sym) {
+            w_set(so, ii, s2 ^ (sc & 1u));          // :587-589
+            w_set(wo, ii, 1u);
+            cur |= 1u << ii;
+        }
+    }
+    return sym;
+}
+
+// One wave64 per workgroup; codeblocks cb_base + 2*blockIdx.x (lanes 0-31) and +1 (lanes 32-63).
+__global__ __launch_bounds__(64, 4) void bpc_decode_kernel(BpcArgs a)
+{
+    const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
+    const int cb = a.cb_base + 2 * (int)blockIdx.x + (int)half;
+    const bool valid = cb < a.nCB;
+    const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
+    const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
+    const int32_t *stage = a.staging + (size_t)(valid ? cb : a.cb_base) * 4096u;
+    const int lut_total = a.g.nRef + a.g.nSig + a.g.nSign;
+    const uint32_t prec = (uint32_t)a.g.prec;
+    const uint32_t upper_mask = half ? 0xFFFFFFFFu : 0u, lower_mask = ~upper_mask;
+
+    uint32_t PLlo[kMaxPlanes], PLhi[kMaxPlanes], PRlo[kMaxPlanes], PRhi[kMaxPlanes];
+#pragma unroll
+    for (int k = 0; k < kMaxPlanes; k++) { PLlo[k] = PLhi[k] = PRlo[k] = PRhi[k] = 0u; }
+    M64 sgnL = { 0u, 0u }, sgnR = { 0u, 0u };
+    int msb = 32;
+    int32_t sz = 0;
+    if (valid) { msb = stage[0]; sz = a.sizes[cb]; }
+    if (valid && sz != 4096 && msb != 32 && (msb < 0 || msb > kMaxPlanes - 1)) {
+        *a.range_flag = 1;
+        msb = kMaxPlanes - 1;
+    }
+    const bool coded = valid && msb != 32 && sz != 4096;
+
+    int level, sb;
+    find_subband(cbx * 64 + 2 * (int)t, cby * 64, a.AW, a.AH, a.wl, level, sb);
+    const int grp = level * a.g.nSub + sb;
+
+    Coder c = { 0u, 0u, 0u, 0u, 0u };
+    M64 sigL = { 0u, 0u }, sigR = { 0u, 0u }, refL = { 0u, 0u }, refR = { 0u, 0u };
+
+    int np = coded ? msb + 1 : 0;
+    { int o = __shfl_xor(np, 32); np = np > o ? np : o; }
+    np = (int)__builtin_amdgcn_readfirstlane((uint32_t)np);
+
+    for (int p = 0; p < np; p++) {
+        const int bp = msb - p;
+        const bool act = coded && bp >= 0;
+        const uint32_t idle = act ? 0u : 1u;
+
+        // make room: plane registers move up so that after the last plane index k = plane k
+        if (act && p > 0) {
+#pragma unroll
+            for (int k = kMaxPlanes - 1; k > 0; k--) {
+                PLlo[k] = PLlo[k - 1]; PLhi[k] = PLhi[k - 1];
+                PRlo[k] = PRlo[k - 1]; PRhi[k] = PRhi[k - 1];
+            }
+            PLlo[0] = PLhi[0] = PRlo[0] = PRhi[0] = 0u;
+        }
+
+        PlaneLut pl = { 0u, 0u, 0u, 0u, 0u };
+        if (act) {
+            int ri = (grp * a.g.nBp + bp) * a.g.cRef;
+            int si = (grp * a.g.nBp + bp) * a.g.cSig + a.g.nRef;
+            int gi = (grp * a.g.nBp + bp) * a.g.cSign + a.g.nRef + a.g.nSig;
+            pl.ref = lut_at(a.lut, ri, lut_total);
+            pl.sig0 = lut_at(a.lut, si + 0, lut_total) | (lut_at(a.lut, si + 1, lut_total) << 8) |
+                      (lut_at(a.lut, si + 2, lut_total) << 16) | (lut_at(a.lut, si + 3, lut_total) << 24);
+            pl.sig1 = lut_at(a.lut, si + 4, lut_total) | (lut_at(a.lut, si + 5, lut_total) << 8) |
+                      (lut_at(a.lut, si + 6, lut_total) << 16) | (lut_at(a.lut, si + 7, lut_total) << 24);
+            pl.sig8 = lut_at(a.lut, si + 8, lut_total);
+            pl.sign = lut_at(a.lut, gi + 0, lut_total) | (lut_at(a.lut, gi + 1, lut_total) << 8) |
+                      (lut_at(a.lut, gi + 2, lut_total) << 16) | (lut_at(a.lut, gi + 3, lut_total) << 24);
+        }
+
+        // ---- significance propagation pass (SPPDecoderLauncher), rows with an insignificant coeff
+#pragma unroll
+        for (int hw = 0; hw < 2; hw++) {
+            M64 wL = to_w(sigL, hw), wR = to_w(sigR, hw);
+            M64 sL = to_w(sgnL, hw), sR = to_w(sgnR, hw);
+            M64 wPR = { from_prev32(wR.lo, t), from_prev32(wR.hi, t) };    // lane-1's right column
+            M64 wNL = { from_next32(wL.lo, t), from_next32(wL.hi, t) };    // lane+1's left column
+            M64 sPR = { from_prev32(sR.lo, t), from_prev32(sR.hi, t) };
+            M64 sNL = { from_next32(sL.lo, t), from_next32(sL.hi, t) };
+            uint32_t curL = hw ? PLhi[0] : PLlo[0], curR = hw ? PRhi[0] : PRlo[0];
+            const uint32_t xl = hw ? sigL.hi : sigL.lo, xr = hw ? sigR.hi : sigR.lo;
+            uint32_t rows = wave_or32(act ? ~(xl & xr) : 0u);
+            while (rows) {
+                const uint32_t ii = (uint32_t)__builtin_ctz(rows);
+                rows &= rows - 1u;
+                // all lanes: left column, neighbours = lane-1's right column | own right column
+                const uint32_t bL = dec_spp_coeff(c, idle, ii, wL, wPR, wR, sL, sPR, sR, curL, pl, prec, lower_mask,
+                                                  upper_mask, stage);
+                // lane+1's left column as it is after this row's left phase (:791, shfl_down)
+                if (__builtin_amdgcn_ballot_w64(bL != 0u) != 0ull) {
+                    wNL.lo = from_next32(wL.lo, t); wNL.hi = from_next32(wL.hi, t);
+                    sNL.lo = from_next32(sL.lo, t); sNL.hi = from_next32(sL.hi, t);
+                }
+                // all lanes: right column, neighbours = own left column | lane+1's left column
+                const uint32_t bR = dec_spp_coeff(c, idle, ii, wR, wL, wNL, sR, sL, sNL, curR, pl, prec, lower_mask,
+                                                  upper_mask, stage);
+                // lane-1's right column as it is after this row's right phase (:804, shfl_up)
+                if (__builtin_amdgcn_ballot_w64(bR != 0u) != 0ull) {
+                    wPR.lo = from_prev32(wR.lo, t); wPR.hi = from_prev32(wR.hi, t);
+                    sPR.lo = from_prev32(sR.lo, t); sPR.hi = from_prev32(sR.hi, t);
+                }
+            }
+            // fold the 32 rows of this half-pass back
+            if (hw == 0) { sigL.lo = w_rows(wL); sigR.lo = w_rows(wR); sgnL.lo = w_rows(sL); sgnR.lo = w_rows(sR);
+                           PLlo[0] = curL; PRlo[0] = curR; }
+            else         { sigL.hi = w_rows(wL); sigR.hi = w_rows(wR); sgnL.hi = w_rows(sL); sgnR.hi = w_rows(sR);
+                           PLhi[0] = curL; PRhi[0] = curR; }
+        }
+
+        // ---- magnitude refinement pass (MRPDecoderLauncher): coefficients significant before this
+        // plane; afterwards every significant one is eligible
+#pragma unroll
+        for (int hw = 0; hw < 2; hw++) {
+            uint32_t curL = hw ? PLhi[0] : PLlo[0], curR = hw ? PRhi[0] : PRlo[0];
+            const uint32_t rL = act ? (hw ? refL.hi : refL.lo) : 0u, rR = act ? (hw ? refR.hi : refR.lo) : 0u;
+            uint32_t rows = wave_or32(rL | rR);
+            while (rows) {
+                const uint32_t ii = (uint32_t)__builtin_ctz(rows);
+                rows &= rows - 1u;
+                const uint32_t iL = ((rL >> ii) & 1u) ^ 1u, iR = ((rR >> ii) & 1u) ^ 1u;
+                if (__builtin_amdgcn_ballot_w64(iL == 0u) != 0ull)
+                    curL |= dec_site(c, iL, pl.ref, prec, lower_mask, upper_mask, stage) << ii;
+                if (__builtin_amdgcn_ballot_w64(iR == 0u) != 0ull)
+                    curR |= dec_site(c, iR, pl.ref, prec, lower_mask, upper_mask, stage) << ii;
+            }
+            if (hw == 0) { PLlo[0] = curL; PRlo[0] = curR; } else { PLhi[0] = curL; PRhi[0] = curR; }
+        }
+        refL = sigL; refR = sigR;
+    }
+
+    if (valid) {
+        // writeCoefficients BPCEngine.cu:94-111 / copyEntireCodeblock :1915-1922
+        for (int i = 0; i < 64; i++) {
+            int32_t v0, v1;
+            if (sz == 4096) {
+                int2 w = *reinterpret_cast<const int2 *>(stage + t * 128u + 2u * (uint32_t)i);
+                v0 = (int32_t)(((uint32_t)w.x & 0xFFFFFFu) >> 1); if (w.x & 1) v0 = -v0;
+                v1 = (int32_t)(((uint32_t)w.y & 0xFFFFFFu) >> 1); if (w.y & 1) v1 = -v1;
+            } else {
+                const uint32_t ii = (uint32_t)i & 31u;
+                uint32_t m0 = 0u, m1 = 0u;
+#pragma unroll
+                for (int k = 0; k < kMaxPlanes; k++) {
+                    uint32_t l = i < 32 ? PLlo[k] : PLhi[k], r = i < 32 ? PRlo[k] : PRhi[k];
+                    m0 |= ((l >> ii) & 1u) << k;
+                    m1 |= ((r >> ii) & 1u) << k;
+                }
+                uint32_t s0 = ((i < 32 ? sgnL.lo : sgnL.hi) >> ii) & 1u;
+                uint32_t s1 = ((i < 32 ? sgnR.lo : sgnR.hi) >> ii) & 1u;
+                v0 = s0 ? -(int32_t)m0 : (int32_t)m0;
+                v1 = s1 ? -(int32_t)m1 : (int32_t)m1;
+            }
+            *reinterpret_cast<int2 *>(a.coeffs_out + cbase + (size_t)i * (size_t)a.AW) = make_int2(v0, v1);
         }
     }
 }

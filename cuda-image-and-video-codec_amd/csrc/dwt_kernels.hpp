@@ -46,7 +46,7 @@ constexpr int kStripUseful = kStripCols - 8 * kEdgeLanes;   // lanes kEdgeLanes 
 // Output rows per band are a template parameter (BAND = 4, 8, 16 or 32): big levels want tall bands
 // (less vertical halo), small levels want many short waves (a level with 18 tall waves is bound by
 // one wave's serial instruction time, not by memory).  Row pairs fetched ahead = min(4, BAND/2).
-constexpr int kInvBandRows = 32;                // output rows per band (inverse)
+// (the inverse kernel takes its band height the same way)
 
 struct DwtFwdArgs {
     const void *src;        // level input: T[ H x W ] (stride src_stride) or u8 at level 0
@@ -413,9 +413,10 @@ __device__ __forceinline__ void store_row4(const DwtInvArgs &a, int y, int c0, b
     }
 }
 
-template <typename T, bool LOSSY>
+template <typename T, bool LOSSY, int BAND>
 __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
 {
+    constexpr int kInvBandRows = BAND;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int strip = blockIdx.x * 4 + wave;
     if (strip * kStripUseful >= a.W) return;
@@ -516,6 +517,37 @@ __global__ __launch_bounds__(256) void level_shift_inv_f32_kernel(float *d, size
         float r = rintf(t);                      // __float2int_rn
         r = r > 255.0f ? 255.0f : r;
         d[i] = r < 0.0f ? 0.0f : r;
+    }
+}
+// removeOffsetAndApplyMaxMin(/Lossy) fused with the u8 conversion the reference does on the host
+// (IOManager::writeImage IO/IOManager.ipp:332-335): one pass T[P] -> u8[P], 4 samples per lane
+__global__ __launch_bounds__(256) void clamp_to_u8_i32_kernel(const int32_t *in, uint8_t *out, size_t n4, int off)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 w = reinterpret_cast<const uint4 *>(in)[i];
+        const int v[4] = { (int)w.x + off, (int)w.y + off, (int)w.z + off, (int)w.w + off };
+        uint32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) o |= (uint32_t)(v[k] > 255 ? 255 : (v[k] < 0 ? 0 : v[k])) << (8 * k);
+        reinterpret_cast<uint32_t *>(out)[i] = o;
+    }
+}
+__global__ __launch_bounds__(256) void clamp_to_u8_f32_kernel(const float *in, uint8_t *out, size_t n4, float off)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 w = reinterpret_cast<const uint4 *>(in)[i];
+        const float v[4] = { __uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w) };
+        uint32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float t = v[k] + off;
+            t = t + 0.01f;
+            float r = rintf(t);                  // __float2int_rn
+            r = r > 255.0f ? 255.0f : r;
+            r = r < 0.0f ? 0.0f : r;
+            o |= (uint32_t)(int)r << (8 * k);
+        }
+        reinterpret_cast<uint32_t *>(out)[i] = o;
     }
 }
 // final image (T, row stride AW, after the inverse level shift) -> u8 crop-free copy

@@ -27,7 +27,7 @@ static const float kQSteps[10][4] = {
 };
 
 struct FwdLaunch { DwtFwdArgs a; unsigned gx, gy; bool u8; int band; };
-struct InvLaunch { DwtInvArgs a; unsigned gx, gy; };
+struct InvLaunch { DwtInvArgs a; unsigned gx, gy; int band; };
 
 // Band height per level: big levels want taller bands (less vertical halo re-read), small levels
 // want many short waves (a level with a handful of tall waves is bound by one wave's serial
@@ -98,8 +98,9 @@ inline std::vector<InvLaunch> plan_dwt_inverse(const int32_t *d_in, void *d_out,
         a.qs = qs;
         for (int k = 0; k < 4; k++) a.q[k] = kQSteps[l][k];
         const int strips = (W + kStripUseful - 1) / kStripUseful;
+        f.band = fwd_band_rows(l, strips, H);
         f.gx = (unsigned)((strips + 3) / 4);
-        f.gy = (unsigned)(((H >> 1) + kInvBandRows / 2 - 1) / (kInvBandRows / 2));
+        f.gy = (unsigned)(((H >> 1) + f.band / 2 - 1) / (f.band / 2));
         v.push_back(f);
         read_off = write_off;
         write_off += (size_t)W * (size_t)H;

@@ -69,6 +69,14 @@ struct picsong_ctx {
 };
 
 template <int BAND>
+static void launch_inv(const picsong_ctx *c, const InvLaunch &f, hipStream_t s)
+{
+    dim3 grid(f.gx, f.gy);
+    if (c->p.lossy) dwt_inv_kernel<float, true, BAND><<<grid, 256, 0, s>>>(f.a);
+    else dwt_inv_kernel<int, false, BAND><<<grid, 256, 0, s>>>(f.a);
+}
+
+template <int BAND>
 static void launch_fwd(const picsong_ctx *c, const FwdLaunch &f, hipStream_t s)
 {
     dim3 grid(f.gx, f.gy);
@@ -376,9 +384,12 @@ int picsong_dwt_inverse(picsong_ctx *c, const int32_t *d_in, void *d_out, void *
     if (!c || !d_in || !d_out) return fail(PICSONG_ERR_ARG, "dwt_inverse: null argument");
     hipStream_t s = (hipStream_t)stream;
     for (const InvLaunch &f : plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs)) {
-        dim3 grid(f.gx, f.gy);
-        if (c->p.lossy) dwt_inv_kernel<float, true><<<grid, 256, 0, s>>>(f.a);
-        else dwt_inv_kernel<int, false><<<grid, 256, 0, s>>>(f.a);
+        switch (f.band) {
+        case 32: launch_inv<32>(c, f, s); break;
+        case 16: launch_inv<16>(c, f, s); break;
+        case 8: launch_inv<8>(c, f, s); break;
+        default: launch_inv<4>(c, f, s); break;
+        }
         HIP_TRY(hipGetLastError());
     }
     return PICSONG_OK;
@@ -435,7 +446,7 @@ int picsong_bpc_decode(picsong_ctx *c, const int32_t *d_staging, const int32_t *
     a.coeffs_out = d_coeffs;
     a.staging = const_cast<int32_t *>(d_staging);
     a.sizes = const_cast<int32_t *>(d_sizes);
-    bpc_kernel<true><<<(unsigned)((c->ncb + 1) / 2), 64, 0, (hipStream_t)stream>>>(a);
+    bpc_decode_kernel<<<(unsigned)((c->ncb + 1) / 2), 64, 0, (hipStream_t)stream>>>(a);
     HIP_TRY(hipGetLastError());
     return PICSONG_OK;
 }
@@ -486,13 +497,12 @@ int picsong_bitstream_pack(picsong_ctx *c, const int32_t *d_staging, const int32
     return PICSONG_OK;
 }
 
-int picsong_bitstream_unpack(picsong_ctx *c, const uint16_t *d_stream, int32_t *d_staging, int32_t *d_sizes,
-                             void *stream)
+static int unpack_impl(picsong_ctx *c, const uint16_t *d_stream, int32_t *d_staging, int32_t *d_sizes,
+                       bool memset_staging, hipStream_t s)
 {
-    if (!c || !d_staging || !d_sizes || !d_stream) return fail(PICSONG_ERR_ARG, "bitstream_unpack: null argument");
-    hipStream_t s = (hipStream_t)stream;
-    // BSEngine::deviceMemoryAllocator BitStreamBuilder.cu:281-284
-    HIP_TRY(hipMemsetAsync(d_staging, 0xFF, c->P * sizeof(int32_t), s));
+    // BSEngine::deviceMemoryAllocator BitStreamBuilder.cu:281-284.  Slots beyond a codeblock's length
+    // are never read by the decoder, so the frame path skips this 4*AW*AH-byte fill.
+    if (memset_staging) HIP_TRY(hipMemsetAsync(d_staging, 0xFF, c->P * sizeof(int32_t), s));
     read_sizes_kernel<<<(unsigned)((c->ncb + 255) / 256), 256, 0, s>>>(d_stream, c->ncb, d_sizes);
     HIP_TRY(hipGetLastError());
     scan_sizes_kernel<<<1, 1024, 0, s>>>(d_sizes, c->ncb, c->d_offsets, c->d_total);
@@ -500,6 +510,13 @@ int picsong_bitstream_unpack(picsong_ctx *c, const uint16_t *d_stream, int32_t *
     unpack_kernel<<<(unsigned)c->ncb, 256, 0, s>>>(d_stream, d_sizes, c->d_offsets, c->ncb, d_staging);
     HIP_TRY(hipGetLastError());
     return PICSONG_OK;
+}
+
+int picsong_bitstream_unpack(picsong_ctx *c, const uint16_t *d_stream, int32_t *d_staging, int32_t *d_sizes,
+                             void *stream)
+{
+    if (!c || !d_staging || !d_sizes || !d_stream) return fail(PICSONG_ERR_ARG, "bitstream_unpack: null argument");
+    return unpack_impl(c, d_stream, d_staging, d_sizes, true, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -569,14 +586,15 @@ int picsong_decode_frame(picsong_ctx *c, const uint16_t *d_stream, uint8_t *d_fr
     int rc = ensure_workspace(c, true);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = picsong_bitstream_unpack(c, d_stream, c->d_staging, c->d_sizes, stream))) return rc;
+    if ((rc = unpack_impl(c, d_stream, c->d_staging, c->d_sizes, false, s))) return rc;
     if ((rc = picsong_bpc_decode(c, c->d_staging, c->d_sizes, c->d_coef_i, stream))) return rc;
     if ((rc = picsong_dwt_inverse(c, c->d_coef_i, c->d_coef, stream))) return rc;
-    void *img = (char *)c->d_coef + c->extra * 4;
-    if ((rc = picsong_level_shift_inv(c, img, stream))) return rc;
-    const int grid = (int)((c->P + 255) / 256 > 8192 ? 8192 : (c->P + 255) / 256);
-    if (c->p.lossy) to_u8_kernel<float><<<grid, 256, 0, s>>>((const float *)img, d_frame_out, c->P);
-    else to_u8_kernel<int32_t><<<grid, 256, 0, s>>>((const int32_t *)img, d_frame_out, c->P);
+    const void *img = (const char *)c->d_coef + c->extra * 4;
+    const size_t n4 = c->P / 4;
+    const int off = 1 << (c->p.bit_depth - 1);
+    const int grid = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
+    if (c->p.lossy) clamp_to_u8_f32_kernel<<<grid, 256, 0, s>>>((const float *)img, d_frame_out, n4, (float)off);
+    else clamp_to_u8_i32_kernel<<<grid, 256, 0, s>>>((const int32_t *)img, d_frame_out, n4, off);
     HIP_TRY(hipGetLastError());
     return PICSONG_OK;
 }

@@ -55,6 +55,13 @@ def level_shift_inv(x):
     return x
 
 
+def clamp_to_u8(x):
+    x = np.ascontiguousarray(x)
+    out = np.empty(x.shape, np.uint8)
+    lib().emu_clamp_to_u8(_p(x), _p(out), C.c_size_t(x.size), int(x.dtype == np.float32))
+    return out
+
+
 def level_shift_fwd(u8, lossy):
     u8 = np.ascontiguousarray(u8)
     out = np.empty(u8.shape, np.float32 if lossy else np.int32)

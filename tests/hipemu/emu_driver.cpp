@@ -10,6 +10,13 @@
 
 using namespace picsong;
 
+template <int BAND> static void emu_inv(const InvLaunch &f, int lossy)
+{
+    DwtInvArgs a = f.a;
+    if (lossy) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<float, true, BAND>(a); });
+    else emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<int, false, BAND>(a); });
+}
+
 template <int BAND> static void emu_fwd(const FwdLaunch &f, int lossy)
 {
     DwtFwdArgs a = f.a;
@@ -39,9 +46,12 @@ void emu_dwt_forward(const void *in, int u8in, void *out, int aw, int ah, int wl
 void emu_dwt_inverse(const int32_t *in, void *out, int aw, int ah, int wl, int lossy, float qs)
 {
     for (const InvLaunch &f : plan_dwt_inverse(in, out, aw, ah, wl, qs)) {
-        DwtInvArgs a = f.a;
-        if (lossy) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<float, true>(a); });
-        else emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<int, false>(a); });
+        switch (f.band) {
+        case 32: emu_inv<32>(f, lossy); break;
+        case 16: emu_inv<16>(f, lossy); break;
+        case 8: emu_inv<8>(f, lossy); break;
+        default: emu_inv<4>(f, lossy); break;
+        }
     }
 }
 
@@ -49,6 +59,12 @@ void emu_level_shift_inv(void *data, size_t n, int lossy)
 {
     if (lossy) emu::launch(dim3(4), dim3(256), [&] { level_shift_inv_f32_kernel((float *)data, n, 128.0f); });
     else emu::launch(dim3(4), dim3(256), [&] { level_shift_inv_i32_kernel((int32_t *)data, n, 128); });
+}
+
+void emu_clamp_to_u8(const void *data, uint8_t *out, size_t n, int lossy)
+{
+    if (lossy) emu::launch(dim3(4), dim3(256), [&] { clamp_to_u8_f32_kernel((const float *)data, out, n / 4, 128.0f); });
+    else emu::launch(dim3(4), dim3(256), [&] { clamp_to_u8_i32_kernel((const int32_t *)data, out, n / 4, 128); });
 }
 
 void emu_level_shift_fwd(const uint8_t *in, void *out, size_t n, int lossy)
@@ -84,7 +100,7 @@ void emu_bpc_decode(const int32_t *staging, const int32_t *sizes, int aw, int ah
 {
     BpcArgs a = mk(aw, ah, wl, lut, geo, const_cast<int32_t *>(staging), const_cast<int32_t *>(sizes), flag);
     a.coeffs_out = coeffs;
-    emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_kernel<true>(a); });
+    emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_decode_kernel(a); });
 }
 
 int emu_pack(const int32_t *staging, const int32_t *sizes, int ncb, const uint16_t *header, uint16_t *out)

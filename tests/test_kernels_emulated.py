@@ -78,6 +78,9 @@ def test_level_shift_kernels(oracle, E):
     xf = (rng.standard_normal(4096) * 150).astype(np.float32)
     xf[:8] = [0.49, 0.5, 1.5, -128.51, 126.49, 126.5, 127.4, -0.5]
     assert np.array_equal(E.level_shift_inv(xf), oracle.level_shift_inv(xf))
+    # fused clamp + u8 conversion of the frame path
+    assert np.array_equal(E.clamp_to_u8(xi), oracle.level_shift_inv(xi).astype(np.uint8))
+    assert np.array_equal(E.clamp_to_u8(xf), oracle.level_shift_inv(xf).astype(np.uint8))
 
 
 @pytest.mark.parametrize("W,H,wl", [(192, 128, 2), (128, 64, 1)])

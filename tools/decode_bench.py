@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Times picsong_decode_frame (unpack + BPC decode + inverse DWT + clamp) on a resident 8K
+codestream; prints Mpixel/s and checks the round trip.  Secondary figure (the headline is encode)."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cuda-image-and-video-codec_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+
+import oracle_lib as orc
+import picsong_amd as pa
+
+lossy = len(sys.argv) > 1 and sys.argv[1] == "lossy"
+W, H, wl, qs = (7680, 4320, 6, 0.5) if lossy else (7680, 4320, 5, 1.0)
+lut = os.path.join(orc.LUT_DIR, "n1_lossy" if lossy else "n1_lossless")
+c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=lut)
+frame = torch.from_numpy(orc.pad_frame(orc.gen_frame(W, H, 0))).cuda()
+s = c.encode_frame(frame).clone()
+for _ in range(3):
+    d = c.decode_frame(s)
+torch.cuda.synchronize()
+n = 20
+t0 = time.perf_counter()
+for _ in range(n):
+    d = c.decode_frame(s)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / n
+ok = bool(torch.equal(d, frame.view(c.ah, c.aw))) if not lossy else None
+print(f"decode {W}x{H} lossy={lossy}: {dt * 1e3:.3f} ms/frame = {W * H / dt / 1e6:.0f} Mpixel/s, roundtrip_ok={ok}")
