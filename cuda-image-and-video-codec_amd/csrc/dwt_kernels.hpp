@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace picsong {
 
 // DWT/DWTGenerator.cuh:16-22
@@ -556,6 +558,84 @@ __global__ __launch_bounds__(256) void to_u8_kernel(const T *in, uint8_t *out, s
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = (uint8_t)(int)in[i];
+}
+
+
+// ---- colour transforms of the RGB path (RGBTransformLossless / RGBTransformLossy, reference
+// Engines/CodingEngine.cu:357-403 and Engines/DecodingEngine.cu:599-650), level shift fused, four
+// samples per lane.  RCT: c0 = floor((R+2G+B)/4), c1 = B-G, c2 = R-G.  ICT: 3x3 matrix, evaluated
+// m0*R then two fmaf (the contraction nvcc applies), so results are bit-identical to the oracle.
+__device__ __forceinline__ void unpack4(uint32_t w, int v[4], int off)
+{
+    v[0] = (int)(w & 0xFFu) - off; v[1] = (int)((w >> 8) & 0xFFu) - off;
+    v[2] = (int)((w >> 16) & 0xFFu) - off; v[3] = (int)(w >> 24) - off;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rgb_forward_kernel(const uint8_t *r, const uint8_t *g, const uint8_t *b,
+                                                          T *c0, T *c1, T *c2, size_t n4, int off)
+{
+    const float M[3][3] = { { 0.299f, 0.587f, 0.114f }, { -0.168736f, -0.331264f, 0.5f }, { 0.5f, -0.418688f, -0.081312f } };
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        int R[4], G[4], B[4];
+        unpack4(reinterpret_cast<const uint32_t *>(r)[i], R, off);
+        unpack4(reinterpret_cast<const uint32_t *>(g)[i], G, off);
+        unpack4(reinterpret_cast<const uint32_t *>(b)[i], B, off);
+        uint4 o0, o1, o2;
+        uint32_t *q0 = &o0.x, *q1 = &o1.x, *q2 = &o2.x;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if constexpr (std::is_integral<T>::value) {                      // integer: RCT
+                q0[k] = (uint32_t)((R[k] + 2 * G[k] + B[k]) >> 2);
+                q1[k] = (uint32_t)(B[k] - G[k]);
+                q2[k] = (uint32_t)(R[k] - G[k]);
+            } else {                                                      // float: ICT
+                const float fr = (float)R[k], fg = (float)G[k], fb = (float)B[k];
+                q0[k] = __float_as_uint(fmaf(M[0][2], fb, fmaf(M[0][1], fg, M[0][0] * fr)));
+                q1[k] = __float_as_uint(fmaf(M[1][2], fb, fmaf(M[1][1], fg, M[1][0] * fr)));
+                q2[k] = __float_as_uint(fmaf(M[2][2], fb, fmaf(M[2][1], fg, M[2][0] * fr)));
+            }
+        }
+        reinterpret_cast<uint4 *>(c0)[i] = o0;
+        reinterpret_cast<uint4 *>(c1)[i] = o1;
+        reinterpret_cast<uint4 *>(c2)[i] = o2;
+    }
+}
+
+__device__ __forceinline__ uint32_t clamp_u8(int v) { return (uint32_t)(v > 255 ? 255 : (v < 0 ? 0 : v)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void rgb_inverse_kernel(const T *c0, const T *c1, const T *c2, uint8_t *r,
+                                                          uint8_t *g, uint8_t *b, size_t n4, int off)
+{
+    const float M[3][3] = { { 1.0f, 0.0f, 1.402f }, { 1.0f, -0.344136f, -0.714136f }, { 1.0f, 1.772f, 0.0f } };
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 w0 = reinterpret_cast<const uint4 *>(c0)[i], w1 = reinterpret_cast<const uint4 *>(c1)[i],
+                    w2 = reinterpret_cast<const uint4 *>(c2)[i];
+        const uint32_t *q0 = &w0.x, *q1 = &w1.x, *q2 = &w2.x;
+        uint32_t oR = 0, oG = 0, oB = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int R, G, B;
+            if constexpr (std::is_integral<T>::value) {
+                const int y = (int)q0[k], cb = (int)q1[k], cr = (int)q2[k];
+                G = y - ((cb + cr) >> 2);
+                R = cr + G;
+                B = cb + G;
+            } else {
+                const float y = __uint_as_float(q0[k]), cb = __uint_as_float(q1[k]), cr = __uint_as_float(q2[k]);
+                R = (int)rintf(fmaf(M[0][2], cr, fmaf(M[0][1], cb, M[0][0] * y)) + 0.01f);
+                G = (int)rintf(fmaf(M[1][2], cr, fmaf(M[1][1], cb, M[1][0] * y)) + 0.01f);
+                B = (int)rintf(fmaf(M[2][2], cr, fmaf(M[2][1], cb, M[2][0] * y)) + 0.01f);
+            }
+            oR |= clamp_u8(R + off) << (8 * k);
+            oG |= clamp_u8(G + off) << (8 * k);
+            oB |= clamp_u8(B + off) << (8 * k);
+        }
+        reinterpret_cast<uint32_t *>(r)[i] = oR;
+        reinterpret_cast<uint32_t *>(g)[i] = oG;
+        reinterpret_cast<uint32_t *>(b)[i] = oB;
+    }
 }
 
 }  // namespace picsong

@@ -50,9 +50,9 @@ struct picsong_ctx {
     int aw, ah, ncb;
     size_t P, extra;
     // LUT
-    picsong_lut_info li;
-    int32_t *d_lut;
-    bool has_lut;
+    picsong_lut_info li[3];
+    int32_t *d_lut[3];
+    bool has_lut[3];
     // small scratch
     int32_t *d_offsets;   // nCB
     int32_t *d_total;     // 1
@@ -122,7 +122,7 @@ int picsong_header_pack(const picsong_params *p, uint16_t o[PICSONG_HDR_SHORTS])
     o[2] = (uint16_t)((p->cp == 2 ? 0 : 1) | (p->cb_height << 1) | (p->cb_width << 8) | ((p->wl & 1) << 15));
     o[3] = (uint16_t)(((p->wl & 7) >> 1) | (p->bit_depth << 3) | ((p->lossy ? 1 : 0) << 10) | ((qs4 & 31) << 11));
     o[4] = (uint16_t)((qs4 >> 5) | ((p->components & 127) << 9));
-    o[5] = (uint16_t)((p->components >> 7) | (0 << 7) | (p->height << 8));
+    o[5] = (uint16_t)((p->components >> 7) | ((p->is_rgb ? 1 : 0) << 7) | (p->height << 8));
     o[6] = (uint16_t)((p->height >> 8) | (0 << 8) | (p->bit_depth << 9) | (0 << 14) | ((p->frames & 1) << 15));
     o[7] = (uint16_t)((p->frames >> 1) & 0xFFFF);
     o[8] = (uint16_t)k3;
@@ -142,6 +142,7 @@ int picsong_header_unpack(const uint16_t e[PICSONG_HDR_SHORTS], picsong_params *
     p->lossy = (e[3] >> 10) & 1;
     p->qs = (float)((((e[3] >> 11) & 31) | ((e[4] & 511) << 5)) / 10000.0);   // DecodingEngine.cu:161
     p->components = ((e[4] >> 9) & 127) | ((e[5] & 127) << 9);
+    p->is_rgb = (e[5] >> 7) & 1;
     p->height = ((e[5] >> 8) & 255) | ((e[6] & 255) << 8);
     p->frames = ((e[6] >> 15) & 1) | ((int)e[7] << 1);
     p->k = (float)(e[8] / 1000.0);
@@ -238,7 +239,9 @@ int picsong_ctx_create(const picsong_params *p, int device, picsong_ctx **out)
     if (p->k != 0.0f) return fail(PICSONG_ERR_ARG, "only -k 0 is implemented");
     if (p->lossy && !(p->qs > 0.0f && p->qs <= 1.0f)) return fail(PICSONG_ERR_ARG, "qs %g outside (0,1]", p->qs);
     if (p->bit_depth != 8) return fail(PICSONG_ERR_ARG, "only 8-bit samples are implemented");
-    if (p->components != 1) return fail(PICSONG_ERR_ARG, "only 1 component is implemented");
+    if (!((p->components == 1 && !p->is_rgb) || (p->components == 3 && p->is_rgb)))
+        return fail(PICSONG_ERR_ARG, "components must be 1 (grey) or 3 with is_rgb (got %d, is_rgb %d)", p->components,
+                    p->is_rgb);
     const int aw = picsong_pad_dim(p->width), ah = picsong_pad_dim(p->height);
     if ((aw >> (p->wl - 1)) < 8 || (ah >> (p->wl - 1)) < 8 || ((aw >> (p->wl - 1)) & 1) || ((ah >> (p->wl - 1)) & 1))
         return fail(PICSONG_ERR_ARG, "image %dx%d too small for %d wavelet levels", aw, ah, p->wl);
@@ -276,7 +279,8 @@ void picsong_ctx_destroy(picsong_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->d_lut) (void)hipFree(c->d_lut);
+    for (int k = 0; k < 3; k++)
+        if (c->d_lut[k]) (void)hipFree(c->d_lut[k]);
     if (c->d_offsets) (void)hipFree(c->d_offsets);
     if (c->d_total) (void)hipFree(c->d_total);
     if (c->d_flag) (void)hipFree(c->d_flag);
@@ -292,9 +296,10 @@ void picsong_ctx_destroy(picsong_ctx *c)
     delete c;
 }
 
-int picsong_ctx_set_lut(picsong_ctx *c, const picsong_lut_info *info, const int32_t *host_table)
+int picsong_ctx_set_lut_component(picsong_ctx *c, int comp, const picsong_lut_info *info, const int32_t *host_table)
 {
     if (!c || !info || !host_table) return fail(PICSONG_ERR_ARG, "set_lut: null argument");
+    if (comp < 0 || comp > 2) return fail(PICSONG_ERR_ARG, "set_lut: component %d outside 0..2", comp);
     // the context formation of BPCEngine.cu:222-308 is fixed to 9 / 4 / 1 contexts
     if (info->ctx_sig != 9 || info->ctx_sign != 4 || info->ctx_ref != 1)
         return fail(PICSONG_ERR_ARG, "LUT contexts must be 9/4/1 (sig/sign/ref), got %d/%d/%d", info->ctx_sig,
@@ -305,12 +310,17 @@ int picsong_ctx_set_lut(picsong_ctx *c, const picsong_lut_info *info, const int3
         if (host_table[i] < 0 || host_table[i] > 255)
             return fail(PICSONG_ERR_ARG, "LUT entry %zu = %d outside 0..255", i, host_table[i]);
     HIP_TRY(hipSetDevice(c->device));
-    if (c->d_lut) { (void)hipFree(c->d_lut); c->d_lut = nullptr; }
-    HIP_TRY(hipMalloc(&c->d_lut, total * sizeof(int32_t)));
-    HIP_TRY(hipMemcpy(c->d_lut, host_table, total * sizeof(int32_t), hipMemcpyHostToDevice));
-    c->li = *info;
-    c->has_lut = true;
+    if (c->d_lut[comp]) { (void)hipFree(c->d_lut[comp]); c->d_lut[comp] = nullptr; }
+    HIP_TRY(hipMalloc(&c->d_lut[comp], total * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(c->d_lut[comp], host_table, total * sizeof(int32_t), hipMemcpyHostToDevice));
+    c->li[comp] = *info;
+    c->has_lut[comp] = true;
     return PICSONG_OK;
+}
+
+int picsong_ctx_set_lut(picsong_ctx *c, const picsong_lut_info *info, const int32_t *host_table)
+{
+    return picsong_ctx_set_lut_component(c, 0, info, host_table);
 }
 
 int picsong_ctx_padded_dims(const picsong_ctx *c, int *aw, int *ah, int *ncb)
@@ -398,24 +408,26 @@ int picsong_dwt_inverse(picsong_ctx *c, const int32_t *d_in, void *d_out, void *
 // ---------------------------------------------------------------------------------------------
 // BPC
 // ---------------------------------------------------------------------------------------------
-static int bpc_args(picsong_ctx *c, BpcArgs &a)
+static int bpc_args(picsong_ctx *c, BpcArgs &a, int comp = 0)
 {
-    if (!c->has_lut) return fail(PICSONG_ERR_ARG, "no LUT loaded: call picsong_ctx_set_lut first");
+    if (comp < 0 || comp > 2) return fail(PICSONG_ERR_ARG, "component %d outside 0..2", comp);
+    if (!c->has_lut[comp]) return fail(PICSONG_ERR_ARG, "no LUT loaded for component %d: call picsong_ctx_set_lut first", comp);
     memset(&a, 0, sizeof a);
+    const picsong_lut_info &li = c->li[comp];
     a.AW = c->aw; a.AH = c->ah; a.wl = c->p.wl; a.nCB = c->ncb; a.ncx = c->aw / PICSONG_CB;
-    a.lut = c->d_lut;
-    a.g.nBp = c->li.n_bitplanes; a.g.nSub = c->li.n_subbands; a.g.cRef = c->li.ctx_ref;
-    a.g.cSign = c->li.ctx_sign; a.g.cSig = c->li.ctx_sig; a.g.prec = c->li.precision;
-    a.g.nRef = c->li.n_ref; a.g.nSig = c->li.n_sig; a.g.nSign = c->li.n_sign;
+    a.lut = c->d_lut[comp];
+    a.g.nBp = li.n_bitplanes; a.g.nSub = li.n_subbands; a.g.cRef = li.ctx_ref;
+    a.g.cSign = li.ctx_sign; a.g.cSig = li.ctx_sig; a.g.prec = li.precision;
+    a.g.nRef = li.n_ref; a.g.nSig = li.n_sig; a.g.nSign = li.n_sign;
     a.range_flag = c->d_flag;
     return PICSONG_OK;
 }
 
 static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_staging, int32_t *d_sizes,
-                           bool memset_staging, hipStream_t s, int cb_begin = 0, int cb_count = -1)
+                           bool memset_staging, hipStream_t s, int cb_begin = 0, int cb_count = -1, int comp = 0)
 {
     BpcArgs a;
-    int rc = bpc_args(c, a);
+    int rc = bpc_args(c, a, comp);
     if (rc) return rc;
     if (cb_count < 0) cb_count = c->ncb - cb_begin;
     a.cb_base = cb_begin;
@@ -436,19 +448,25 @@ int picsong_bpc_encode(picsong_ctx *c, const void *d_coeffs, int32_t *d_staging,
     return bpc_encode_impl(c, d_coeffs, d_staging, d_sizes, true, (hipStream_t)stream);
 }
 
-int picsong_bpc_decode(picsong_ctx *c, const int32_t *d_staging, const int32_t *d_sizes, int32_t *d_coeffs,
-                       void *stream)
+static int bpc_decode_impl(picsong_ctx *c, const int32_t *d_staging, const int32_t *d_sizes, int32_t *d_coeffs,
+                           hipStream_t s, int comp = 0)
 {
-    if (!c || !d_coeffs || !d_staging || !d_sizes) return fail(PICSONG_ERR_ARG, "bpc_decode: null argument");
     BpcArgs a;
-    int rc = bpc_args(c, a);
+    int rc = bpc_args(c, a, comp);
     if (rc) return rc;
     a.coeffs_out = d_coeffs;
     a.staging = const_cast<int32_t *>(d_staging);
     a.sizes = const_cast<int32_t *>(d_sizes);
-    bpc_decode_kernel<<<(unsigned)((c->ncb + 1) / 2), 64, 0, (hipStream_t)stream>>>(a);
+    bpc_decode_kernel<<<(unsigned)((c->ncb + 1) / 2), 64, 0, s>>>(a);
     HIP_TRY(hipGetLastError());
     return PICSONG_OK;
+}
+
+int picsong_bpc_decode(picsong_ctx *c, const int32_t *d_staging, const int32_t *d_sizes, int32_t *d_coeffs,
+                       void *stream)
+{
+    if (!c || !d_coeffs || !d_staging || !d_sizes) return fail(PICSONG_ERR_ARG, "bpc_decode: null argument");
+    return bpc_decode_impl(c, d_staging, d_sizes, d_coeffs, (hipStream_t)stream);
 }
 
 int picsong_range_flag(picsong_ctx *c, void *stream, int *h_flag)
@@ -613,6 +631,61 @@ int picsong_encode_frame_stripe(picsong_ctx *c, const uint8_t *d_frame, int cb_b
     if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, s, cb_begin, cb_count))) return rc;
     return pack_range(c, c->d_staging + (size_t)cb_begin * PICSONG_CB_WORDS, c->d_sizes + cb_begin, cb_count, nullptr,
                       d_stream, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// RGB path
+// ---------------------------------------------------------------------------------------------
+int picsong_rgb_forward(picsong_ctx *c, const uint8_t *d_r, const uint8_t *d_g, const uint8_t *d_b, void *d_c0,
+                        void *d_c1, void *d_c2, void *stream)
+{
+    if (!c || !d_r || !d_g || !d_b || !d_c0 || !d_c1 || !d_c2) return fail(PICSONG_ERR_ARG, "rgb_forward: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n4 = c->P / 4;
+    const int off = 1 << (c->p.bit_depth - 1);
+    const int grid = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
+    if (c->p.lossy) rgb_forward_kernel<float><<<grid, 256, 0, s>>>(d_r, d_g, d_b, (float *)d_c0, (float *)d_c1, (float *)d_c2, n4, off);
+    else rgb_forward_kernel<int32_t><<<grid, 256, 0, s>>>(d_r, d_g, d_b, (int32_t *)d_c0, (int32_t *)d_c1, (int32_t *)d_c2, n4, off);
+    HIP_TRY(hipGetLastError());
+    return PICSONG_OK;
+}
+
+int picsong_rgb_inverse(picsong_ctx *c, const void *d_c0, const void *d_c1, const void *d_c2, uint8_t *d_r,
+                        uint8_t *d_g, uint8_t *d_b, void *stream)
+{
+    if (!c || !d_r || !d_g || !d_b || !d_c0 || !d_c1 || !d_c2) return fail(PICSONG_ERR_ARG, "rgb_inverse: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n4 = c->P / 4;
+    const int off = 1 << (c->p.bit_depth - 1);
+    const int grid = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
+    if (c->p.lossy) rgb_inverse_kernel<float><<<grid, 256, 0, s>>>((const float *)d_c0, (const float *)d_c1, (const float *)d_c2, d_r, d_g, d_b, n4, off);
+    else rgb_inverse_kernel<int32_t><<<grid, 256, 0, s>>>((const int32_t *)d_c0, (const int32_t *)d_c1, (const int32_t *)d_c2, d_r, d_g, d_b, n4, off);
+    HIP_TRY(hipGetLastError());
+    return PICSONG_OK;
+}
+
+int picsong_encode_plane(picsong_ctx *c, const void *d_plane, int comp, int with_header, uint16_t *d_stream, void *stream)
+{
+    if (!c || !d_plane || !d_stream) return fail(PICSONG_ERR_ARG, "encode_plane: null argument");
+    int rc = ensure_workspace(c, false);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = dwt_forward_impl(c, d_plane, false, c->d_coef, s))) return rc;
+    if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, s, 0, -1, comp))) return rc;
+    uint16_t hdr[PICSONG_HDR_SHORTS];
+    if (with_header) picsong_header_pack(&c->p, hdr);
+    return pack_range(c, c->d_staging, c->d_sizes, c->ncb, with_header ? hdr : nullptr, d_stream, s);
+}
+
+int picsong_decode_plane(picsong_ctx *c, const uint16_t *d_stream, int comp, void *d_plane_out, void *stream)
+{
+    if (!c || !d_plane_out || !d_stream) return fail(PICSONG_ERR_ARG, "decode_plane: null argument");
+    int rc = ensure_workspace(c, true);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = unpack_impl(c, d_stream, c->d_staging, c->d_sizes, false, s))) return rc;
+    if ((rc = bpc_decode_impl(c, c->d_staging, c->d_sizes, c->d_coef_i, s, comp))) return rc;
+    return picsong_dwt_inverse(c, c->d_coef_i, d_plane_out, stream);
 }
 
 int picsong_pad_frame_host(const uint8_t *in, int w, int h, uint8_t *out, int aw, int ah)

@@ -1,9 +1,9 @@
 // PICSONG command-line tool for MI355X -- host side (C++) of the hot path, written over the C ABI
 // of include/picsong_hip.h.  It keeps the reference's flags, defaults, validation, file formats and
 // console vocabulary (Launcher.cu:8-29,36-163; IO/IOManager.ipp:72-112,176-231,267-344,615-620) so
-// it is a drop-in for the greyscale image / video encode + decode paths.  What the reference builds
-// around that path (RGB colour transforms, -cp 3, -k > 0) is out of scope here and is refused with a
-// message instead of being silently ignored.
+// it is a drop-in for the greyscale and RGB (planar R,G,B; RCT / ICT) image / video encode + decode
+// paths.  The reference's -cp 3 (deprecated, LUT files not shipped) and -k > 0 modes are not built
+// and are refused with a message instead of being silently ignored.
 //
 // Pipeline (video): `-numberOfStreams N` HIP streams, each with its own picsong_ctx, pinned host
 // frame buffer and device buffers; frame f runs on stream f mod N; while the GPU works on up to N
@@ -79,6 +79,7 @@ void help()
         " -video 0|1 -frames F  video mode (raw planar frames; output + <o>_SIZE sidecar)\n"
         " -LUTFolder <dir>    probability tables (header.txt, {ref,sig,sign}R.txt_0)\n"
         " -numberOfStreams N  frames in flight (default 2)\n"
+        " -isRGB 1 -components 3  planar R,G,B planes per frame (RCT lossless / ICT lossy)\n"
         " -k 0                complexity-scalable mode is not built here\n"
         " -device D           GPU index (default 0);  --metrics <file>  JSON stage timings\n"
         " --lut-fill V        value of LUT entries the loader never writes (default 0)\n";
@@ -149,14 +150,17 @@ struct Worker {
     long frame = -1;
 };
 
-void load_lut(picsong_ctx *ctx, const Options &o, int wl)
+// component c uses the {ref,sig,sign}{R,G,B}.txt_0 files (Engine::initLUT Engines/Engine.cu:124-136)
+void load_lut(picsong_ctx *ctx, const Options &o, int wl, int components = 1)
 {
     if (o.lut_folder.empty()) die("Incorrect parameters. Please choose valid values. (-LUTFolder is required)");
-    picsong_lut_info info;
-    CK(picsong_lut_load(o.lut_folder.c_str(), 1, wl, o.lut_fill, &info, nullptr, 0));
-    std::vector<int32_t> table((size_t)info.n_ref + info.n_sig + info.n_sign);
-    CK(picsong_lut_load(o.lut_folder.c_str(), 1, wl, o.lut_fill, &info, table.data(), table.size()));
-    CK(picsong_ctx_set_lut(ctx, &info, table.data()));
+    for (int c = 0; c < components; c++) {
+        picsong_lut_info info;
+        CK(picsong_lut_load(o.lut_folder.c_str(), c + 1, wl, o.lut_fill, &info, nullptr, 0));
+        std::vector<int32_t> table((size_t)info.n_ref + info.n_sig + info.n_sign);
+        CK(picsong_lut_load(o.lut_folder.c_str(), c + 1, wl, o.lut_fill, &info, table.data(), table.size()));
+        CK(picsong_ctx_set_lut_component(ctx, c, &info, table.data()));
+    }
 }
 
 picsong_params make_params(const Options &o)
@@ -166,6 +170,7 @@ picsong_params make_params(const Options &o)
     p.width = o.x; p.height = o.y; p.wl = o.wl; p.cp = o.cp; p.lossy = o.type ? 1 : 0; p.qs = o.qs; p.k = o.k;
     p.cb_width = o.cb_width; p.cb_height = o.cb_height; p.bit_depth = o.bps; p.frames = o.frames;
     p.components = o.components;
+    p.is_rgb = o.is_rgb ? 1 : 0;
     return p;
 }
 
@@ -178,6 +183,66 @@ void write_metrics(const Options &o, const char *mode, long frames, double secon
       << ", \"mpixels_per_s\": " << (seconds > 0 ? (double)frames * o.x * o.y / seconds / 1e6 : 0.0)
       << ", \"dwt_ms\": " << dwt << ", \"bpc_ms\": " << bpc << ", \"pack_ms\": " << pack
       << ", \"stream_shorts\": " << shorts << "}\n";
+}
+
+// ---- RGB coding (CodingEngine::runImage / runVideo, RGB branches: CodingEngine.cu:598-633,676-712,
+// 760-818,873-930): the input holds planar R, G, B planes per frame; RCT / ICT with the level shift
+// fused, then every component is coded as a frame of its own with its own LUT and appended to <o>,
+// its length to <o>_SIZE.  Header: image -> component 0 only (iter = component), video -> all three
+// components of frame 0 (iter = frame).
+int run_encode_rgb(const Options &o, size_t file_base, long nframes)
+{
+    HIPCK(hipSetDevice(o.device));
+    const int aw = picsong_pad_dim(o.x), ah = picsong_pad_dim(o.y);
+    const size_t P = (size_t)aw * ah, max_shorts = picsong_max_stream_shorts(aw, ah);
+    picsong_params params = make_params(o);
+    picsong_ctx *ctx = nullptr;
+    CK(picsong_ctx_create(&params, o.device, &ctx));
+    load_lut(ctx, o, o.wl, 3);
+    hipStream_t s;
+    HIPCK(hipStreamCreate(&s));
+    uint8_t *h_in, *d_in[3];
+    void *d_c[3];
+    uint16_t *h_out, *d_out;
+    HIPCK(hipHostMalloc(&h_in, P));
+    for (int c = 0; c < 3; c++) { HIPCK(hipMalloc(&d_in[c], P)); HIPCK(hipMalloc(&d_c[c], P * 4)); }
+    HIPCK(hipHostMalloc(&h_out, max_shorts * 2));
+    HIPCK(hipMalloc(&d_out, max_shorts * 2));
+    std::vector<uint8_t> raw((size_t)o.x * o.y);
+    std::ifstream in(o.input, std::ios::binary);
+    if (!in) die("Cannot open input file " + o.input);
+    std::ofstream out(o.output, std::ios::binary | std::ios::app);
+    std::ofstream sizes(o.output + "_SIZE", std::ios::binary | std::ios::app);
+    long total_shorts = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    for (long f = 0; f < nframes; f++) {
+        for (int c = 0; c < 3; c++) {
+            if (!read_frame(in, file_base, (size_t)(f * 3 + c), o.x, o.y, raw.data())) die("Input file is shorter than the requested frames.");
+            CK(picsong_pad_frame_host(raw.data(), o.x, o.y, h_in, aw, ah));
+            HIPCK(hipMemcpyAsync(d_in[c], h_in, P, hipMemcpyHostToDevice, s));
+            HIPCK(hipStreamSynchronize(s));          // h_in is reused for the next plane
+        }
+        CK(picsong_rgb_forward(ctx, d_in[0], d_in[1], d_in[2], d_c[0], d_c[1], d_c[2], s));
+        for (int c = 0; c < 3; c++) {
+            const int with_header = o.video ? (f == 0) : (c == 0);
+            CK(picsong_encode_plane(ctx, d_c[c], c, with_header, d_out, s));
+            int total = 0;
+            CK(picsong_last_total(ctx, s, &total));
+            HIPCK(hipMemcpyAsync(h_out, d_out, (size_t)total * 2, hipMemcpyDeviceToHost, s));
+            HIPCK(hipStreamSynchronize(s));
+            out.write(reinterpret_cast<const char *>(h_out), (std::streamsize)total * 2);
+            if (f == 0 && c == 0) sizes << total; else sizes << "," << total;
+            total_shorts += total;
+        }
+    }
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::cout << "The time spent with the app without considering allocation periods is: " << sec << std::endl;
+    write_metrics(o, "encode_rgb", nframes, sec, 0, 0, 0, total_shorts);
+    picsong_ctx_destroy(ctx);
+    (void)hipStreamDestroy(s);
+    (void)hipHostFree(h_in); (void)hipHostFree(h_out); (void)hipFree(d_out);
+    for (int c = 0; c < 3; c++) { (void)hipFree(d_in[c]); (void)hipFree(d_c[c]); }
+    return 0;
 }
 
 // ---- coding engine: CodingEngine::runImage / runVideo call sequence ---------------------------
@@ -193,12 +258,14 @@ int run_encode(Options o)
     if (o.qs < 0 || o.qs > 1 || o.wl < 1 || o.x <= 0 || o.y <= 0 || o.wl > 10 || o.input.empty() || o.output.empty() ||
         o.cb_width % 64 != 0 || o.cb_height > 20 || o.cb_height < 18 || o.cp < 2 || o.cp > 3 || o.k < 0 || o.k > 65.535f)
         die("Incorrect parameters. Please choose valid values.");
-    if (o.is_rgb || o.components != 1) die("RGB / multi-component input is not built in this MI355X hot-path build.");
+    if (!((o.is_rgb && o.components == 3) || (!o.is_rgb && o.components == 1)))
+        die("Incorrect parameters. Use -components 1, or -isRGB 1 -components 3 (planar R,G,B planes).");
     if (o.cp != 2) die("-cp 3 (deprecated in the reference) is not built in this MI355X hot-path build.");
     if (o.k != 0) die("-k > 0 (complexity-scalable mode) is not built in this MI355X hot-path build.");
     if (o.signed_or_unsigned != 0 || o.bps != 8) die("Only unsigned 8-bit samples are built in this MI355X hot-path build.");
     const long nframes = o.video ? o.frames : 1;
     if (nframes <= 0) die("Incorrect parameters. Please choose valid values. (-frames)");
+    if (o.is_rgb) return run_encode_rgb(o, pgm.is_pgm ? pgm.offset : 0, nframes);
     const int nstreams = o.video ? (o.streams < 1 ? 1 : o.streams) : 1;
 
     HIPCK(hipSetDevice(o.device));
@@ -280,6 +347,60 @@ void write_pgm(const std::string &path, const uint8_t *pix, int w, int h, int bi
     f.write(reinterpret_cast<const char *>(pix), (std::streamsize)((size_t)w * h));
 }
 
+// ---- RGB decoding (DecodingEngine::runImage / runVideo RGB branches, Engines/DecodingEngine.cu:
+// 736-769,868-940): three component streams per frame -> Decode + DWTDecode each -> inverse colour
+// transform (offset + clamp fused) -> planar R, G, B planes of W*H bytes appended to <o>
+// (IOManager::writeDecodedFrameUChar / writeDecodedFrameComponentUChar, IO/IOManager.ipp:236-262).
+int run_decode_rgb(const Options &o, const picsong_params &p, picsong_ctx *ctx, std::ifstream &in,
+                   const std::vector<long> &shorts, long nframes, int aw, int ah)
+{
+    const size_t P = (size_t)aw * ah, max_shorts = picsong_max_stream_shorts(aw, ah);
+    const size_t extra = picsong_dwt_extra(aw, ah, p.wl);
+    hipStream_t s;
+    HIPCK(hipStreamCreate(&s));
+    uint16_t *h_in, *d_in;
+    uint8_t *h_pix, *d_pix[3];
+    char *d_plane[3];
+    HIPCK(hipHostMalloc(&h_in, max_shorts * 2));
+    HIPCK(hipMalloc(&d_in, max_shorts * 2));
+    HIPCK(hipHostMalloc(&h_pix, P));
+    for (int c = 0; c < 3; c++) { HIPCK(hipMalloc(&d_pix[c], P)); HIPCK(hipMalloc(&d_plane[c], (P + extra) * 4)); }
+    std::vector<uint8_t> crop((size_t)p.width * p.height);
+    { std::ofstream trunc(o.output, std::ios::binary | std::ios::trunc); }
+    auto t0 = std::chrono::steady_clock::now();
+    size_t pos = 0;
+    for (long f = 0; f < nframes; f++) {
+        for (int c = 0; c < 3; c++) {
+            const size_t n = (size_t)shorts[(size_t)(f * 3 + c)];
+            if (n > max_shorts) die("Component codestream longer than the maximum for this geometry.");
+            in.clear();
+            in.seekg((std::streamoff)(pos * 2));
+            in.read(reinterpret_cast<char *>(h_in), (std::streamsize)(n * 2));
+            if ((size_t)in.gcount() != n * 2) die("Input file is shorter than its _SIZE sidecar says.");
+            pos += n;
+            HIPCK(hipMemcpyAsync(d_in, h_in, n * 2, hipMemcpyHostToDevice, s));
+            CK(picsong_decode_plane(ctx, d_in, c, d_plane[c], s));
+            HIPCK(hipStreamSynchronize(s));          // h_in / d_in are reused for the next component
+        }
+        CK(picsong_rgb_inverse(ctx, d_plane[0] + extra * 4, d_plane[1] + extra * 4, d_plane[2] + extra * 4, d_pix[0],
+                               d_pix[1], d_pix[2], s));
+        std::ofstream out(o.output, std::ios::binary | std::ios::app);
+        for (int c = 0; c < 3; c++) {
+            HIPCK(hipMemcpyAsync(h_pix, d_pix[c], P, hipMemcpyDeviceToHost, s));
+            HIPCK(hipStreamSynchronize(s));
+            for (int y = 0; y < p.height; y++) memcpy(&crop[(size_t)y * p.width], h_pix + (size_t)y * aw, (size_t)p.width);
+            out.write(reinterpret_cast<const char *>(crop.data()), (std::streamsize)crop.size());
+        }
+    }
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::cout << "The time spent with the app without considering allocation periods and I/O is: " << sec << std::endl;
+    picsong_ctx_destroy(ctx);
+    (void)hipStreamDestroy(s);
+    (void)hipHostFree(h_in); (void)hipFree(d_in); (void)hipHostFree(h_pix);
+    for (int c = 0; c < 3; c++) { (void)hipFree(d_pix[c]); (void)hipFree(d_plane[c]); }
+    return 0;
+}
+
 int run_decode(const Options &o)
 {
     if (o.input.empty() || o.output.empty()) die("Incorrect parameters. Please choose valid values.");
@@ -290,16 +411,17 @@ int run_decode(const Options &o)
     if ((size_t)in.gcount() != sizeof hdr) die("Input file too short for a PICSONG header.");
     picsong_params p;
     CK(picsong_header_unpack(hdr, &p));
-    if (p.cp != 2 || p.k != 0 || p.components != 1) die("This stream uses -cp 3 / -k / components not built here.");
+    if (p.cp != 2 || p.k != 0 || !((p.components == 1 && !p.is_rgb) || (p.components == 3 && p.is_rgb)))
+        die("This stream uses -cp 3 / -k / a component layout not built here.");
     const long nframes = o.video ? p.frames : 1;
     std::vector<long> frame_shorts;
-    if (o.video) {
+    if (o.video || p.is_rgb) {
         // IOManager::readBulkSizes IO/IOManager.ipp:196-208
         std::ifstream sz(o.input + "_SIZE");
         if (!sz) die("Cannot open " + o.input + "_SIZE");
         std::string tok;
         while (std::getline(sz, tok, ',')) if (!tok.empty()) frame_shorts.push_back(std::stol(tok));
-        if ((long)frame_shorts.size() < nframes) die("_SIZE sidecar lists fewer frames than the header.");
+        if ((long)frame_shorts.size() < nframes * p.components) die("_SIZE sidecar lists fewer streams than the header.");
     } else {
         in.seekg(0, std::ios::end);
         frame_shorts.push_back((long)((size_t)in.tellg() / 2));
@@ -308,9 +430,10 @@ int run_decode(const Options &o)
     picsong_ctx *ctx = nullptr;
     CK(picsong_ctx_create(&p, o.device, &ctx));
     Options lo = o;
-    load_lut(ctx, lo, p.wl);
+    load_lut(ctx, lo, p.wl, p.components);
     int aw, ah, ncb;
     CK(picsong_ctx_padded_dims(ctx, &aw, &ah, &ncb));
+    if (p.is_rgb) return run_decode_rgb(o, p, ctx, in, frame_shorts, nframes, aw, ah);
     const size_t P = (size_t)aw * ah, max_shorts = picsong_max_stream_shorts(aw, ah);
     hipStream_t s;
     HIPCK(hipStreamCreate(&s));

@@ -19,7 +19,7 @@ class Params(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("wl", C.c_int), ("cp", C.c_int),
                 ("lossy", C.c_int), ("qs", C.c_float), ("k", C.c_float), ("cb_width", C.c_int),
                 ("cb_height", C.c_int), ("bit_depth", C.c_int), ("frames", C.c_int),
-                ("components", C.c_int)]
+                ("components", C.c_int), ("is_rgb", C.c_int)]
 
 
 class LutInfo(C.Structure):
@@ -35,7 +35,8 @@ EXPORTS = [
     "picsong_dwt_forward_u8", "picsong_bpc_encode", "picsong_bpc_decode", "picsong_bitstream_pack",
     "picsong_bitstream_unpack", "picsong_last_total", "picsong_encode_frame", "picsong_decode_frame",
     "picsong_pad_frame_host", "picsong_range_flag", "picsong_profile_begin", "picsong_profile_read",
-    "picsong_encode_frame_stripe",
+    "picsong_encode_frame_stripe", "picsong_ctx_set_lut_component", "picsong_rgb_forward", "picsong_rgb_inverse",
+    "picsong_encode_plane", "picsong_decode_plane",
 ]
 
 _lib = None
@@ -83,6 +84,11 @@ def load():
     L.picsong_encode_frame.argtypes = [vp, vp, i, vp, vp]
     L.picsong_decode_frame.argtypes = [vp, vp, vp, vp]
     L.picsong_encode_frame_stripe.argtypes = [vp, vp, i, i, vp, vp]
+    L.picsong_ctx_set_lut_component.argtypes = [vp, i, C.POINTER(LutInfo), vp]
+    L.picsong_rgb_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.picsong_rgb_inverse.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.picsong_encode_plane.argtypes = [vp, vp, i, i, vp, vp]
+    L.picsong_decode_plane.argtypes = [vp, vp, i, vp, vp]
     L.picsong_pad_frame_host.argtypes = [vp, i, i, vp, i, i]
     L.picsong_range_flag.argtypes = [vp, vp, C.POINTER(i)]
     L.picsong_profile_begin.argtypes = [vp, i]
@@ -119,9 +125,10 @@ def lut_load(folder, wl, component=1, fill=0):
     return info, table
 
 
-def make_params(width, height, wl=5, lossy=False, qs=1.0, frames=0):
+def make_params(width, height, wl=5, lossy=False, qs=1.0, frames=0, rgb=False):
     return Params(width=width, height=height, wl=wl, cp=2, lossy=int(lossy), qs=qs, k=0.0,
-                  cb_width=64, cb_height=18, bit_depth=8, frames=frames, components=1)
+                  cb_width=64, cb_height=18, bit_depth=8, frames=frames, components=3 if rgb else 1,
+                  is_rgb=int(rgb))
 
 
 def header_pack(params):
@@ -142,13 +149,14 @@ class Codec:
     objects + the LUT upload of Engine::initLUT).  All tensor arguments are torch CUDA tensors."""
 
     def __init__(self, width, height, wl=5, lossy=False, qs=1.0, lut_folder=None, lut_fill=0,
-                 device=0, frames=0):
+                 device=0, frames=0, rgb=False):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("no GPU visible: the picsong HIP path has no CPU fallback")
         self.torch = torch
         self.L = load()
-        self.params = make_params(width, height, wl, lossy, qs, frames)
+        self.params = make_params(width, height, wl, lossy, qs, frames, rgb)
+        self.rgb = bool(rgb)
         self.device = device
         h = C.c_void_p()
         _check(self.L.picsong_ctx_create(C.byref(self.params), device, C.byref(h)))
@@ -162,8 +170,9 @@ class Codec:
         self.dtype = torch.float32 if lossy else torch.int32
         self.dev = torch.device("cuda", device)
         if lut_folder is not None:
-            info, table = lut_load(lut_folder, wl, 1, lut_fill)
-            self.set_lut(info, table)
+            for comp in range(3 if rgb else 1):
+                info, table = lut_load(lut_folder, wl, comp + 1, lut_fill)     # files ...R/G/B.txt_0
+                self.set_lut(info, table, comp)
 
     def close(self):
         if getattr(self, "h", None):
@@ -183,9 +192,34 @@ class Codec:
     def _p(t):
         return C.c_void_p(t.data_ptr())
 
-    def set_lut(self, info, table):
+    def set_lut(self, info, table, component=0):
         table = np.ascontiguousarray(table, np.int32)
-        _check(self.L.picsong_ctx_set_lut(self.h, C.byref(info), table.ctypes.data_as(C.c_void_p)))
+        _check(self.L.picsong_ctx_set_lut_component(self.h, component, C.byref(info),
+                                                    table.ctypes.data_as(C.c_void_p)))
+
+    # ---- RGB path ----
+    def rgb_forward(self, r, g, b):
+        outs = [self.torch.empty(self.P, dtype=self.dtype, device=self.dev) for _ in range(3)]
+        _check(self.L.picsong_rgb_forward(self.h, self._p(r), self._p(g), self._p(b), self._p(outs[0]),
+                                          self._p(outs[1]), self._p(outs[2]), self._stream()))
+        return outs
+
+    def rgb_inverse(self, c0, c1, c2):
+        outs = [self.torch.empty(self.P, dtype=self.torch.uint8, device=self.dev) for _ in range(3)]
+        _check(self.L.picsong_rgb_inverse(self.h, self._p(c0), self._p(c1), self._p(c2), self._p(outs[0]),
+                                          self._p(outs[1]), self._p(outs[2]), self._stream()))
+        return [o.view(self.ah, self.aw) for o in outs]
+
+    def encode_plane(self, plane, component, with_header):
+        out = self.torch.empty(self.max_stream_shorts(), dtype=self.torch.int16, device=self.dev)
+        _check(self.L.picsong_encode_plane(self.h, self._p(plane), component, int(with_header), self._p(out),
+                                           self._stream()))
+        return out[:self.last_total()]
+
+    def decode_plane(self, stream, component):
+        out = self.torch.empty(self.P + self.extra, dtype=self.dtype, device=self.dev)
+        _check(self.L.picsong_decode_plane(self.h, self._p(stream), component, self._p(out), self._stream()))
+        return out[self.extra:]
 
     # ---- stage functions (device tensors in/out) ----
     def level_shift_fwd(self, u8):

@@ -49,7 +49,8 @@ typedef struct picsong_params {
     int cb_width, cb_height;/* -cbWidth / -cbHeight: header-only */
     int bit_depth;          /* -bps (8) */
     int frames;             /* -frames (header only) */
-    int components;         /* 1 */
+    int components;         /* -components: 1 (grey) or 3 (with is_rgb) */
+    int is_rgb;             /* -isRGB: planar R,G,B planes, RCT (lossless) / ICT (lossy) colour transform */
 } picsong_params;
 
 /* LUT geometry == header.txt (Engines/Engine.cu:190-210) + section sizes
@@ -90,6 +91,10 @@ int  picsong_ctx_create(const picsong_params *p, int device, picsong_ctx **out);
 void picsong_ctx_destroy(picsong_ctx *ctx);
 int  picsong_ctx_set_lut(picsong_ctx *ctx, const picsong_lut_info *info, const int32_t *host_table);
 int  picsong_ctx_padded_dims(const picsong_ctx *ctx, int *aw, int *ah, int *n_codeblocks);
+/* RGB: component c (0,1,2) uses its own table, files {ref,sig,sign}{R,G,B}.txt_0
+ * (Engine::initLUT Engines/Engine.cu:124-136: _LUTInformation[i]); picsong_ctx_set_lut == component 0 */
+int  picsong_ctx_set_lut_component(picsong_ctx *ctx, int component, const picsong_lut_info *info,
+                                   const int32_t *host_table);
 
 /* ---- level shift: offsetImage<T> Engines/CodingEngine.cu:581-588 and
  *      removeOffsetAndApplyMaxMin(/Lossy) Engines/DecodingEngine.cu:706-729.
@@ -140,6 +145,22 @@ int picsong_encode_frame(picsong_ctx *ctx, const uint8_t *d_frame, int iter, uin
                          void *stream);
 int picsong_decode_frame(picsong_ctx *ctx, const uint16_t *d_stream, uint8_t *d_frame_out,
                          void *stream);
+/* ---- RGB path: RGBTransformLossless / RGBTransformLossy with the level shift
+ *      fused (Engines/CodingEngine.cu:357-403,408-449; Engines/DecodingEngine.cu:599-701), then each
+ *      component is coded as a frame of its own with its own LUT (CodingEngine.cu:598-633,676-712).
+ *      Planes are padded AW*AH arrays; T = int32 (lossless ctx) or float (lossy ctx).
+ *      encode_plane = DWTEncode + Code for one component; with_header == the reference's iter == 0.
+ *      decode_plane = Decode + DWTDecode: d_plane_out has AW*AH + picsong_dwt_extra() elements, the
+ *      component lands at d_plane_out + extra (no clamp: the inverse colour transform clamps). ---- */
+int picsong_rgb_forward(picsong_ctx *ctx, const uint8_t *d_r, const uint8_t *d_g, const uint8_t *d_b,
+                        void *d_c0, void *d_c1, void *d_c2, void *stream);
+int picsong_rgb_inverse(picsong_ctx *ctx, const void *d_c0, const void *d_c1, const void *d_c2,
+                        uint8_t *d_r, uint8_t *d_g, uint8_t *d_b, void *stream);
+int picsong_encode_plane(picsong_ctx *ctx, const void *d_plane, int component, int with_header,
+                         uint16_t *d_stream, void *stream);
+int picsong_decode_plane(picsong_ctx *ctx, const uint16_t *d_stream, int component, void *d_plane_out,
+                         void *stream);
+
 /* ---- intra-frame sharding (BASELINE config 5): codeblocks are independent
  *      (correctCBBorders zeroes outside neighbours, BPC/BPCEngine.cu:465-484), so a rank can code
  *      the stripe [cb_begin, cb_begin + cb_count) of the frame's raster-ordered codeblocks.  The

@@ -126,6 +126,75 @@ void po_level_shift_inv_f32(float *data, size_t n, int bit_depth)
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* colour transforms (RGB path)                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Engines/CodingEngine.cuh:25, Engines/DecodingEngine.cuh:41 */
+static const float PO_ICT_F[3][3] = { { 0.299f, 0.587f, 0.114f }, { -0.168736f, -0.331264f, 0.5f },
+                                      { 0.5f, -0.418688f, -0.081312f } };
+static const float PO_ICT_B[3][3] = { { 1.0f, 0.0f, 1.402f }, { 1.0f, -0.344136f, -0.714136f },
+                                      { 1.0f, 1.772f, 0.0f } };
+
+/* RGBTransformLossless Engines/CodingEngine.cu:357-379: level shift, then
+ * c0 = floor((R + 2G + B) / 4), c1 = B - G, c2 = R - G */
+void po_rct_forward(const uint8_t *r, const uint8_t *g, const uint8_t *b, int32_t *c0, int32_t *c1,
+                    int32_t *c2, size_t n, int bit_depth)
+{
+    int off = 1 << (bit_depth - 1);
+    for (size_t i = 0; i < n; i++) {
+        int R = (int)r[i] - off, G = (int)g[i] - off, B = (int)b[i] - off;
+        c0[i] = (R + 2 * G + B) >> 2;          /* floor: arithmetic shift */
+        c1[i] = B - G;
+        c2[i] = R - G;
+    }
+}
+
+/* RGBTransformLossless Engines/DecodingEngine.cu:599-623: G = c0 - floor((c1 + c2) / 4),
+ * R = c2 + G, B = c1 + G, + offset, clamp to 0..255 */
+void po_rct_inverse(const int32_t *c0, const int32_t *c1, const int32_t *c2, uint8_t *r, uint8_t *g,
+                    uint8_t *b, size_t n, int bit_depth)
+{
+    int off = 1 << (bit_depth - 1);
+    for (size_t i = 0; i < n; i++) {
+        int G = c0[i] - ((c1[i] + c2[i]) >> 2);
+        int R = c2[i] + G, B = c1[i] + G;
+        R += off; G += off; B += off;
+        r[i] = (uint8_t)(R > 255 ? 255 : (R < 0 ? 0 : R));
+        g[i] = (uint8_t)(G > 255 ? 255 : (G < 0 ? 0 : G));
+        b[i] = (uint8_t)(B > 255 ? 255 : (B < 0 ? 0 : B));
+    }
+}
+
+/* RGBTransformLossy Engines/CodingEngine.cu:384-403: m0*R + m1*G + m2*B left to right, with the
+ * contraction nvcc applies by default: fmaf(m2, B, fmaf(m1, G, m0*R)) */
+void po_ict_forward(const uint8_t *r, const uint8_t *g, const uint8_t *b, float *c0, float *c1, float *c2,
+                    size_t n, int bit_depth)
+{
+    float off = (float)(1 << (bit_depth - 1));
+    float *out[3] = { c0, c1, c2 };
+    for (size_t i = 0; i < n; i++) {
+        float R = (float)r[i] - off, G = (float)g[i] - off, B = (float)b[i] - off;
+        for (int k = 0; k < 3; k++)
+            out[k][i] = fmaf(PO_ICT_F[k][2], B, fmaf(PO_ICT_F[k][1], G, PO_ICT_F[k][0] * R));
+    }
+}
+
+/* RGBTransformLossy Engines/DecodingEngine.cu:628-650: __float2int_rn(m . c + 0.01f) + offset, clamp */
+void po_ict_inverse(const float *c0, const float *c1, const float *c2, uint8_t *r, uint8_t *g, uint8_t *b,
+                    size_t n, int bit_depth)
+{
+    int off = 1 << (bit_depth - 1);
+    uint8_t *out[3] = { r, g, b };
+    for (size_t i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) {
+            float t = fmaf(PO_ICT_B[k][2], c2[i], fmaf(PO_ICT_B[k][1], c1[i], PO_ICT_B[k][0] * c0[i]));
+            t = t + 0.01f;
+            int v = (int)rintf(t) + off;
+            out[k][i] = (uint8_t)(v > 255 ? 255 : (v < 0 ? 0 : v));
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* DWT                                                                                          */
 /* ------------------------------------------------------------------------------------------ */
 

@@ -80,6 +80,17 @@ void po_level_shift_fwd_f32(const uint8_t *in, float *out, size_t n, int bit_dep
 void po_level_shift_inv_i32(int32_t *data, size_t n, int bit_depth);
 void po_level_shift_inv_f32(float *data, size_t n, int bit_depth);
 
+/* ---- colour transforms of the RGB path (Engines/CodingEngine.cu:357-403,
+ *      Engines/DecodingEngine.cu:599-650), level shift fused as in the reference */
+void po_rct_forward(const uint8_t *r, const uint8_t *g, const uint8_t *b, int32_t *c0, int32_t *c1,
+                    int32_t *c2, size_t n, int bit_depth);
+void po_rct_inverse(const int32_t *c0, const int32_t *c1, const int32_t *c2, uint8_t *r, uint8_t *g,
+                    uint8_t *b, size_t n, int bit_depth);
+void po_ict_forward(const uint8_t *r, const uint8_t *g, const uint8_t *b, float *c0, float *c1, float *c2,
+                    size_t n, int bit_depth);
+void po_ict_inverse(const float *c0, const float *c1, const float *c2, uint8_t *r, uint8_t *g, uint8_t *b,
+                    size_t n, int bit_depth);
+
 /* ---- DWT (DWT/DWTGenerator.cu) ; out buffers hold P + po_dwt_extra() elements */
 size_t po_dwt_extra(int AW, int AH, int wl);
 void po_dwt53_forward(const int32_t *in, int32_t *out, int AW, int AH, int wl);

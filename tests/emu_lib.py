@@ -62,6 +62,21 @@ def clamp_to_u8(x):
     return out
 
 
+def rgb_forward(r, g, b, lossy):
+    r, g, b = (np.ascontiguousarray(x) for x in (r, g, b))
+    outs = [np.empty(r.shape, np.float32 if lossy else np.int32) for _ in range(3)]
+    lib().emu_rgb_forward(_p(r), _p(g), _p(b), _p(outs[0]), _p(outs[1]), _p(outs[2]), C.c_size_t(r.size), int(lossy))
+    return outs
+
+
+def rgb_inverse(c0, c1, c2):
+    c0, c1, c2 = (np.ascontiguousarray(x) for x in (c0, c1, c2))
+    outs = [np.empty(c0.shape, np.uint8) for _ in range(3)]
+    lib().emu_rgb_inverse(_p(c0), _p(c1), _p(c2), _p(outs[0]), _p(outs[1]), _p(outs[2]), C.c_size_t(c0.size),
+                          int(c0.dtype == np.float32))
+    return outs
+
+
 def level_shift_fwd(u8, lossy):
     u8 = np.ascontiguousarray(u8)
     out = np.empty(u8.shape, np.float32 if lossy else np.int32)

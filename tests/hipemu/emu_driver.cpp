@@ -67,6 +67,18 @@ void emu_clamp_to_u8(const void *data, uint8_t *out, size_t n, int lossy)
     else emu::launch(dim3(4), dim3(256), [&] { clamp_to_u8_i32_kernel((const int32_t *)data, out, n / 4, 128); });
 }
 
+void emu_rgb_forward(const uint8_t *r, const uint8_t *g, const uint8_t *b, void *c0, void *c1, void *c2, size_t n, int lossy)
+{
+    if (lossy) emu::launch(dim3(3), dim3(256), [&] { rgb_forward_kernel<float>(r, g, b, (float *)c0, (float *)c1, (float *)c2, n / 4, 128); });
+    else emu::launch(dim3(3), dim3(256), [&] { rgb_forward_kernel<int32_t>(r, g, b, (int32_t *)c0, (int32_t *)c1, (int32_t *)c2, n / 4, 128); });
+}
+
+void emu_rgb_inverse(const void *c0, const void *c1, const void *c2, uint8_t *r, uint8_t *g, uint8_t *b, size_t n, int lossy)
+{
+    if (lossy) emu::launch(dim3(3), dim3(256), [&] { rgb_inverse_kernel<float>((const float *)c0, (const float *)c1, (const float *)c2, r, g, b, n / 4, 128); });
+    else emu::launch(dim3(3), dim3(256), [&] { rgb_inverse_kernel<int32_t>((const int32_t *)c0, (const int32_t *)c1, (const int32_t *)c2, r, g, b, n / 4, 128); });
+}
+
 void emu_level_shift_fwd(const uint8_t *in, void *out, size_t n, int lossy)
 {
     if (lossy) emu::launch(dim3(4), dim3(256), [&] { level_shift_fwd_kernel<float>(in, (float *)out, n / 4, 128); });

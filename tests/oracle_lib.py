@@ -83,6 +83,8 @@ def lib():
     L.po_encode_frame.argtypes = [vp, i32, i32, i32, i32, f32, C.POINTER(PoLut), i32, i32, vp]
     L.po_decode_frame.restype = i32
     L.po_decode_frame.argtypes = [vp, i32, i32, i32, i32, f32, C.POINTER(PoLut), vp]
+    for fn in (L.po_rct_forward, L.po_rct_inverse, L.po_ict_forward, L.po_ict_inverse):
+        fn.argtypes = [vp, vp, vp, vp, vp, vp, sz, i32]
     L.po_set_threads.argtypes = [i32]
     L.po_get_threads.restype = i32
     L.po_max_threads.restype = i32
@@ -149,6 +151,45 @@ def pad_frame(img):
     img = np.ascontiguousarray(img)
     lib().po_pad_frame(_p(img), W, H, _p(out), AW, AH)
     return out
+
+
+def rgb_forward(r, g, b, lossy):
+    """RCT (lossless) / ICT (lossy) with the level shift fused; planes in, 3 component planes out."""
+    r, g, b = (np.ascontiguousarray(x, np.uint8) for x in (r, g, b))
+    outs = [np.empty(r.shape, np.float32 if lossy else np.int32) for _ in range(3)]
+    (lib().po_ict_forward if lossy else lib().po_rct_forward)(_p(r), _p(g), _p(b), _p(outs[0]), _p(outs[1]),
+                                                              _p(outs[2]), r.size, 8)
+    return outs
+
+
+def rgb_inverse(c0, c1, c2):
+    c0, c1, c2 = (np.ascontiguousarray(x) for x in (c0, c1, c2))
+    lossy = c0.dtype == np.float32
+    outs = [np.empty(c0.shape, np.uint8) for _ in range(3)]
+    (lib().po_ict_inverse if lossy else lib().po_rct_inverse)(_p(c0), _p(c1), _p(c2), _p(outs[0]), _p(outs[1]),
+                                                              _p(outs[2]), c0.size, 8)
+    return outs
+
+
+def lut_for_component(lossy, wl, component, fill=0):
+    """component 0/1/2 -> the R/G/B table files of the fixture folder."""
+    return Lut(os.path.join(LUT_DIR, "n1_lossy" if lossy else "n1_lossless"), wl, component + 1, fill)
+
+
+def encode_plane(plane, wl, lossy, qs, lut, header):
+    """One component: DWT + BPC + pack of an already transformed / shifted padded plane."""
+    AH, AW = plane.shape
+    f = dwt_forward(np.ascontiguousarray(plane), wl, qs)
+    st, sz = bpc_encode(f[:AW * AH].reshape(AH, AW), wl, lut)
+    return bitstream_pack(st, sz, header)
+
+
+def decode_plane(stream, AW, AH, wl, lossy, qs, lut):
+    """Inverse of encode_plane up to (not including) clamping: returns the (AH, AW) component."""
+    st, sz = bitstream_unpack(stream, (AW // 64) * (AH // 64))
+    coef = bpc_decode(st, sz, AW, AH, wl, lut)
+    out, extra = dwt_inverse(coef, wl, lossy, qs)
+    return out[extra:].reshape(AH, AW)
 
 
 def level_shift_fwd(u8, lossy):

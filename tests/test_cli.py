@@ -28,7 +28,8 @@ def test_help_and_validation():
     assert "User entered -xSize command 0" in r.stdout
     for extra, msg in ((("-wl", 11), "Incorrect parameters"), (("-cbWidth", 65), "Incorrect parameters"),
                        (("-cbHeight", 21), "Incorrect parameters"), (("-qs", 1.5), "Incorrect parameters"),
-                       (("-isRGB", 1), "not built"), (("-cp", 3), "not built"), (("-k", 0.5), "not built")):
+                       (("-isRGB", 1), "Incorrect parameters"), (("-components", 3), "Incorrect parameters"),
+                       (("-cp", 3), "not built"), (("-k", 0.5), "not built")):
         base = () if extra[0] == "-wl" else ("-wl", 1)
         r = _run("-cd", 0, "-i", "/etc/hostname", "-o", "/tmp/x", "-xSize", 64, "-ySize", 64, *base, *extra)
         assert r.returncode == 255 and msg in r.stdout, (extra, r.stdout)
@@ -80,3 +81,45 @@ def test_video_files_roundtrip(oracle, tmp_path):
     got = np.fromfile(dec, np.uint8).reshape(F, H, W)
     for f in range(F):
         assert np.array_equal(got[f], oracle.decode_frame(ref[f], W, H, wl, True, 0.5, lut))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lossy,video", [(False, False), (True, True)])
+def test_rgb_files_roundtrip_and_oracle_parity(oracle, tmp_path, lossy, video):
+    """-isRGB 1 -components 3: planar R,G,B planes; every component stream equals the oracle's
+    (RCT/ICT + per-component LUT), header on component 0 (image) / on frame 0's three components
+    (video), decode returns planar planes."""
+    W, H, wl, qs, F = 256, 192, 2, (0.5 if lossy else 1.0), (2 if video else 1)
+    lutdir = os.path.join(oracle.LUT_DIR, "n1_lossy" if lossy else "n1_lossless")
+    planes = [[oracle.gen_frame(W, H, 10 * f + c) for c in range(3)] for f in range(F)]
+    raw, enc, dec = tmp_path / "rgb.raw", tmp_path / "rgb.enc", tmp_path / "rgb.dec"
+    np.concatenate([p.ravel() for fr in planes for p in fr]).tofile(raw)
+    args = ["-cd", 0, "-i", raw, "-o", enc, "-xSize", W, "-ySize", H, "-wl", wl, "-type", int(lossy), "-qs", qs,
+            "-isRGB", 1, "-components", 3, "-LUTFolder", lutdir]
+    if video:
+        args += ["-video", 1, "-frames", F]
+    r = _run(*args)
+    assert r.returncode == 0, r.stdout + r.stderr
+    hdr = oracle.header_pack(n_samples=W * H * 3, cp=2, cb_height=18, cb_width=64, wl=wl, bit_depth=8, lossy=int(lossy),
+                             qs_1e4=int(qs * 10000), components=3, is_rgb=1, height=H, endianess=0, bps=8,
+                             is_signed=0, frames=F if video else 0, k_1e3=0)
+    ref = []
+    for f in range(F):
+        comps = oracle.rgb_forward(*[oracle.pad_frame(p) for p in planes[f]], lossy)
+        for c in range(3):
+            with_hdr = (f == 0) if video else (c == 0)
+            ref.append(oracle.encode_plane(comps[c], wl, lossy, qs, oracle.lut_for_component(lossy, wl, c),
+                                           hdr if with_hdr else None))
+    assert np.array_equal(np.fromfile(enc, np.uint16), np.concatenate(ref))
+    assert open(str(enc) + "_SIZE").read() == ",".join(str(x.size) for x in ref)
+    args = ["-cd", 1, "-i", enc, "-o", dec, "-LUTFolder", lutdir] + (["-video", 1] if video else [])
+    r = _run(*args)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(dec, np.uint8).reshape(F, 3, H, W)
+    for f in range(F):
+        for c in range(3):
+            if not lossy:
+                assert np.array_equal(got[f, c], planes[f][c])
+            else:
+                mse = np.mean((got[f, c].astype(np.float64) - planes[f][c]) ** 2)
+                assert 10 * np.log10(255 ** 2 / mse) > 35.0

@@ -192,3 +192,27 @@ def test_whole_frame_codestream_identical_to_oracle(oracle, E):
     c2 = E.bpc_decode(st2, sz2, W, H, wl, lut)
     out = E.level_shift_inv(E.dwt_inverse(c2, wl, False, extra=extra)[extra:]).reshape(H, W)
     assert np.array_equal(out.astype(np.uint8), img)
+
+
+@pytest.mark.parametrize("lossy", [False, True])
+def test_rgb_colour_transform_kernels(oracle, E, lossy):
+    r, g, b = (oracle.gen_frame(128, 64, k) for k in (1, 2, 3))
+    r[0, :8] = [0, 255, 0, 255, 128, 127, 1, 254]
+    g[0, :8] = [255, 0, 0, 255, 128, 129, 3, 2]
+    b[0, :8] = [0, 0, 255, 255, 128, 126, 200, 100]
+    ref = oracle.rgb_forward(r, g, b, lossy)
+    got = E.rgb_forward(r, g, b, lossy)
+    view = np.uint32 if lossy else np.int32
+    for x, y in zip(got, ref):
+        assert np.array_equal(x.view(view), y.view(view))
+    back_ref = oracle.rgb_inverse(*ref)
+    back = E.rgb_inverse(*ref)
+    for x, y in zip(back, back_ref):
+        assert np.array_equal(x, y)
+    if not lossy:
+        for x, y in zip(back, (r, g, b)):
+            assert np.array_equal(x, y)                      # RCT is reversible
+    # out-of-range components clamp like the reference
+    big = [np.full((64, 128), v, np.float32 if lossy else np.int32) for v in (300, -300, 50)]
+    for x, y in zip(E.rgb_inverse(*big), oracle.rgb_inverse(*big)):
+        assert np.array_equal(x, y)
