@@ -20,6 +20,13 @@
 //     lifting is exact; the first/last lane of a wave and the first rows of a band are overlap
 //     that is recomputed, never written (4 columns each side: 1.6 % re-read per strip);
 //   * subband writes are 8-byte vectors, contiguous across the wave per subband row.
+//   * VEC instantiations (level width a multiple of 4, 16-byte aligned rows -- every level of every
+//     frame the CLI accepts down to W = 4) contain ONLY vector memory instructions: 4-byte (u8) or
+//     16-byte loads, 8-byte subband stores, 16-byte image stores.  They need no mirrored column
+//     loads at all: the extended signal is symmetric about column 0 and column W-1, every lifting
+//     step preserves that symmetry, so the lane that owns column 0 (W-1) takes the value it would
+//     have fetched from its left (right) neighbour from its own mirrored sample instead.  The
+//     !VEC instantiations keep per-column mirrored scalar accesses for odd geometries.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -116,56 +123,63 @@ template <> __device__ __forceinline__ float dpp_next<float>(float v)
 { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x130, 0xf, 0xf, false)); }
 
 // ---- horizontal analysis of one row held as (e0,o0,e1,o1) per lane ----------------------------
-__device__ __forceinline__ void hfwd(int v[4])
+// le / re: the lane owns the first / last four columns of the row (VEC kernels): the neighbour
+// sample it needs is its own mirror image (x[-1] = x[1], x[W] = x[W-2]; same for every
+// intermediate of the lifting).  Both are false in the !VEC kernels, whose edge lanes were loaded
+// with mirrored columns.
+template <typename T> __device__ __forceinline__ T nxt(T own, T mine, bool re) { T n = dpp_next<T>(own); return re ? mine : n; }
+template <typename T> __device__ __forceinline__ T prv(T own, T mine, bool le) { T n = dpp_prev<T>(own); return le ? mine : n; }
+
+__device__ __forceinline__ void hfwd(int v[4], bool le, bool re)
 {   // DWTGenerator.cu:279-292, lifting :72-76
-    int en = dpp_next<int>(v[0]);
+    int en = nxt<int>(v[0], v[2], re);
     v[1] -= (v[0] + v[2]) >> 1;
     v[3] -= (v[2] + en) >> 1;
-    int dp = dpp_prev<int>(v[3]);
+    int dp = prv<int>(v[3], v[1], le);
     v[0] += (dp + v[1] + 2) >> 2;
     v[2] += (v[1] + v[3] + 2) >> 2;
 }
-__device__ __forceinline__ void hfwd(float v[4])
+__device__ __forceinline__ void hfwd(float v[4], bool le, bool re)
 {   // DWTGenerator.cu:311-323, lifting :91-104
-    float en = dpp_next<float>(v[0]);
+    float en = nxt<float>(v[0], v[2], re);
     v[1] = fmaf(v[0] + v[2], PS_A1, v[1]);
     v[3] = fmaf(v[2] + en, PS_A1, v[3]);
-    float dp = dpp_prev<float>(v[3]);
+    float dp = prv<float>(v[3], v[1], le);
     v[0] = fmaf(v[1] + dp, PS_A2, v[0]);
     v[2] = fmaf(v[3] + v[1], PS_A2, v[2]);
-    float sn = dpp_next<float>(v[0]);
+    float sn = nxt<float>(v[0], v[2], re);
     v[1] = fmaf(v[0] + v[2], PS_A3, v[1]);
     v[3] = fmaf(v[2] + sn, PS_A3, v[3]);
-    dp = dpp_prev<float>(v[3]);
+    dp = prv<float>(v[3], v[1], le);
     v[0] = fmaf(v[1] + dp, PS_A4, v[0]) * PS_N2;
     v[2] = fmaf(v[3] + v[1], PS_A4, v[2]) * PS_N2;
     v[1] *= PS_N1;
     v[3] *= PS_N1;
 }
 // ---- horizontal synthesis of one row held as (s0,d0,s1,d1) per lane ---------------------------
-__device__ __forceinline__ void hinv(int v[4])
+__device__ __forceinline__ void hinv(int v[4], bool le, bool re)
 {   // DWTGenerator.cu:295-308, lifting :81-85
-    int dp = dpp_prev<int>(v[3]);
+    int dp = prv<int>(v[3], v[1], le);
     v[0] -= (v[1] + dp + 2) >> 2;
     v[2] -= (v[3] + v[1] + 2) >> 2;
-    int sn = dpp_next<int>(v[0]);
+    int sn = nxt<int>(v[0], v[2], re);
     v[1] += (v[0] + v[2]) >> 1;
     v[3] += (v[2] + sn) >> 1;
 }
-__device__ __forceinline__ void hinv(float v[4])
+__device__ __forceinline__ void hinv(float v[4], bool le, bool re)
 {   // DWTGenerator.cu:326-339, lifting :110-122
     v[1] = v[1] / PS_N1;
     v[3] = v[3] / PS_N1;
-    float dp = dpp_prev<float>(v[3]);
+    float dp = prv<float>(v[3], v[1], le);
     v[0] = fmaf(-(v[1] + dp), PS_A4, v[0] / PS_N2);
     v[2] = fmaf(-(v[3] + v[1]), PS_A4, v[2] / PS_N2);
-    float sn = dpp_next<float>(v[0]);
+    float sn = nxt<float>(v[0], v[2], re);
     v[1] = fmaf(-(v[0] + v[2]), PS_A3, v[1]);
     v[3] = fmaf(-(v[2] + sn), PS_A3, v[3]);
-    dp = dpp_prev<float>(v[3]);
+    dp = prv<float>(v[3], v[1], le);
     v[0] = fmaf(-(v[1] + dp), PS_A2, v[0]);
     v[2] = fmaf(-(v[3] + v[1]), PS_A2, v[2]);
-    sn = dpp_next<float>(v[0]);
+    sn = nxt<float>(v[0], v[2], re);
     v[1] = fmaf(-(v[0] + v[2]), PS_A1, v[1]);
     v[3] = fmaf(-(v[2] + sn), PS_A1, v[3]);
 }
@@ -177,14 +191,14 @@ template <bool U8IN> struct RawRow;
 template <> struct RawRow<true> { uint32_t w; };
 template <> struct RawRow<false> { uint32_t w[4]; };
 
-template <typename T, bool U8IN>
-__device__ __forceinline__ RawRow<U8IN> load_raw(const DwtFwdArgs &a, int y, int c0, bool vec)
+template <typename T, bool U8IN, bool VEC>
+__device__ __forceinline__ RawRow<U8IN> load_raw(const DwtFwdArgs &a, int y, int c0)
 {
     RawRow<U8IN> r;
     const int ry = reflect(y, a.H);
     if constexpr (U8IN) {
         const uint8_t *p = (const uint8_t *)a.src + (size_t)ry * (size_t)a.src_stride;
-        if (vec) {
+        if constexpr (VEC) {
             r.w = *reinterpret_cast<const uint32_t *>(p + c0);
         } else {
             r.w = (uint32_t)p[reflect(c0, a.W)] | ((uint32_t)p[reflect(c0 + 1, a.W)] << 8) |
@@ -192,7 +206,7 @@ __device__ __forceinline__ RawRow<U8IN> load_raw(const DwtFwdArgs &a, int y, int
         }
     } else {
         const uint32_t *p = (const uint32_t *)a.src + (size_t)ry * (size_t)a.src_stride;
-        if (vec) {
+        if constexpr (VEC) {
             const uint4 q = *reinterpret_cast<const uint4 *>(p + c0);
             r.w[0] = q.x; r.w[1] = q.y; r.w[2] = q.z; r.w[3] = q.w;
         } else {
@@ -216,16 +230,10 @@ __device__ __forceinline__ void unpack_row(const RawRow<U8IN> &r, T v[4])
     }
 }
 
-template <typename T, bool U8IN>
-__device__ __forceinline__ void load_row4(const DwtFwdArgs &a, int y, int c0, bool vec, T v[4])
+template <typename T, bool VEC>
+__device__ __forceinline__ void store2(T *p, T x, T y, bool two)
 {
-    unpack_row<T, U8IN>(load_raw<T, U8IN>(a, y, c0, vec), v);
-}
-
-template <typename T>
-__device__ __forceinline__ void store2(T *p, T x, T y, bool vec, bool two)
-{
-    if (vec) {
+    if constexpr (VEC) {
         uint2 w;
         w.x = as_u32(x);
         w.y = as_u32(y);
@@ -235,12 +243,12 @@ __device__ __forceinline__ void store2(T *p, T x, T y, bool vec, bool two)
 
 // writeSubbands DWTGenerator.cu:403-433 + placement :719-723.  Lrow/Hrow: vertically low / high
 // rows after horizontal analysis (s0,d0,s1,d1): s -> LL / LH, d -> HL / HH.
-template <typename T, bool LOSSY>
-__device__ __forceinline__ void emit_pair(const DwtFwdArgs &a, int m, int pc, bool wr, bool vst,
+template <typename T, bool LOSSY, bool VEC>
+__device__ __forceinline__ void emit_pair(const DwtFwdArgs &a, int m, int pc, bool wr, bool le, bool re,
                                           T Lr[4], T Hr[4])
 {
-    hfwd(Lr);
-    hfwd(Hr);
+    hfwd(Lr, le, re);
+    hfwd(Hr, le, re);
     if (!wr || m < 0 || m >= (a.H >> 1)) return;
     T ll0 = Lr[0], ll1 = Lr[2], hl0 = Lr[1], hl1 = Lr[3];
     T lh0 = Hr[0], lh1 = Hr[2], hh0 = Hr[1], hh1 = Hr[3];
@@ -253,14 +261,14 @@ __device__ __forceinline__ void emit_pair(const DwtFwdArgs &a, int m, int pc, bo
     const int hW = a.W >> 1, hH = a.H >> 1;
     const bool two = pc + 1 < hW;
     T *mal = (T *)a.mallat;
-    store2((T *)a.ll + (size_t)m * (size_t)a.ll_stride + pc, ll0, ll1, vst, two);
-    store2(mal + (size_t)m * (size_t)a.AW + hW + pc, hl0, hl1, vst, two);
-    store2(mal + (size_t)(m + hH) * (size_t)a.AW + pc, lh0, lh1, vst, two);
-    store2(mal + (size_t)(m + hH) * (size_t)a.AW + hW + pc, hh0, hh1, vst, two);
+    store2<T, VEC>((T *)a.ll + (size_t)m * (size_t)a.ll_stride + pc, ll0, ll1, two);
+    store2<T, VEC>(mal + (size_t)m * (size_t)a.AW + hW + pc, hl0, hl1, two);
+    store2<T, VEC>(mal + (size_t)(m + hH) * (size_t)a.AW + pc, lh0, lh1, two);
+    store2<T, VEC>(mal + (size_t)(m + hH) * (size_t)a.AW + hW + pc, hh0, hh1, two);
 }
 
 // grid.x = ceil(strips / 4), grid.y = bands; block = 256 threads = 4 waves = 4 adjacent strips
-template <typename T, bool LOSSY, bool U8IN, int BAND>
+template <typename T, bool LOSSY, bool U8IN, int BAND, bool VEC>
 __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwtFwdArgs a)
 {
     constexpr int kFwdBandRows = BAND;
@@ -272,11 +280,12 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwtFwdArgs a)
     const int m0 = blockIdx.y * (kFwdBandRows / 2);
     int m1 = m0 + kFwdBandRows / 2;
     if (m1 > (a.H >> 1)) m1 = a.H >> 1;
-    const bool inside = c0 >= 0 && c0 + 3 < a.W;
-    const bool vld = inside && (a.src_stride & 3) == 0;
     const bool wr = lane >= kEdgeLanes && lane <= 63 - kEdgeLanes && c0 >= 0 && c0 < a.W;
-    const bool vst = ((a.W >> 1) & 1) == 0 && (a.ll_stride & 1) == 0;
     const int pc = c0 >> 1;
+    // VEC: every lane loads a whole in-image vector (out-of-image lanes a clamped one they never
+    // use); the lanes owning columns 0 / W-4 mirror in registers (hfwd).  !VEC: per-column mirrors.
+    const bool le = VEC && c0 == 0, re = VEC && c0 + 4 == a.W;
+    const int cl = VEC ? (c0 < 0 ? 0 : (c0 > a.W - 4 ? a.W - 4 : c0)) : c0;
 
     // Rows are fetched a chunk (kFwdChunk row pairs) at a time into raw registers, double-buffered:
     // chunk c+1's loads are issued BEFORE chunk c's subband stores.  vmcnt counts loads and stores
@@ -288,11 +297,11 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwtFwdArgs a)
         constexpr int NCH = (kFwdBandRows / 2 + kFwdChunk - 1) / kFwdChunk;
         T xe[4], xo[4], xn[4], dp[4];
         RawRow<U8IN> raw[2][2 * kFwdChunk];
-        const RawRow<U8IN> r0 = load_raw<T, U8IN>(a, 2 * m0 - 2, c0, vld);
-        const RawRow<U8IN> r1 = load_raw<T, U8IN>(a, 2 * m0 - 1, c0, vld);
-        const RawRow<U8IN> r2 = load_raw<T, U8IN>(a, 2 * m0, c0, vld);
+        const RawRow<U8IN> r0 = load_raw<T, U8IN, VEC>(a, 2 * m0 - 2, cl);
+        const RawRow<U8IN> r1 = load_raw<T, U8IN, VEC>(a, 2 * m0 - 1, cl);
+        const RawRow<U8IN> r2 = load_raw<T, U8IN, VEC>(a, 2 * m0, cl);
 #pragma unroll
-        for (int r = 0; r < 2 * kFwdChunk; r++) raw[0][r] = load_raw<T, U8IN>(a, 2 * m0 + 1 + r, c0, vld);
+        for (int r = 0; r < 2 * kFwdChunk; r++) raw[0][r] = load_raw<T, U8IN, VEC>(a, 2 * m0 + 1 + r, cl);
         unpack_row<T, U8IN>(r0, xe);
         unpack_row<T, U8IN>(r1, xo);
         unpack_row<T, U8IN>(r2, xn);
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwtFwdArgs a)
             if (c + 1 < NCH) {
 #pragma unroll
                 for (int r = 0; r < 2 * kFwdChunk; r++)
-                    raw[(c + 1) & 1][r] = load_raw<T, U8IN>(a, 2 * (mc + kFwdChunk) + 1 + r, c0, vld);
+                    raw[(c + 1) & 1][r] = load_raw<T, U8IN, VEC>(a, 2 * (mc + kFwdChunk) + 1 + r, cl);
             }
 #pragma unroll
             for (int q = 0; q < kFwdChunk; q++) {
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwtFwdArgs a)
                     Hr[k] = d;
                     dp[k] = d; xe[k] = xn[k];
                 }
-                emit_pair<T, LOSSY>(a, m, pc, wr && m < m1, vst, Lr, Hr);
+                emit_pair<T, LOSSY, VEC>(a, m, pc, wr && m < m1, le, re, Lr, Hr);
             }
         }
     } else {
@@ -329,9 +338,9 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwtFwdArgs a)
 #pragma unroll
         for (int k = 0; k < 4; k++) { d1p[k] = s1p[k] = d2p[k] = (T)0; }
         RawRow<U8IN> raw[2][2 * kFwdChunk];
-        const RawRow<U8IN> r0 = load_raw<T, U8IN>(a, 2 * m0 - 4, c0, vld);
+        const RawRow<U8IN> r0 = load_raw<T, U8IN, VEC>(a, 2 * m0 - 4, cl);
 #pragma unroll
-        for (int r = 0; r < 2 * kFwdChunk; r++) raw[0][r] = load_raw<T, U8IN>(a, 2 * (m0 - 2) + 1 + r, c0, vld);
+        for (int r = 0; r < 2 * kFwdChunk; r++) raw[0][r] = load_raw<T, U8IN, VEC>(a, 2 * (m0 - 2) + 1 + r, cl);
         unpack_row<T, U8IN>(r0, xe);
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwtFwdArgs a)
             if (c + 1 < NCH) {
 #pragma unroll
                 for (int r = 0; r < 2 * kFwdChunk; r++)
-                    raw[(c + 1) & 1][r] = load_raw<T, U8IN>(a, 2 * (jc + kFwdChunk) + 1 + r, c0, vld);
+                    raw[(c + 1) & 1][r] = load_raw<T, U8IN, VEC>(a, 2 * (jc + kFwdChunk) + 1 + r, cl);
             }
 #pragma unroll
             for (int q = 0; q < kFwdChunk; q++) {
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwtFwdArgs a)
                     Hr[k] = (T)(d2 * PS_N1);
                     d1p[k] = (T)d1; s1p[k] = (T)s1; d2p[k] = (T)d2; xe[k] = xn[k];
                 }
-                emit_pair<T, LOSSY>(a, j - 1, pc, wr && j - 1 >= m0 && j <= m1, vst, Lr, Hr);
+                emit_pair<T, LOSSY, VEC>(a, j - 1, pc, wr && j - 1 >= m0 && j <= m1, le, re, Lr, Hr);
             }
         }
     }
@@ -374,25 +383,41 @@ __device__ __forceinline__ float dequant(int32_t v, float q, float qs)
 }
 
 // one subband row pair-segment: s-type values for pair columns pc, pc+1 and d-type likewise
-template <typename T, bool LOSSY>
+template <typename T, bool LOSSY, bool VEC>
 __device__ __forceinline__ void load_sub4(const DwtInvArgs &a, int row_s_or_d, bool high_row,
-                                          int pc, bool vec, T v[4])
+                                          int pc, bool inside, T v[4])
 {
     // row index already reflected by the caller.  low row: s = LL, d = HL; high row: s = LH, d = HH
     const int hW = a.W >> 1, hH = a.H >> 1;
     const int32_t *mrow = a.mallat + (size_t)(row_s_or_d + (high_row ? hH : 0)) * (size_t)a.AW;
+    const float qd = high_row ? a.q[3] : a.q[1];
+    const float qsb = high_row ? a.q[2] : a.q[0];
+    if constexpr (VEC) {
+        // pc is even and already clamped into [0, hW-2]: two aligned 8-byte loads per subband row
+        const uint2 d = *reinterpret_cast<const uint2 *>(mrow + hW + pc);
+        if (LOSSY) { v[1] = (T)dequant((int32_t)d.x, qd, a.qs); v[3] = (T)dequant((int32_t)d.y, qd, a.qs); }
+        else { v[1] = (T)(int32_t)d.x; v[3] = (T)(int32_t)d.y; }
+        if (high_row || a.first) {
+            const uint2 sv = *reinterpret_cast<const uint2 *>(mrow + pc);
+            if (LOSSY) { v[0] = (T)dequant((int32_t)sv.x, qsb, a.qs); v[2] = (T)dequant((int32_t)sv.y, qsb, a.qs); }
+            else { v[0] = (T)(int32_t)sv.x; v[2] = (T)(int32_t)sv.y; }
+        } else {
+            const T *lrow = (const T *)a.ll + (size_t)row_s_or_d * (size_t)a.ll_stride;
+            const uint2 sv = *reinterpret_cast<const uint2 *>(lrow + pc);
+            v[0] = from_u32<T>(sv.x); v[2] = from_u32<T>(sv.y);
+        }
+        return;
+    }
     int cs0 = pc, cs1 = pc + 1, cd0 = pc, cd1 = pc + 1;
-    if (!vec) {
+    if (!inside) {
         cs0 = reflect_s(pc, hW); cs1 = reflect_s(pc + 1, hW);
         cd0 = reflect_d(pc, hW); cd1 = reflect_d(pc + 1, hW);
     }
     int32_t d0 = mrow[hW + cd0], d1 = mrow[hW + cd1];
-    const float qd = high_row ? a.q[3] : a.q[1];
     if (LOSSY) { v[1] = (T)dequant(d0, qd, a.qs); v[3] = (T)dequant(d1, qd, a.qs); }
     else { v[1] = (T)d0; v[3] = (T)d1; }
     if (high_row || a.first) {
         int32_t s0 = mrow[cs0], s1 = mrow[cs1];
-        const float qsb = high_row ? a.q[2] : a.q[0];
         if (LOSSY) { v[0] = (T)dequant(s0, qsb, a.qs); v[2] = (T)dequant(s1, qsb, a.qs); }
         else { v[0] = (T)s0; v[2] = (T)s1; }
     } else {
@@ -401,11 +426,11 @@ __device__ __forceinline__ void load_sub4(const DwtInvArgs &a, int row_s_or_d, b
     }
 }
 
-template <typename T>
-__device__ __forceinline__ void store_row4(const DwtInvArgs &a, int y, int c0, bool vec, const T v[4])
+template <typename T, bool VEC>
+__device__ __forceinline__ void store_row4(const DwtInvArgs &a, int y, int c0, const T v[4])
 {
     T *p = (T *)a.dst + (size_t)y * (size_t)a.W + c0;
-    if (vec) {
+    if constexpr (VEC) {
         uint4 w;
         w.x = as_u32(v[0]); w.y = as_u32(v[1]); w.z = as_u32(v[2]); w.w = as_u32(v[3]);
         *reinterpret_cast<uint4 *>(p) = w;
@@ -415,7 +440,7 @@ __device__ __forceinline__ void store_row4(const DwtInvArgs &a, int y, int c0, b
     }
 }
 
-template <typename T, bool LOSSY, int BAND>
+template <typename T, bool LOSSY, int BAND, bool VEC>
 __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
 {
     constexpr int kInvBandRows = BAND;
@@ -430,7 +455,8 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
     if (m1 > hH) m1 = hH;
     const bool inside = pc >= 0 && pc + 1 < hW;
     const bool wr = lane >= kEdgeLanes && lane <= 63 - kEdgeLanes && c0 >= 0 && c0 < a.W;
-    const bool vst = (a.W & 3) == 0;
+    const bool le = VEC && c0 == 0, re = VEC && c0 + 4 == a.W;
+    const int pl = VEC ? (pc < 0 ? 0 : (pc > hW - 2 ? hW - 2 : pc)) : pc;
 
     if constexpr (!LOSSY) {
         // vertical 5/3 synthesis, DWTGenerator.cu:160-181, streamed: at step j pair j-1 completes
@@ -440,10 +466,10 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
 #pragma unroll PICSONG_DWT_UNROLL
         for (int j = m0 - 1; j <= m1; j++) {
             T Lr[4], Hr[4];
-            load_sub4<T, LOSSY>(a, reflect_s(j, hH), false, pc, inside, Lr);
-            load_sub4<T, LOSSY>(a, reflect_d(j, hH), true, pc, inside, Hr);
-            hinv(Lr);
-            hinv(Hr);
+            load_sub4<T, LOSSY, VEC>(a, reflect_s(j, hH), false, pl, inside, Lr);
+            load_sub4<T, LOSSY, VEC>(a, reflect_d(j, hH), true, pl, inside, Hr);
+            hinv(Lr, le, re);
+            hinv(Hr, le, re);
             T ev[4], od[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -453,8 +479,8 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
                 sp[k] = s; Hp[k] = Hr[k];
             }
             if (j - 1 >= m0 && wr) {
-                store_row4<T>(a, 2 * (j - 1), c0, vst, ev);
-                store_row4<T>(a, 2 * (j - 1) + 1, c0, vst, od);
+                store_row4<T, VEC>(a, 2 * (j - 1), c0, ev);
+                store_row4<T, VEC>(a, 2 * (j - 1) + 1, c0, od);
             }
         }
     } else {
@@ -465,10 +491,10 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
 #pragma unroll PICSONG_DWT_UNROLL
         for (int j = m0 - 2; j <= m1 + 1; j++) {
             T Lr[4], Hr[4];
-            load_sub4<T, LOSSY>(a, reflect_s(j, hH), false, pc, inside, Lr);
-            load_sub4<T, LOSSY>(a, reflect_d(j, hH), true, pc, inside, Hr);
-            hinv(Lr);
-            hinv(Hr);
+            load_sub4<T, LOSSY, VEC>(a, reflect_s(j, hH), false, pl, inside, Lr);
+            load_sub4<T, LOSSY, VEC>(a, reflect_d(j, hH), true, pl, inside, Hr);
+            hinv(Lr, le, re);
+            hinv(Hr, le, re);
             T ev[4], od[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -482,8 +508,8 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
                 ddp[k] = (T)dd; s1p[k] = (T)s1; d1p[k] = (T)d1; s0p[k] = (T)s0;
             }
             if (j - 2 >= m0 && wr) {
-                store_row4<T>(a, 2 * (j - 2), c0, vst, ev);
-                store_row4<T>(a, 2 * (j - 2) + 1, c0, vst, od);
+                store_row4<T, VEC>(a, 2 * (j - 2), c0, ev);
+                store_row4<T, VEC>(a, 2 * (j - 2) + 1, c0, od);
             }
         }
     }

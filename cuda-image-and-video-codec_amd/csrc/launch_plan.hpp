@@ -26,8 +26,16 @@ static const float kQSteps[10][4] = {
     { 1086.1624f, 550.43286f, 550.43286f, 278.94202f }
 };
 
-struct FwdLaunch { DwtFwdArgs a; unsigned gx, gy; bool u8; int band; };
-struct InvLaunch { DwtInvArgs a; unsigned gx, gy; int band; };
+struct FwdLaunch { DwtFwdArgs a; unsigned gx, gy; bool u8; int band; bool vec; };
+struct InvLaunch { DwtInvArgs a; unsigned gx, gy; int band; bool vec; };
+
+// The vector-only kernel instantiations need whole 4-column groups and 16-byte aligned rows
+// (PICSONG_DWT_NOVEC=1 forces the per-column kernels, used by the tests to cross-check both).
+inline bool dwt_vec_ok(int W, int aw, const void *p0, const void *p1)
+{
+    if (const char *e = getenv("PICSONG_DWT_NOVEC")) if (atoi(e) != 0) return false;
+    return W >= 4 && (W & 3) == 0 && (aw & 3) == 0 && (((uintptr_t)p0 | (uintptr_t)p1) & 15u) == 0;
+}
 
 // Band height per level: big levels want taller bands (less vertical halo re-read), small levels
 // want many short waves (a level with a handful of tall waves is bound by one wave's serial
@@ -71,6 +79,9 @@ inline std::vector<FwdLaunch> plan_dwt_forward(const void *d_in, bool u8in, void
         f.gx = (unsigned)((strips + 3) / 4);
         f.gy = (unsigned)(((H >> 1) + f.band / 2 - 1) / (f.band / 2));
         f.u8 = u8in && l == 0;
+        // rows of every buffer this level touches start 16-byte aligned when W % 4 == 0: strides are
+        // aw, W or W/2 (even), scratch offsets are sums of W*H (multiples of 16 elements)
+        f.vec = dwt_vec_ok(W, aw, d_in, d_out) && (W >> 1) % 2 == 0;
         v.push_back(f);
         src = (const char *)d_out + off * 4;
         src_stride = W >> 1;
@@ -101,6 +112,7 @@ inline std::vector<InvLaunch> plan_dwt_inverse(const int32_t *d_in, void *d_out,
         f.band = fwd_band_rows(l, strips, H);
         f.gx = (unsigned)((strips + 3) / 4);
         f.gy = (unsigned)(((H >> 1) + f.band / 2 - 1) / (f.band / 2));
+        f.vec = dwt_vec_ok(W, aw, d_in, d_out);
         v.push_back(f);
         read_off = write_off;
         write_off += (size_t)W * (size_t)H;

@@ -72,21 +72,33 @@ template <int BAND>
 static void launch_inv(const picsong_ctx *c, const InvLaunch &f, hipStream_t s)
 {
     dim3 grid(f.gx, f.gy);
-    if (c->p.lossy) dwt_inv_kernel<float, true, BAND><<<grid, 256, 0, s>>>(f.a);
-    else dwt_inv_kernel<int, false, BAND><<<grid, 256, 0, s>>>(f.a);
+    if (f.vec) {
+        if (c->p.lossy) dwt_inv_kernel<float, true, BAND, true><<<grid, 256, 0, s>>>(f.a);
+        else dwt_inv_kernel<int, false, BAND, true><<<grid, 256, 0, s>>>(f.a);
+    } else {
+        if (c->p.lossy) dwt_inv_kernel<float, true, BAND, false><<<grid, 256, 0, s>>>(f.a);
+        else dwt_inv_kernel<int, false, BAND, false><<<grid, 256, 0, s>>>(f.a);
+    }
+}
+
+template <int BAND, bool VEC>
+static void launch_fwd_v(bool lossy, const FwdLaunch &f, dim3 grid, hipStream_t s)
+{
+    if (lossy) {
+        if (f.u8) dwt_fwd_kernel<float, true, true, BAND, VEC><<<grid, 256, 0, s>>>(f.a);
+        else dwt_fwd_kernel<float, true, false, BAND, VEC><<<grid, 256, 0, s>>>(f.a);
+    } else {
+        if (f.u8) dwt_fwd_kernel<int, false, true, BAND, VEC><<<grid, 256, 0, s>>>(f.a);
+        else dwt_fwd_kernel<int, false, false, BAND, VEC><<<grid, 256, 0, s>>>(f.a);
+    }
 }
 
 template <int BAND>
 static void launch_fwd(const picsong_ctx *c, const FwdLaunch &f, hipStream_t s)
 {
     dim3 grid(f.gx, f.gy);
-    if (c->p.lossy) {
-        if (f.u8) dwt_fwd_kernel<float, true, true, BAND><<<grid, 256, 0, s>>>(f.a);
-        else dwt_fwd_kernel<float, true, false, BAND><<<grid, 256, 0, s>>>(f.a);
-    } else {
-        if (f.u8) dwt_fwd_kernel<int, false, true, BAND><<<grid, 256, 0, s>>>(f.a);
-        else dwt_fwd_kernel<int, false, false, BAND><<<grid, 256, 0, s>>>(f.a);
-    }
+    if (f.vec) launch_fwd_v<BAND, true>(c->p.lossy != 0, f, grid, s);
+    else launch_fwd_v<BAND, false>(c->p.lossy != 0, f, grid, s);
 }
 
 extern "C" {

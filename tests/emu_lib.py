@@ -31,11 +31,31 @@ def _geo(lut):
                      g["precision"], g["n_ref"], g["n_sig"], g["n_sign"]], np.int32)
 
 
+def aligned_zeros(n, dtype, align=64):
+    """numpy buffer whose data pointer is `align`-byte aligned (the vector kernels need 16)."""
+    raw = np.zeros(n * np.dtype(dtype).itemsize + align, np.uint8)
+    off = (-raw.ctypes.data) % align
+    return raw[off:off + n * np.dtype(dtype).itemsize].view(dtype)
+
+
+def aligned_copy(x):
+    out = aligned_zeros(x.size, x.dtype).reshape(x.shape)
+    out[...] = x
+    return out
+
+
+def dwt_vec_levels(AW, AH, wl):
+    """Levels (forward + inverse plans) that run the vector-only kernel instantiations."""
+    a = aligned_zeros(AW * AH * 2, np.int32)
+    b = aligned_zeros(AW * AH * 2, np.int32)
+    return lib().emu_dwt_vec_levels(_p(a), _p(b), AW, AH, wl)
+
+
 def dwt_forward(x, wl, lossy, qs=1.0, extra=0):
     """x: (AH, AW) uint8 (fused level shift) / int32 / float32."""
     AH, AW = x.shape
-    x = np.ascontiguousarray(x)
-    out = np.zeros(AW * AH + extra, np.float32 if lossy else np.int32)
+    x = aligned_copy(np.ascontiguousarray(x))
+    out = aligned_zeros(AW * AH + extra, np.float32 if lossy else np.int32)
     lib().emu_dwt_forward(_p(x), int(x.dtype == np.uint8), _p(out), AW, AH, wl, int(lossy),
                           C.c_float(qs))
     return out
@@ -43,8 +63,8 @@ def dwt_forward(x, wl, lossy, qs=1.0, extra=0):
 
 def dwt_inverse(coef, wl, lossy, qs=1.0, extra=0):
     AH, AW = coef.shape
-    coef = np.ascontiguousarray(coef, np.int32)
-    out = np.zeros(AW * AH + extra, np.float32 if lossy else np.int32)
+    coef = aligned_copy(np.ascontiguousarray(coef, np.int32))
+    out = aligned_zeros(AW * AH + extra, np.float32 if lossy else np.int32)
     lib().emu_dwt_inverse(_p(coef), _p(out), AW, AH, wl, int(lossy), C.c_float(qs))
     return out
 

@@ -10,26 +10,43 @@
 
 using namespace picsong;
 
-template <int BAND> static void emu_inv(const InvLaunch &f, int lossy)
+template <int BAND, bool VEC> static void emu_inv_v(const InvLaunch &f, int lossy)
 {
     DwtInvArgs a = f.a;
-    if (lossy) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<float, true, BAND>(a); });
-    else emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<int, false, BAND>(a); });
+    if (lossy) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<float, true, BAND, VEC>(a); });
+    else emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<int, false, BAND, VEC>(a); });
+}
+template <int BAND> static void emu_inv(const InvLaunch &f, int lossy)
+{
+    if (f.vec) emu_inv_v<BAND, true>(f, lossy); else emu_inv_v<BAND, false>(f, lossy);
 }
 
-template <int BAND> static void emu_fwd(const FwdLaunch &f, int lossy)
+template <int BAND, bool VEC> static void emu_fwd_v(const FwdLaunch &f, int lossy)
 {
     DwtFwdArgs a = f.a;
     if (lossy) {
-        if (f.u8) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_fwd_kernel<float, true, true, BAND>(a); });
-        else emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_fwd_kernel<float, true, false, BAND>(a); });
+        if (f.u8) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_fwd_kernel<float, true, true, BAND, VEC>(a); });
+        else emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_fwd_kernel<float, true, false, BAND, VEC>(a); });
     } else {
-        if (f.u8) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_fwd_kernel<int, false, true, BAND>(a); });
-        else emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_fwd_kernel<int, false, false, BAND>(a); });
+        if (f.u8) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_fwd_kernel<int, false, true, BAND, VEC>(a); });
+        else emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_fwd_kernel<int, false, false, BAND, VEC>(a); });
     }
+}
+template <int BAND> static void emu_fwd(const FwdLaunch &f, int lossy)
+{
+    if (f.vec) emu_fwd_v<BAND, true>(f, lossy); else emu_fwd_v<BAND, false>(f, lossy);
 }
 
 extern "C" {
+
+// how many levels of the plans take the vector-only kernel instantiations (tests assert on it)
+int emu_dwt_vec_levels(const void *in, void *out, int aw, int ah, int wl)
+{
+    int n = 0;
+    for (const FwdLaunch &f : plan_dwt_forward(in, true, out, aw, ah, wl, 1.0f)) n += f.vec ? 1 : 0;
+    for (const InvLaunch &f : plan_dwt_inverse((const int32_t *)in, out, aw, ah, wl, 1.0f)) n += f.vec ? 1 : 0;
+    return n;
+}
 
 void emu_dwt_forward(const void *in, int u8in, void *out, int aw, int ah, int wl, int lossy, float qs)
 {

@@ -20,8 +20,28 @@ def _coef(oracle, img, wl, lossy, qs=1.0):
     return f[:x.size].reshape(x.shape)
 
 
-@pytest.mark.parametrize("W,H,wl", [(320, 192, 3), (512, 64, 1), (128, 128, 2), (768, 128, 2)])
-def test_dwt53_forward_inverse_bit_exact(oracle, E, W, H, wl):
+@pytest.fixture(params=["vec", "novec"])
+def dwt_path(request, monkeypatch):
+    """Run the DWT tests through both kernel families: vector-only instantiations (the default for
+    every real frame) and the per-column ones (PICSONG_DWT_NOVEC=1, odd geometries)."""
+    if request.param == "novec":
+        monkeypatch.setenv("PICSONG_DWT_NOVEC", "1")
+    else:
+        monkeypatch.delenv("PICSONG_DWT_NOVEC", raising=False)
+    return request.param
+
+
+def test_dwt_vector_kernels_are_selected(E, monkeypatch):
+    monkeypatch.delenv("PICSONG_DWT_NOVEC", raising=False)
+    assert E.dwt_vec_levels(320, 192, 3) == 6          # W = 320, 160, 80: all multiples of 4
+    assert E.dwt_vec_levels(64, 64, 5) == 10           # down to W = 4
+    assert E.dwt_vec_levels(64, 64, 6) == 10           # W = 2 at the sixth level: per-column kernel
+    monkeypatch.setenv("PICSONG_DWT_NOVEC", "1")
+    assert E.dwt_vec_levels(320, 192, 3) == 0
+
+
+@pytest.mark.parametrize("W,H,wl", [(320, 192, 3), (512, 64, 1), (128, 128, 2), (768, 128, 2), (64, 64, 5)])
+def test_dwt53_forward_inverse_bit_exact(oracle, E, dwt_path, W, H, wl):
     img = oracle.gen_frame(W, H, 3)
     x = oracle.level_shift_fwd(img, False)
     extra = oracle.dwt_extra(W, H, wl)
@@ -35,8 +55,8 @@ def test_dwt53_forward_inverse_bit_exact(oracle, E, W, H, wl):
     assert np.array_equal(gi[extra:].reshape(H, W), x)
 
 
-@pytest.mark.parametrize("W,H,wl,qs", [(320, 192, 3, 0.5), (256, 128, 2, 1.0), (576, 64, 1, 0.25)])
-def test_dwt97_forward_inverse_bit_exact(oracle, E, W, H, wl, qs):
+@pytest.mark.parametrize("W,H,wl,qs", [(320, 192, 3, 0.5), (256, 128, 2, 1.0), (576, 64, 1, 0.25), (64, 128, 5, 0.5)])
+def test_dwt97_forward_inverse_bit_exact(oracle, E, dwt_path, W, H, wl, qs):
     img = oracle.gen_frame(W, H, 5)
     xf = oracle.level_shift_fwd(img, True)
     extra = oracle.dwt_extra(W, H, wl)
