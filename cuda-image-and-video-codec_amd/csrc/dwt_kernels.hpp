@@ -199,7 +199,8 @@ __device__ __forceinline__ RawRow<U8IN> load_raw(const DwtFwdArgs &a, int y, int
     if constexpr (U8IN) {
         const uint8_t *p = (const uint8_t *)a.src + (size_t)ry * (size_t)a.src_stride;
         if constexpr (VEC) {
-            r.w = *reinterpret_cast<const uint32_t *>(p + c0);
+            // uniform row base + unsigned 32-bit lane offset: the saddr addressing form, no 64-bit VALU
+            r.w = *reinterpret_cast<const uint32_t *>(p + (uint32_t)c0);
         } else {
             r.w = (uint32_t)p[reflect(c0, a.W)] | ((uint32_t)p[reflect(c0 + 1, a.W)] << 8) |
                   ((uint32_t)p[reflect(c0 + 2, a.W)] << 16) | ((uint32_t)p[reflect(c0 + 3, a.W)] << 24);
@@ -207,7 +208,7 @@ __device__ __forceinline__ RawRow<U8IN> load_raw(const DwtFwdArgs &a, int y, int
     } else {
         const uint32_t *p = (const uint32_t *)a.src + (size_t)ry * (size_t)a.src_stride;
         if constexpr (VEC) {
-            const uint4 q = *reinterpret_cast<const uint4 *>(p + c0);
+            const uint4 q = *reinterpret_cast<const uint4 *>(p + (uint32_t)c0);
             r.w[0] = q.x; r.w[1] = q.y; r.w[2] = q.z; r.w[3] = q.w;
         } else {
 #pragma unroll
@@ -261,6 +262,17 @@ __device__ __forceinline__ void emit_pair(const DwtFwdArgs &a, int m, int pc, bo
     const int hW = a.W >> 1, hH = a.H >> 1;
     const bool two = pc + 1 < hW;
     T *mal = (T *)a.mallat;
+    if constexpr (VEC) {
+        // uniform row bases (SALU) + one unsigned 32-bit lane offset shared by the four stores
+        const uint32_t vo = (uint32_t)pc;
+        T *rl = (T *)a.ll + (size_t)m * (size_t)a.ll_stride;
+        T *r0 = mal + (size_t)m * (size_t)a.AW, *r1 = mal + (size_t)(m + hH) * (size_t)a.AW;
+        store2<T, true>(rl + vo, ll0, ll1, true);
+        store2<T, true>(r0 + hW + vo, hl0, hl1, true);
+        store2<T, true>(r1 + vo, lh0, lh1, true);
+        store2<T, true>(r1 + hW + vo, hh0, hh1, true);
+        return;
+    }
     store2<T, VEC>((T *)a.ll + (size_t)m * (size_t)a.ll_stride + pc, ll0, ll1, two);
     store2<T, VEC>(mal + (size_t)m * (size_t)a.AW + hW + pc, hl0, hl1, two);
     store2<T, VEC>(mal + (size_t)(m + hH) * (size_t)a.AW + pc, lh0, lh1, two);
@@ -268,11 +280,21 @@ __device__ __forceinline__ void emit_pair(const DwtFwdArgs &a, int m, int pc, bo
 }
 
 // grid.x = ceil(strips / 4), grid.y = bands; block = 256 threads = 4 waves = 4 adjacent strips
+#ifdef PICSONG_DWT_WAVES_PER_EU
+#define PS_DWT_OCC __attribute__((amdgpu_waves_per_eu(PICSONG_DWT_WAVES_PER_EU, PICSONG_DWT_WAVES_PER_EU)))
+#else
+#define PS_DWT_OCC
+#endif
 template <typename T, bool LOSSY, bool U8IN, int BAND, bool VEC>
-__global__ __launch_bounds__(256) void dwt_fwd_kernel(DwtFwdArgs a)
+__global__ __launch_bounds__(256) PS_DWT_OCC void dwt_fwd_kernel(DwtFwdArgs a)
 {
     constexpr int kFwdBandRows = BAND;
+#ifdef PICSONG_DWT_CHUNKED
     constexpr int kFwdChunk = BAND / 2 < 4 ? BAND / 2 : 4;
+#else
+    // the whole band's input rows are fetched before the first store is issued (see below)
+    constexpr int kFwdChunk = LOSSY ? BAND / 2 + 3 : BAND / 2;
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int strip = blockIdx.x * 4 + wave;
     if (strip * kStripUseful >= a.W) return;               // whole wave idle (no cross-lane use)
@@ -281,16 +303,17 @@ __global__ __launch_bounds__(256) void dwt_fwd_kernel(DwtFwdArgs a)
     int m1 = m0 + kFwdBandRows / 2;
     if (m1 > (a.H >> 1)) m1 = a.H >> 1;
     const bool wr = lane >= kEdgeLanes && lane <= 63 - kEdgeLanes && c0 >= 0 && c0 < a.W;
-    const int pc = c0 >> 1;
     // VEC: every lane loads a whole in-image vector (out-of-image lanes a clamped one they never
     // use); the lanes owning columns 0 / W-4 mirror in registers (hfwd).  !VEC: per-column mirrors.
     const bool le = VEC && c0 == 0, re = VEC && c0 + 4 == a.W;
     const int cl = VEC ? (c0 < 0 ? 0 : (c0 > a.W - 4 ? a.W - 4 : c0)) : c0;
+    const int pc = cl >> 1;                                  // (lanes with a clamped column never write)
 
-    // Rows are fetched a chunk (kFwdChunk row pairs) at a time into raw registers, double-buffered:
-    // chunk c+1's loads are issued BEFORE chunk c's subband stores.  vmcnt counts loads and stores
-    // in one in-order queue, so loads issued after stores could only be waited for by draining
-    // those stores too; issued first, the wait is a counted vmcnt that leaves the stores in flight.
+    // All input rows of the band are fetched into raw registers before the first subband store is
+    // issued (19 dwords for a 16-row u8 band, 44 for an 8-row int32 band).  vmcnt counts loads and
+    // stores in one in-order queue, so a load issued after a store could only be waited for by
+    // draining that store too; issued first, every wait is a counted vmcnt that leaves the stores in
+    // flight.  (-DPICSONG_DWT_CHUNKED fetches 4 row pairs at a time, double-buffered, instead.)
     if constexpr (!LOSSY) {
         // vertical 5/3, DWTGenerator.cu:137-157: d[m] = x[2m+1] - ((x[2m]+x[2m+2])>>1);
         // s[m] = x[2m] + ((d[m-1]+d[m]+2)>>2)

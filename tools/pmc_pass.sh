@@ -1,0 +1,17 @@
+#!/bin/bash
+# usage: tools/pmc_pass.sh <name> "<counters>" [bench args]  -- one rocprofv3 --pmc pass over a short
+# single-stream bench run (counters in their own pass: never combined with sys/runtime traces).
+name=$1; ctr=$2; shift 2
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d gpurun_out/pmc_$name -- python3 bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline "$@" > gpurun_out/pmc_$name.log 2>&1
+python3 - <<PY
+import csv,glob,collections
+f=glob.glob("gpurun_out/pmc_$name/*/*counter_collection.csv")[0]
+acc=collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(f)):
+    if "picsong" in r["Kernel_Name"]:
+        acc[r["Kernel_Name"][:64]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k,v in acc.items():
+    print(k)
+    print("    "+"  ".join("%s=%.4g"%(c,sum(x)/len(x)) for c,x in sorted(v.items())))
+PY
