@@ -476,14 +476,14 @@ static int po_lut_header(const char *folder, po_lut *l)
  * Lines "lvl sb bp : v0 .. v(C-1)".  On a group change (bp <= previous bp) the previous group's
  * remaining planes are filled with 64 and the write index advances by nBp*C; the break test
  * (lvl+1 > wl && sb > 0) comes after that.  Entries never written keep `fill`. */
-static int po_lut_section(const char *folder, const char *stem, int component, int C, int nBp,
-                          int wl, int32_t *T, int base)
+static int po_lut_section(const char *folder, const char *stem, int component, int file_index, int C,
+                          int nBp, int wl, int32_t *T, int base)
 {
     static const char *suffix[4] = { ".txt_", "R.txt_", "G.txt_", "B.txt_" };
     char path[1024];
     size_t fl = strlen(folder);
     const char *sep = (fl && folder[fl - 1] != '/') ? "/" : "";
-    snprintf(path, sizeof path, "%s%s%s%s0", folder, sep, stem, suffix[component & 3]);
+    snprintf(path, sizeof path, "%s%s%s%s%d", folder, sep, stem, suffix[component & 3], file_index);
     FILE *f = fopen(path, "rb");
     if (!f) return -1;
     int i = base, prev = -1, lvl, sb, bp, v[16];
@@ -505,11 +505,17 @@ static int po_lut_section(const char *folder, const char *stem, int component, i
     return 0;
 }
 
-int po_lut_load(const char *folder, int component, int wl, int fill, po_lut *l)
+/* k > 0 (Engines/Engine.cu:12-56): the tables of files _0 .. _(n_tables-1) are laid out back to
+ * back, table j at offset j * (n_ref + n_sig + n_sign) == j * _LUTPointerSizePerS
+ * (BPC/BPCEngine.cu:333,1959-1961).  n_tables <= 0 means "all AMOUNT_OF_BITPLANE_FILES". */
+int po_lut_load_k(const char *folder, int component, int wl, int fill, int n_tables, po_lut *l)
 {
     memset(l, 0, sizeof *l);
     if (po_lut_header(folder, l)) return -1;
     l->wl = wl;
+    if (n_tables <= 0) n_tables = l->n_bp_files;
+    if (n_tables < 1) n_tables = 1;
+    l->n_tables = n_tables;
     int nBp = l->n_bitplanes, nS = l->n_subbands;
     /* section sizes, IOManager.ipp:431-433 */
     l->n_ref = nS * nBp * l->ctx_ref * wl + nBp * l->ctx_ref;
@@ -517,16 +523,26 @@ int po_lut_load(const char *folder, int component, int wl, int fill, po_lut *l)
     l->n_sign = nS * nBp * l->ctx_sign * wl + nBp * l->ctx_sign;
     int total = l->n_ref + l->n_sig + l->n_sign;
     /* generous tail: a group-change fill on the very last group may write one group past it */
-    l->table = (int32_t *)malloc(((size_t)total + (size_t)nBp * 16) * sizeof(int32_t));
+    size_t n = (size_t)total * (size_t)n_tables + (size_t)nBp * 16;
+    l->table = (int32_t *)malloc(n * sizeof(int32_t));
     if (!l->table) return -3;
-    for (int i = 0; i < total + nBp * 16; i++) l->table[i] = fill;
+    for (size_t i = 0; i < n; i++) l->table[i] = fill;
     /* sections are loaded in order ref, sig, sign; a later section's group-change fill can spill
      * into nothing (it stays inside its own section for the shipped files). */
-    if (po_lut_section(folder, "ref", component, l->ctx_ref, nBp, wl, l->table, 0)) return -4;
-    if (po_lut_section(folder, "sig", component, l->ctx_sig, nBp, wl, l->table, l->n_ref)) return -5;
-    if (po_lut_section(folder, "sign", component, l->ctx_sign, nBp, wl, l->table,
-                       l->n_ref + l->n_sig)) return -6;
+    for (int j = 0; j < n_tables; j++) {
+        int32_t *T = l->table + (size_t)j * (size_t)total;
+        if (po_lut_section(folder, "ref", component, j, l->ctx_ref, nBp, wl, T, 0)) return -4;
+        if (po_lut_section(folder, "sig", component, j, l->ctx_sig, nBp, wl, T, l->n_ref)) return -5;
+        if (po_lut_section(folder, "sign", component, j, l->ctx_sign, nBp, wl, T, l->n_ref + l->n_sig))
+            return -6;
+    }
     return 0;
+}
+
+/* k = 0 (Engines/Engine.cu:101-141): file _0 only */
+int po_lut_load(const char *folder, int component, int wl, int fill, po_lut *l)
+{
+    return po_lut_load_k(folder, component, wl, fill, 1, l);
 }
 
 void po_lut_free(po_lut *l) { free(l->table); l->table = NULL; }
@@ -558,7 +574,8 @@ typedef struct {
     int count;                   /* codeStreamShared[warp], :1996 */
     int ref_p[32], sig_p[32], sign_p[32];   /* LUT pointers per lane, :329-350 */
     const po_lut *lut;
-    int lut_total;
+    int lut_total;               /* ints in the whole table array (n_tables tables) */
+    int lut_off;                 /* s * _LUTPointerSizePerS of this codeblock, BPCEngine.cu:333 */
     int32_t *stage;              /* this codeblock's 4096 ints */
 } po_cb;
 
@@ -570,15 +587,46 @@ static int po_lut_at(const po_cb *cb, int idx)
     return cb->lut->table[idx];
 }
 
-/* BPCEngine.cu:329-350 with s = 0 */
+/* BPCEngine.cu:329-350; LUTOffset = s * _LUTPointerSizePerS is cb->lut_off (0 when k = 0) */
 static void po_lut_init(po_cb *cb, int t, int level, int sb, int msb)
 {
     const po_lut *l = cb->lut;
     int nS = l->n_subbands, nB = l->n_bitplanes;
-    cb->ref_p[t] = level * nS * nB * l->ctx_ref + sb * nB * l->ctx_ref + msb * l->ctx_ref;
-    cb->sig_p[t] = level * nS * nB * l->ctx_sig + sb * nB * l->ctx_sig + msb * l->ctx_sig + l->n_ref;
+    cb->ref_p[t] = level * nS * nB * l->ctx_ref + sb * nB * l->ctx_ref + msb * l->ctx_ref + cb->lut_off;
+    cb->sig_p[t] = level * nS * nB * l->ctx_sig + sb * nB * l->ctx_sig + msb * l->ctx_sig + l->n_ref +
+                   cb->lut_off;
     cb->sign_p[t] = level * nS * nB * l->ctx_sign + sb * nB * l->ctx_sign + msb * l->ctx_sign +
-                    l->n_ref + l->n_sig;
+                    l->n_ref + l->n_sig + cb->lut_off;
+}
+
+/* L2Norm, BPC/BPCEngine.cuh:158-169 (columns LL, HL, LH, HH; row = level) */
+static const float PO_L2NORM[10][4] = {
+    { 1.965908f, 1.0112865f, 1.0112865f, 0.52021784f },
+    { 4.1224113f, 1.9968134f, 1.9968134f, 0.96721643f },
+    { 8.416739f, 4.1833673f, 4.1833673f, 2.0792568f },
+    { 16.935543f, 8.534108f, 8.534108f, 4.3004827f },
+    { 33.924816f, 17.166693f, 17.166693f, 8.686718f },
+    { 67.87687f, 34.385098f, 34.385098f, 17.41882f },
+    { 135.76744f, 68.7964f, 68.7964f, 34.860676f },
+    { 271.5416f, 137.60588f, 137.60588f, 69.73287f },
+    { 543.0866f, 275.21814f, 275.21814f, 139.47136f },
+    { 1086.1624f, 550.43286f, 550.43286f, 278.94202f }
+};
+
+/* consecutiveBitplanes, Encode BPCEngine.cu:1684-1692 / Decode :1794-1802: IEEE float division and
+ * product, floor, max 0.  (The reference is built -use_fast_math, so its quotient may differ in the
+ * last place: parity of k > 0 with the CUDA binary is unpinned like everything else.)  The level /
+ * subband are those of the codeblock's lane 0: the reference evaluates them per lane, which for a
+ * codeblock straddling subbands would make the warp's plane loops diverge around full-mask shuffles
+ * (undefined there); frames the CLI accepts at the default wl never straddle. */
+int po_consecutive_bitplanes(int msb, float k, int level, int sb, int wl)
+{
+    if (!(k > 0.0f)) return 0;
+    int lv = level > 9 ? 9 : level;
+    float nrm = (wl == level) ? PO_L2NORM[(lv - 1) > 0 ? (lv - 1) : 0][0] : PO_L2NORM[lv][3 - sb];
+    float q = k / nrm;
+    int c = (int)floorf((float)msb * q);
+    return c > 0 ? c : 0;
 }
 
 /* BPCEngine.cu:252-293 */
@@ -740,41 +788,163 @@ static void po_mrp(po_cb *cb, int bp, int decode, uint32_t mask)
         }
 }
 
-/* Encode BPCEngine.cu:1668-1721 (k = 0: consecutiveBitplanes = 0) */
-static void po_cb_encode(po_cb *cb, int msb)
+/* computeContextBulk BPCEngine.cu:236-243 */
+static int po_ctx_bulk(const uint32_t n[8], int B)
+{
+    int c = 0;
+    for (int j = 0; j < 8; j++) c += (int)(((n[j] >> 24) & 31u) >= (uint32_t)B);
+    return c;
+}
+
+/* computeSignContextBulk BPCEngine.cu:311-323 */
+static int po_sign_ctx_bulk(uint32_t up, uint32_t left, uint32_t right, uint32_t bottom, int q)
+{
+#define PO_CONTRIB_B(w) ((((w) >> 31) == 0 || (((w) >> 24) & 31u) < (uint32_t)q) ? 0 : (((w) & 1u) ? -1 : 1))
+    int h = PO_CONTRIB_B(left) + PO_CONTRIB_B(right);
+    int v = PO_CONTRIB_B(up) + PO_CONTRIB_B(bottom);
+#undef PO_CONTRIB_B
+    return po_sign_ctx_hv(h, v);
+}
+
+/* Complexity-scalable bulk mode: encodeBulkMode / decodeBulkMode BPCEngine.cu:1640-1662,
+ * encode/decodeLeft/RightCoefficients :1320-1448 / :1506-1634, encode/decodeBulkProcessing
+ * :1285-1314 / :1454-1500.  Row by row; all lanes their left coefficient, then all lanes their
+ * right one; per coefficient ALL planes B..0 in one go: refinement call site (already significant),
+ * significance call site, sign call site -- three lock-step call sites per plane.  The 8-neighbour
+ * context is taken ONCE per coefficient, from the words as they stand when the row/side is reached
+ * (computeContextBulk for B != 0: neighbours whose significance plane field is >= B; plain
+ * computeContext for B == 0), the four sign neighbours are captured at the same moment (by value,
+ * :1345,:1374...) and filtered per plane by computeSignContextBulk.  LUT entries of plane q are the
+ * plane-B pointers minus ctx * (B - q) (:1293,:1298,:1308). */
+static void po_bulk(po_cb *cb, int B, int decode, uint32_t mask0)
+{
+    uint8_t act[32], sym[32], newsig[32];
+    int prob[32], ctx[32], sctx[32];
+    uint32_t nb[32][4];
+    const po_lut *l = cb->lut;
+    for (int i = 0; i < 64; i++)
+        for (int side = 0; side < 2; side++) {
+            for (int t = 0; t < 32; t++) {
+                int col = 2 * t + side;
+                uint32_t n[8] = { po_w(cb, i - 1, col - 1), po_w(cb, i - 1, col), po_w(cb, i - 1, col + 1),
+                                  po_w(cb, i, col - 1), po_w(cb, i, col + 1), po_w(cb, i + 1, col - 1),
+                                  po_w(cb, i + 1, col), po_w(cb, i + 1, col + 1) };
+                if (B != 0) ctx[t] = po_ctx_bulk(n, B);
+                else {
+                    ctx[t] = 0;
+                    for (int j = 0; j < 8; j++) ctx[t] += (int)(n[j] >> 31);
+                }
+                nb[t][0] = n[1]; nb[t][1] = n[3]; nb[t][2] = n[4]; nb[t][3] = n[6];
+            }
+            uint32_t mask = mask0;
+            for (int q = B; q >= 0; q--) {
+                int d = B - q;
+                /* refinement call site: coefficients that are significant now (:1291 / :1463) */
+                for (int t = 0; t < 32; t++) {
+                    uint32_t w = cb->TD[t][2 * i + side];
+                    act[t] = (uint8_t)(w >> 31);
+                    sym[t] = (uint8_t)((w >> (q + 1)) & 1u);
+                    prob[t] = po_lut_at(cb, cb->ref_p[t] - l->ctx_ref * d);
+                }
+                if (decode) {
+                    po_dec_site(cb, act, sym, prob);
+                    for (int t = 0; t < 32; t++)
+                        if (act[t]) {
+                            uint32_t *w = &cb->TD[t][2 * i + side];
+                            *w &= ~mask;                                              /* :1467 */
+                            *w |= (mask & ((((uint32_t)sym[t] << 1) + 1u) << q));     /* :1469 */
+                        }
+                } else {
+                    po_enc_site(cb, act, sym, prob);
+                }
+                /* significance call site: the others (:1296 / :1472) */
+                for (int t = 0; t < 32; t++) {
+                    uint32_t w = cb->TD[t][2 * i + side];
+                    act[t] = (uint8_t)!(w >> 31);
+                    sym[t] = (uint8_t)((w >> (q + 1)) & 1u);
+                    prob[t] = po_lut_at(cb, cb->sig_p[t] + ctx[t] - l->ctx_sig * d);
+                }
+                if (decode) po_dec_site(cb, act, sym, prob);
+                else po_enc_site(cb, act, sym, prob);
+                for (int t = 0; t < 32; t++) {
+                    newsig[t] = (uint8_t)(act[t] && sym[t] == 1);
+                    if (!newsig[t]) continue;
+                    uint32_t *w = &cb->TD[t][2 * i + side];
+                    if (decode) *w |= mask;                       /* :1478 */
+                    *w |= (1u << 31);                             /* :1302 / :1480 */
+                    *w |= ((uint32_t)q << 24);                    /* :1304 / :1482 */
+                    sctx[t] = po_sign_ctx_bulk(nb[t][0], nb[t][1], nb[t][2], nb[t][3], q);
+                    prob[t] = po_lut_at(cb, cb->sign_p[t] + (sctx[t] >> 1) - l->ctx_sign * d);
+                    sym[t] = (uint8_t)((((*w) & 1u) == (uint32_t)(sctx[t] & 1)) ? 0 : 1);   /* :1308 */
+                }
+                /* sign call site */
+                if (decode) {
+                    po_dec_site(cb, newsig, sym, prob);
+                    for (int t = 0; t < 32; t++)
+                        if (newsig[t]) {
+                            uint32_t sg = ((sym[t] & 1u) == (uint32_t)(sctx[t] & 1)) ? 0u : 1u;   /* :1488 */
+                            cb->TD[t][2 * i + side] |= sg;
+                        }
+                } else {
+                    po_enc_site(cb, newsig, sym, prob);
+                }
+                mask >>= 1;                                       /* :1494-1496 */
+                if (q == 1) mask = 0x2u;
+            }
+        }
+}
+
+static void po_lut_step(po_cb *cb)
+{
+    for (int t = 0; t < 32; t++) {        /* updateLUTPointers :353-358 */
+        cb->sig_p[t] -= cb->lut->ctx_sig;
+        cb->sign_p[t] -= cb->lut->ctx_sign;
+        cb->ref_p[t] -= cb->lut->ctx_ref;
+    }
+}
+
+/* Encode BPCEngine.cu:1668-1721; cbp = consecutiveBitplanes (0 when k = 0) */
+static void po_cb_encode(po_cb *cb, int msb, int cbp)
 {
     for (int t = 0; t < 32; t++) { cb->L[t] = 0; cb->S[t] = 0; cb->slot[t] = -1; }
-    for (int bp = msb; bp >= 0; bp--) {
+    int bp = msb;
+    for (; bp >= cbp; bp--) {
         po_spp(cb, bp, 0, 0);
         po_mrp(cb, bp, 0, 0);
-        for (int t = 0; t < 32; t++) {        /* updateLUTPointers :353-358 */
-            cb->sig_p[t] -= cb->lut->ctx_sig;
-            cb->sign_p[t] -= cb->lut->ctx_sign;
-            cb->ref_p[t] -= cb->lut->ctx_ref;
-        }
+        po_lut_step(cb);
     }
+    if (bp >= 0) po_bulk(cb, bp, 0, 0);   /* :1712-1716 */
     /* flush :1719 -- every lane stores its L into its current slot */
     for (int t = 0; t < 32; t++)
         if (cb->slot[t] >= 0) cb->stage[1 + cb->slot[t]] = (int32_t)cb->L[t];
 }
 
 /* Decode BPCEngine.cu:1777-1837 */
-static void po_cb_decode(po_cb *cb, int msb)
+static void po_cb_decode(po_cb *cb, int msb, int cbp)
 {
     for (int t = 0; t < 32; t++) { cb->L[t] = 0; cb->S[t] = 0; cb->cw[t] = 0; }
     uint32_t mask = 0x3u << msb;
     if (msb == 0) mask &= 0x2u;
-    for (int bp = msb; bp >= 0; bp--) {
+    int bp = msb;
+    for (; bp >= cbp; bp--) {
         po_spp(cb, bp, 1, mask);
         po_mrp(cb, bp, 1, mask);
         mask >>= 1;
         if (bp == 1) mask = 0x2u;
-        for (int t = 0; t < 32; t++) {
-            cb->sig_p[t] -= cb->lut->ctx_sig;
-            cb->sign_p[t] -= cb->lut->ctx_sign;
-            cb->ref_p[t] -= cb->lut->ctx_ref;
-        }
+        po_lut_step(cb);
     }
+    if (bp >= 0) po_bulk(cb, bp, 1, mask);   /* :1831-1835 */
+}
+
+/* table index s = min(consecutiveBitplanes, MSB) (:1694-1697 / :1807-1810), clamped to the tables
+ * that were loaded */
+static void po_cb_select_table(po_cb *cb, int msb, int cbp, float k)
+{
+    int s = 0;
+    if (k > 0.0f) s = cbp < msb ? cbp : msb;
+    int nt = cb->lut->n_tables > 0 ? cb->lut->n_tables : 1;
+    if (s > nt - 1) s = nt - 1;
+    cb->lut_off = s * (cb->lut->n_ref + cb->lut->n_sig + cb->lut->n_sign);
 }
 
 static int po_msb_of(const po_cb *cb)
@@ -803,6 +973,12 @@ static int po_cb_finish_encode(po_cb *cb)
 void po_bpc_encode(const void *coeffs, int is_float, int AW, int AH, int wl, const po_lut *lut,
                    int32_t *staging, int32_t *sizes)
 {
+    po_bpc_encode_k(coeffs, is_float, AW, AH, wl, lut, 0.0f, staging, sizes);
+}
+
+void po_bpc_encode_k(const void *coeffs, int is_float, int AW, int AH, int wl, const po_lut *lut, float k,
+                     int32_t *staging, int32_t *sizes)
+{
     int ncx = AW / PO_CB, ncy = AH / PO_CB;
     /* BPCEngine::deviceMemoryAllocator :2429-2441 -- staging memset to 0xFF */
     memset(staging, 0xFF, (size_t)AW * AH * sizeof(int32_t));
@@ -810,7 +986,8 @@ void po_bpc_encode(const void *coeffs, int is_float, int AW, int AH, int wl, con
     {
     po_cb *cb = (po_cb *)malloc(sizeof(po_cb));
     cb->lut = lut;
-    cb->lut_total = lut->n_ref + lut->n_sig + lut->n_sign;
+    cb->lut_total = (lut->n_ref + lut->n_sig + lut->n_sign) * (lut->n_tables > 0 ? lut->n_tables : 1);
+    cb->lut_off = 0;
     _Pragma("omp for schedule(dynamic, 4)")
     for (int id = 0; id < ncx * ncy; id++) {
             int cy = id / ncx, cx = id % ncx;
@@ -834,8 +1011,10 @@ void po_bpc_encode(const void *coeffs, int is_float, int AW, int AH, int wl, con
             cb->count = 0;
             cb->stage[0] = msb;
             if (msb != 32) {
+                int cbp = po_consecutive_bitplanes(msb, k, level[0], sb[0], wl);
+                po_cb_select_table(cb, msb, cbp, k);
                 for (int t = 0; t < 32; t++) po_lut_init(cb, t, level[t], sb[t], msb);
-                po_cb_encode(cb, msb);
+                po_cb_encode(cb, msb, cbp);
             }
             sizes[id] = po_cb_finish_encode(cb);
     }
@@ -849,7 +1028,8 @@ int po_bpc_encode_block_uniform(const int32_t *block, int level, int sb, int wl,
     (void)wl;
     po_cb *cb = (po_cb *)malloc(sizeof(po_cb));
     cb->lut = lut;
-    cb->lut_total = lut->n_ref + lut->n_sig + lut->n_sign;
+    cb->lut_total = (lut->n_ref + lut->n_sig + lut->n_sign) * (lut->n_tables > 0 ? lut->n_tables : 1);
+    cb->lut_off = 0;
     cb->stage = staging4096;
     memset(staging4096, 0xFF, PO_CB_WORDS * sizeof(int32_t));
     for (int t = 0; t < 32; t++)
@@ -865,7 +1045,7 @@ int po_bpc_encode_block_uniform(const int32_t *block, int level, int sb, int wl,
     cb->stage[0] = msb;
     if (msb != 32) {
         for (int t = 0; t < 32; t++) po_lut_init(cb, t, level, sb, msb);
-        po_cb_encode(cb, msb);
+        po_cb_encode(cb, msb, 0);
     }
     int size = po_cb_finish_encode(cb);
     free(cb);
@@ -877,10 +1057,17 @@ int po_bpc_encode_block_uniform(const int32_t *block, int level, int sb, int wl,
 void po_bpc_decode(const int32_t *staging, const int32_t *sizes, int AW, int AH, int wl,
                    const po_lut *lut, int32_t *coeffs)
 {
+    po_bpc_decode_k(staging, sizes, AW, AH, wl, lut, 0.0f, coeffs);
+}
+
+void po_bpc_decode_k(const int32_t *staging, const int32_t *sizes, int AW, int AH, int wl,
+                     const po_lut *lut, float k, int32_t *coeffs)
+{
     int ncx = AW / PO_CB, ncy = AH / PO_CB;
     po_cb *cb = (po_cb *)malloc(sizeof(po_cb));
     cb->lut = lut;
-    cb->lut_total = lut->n_ref + lut->n_sig + lut->n_sign;
+    cb->lut_total = (lut->n_ref + lut->n_sig + lut->n_sign) * (lut->n_tables > 0 ? lut->n_tables : 1);
+    cb->lut_off = 0;
     for (int cy = 0; cy < ncy; cy++)
         for (int cx = 0; cx < ncx; cx++) {
             int id = cy * ncx + cx;
@@ -892,12 +1079,16 @@ void po_bpc_decode(const int32_t *staging, const int32_t *sizes, int AW, int AH,
                 for (int t = 0; t < 32; t++)
                     for (int i = 0; i < 128; i++) cb->TD[t][i] = (uint32_t)cb->stage[t * 128 + i];
             } else if (msb != 32) {
+                int level0, sb0;
+                po_find_subband(cx * 64, cy * 64, AW, AH, wl, &level0, &sb0);
+                int cbp = po_consecutive_bitplanes(msb, k, level0, sb0, wl);
+                po_cb_select_table(cb, msb, cbp, k);
                 for (int t = 0; t < 32; t++) {
                     int level, sb;
                     po_find_subband(cx * 64 + 2 * t, cy * 64, AW, AH, wl, &level, &sb);
                     po_lut_init(cb, t, level, sb, msb);
                 }
-                po_cb_decode(cb, msb);
+                po_cb_decode(cb, msb, cbp);
             }
             for (int t = 0; t < 32; t++)
                 for (int i = 0; i < 64; i++)
@@ -1001,6 +1192,15 @@ void po_bitstream_unpack(const uint16_t *in, int n_cb, int32_t *staging, int32_t
 size_t po_encode_frame(const uint8_t *frame, int W, int H, int wl, int lossy, float qs,
                        const po_lut *lut, int iter, int frames, uint16_t *out)
 {
+    return po_encode_frame_k(frame, W, H, wl, lossy, qs, 0.0f, lut, iter, frames, out);
+}
+
+/* k > 0: `lut` must hold the bit-plane tables (po_lut_load_k); the header carries (int)(k * 1000)
+ * (BitStreamBuilder.cpp:82-93) and the decoding side works with that value / 1000.0
+ * (Engines/DecodingEngine.cu:56,163). */
+size_t po_encode_frame_k(const uint8_t *frame, int W, int H, int wl, int lossy, float qs, float k,
+                         const po_lut *lut, int iter, int frames, uint16_t *out)
+{
     int AW = po_pad_dim(W), AH = po_pad_dim(H);
     size_t P = (size_t)AW * AH, extra = po_dwt_extra(AW, AH, wl);
     int n_cb = (AW / PO_CB) * (AH / PO_CB);
@@ -1013,14 +1213,14 @@ size_t po_encode_frame(const uint8_t *frame, int W, int H, int wl, int lossy, fl
         int32_t *b = (int32_t *)malloc((P + extra) * sizeof(int32_t));
         po_level_shift_fwd_i32(pad, a, P, 8);
         po_dwt53_forward(a, b, AW, AH, wl);
-        po_bpc_encode(b, 0, AW, AH, wl, lut, staging, sizes);
+        po_bpc_encode_k(b, 0, AW, AH, wl, lut, k, staging, sizes);
         free(a); free(b);
     } else {
         float *a = (float *)malloc(P * sizeof(float));
         float *b = (float *)malloc((P + extra) * sizeof(float));
         po_level_shift_fwd_f32(pad, a, P, 8);
         po_dwt97_forward(a, b, AW, AH, wl, qs);
-        po_bpc_encode(b, 1, AW, AH, wl, lut, staging, sizes);
+        po_bpc_encode_k(b, 1, AW, AH, wl, lut, k, staging, sizes);
         free(a); free(b);
     }
     uint16_t hdr[PO_HDR_SHORTS];
@@ -1029,7 +1229,7 @@ size_t po_encode_frame(const uint8_t *frame, int W, int H, int wl, int lossy, fl
     h.n_samples = (uint32_t)W * (uint32_t)H;
     h.cp = 2; h.cb_height = 18; h.cb_width = 64; h.wl = wl; h.bit_depth = 8; h.lossy = lossy;
     h.qs_1e4 = (int)(qs * 10000); h.components = 1; h.is_rgb = 0; h.height = H; h.endianess = 0;
-    h.bps = 8; h.is_signed = 0; h.frames = frames; h.k_1e3 = 0;
+    h.bps = 8; h.is_signed = 0; h.frames = frames; h.k_1e3 = (int)(k * 1000);
     po_header_pack(&h, hdr);
     size_t total = po_bitstream_pack(staging, sizes, n_cb, iter == 0 ? hdr : NULL, out);
     free(pad); free(staging); free(sizes);
@@ -1039,6 +1239,12 @@ size_t po_encode_frame(const uint8_t *frame, int W, int H, int wl, int lossy, fl
 int po_decode_frame(const uint16_t *stream, int W, int H, int wl, int lossy, float qs,
                     const po_lut *lut, uint8_t *frame_out)
 {
+    return po_decode_frame_k(stream, W, H, wl, lossy, qs, 0.0f, lut, frame_out);
+}
+
+int po_decode_frame_k(const uint16_t *stream, int W, int H, int wl, int lossy, float qs, float k,
+                      const po_lut *lut, uint8_t *frame_out)
+{
     int AW = po_pad_dim(W), AH = po_pad_dim(H);
     size_t P = (size_t)AW * AH, extra = po_dwt_extra(AW, AH, wl);
     int n_cb = (AW / PO_CB) * (AH / PO_CB);
@@ -1046,7 +1252,7 @@ int po_decode_frame(const uint16_t *stream, int W, int H, int wl, int lossy, flo
     int32_t *sizes = (int32_t *)malloc((size_t)n_cb * sizeof(int32_t));
     int32_t *coef = (int32_t *)malloc(P * sizeof(int32_t));
     po_bitstream_unpack(stream, n_cb, staging, sizes);
-    po_bpc_decode(staging, sizes, AW, AH, wl, lut, coef);
+    po_bpc_decode_k(staging, sizes, AW, AH, wl, lut, k, coef);
     if (!lossy) {
         int32_t *img = (int32_t *)malloc((P + extra) * sizeof(int32_t));
         po_dwt53_inverse(coef, img, AW, AH, wl);

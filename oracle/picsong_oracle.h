@@ -39,7 +39,8 @@ typedef struct po_lut {
     int n_bp_files;    /* AMOUNT_OF_BITPLANE_FILES (capped 32) */
     int wl;            /* wavelet levels the table was laid out for */
     int n_ref, n_sig, n_sign;  /* section sizes in ints */
-    int32_t *table;    /* [ref | sig | sign], malloc'd, n_ref+n_sig+n_sign ints */
+    int32_t *table;    /* n_tables x [ref | sig | sign], malloc'd */
+    int n_tables;      /* 1 for k = 0; the bit-plane files _0.._(n-1) for k > 0 (Engine.cu:12-56) */
 } po_lut;
 
 /* Header fields (BitStreamBuilder.cpp:35-94 <-> Engines/DecodingEngine.cu:567-585). */
@@ -103,6 +104,10 @@ void po_dwt97_inverse(const int32_t *in, float *out, int AW, int AH, int wl, flo
  * fill: value for table entries the reference loader never writes; the
  * reference leaves them uninitialised, de-facto 0.  Returns 0 on success. */
 int  po_lut_load(const char *folder, int component, int wl, int fill, po_lut *out);
+/* k > 0: tables of files _0 .. _(n_tables-1) back to back (n_tables <= 0: all of them) */
+int  po_lut_load_k(const char *folder, int component, int wl, int fill, int n_tables, po_lut *out);
+/* consecutiveBitplanes of a codeblock, BPC/BPCEngine.cu:1684-1692 */
+int  po_consecutive_bitplanes(int msb, float k, int level, int sb, int wl);
 void po_lut_free(po_lut *lut);
 
 /* ---- BPC, 2 coding passes, k = 0 (BPC/BPCEngine.cu) */
@@ -113,6 +118,13 @@ void po_bpc_encode(const void *coeffs, int is_float, int AW, int AH, int wl, con
                    int32_t *sizes /* nCB */);
 void po_bpc_decode(const int32_t *staging, const int32_t *sizes, int AW, int AH, int wl,
                    const po_lut *lut, int32_t *coeffs /* AW*AH Mallat */);
+/* complexity-scalable mode -k > 0 (encodeBulkMode / decodeBulkMode BPC/BPCEngine.cu:1285-1662,
+ * Encode :1684-1716, Decode :1794-1835): planes below consecutiveBitplanes are coded in one
+ * row-major bulk scan; lut must come from po_lut_load_k.  k = 0 == the functions above. */
+void po_bpc_encode_k(const void *coeffs, int is_float, int AW, int AH, int wl, const po_lut *lut, float k,
+                     int32_t *staging, int32_t *sizes);
+void po_bpc_decode_k(const int32_t *staging, const int32_t *sizes, int AW, int AH, int wl,
+                     const po_lut *lut, float k, int32_t *coeffs);
 /* single-codeblock entry used by the known-answer tests: all 32 lanes use (level, sb) */
 int  po_bpc_encode_block_uniform(const int32_t *block64x64, int level, int sb, int wl,
                                  const po_lut *lut, int32_t *staging4096);
@@ -133,6 +145,10 @@ size_t po_encode_frame(const uint8_t *frame, int W, int H, int wl, int lossy, fl
                        const po_lut *lut, int iter, int frames, uint16_t *out);
 int po_decode_frame(const uint16_t *stream, int W, int H, int wl, int lossy, float qs,
                     const po_lut *lut, uint8_t *frame_out);
+size_t po_encode_frame_k(const uint8_t *frame, int W, int H, int wl, int lossy, float qs, float k,
+                         const po_lut *lut, int iter, int frames, uint16_t *out);
+int po_decode_frame_k(const uint16_t *stream, int W, int H, int wl, int lossy, float qs, float k,
+                      const po_lut *lut, uint8_t *frame_out);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,8 @@ def build(force=False):
 class PoLut(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "n_bitplanes", "n_subbands", "ctx_ref", "ctx_sign", "ctx_sig", "precision", "n_files",
-        "n_bp_files", "wl", "n_ref", "n_sig", "n_sign")] + [("table", C.POINTER(C.c_int32))]
+        "n_bp_files", "wl", "n_ref", "n_sig", "n_sign")] + [("table", C.POINTER(C.c_int32)),
+                                                              ("n_tables", C.c_int)]
 
 
 class PoHeader(C.Structure):
@@ -66,10 +67,16 @@ def lib():
     L.po_dwt97_inverse.argtypes = [vp, vp, i32, i32, i32, f32]
     L.po_lut_load.restype = i32
     L.po_lut_load.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(PoLut)]
+    L.po_lut_load_k.restype = i32
+    L.po_lut_load_k.argtypes = [C.c_char_p, i32, i32, i32, i32, C.POINTER(PoLut)]
+    L.po_consecutive_bitplanes.restype = i32
+    L.po_consecutive_bitplanes.argtypes = [i32, f32, i32, i32, i32]
     L.po_lut_free.argtypes = [C.POINTER(PoLut)]
     L.po_find_subband.argtypes = [i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
     L.po_bpc_encode.argtypes = [vp, i32, i32, i32, i32, C.POINTER(PoLut), vp, vp]
     L.po_bpc_decode.argtypes = [vp, vp, i32, i32, i32, C.POINTER(PoLut), vp]
+    L.po_bpc_encode_k.argtypes = [vp, i32, i32, i32, i32, C.POINTER(PoLut), f32, vp, vp]
+    L.po_bpc_decode_k.argtypes = [vp, vp, i32, i32, i32, C.POINTER(PoLut), f32, vp]
     L.po_bpc_encode_block_uniform.restype = i32
     L.po_bpc_encode_block_uniform.argtypes = [vp, i32, i32, i32, C.POINTER(PoLut), vp]
     L.po_header_pack.argtypes = [C.POINTER(PoHeader), vp]
@@ -83,6 +90,10 @@ def lib():
     L.po_encode_frame.argtypes = [vp, i32, i32, i32, i32, f32, C.POINTER(PoLut), i32, i32, vp]
     L.po_decode_frame.restype = i32
     L.po_decode_frame.argtypes = [vp, i32, i32, i32, i32, f32, C.POINTER(PoLut), vp]
+    L.po_encode_frame_k.restype = sz
+    L.po_encode_frame_k.argtypes = [vp, i32, i32, i32, i32, f32, f32, C.POINTER(PoLut), i32, i32, vp]
+    L.po_decode_frame_k.restype = i32
+    L.po_decode_frame_k.argtypes = [vp, i32, i32, i32, i32, f32, f32, C.POINTER(PoLut), vp]
     for fn in (L.po_rct_forward, L.po_rct_inverse, L.po_ict_forward, L.po_ict_inverse):
         fn.argtypes = [vp, vp, vp, vp, vp, vp, sz, i32]
     L.po_set_threads.argtypes = [i32]
@@ -107,14 +118,16 @@ def max_threads():
 class Lut:
     """Loaded LUT (keeps the C struct alive; .table is a numpy copy)."""
 
-    def __init__(self, folder, wl, component=1, fill=0):
+    def __init__(self, folder, wl, component=1, fill=0, n_tables=1):
+        """n_tables = 1: file _0 (k = 0); n_tables = 0: every bit-plane file (k > 0)."""
         self.c = PoLut()
         f = folder if folder.endswith("/") else folder + "/"
-        rc = lib().po_lut_load(f.encode(), component, wl, fill, C.byref(self.c))
+        rc = lib().po_lut_load_k(f.encode(), component, wl, fill, n_tables, C.byref(self.c))
         if rc != 0:
-            raise RuntimeError(f"po_lut_load({folder}) failed: {rc}")
-        self.total = self.c.n_ref + self.c.n_sig + self.c.n_sign
-        self.table = np.ctypeslib.as_array(self.c.table, shape=(self.total,)).copy()
+            raise RuntimeError(f"po_lut_load_k({folder}) failed: {rc}")
+        self.total = self.c.n_ref + self.c.n_sig + self.c.n_sign      # one table
+        self.n_tables = self.c.n_tables
+        self.table = np.ctypeslib.as_array(self.c.table, shape=(self.total * self.n_tables,)).copy()
         self.wl = wl
 
     def geometry(self):
@@ -132,6 +145,15 @@ class Lut:
 
 def lut_for(lossy, wl, fill=0):
     return Lut(os.path.join(LUT_DIR, "n1_lossy" if lossy else "n1_lossless"), wl, 1, fill)
+
+
+def lut_for_k(lossy, wl, fill=0):
+    """All bit-plane tables (files _0 .. _14) of the R component: the -k > 0 layout."""
+    return Lut(os.path.join(LUT_DIR, "n1_lossy" if lossy else "n1_lossless"), wl, 1, fill, n_tables=0)
+
+
+def consecutive_bitplanes(msb, k, level, sb, wl):
+    return lib().po_consecutive_bitplanes(msb, k, level, sb, wl)
 
 
 def pad_dim(v):
@@ -238,7 +260,7 @@ def dwt_inverse(coef, wl, lossy, qs=1.0):
     return out, extra
 
 
-def bpc_encode(coef, wl, lut):
+def bpc_encode(coef, wl, lut, k=0.0):
     AH, AW = coef.shape
     coef = np.ascontiguousarray(coef)
     is_float = int(coef.dtype == np.float32)
@@ -246,15 +268,15 @@ def bpc_encode(coef, wl, lut):
         coef = coef.astype(np.int32, copy=False)
     staging = np.empty(AW * AH, np.int32)
     sizes = np.empty((AW // 64) * (AH // 64), np.int32)
-    lib().po_bpc_encode(_p(coef), is_float, AW, AH, wl, C.byref(lut.c), _p(staging), _p(sizes))
+    lib().po_bpc_encode_k(_p(coef), is_float, AW, AH, wl, C.byref(lut.c), k, _p(staging), _p(sizes))
     return staging, sizes
 
 
-def bpc_decode(staging, sizes, AW, AH, wl, lut):
+def bpc_decode(staging, sizes, AW, AH, wl, lut, k=0.0):
     staging = np.ascontiguousarray(staging, np.int32)
     sizes = np.ascontiguousarray(sizes, np.int32)
     coef = np.empty((AH, AW), np.int32)
-    lib().po_bpc_decode(_p(staging), _p(sizes), AW, AH, wl, C.byref(lut.c), _p(coef))
+    lib().po_bpc_decode_k(_p(staging), _p(sizes), AW, AH, wl, C.byref(lut.c), k, _p(coef))
     return coef
 
 
@@ -300,18 +322,18 @@ def bitstream_unpack(stream, n_cb):
     return staging, sizes
 
 
-def encode_frame(img, wl, lossy, qs, lut, iter_=0, frames=0):
+def encode_frame(img, wl, lossy, qs, lut, iter_=0, frames=0, k=0.0):
     H, W = img.shape
     img = np.ascontiguousarray(img, np.uint8)
     AW, AH = pad_dim(W), pad_dim(H)
     out = np.empty(9 + 2 * (AW // 64) * (AH // 64) + AW * AH + 1, np.uint16)
-    n = lib().po_encode_frame(_p(img), W, H, wl, int(lossy), qs, C.byref(lut.c), iter_, frames,
-                              _p(out))
+    n = lib().po_encode_frame_k(_p(img), W, H, wl, int(lossy), qs, k, C.byref(lut.c), iter_, frames,
+                                _p(out))
     return out[:n].copy()
 
 
-def decode_frame(stream, W, H, wl, lossy, qs, lut):
+def decode_frame(stream, W, H, wl, lossy, qs, lut, k=0.0):
     stream = np.ascontiguousarray(stream, np.uint16)
     out = np.empty((H, W), np.uint8)
-    lib().po_decode_frame(_p(stream), W, H, wl, int(lossy), qs, C.byref(lut.c), _p(out))
+    lib().po_decode_frame_k(_p(stream), W, H, wl, int(lossy), qs, k, C.byref(lut.c), _p(out))
     return out

@@ -242,3 +242,74 @@ def test_pack_unpack_inverse(oracle):
     assert s.size == 9 + 2 * n_cb + int((sizes - 1).sum()) + 1
     st2, sz2 = oracle.bitstream_unpack(s, n_cb)
     assert np.array_equal(sz2, sizes) and np.array_equal(st2, staging)
+
+
+# ---- complexity-scalable mode, -k > 0 -------------------------------------------
+
+def _k_coeffs(O, W=256, H=192, wl=2, seed=5):
+    rng = np.random.default_rng(seed)
+    img = (np.clip(rng.normal(128, 40, (H, W)), 0, 255)).astype(np.uint8)
+    img[40:90, 60:200] = 200
+    x = O.level_shift_fwd(img, False)
+    return O.dwt_forward(x, wl)[:W * H].reshape(H, W)
+
+
+def test_consecutive_bitplanes_formula(oracle):
+    O = oracle
+    # Encode BPCEngine.cu:1684-1692: LL uses L2Norm[max(level-1,0)][0], others L2Norm[level][3-sb]
+    assert O.consecutive_bitplanes(10, 0.0, 0, 2, 5) == 0
+    assert O.consecutive_bitplanes(10, 1.0, 0, 2, 5) == int(np.floor(np.float32(10) * (np.float32(1.0) / np.float32(1.0112865))))
+    assert O.consecutive_bitplanes(10, 1.0, 0, 0, 5) == int(np.floor(np.float32(10) * (np.float32(1.0) / np.float32(0.52021784))))
+    assert O.consecutive_bitplanes(12, 2.0, 5, 0, 5) == int(np.floor(np.float32(12) * (np.float32(2.0) / np.float32(33.924816))))
+    assert O.consecutive_bitplanes(7, 65.0, 1, 1, 5) > 7          # everything in bulk
+
+
+def test_lut_multi_table_layout(oracle):
+    O = oracle
+    l1 = O.lut_for(False, 3)
+    lk = O.lut_for_k(False, 3)
+    assert lk.n_tables == 15 and lk.table.size == 15 * l1.total
+    assert np.array_equal(lk.table[:l1.total], l1.table)          # table 0 == the k = 0 table
+    assert np.array_equal(lk.table[l1.total:2 * l1.total], l1.table)          # shipped _1 == _0
+    assert not np.array_equal(lk.table[2 * l1.total:3 * l1.total], l1.table)  # _2 onward differ
+
+
+@pytest.mark.parametrize("k", [0.05, 0.3, 1.0, 4.0, 65.0])
+def test_bulk_mode_round_trip_lossless(oracle, k):
+    O = oracle
+    wl = 2
+    coef = _k_coeffs(O, wl=wl)
+    H, W = coef.shape
+    lut = O.lut_for_k(False, wl)
+    st, sz = O.bpc_encode(coef, wl, lut, k=k)
+    back = O.bpc_decode(st, sz, W, H, wl, lut, k=k)
+    assert np.array_equal(back, coef)
+    assert (sz > 1).all()
+
+
+def test_bulk_mode_k0_equals_plain_and_small_k_differs(oracle):
+    O = oracle
+    wl = 2
+    coef = _k_coeffs(O, wl=wl)
+    lut0 = O.lut_for(False, wl)
+    lutk = O.lut_for_k(False, wl)
+    st0, sz0 = O.bpc_encode(coef, wl, lut0)
+    stk, szk = O.bpc_encode(coef, wl, lutk, k=0.0)
+    assert np.array_equal(sz0, szk) and np.array_equal(st0, stk)
+    st1, sz1 = O.bpc_encode(coef, wl, lutk, k=1.0)
+    assert not np.array_equal(sz1, sz0)
+
+
+def test_bulk_mode_frame_round_trip_and_header(oracle):
+    O = oracle
+    W, H, wl = 200, 150, 3
+    img = O.gen_frame(W, H, 1)
+    lut = O.lut_for_k(False, wl)
+    s = O.encode_frame(img, wl, False, 1.0, lut, k=0.3)
+    assert O.header_unpack(s[:9])["k_1e3"] == 300
+    assert np.array_equal(O.decode_frame(s, W, H, wl, False, 1.0, lut, k=0.3), img)
+    lutl = O.lut_for_k(True, wl)
+    sl = O.encode_frame(img, wl, True, 0.5, lutl, k=0.5)
+    d = O.decode_frame(sl, W, H, wl, True, 0.5, lutl, k=0.5).astype(np.float64)
+    mse = np.mean((d - img) ** 2)
+    assert 10 * np.log10(255 ** 2 / mse) > 35
