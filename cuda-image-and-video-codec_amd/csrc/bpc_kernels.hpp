@@ -1,4 +1,5 @@
-// bpc_kernels.hpp -- BPC-PaCo bit-plane coder / decoder for gfx950 (CDNA4), 2 coding passes, k = 0.
+// bpc_kernels.hpp -- BPC-PaCo bit-plane coder / decoder for gfx950 (CDNA4), 2 coding passes,
+// k = 0 and the complexity-scalable mode k > 0 (BULK instantiations).
 //
 // Replaces kernelBPCCoder<T> / kernelBPCDecoder<int> (reference BPC/BPCEngine.cu:1929-2026,
 // 2126-2215) and everything they call (SPP :490-516/:559-594/:770-843, MRP :726-762/:1249-1279,
@@ -43,6 +44,8 @@ struct BpcArgs {
     int32_t *staging;              // int32[nCB*4096]
     int32_t *sizes;                // int32[nCB]
     int *range_flag;               // set to 1 if a codeblock has MSB > 15
+    float k;                       // complexity-scalability factor (-k); > 0 only in BULK kernels
+    int n_tables;                  // bit-plane tables laid back to back in `lut` (1 when k = 0)
 };
 
 // ---- cross-lane helpers ---------------------------------------------------------------------
@@ -300,18 +303,187 @@ __device__ __forceinline__ void enc_spp_coeff(Coder &c, uint32_t ii, uint32_t A,
     }
 }
 
+__device__ __forceinline__ uint32_t dec_site(Coder &c, uint32_t inact, uint32_t p, uint32_t prec,
+                                             uint32_t lower_mask, uint32_t upper_mask, const int32_t *stage);
+
+// =============================================================================================
+// Complexity-scalable mode, -k > 0 (Encode BPCEngine.cu:1684-1716, Decode :1794-1835,
+// encode/decodeBulkMode :1640-1662 and callees :1285-1634).  A codeblock codes its planes
+// MSB .. cbp with the ordinary two passes and the planes below cbp = floor(MSB * k / L2Norm) in ONE
+// row-major scan: per coefficient all remaining planes, three lock-step call sites per plane
+// (refinement if already significant, else significance, then sign).  The LUT is table
+// s = min(cbp, MSB) of the bit-plane files.
+//
+// The bulk scan needs, per neighbour, "is it significant, since which plane, which sign".  The
+// reference keeps that in flag bits of 128 live coefficient words per lane; here every coefficient
+// the scan has to look at is one packed word pw built when the scan reaches its row:
+//     bit 0 = sign, bit 1 = significant before the bulk scan, bits 2.. = the B+1 low magnitude bits
+//     (only once the scan has PROCESSED the coefficient; 0 before)
+// so that  computeContextBulk's "plane field >= B"  ==  bit1 | bit(2+B)   (:236-243; also == the
+// plain count computeContext takes when B = 0), and computeSignContextBulk's "significant and plane
+// field >= q"  ==  bit1 | (pw >> (2+q)) != 0   (:311-323).  A lane keeps the processed words of the
+// row above for its two columns; the neighbour lanes' words come by DPP, the row below is
+// unprocessed by construction.  The plane-q probabilities are read from an LDS copy of table s.
+// =============================================================================================
+
+constexpr int kBulkLutMax = 4672;      // bytes of one table held in LDS per codeblock (wl <= 7: 15*22*14 = 4620)
+
+// L2Norm, BPC/BPCEngine.cuh:158-169
+__device__ __forceinline__ float l2norm(int level, int col)
+{
+    const float T[10][4] = {
+        { 1.965908f, 1.0112865f, 1.0112865f, 0.52021784f }, { 4.1224113f, 1.9968134f, 1.9968134f, 0.96721643f },
+        { 8.416739f, 4.1833673f, 4.1833673f, 2.0792568f }, { 16.935543f, 8.534108f, 8.534108f, 4.3004827f },
+        { 33.924816f, 17.166693f, 17.166693f, 8.686718f }, { 67.87687f, 34.385098f, 34.385098f, 17.41882f },
+        { 135.76744f, 68.7964f, 68.7964f, 34.860676f }, { 271.5416f, 137.60588f, 137.60588f, 69.73287f },
+        { 543.0866f, 275.21814f, 275.21814f, 139.47136f }, { 1086.1624f, 550.43286f, 550.43286f, 278.94202f } };
+    return T[level > 9 ? 9 : level][col];
+}
+
+// consecutiveBitplanes :1684-1692 for the codeblock of this half (level / subband of its lane 0)
+__device__ __forceinline__ int consecutive_bitplanes(int msb, float k, int level, int sb, int wl)
+{
+    const float nrm = (wl == level) ? l2norm(level - 1 > 0 ? level - 1 : 0, 0) : l2norm(level, 3 - sb);
+    const float q = k / nrm;
+    const int c = (int)floorf((float)msb * q);
+    return c > 0 ? c : 0;
+}
+
+struct BulkLane {
+    int Bh;                        // first (highest) bulk plane of this lane's codeblock, -1 = none
+    uint32_t ref0, sig0, sign0;    // LDS byte index of the plane-0 entries of the lane's LUT group
+    uint32_t cRef, cSig, cSign;    // contexts per plane
+    uint32_t total;                // entries of one table (index clamp, as lut_at)
+    const uint8_t *lds;            // this half's table
+};
+
+__device__ __forceinline__ uint32_t bulk_lut(const BulkLane &b, uint32_t idx)
+{
+    return b.lds[idx >= b.total ? b.total - 1u : idx];
+}
+// computeContextBulk / computeContext term of one neighbour word
+__device__ __forceinline__ uint32_t bulk_cc(uint32_t pw, uint32_t sh) { return ((pw >> 1) | (pw >> sh)) & 1u; }
+// computeSignContextBulk term of one neighbour word at plane q: -1 / 0 / +1
+__device__ __forceinline__ int bulk_sc(uint32_t pw, uint32_t q)
+{
+    const bool on = ((pw >> 1) & 1u) != 0u || (pw >> (2u + q)) != 0u;
+    return on ? ((pw & 1u) ? -1 : 1) : 0;
+}
+
+// All remaining planes of ONE coefficient (encodeBulkProcessing :1285-1314 / decodeBulkProcessing
+// :1454-1500).  u: the coefficient's unprocessed word; low: its low magnitude bits (encoder).
+// Returns the processed word.
+template <bool DEC>
+__device__ __forceinline__ uint32_t bulk_coeff(Coder &c, uint32_t u, uint32_t low, uint32_t ctx, uint32_t up,
+                                               uint32_t lf, uint32_t rt, uint32_t dn, const BulkLane &b, int Bmax,
+                                               uint32_t prec, uint32_t lower_mask, uint32_t upper_mask,
+                                               int32_t *st)
+{
+    uint32_t sig = (u >> 1) & 1u, neg = u & 1u;
+    if (DEC) low = 0u;
+    for (int q = Bmax; q >= 0; q--) {
+        const uint32_t on = q <= b.Bh ? 1u : 0u;
+        const uint32_t bit = (low >> q) & 1u;
+        // refinement call site: coefficients that are significant by now
+        const uint32_t iA = (on & sig) ^ 1u;
+        if (__builtin_amdgcn_ballot_w64(iA == 0u) != 0ull) {
+            const uint32_t p = bulk_lut(b, b.ref0 + (uint32_t)q * b.cRef);
+            if (DEC) low |= dec_site(c, iA, p, prec, lower_mask, upper_mask, st) << q;
+            else enc_site(c, iA, bit, p, prec, lower_mask, upper_mask, st);
+        }
+        // significance call site: the others
+        const uint32_t iB = (on & (sig ^ 1u)) ^ 1u;
+        uint32_t ns = 0u;
+        if (__builtin_amdgcn_ballot_w64(iB == 0u) != 0ull) {
+            const uint32_t p = bulk_lut(b, b.sig0 + (uint32_t)q * b.cSig + ctx);
+            if (DEC) { ns = dec_site(c, iB, p, prec, lower_mask, upper_mask, st); low |= ns << q; }
+            else { enc_site(c, iB, bit, p, prec, lower_mask, upper_mask, st); ns = (iB ^ 1u) & bit; }
+        }
+        // sign call site: coefficients that just became significant
+        if (__builtin_amdgcn_ballot_w64(ns != 0u) != 0ull) {
+            const uint32_t sc = sign_ctx(bulk_sc(lf, (uint32_t)q) + bulk_sc(rt, (uint32_t)q),
+                                         bulk_sc(up, (uint32_t)q) + bulk_sc(dn, (uint32_t)q));
+            const uint32_t p = bulk_lut(b, b.sign0 + (uint32_t)q * b.cSign + (sc >> 1));
+            if (DEC) {
+                const uint32_t s2 = dec_site(c, ns ^ 1u, p, prec, lower_mask, upper_mask, st);
+                if (ns) neg = s2 ^ (sc & 1u);                  // :1488-1490
+            } else {
+                enc_site(c, ns ^ 1u, neg ^ (sc & 1u), p, prec, lower_mask, upper_mask, st);   // :1308
+            }
+            sig |= ns;
+        }
+    }
+    return neg | (u & 2u) | (low << 2);
+}
+
+// One row of the bulk scan for the lane's two columns.  uL/uR: unprocessed words of the row,
+// dL/dR: of the row below, pUL/pUR: processed words of the row above (updated to this row's).
+template <bool DEC>
+__device__ __forceinline__ void bulk_row(Coder &c, uint32_t t, uint32_t uL, uint32_t uR, uint32_t lowL, uint32_t lowR,
+                                         uint32_t dL, uint32_t dR, uint32_t &pUL, uint32_t &pUR, const BulkLane &b,
+                                         int Bmax, uint32_t prec, uint32_t lower_mask, uint32_t upper_mask,
+                                         int32_t *st)
+{
+    const uint32_t sh = 2u + (uint32_t)(b.Bh < 0 ? 0 : b.Bh);
+    // lane-1's right column (rows above / this / below) and lane+1's left column (above, below)
+    const uint32_t P_ur = from_prev32(pUR, t), P_r = from_prev32(uR, t), P_dr = from_prev32(dR, t);
+    const uint32_t N_ul = from_next32(pUL, t), N_dl = from_next32(dL, t);
+    // left coefficients of all lanes (encodeLeftCoefficients :1320-1381)
+    const uint32_t ctxL = bulk_cc(P_ur, sh) + bulk_cc(pUL, sh) + bulk_cc(pUR, sh) + bulk_cc(P_r, sh) +
+                          bulk_cc(uR, sh) + bulk_cc(P_dr, sh) + bulk_cc(dL, sh) + bulk_cc(dR, sh);
+    const uint32_t nL = bulk_coeff<DEC>(c, uL, lowL, ctxL, pUL, P_r, uR, dL, b, Bmax, prec, lower_mask, upper_mask, st);
+    // right coefficients (encodeRightCoefficients :1387-1448): the left ones of this row are done
+    const uint32_t N_l = from_next32(nL, t);
+    const uint32_t ctxR = bulk_cc(pUL, sh) + bulk_cc(pUR, sh) + bulk_cc(N_ul, sh) + bulk_cc(nL, sh) +
+                          bulk_cc(N_l, sh) + bulk_cc(dL, sh) + bulk_cc(dR, sh) + bulk_cc(N_dl, sh);
+    const uint32_t nR = bulk_coeff<DEC>(c, uR, lowR, ctxR, pUR, nL, N_l, dR, b, Bmax, prec, lower_mask, upper_mask, st);
+    pUL = nL; pUR = nR;
+}
+
+// Per-half set-up shared by both kernels: consecutive planes, table choice, LDS copy of the table.
+// Returns cbp; fills b (Bh, LDS indices) and loff (int offset of table s inside a.lut).
+__device__ __forceinline__ int bulk_setup(const BpcArgs &a, bool coded, int msb, int cbx, int cby, int grp,
+                                          uint32_t t, uint8_t *lds_half, BulkLane &b, int &loff)
+{
+    const int total = a.g.nRef + a.g.nSig + a.g.nSign;
+    // level / subband of the codeblock's lane 0 (see oracle note: per-lane values would diverge)
+    int lv0, sb0;
+    find_subband(cbx * 64, cby * 64, a.AW, a.AH, a.wl, lv0, sb0);
+    int cbp = 0, s = 0;
+    if (coded) {
+        cbp = consecutive_bitplanes(msb, a.k, lv0, sb0, a.wl);
+        s = cbp < msb ? cbp : msb;
+        if (s > a.n_tables - 1) s = a.n_tables - 1;
+    }
+    loff = s * total;
+    for (int j = (int)t; j < total; j += 32) lds_half[j] = (uint8_t)((uint32_t)a.lut[loff + j] & 0xFFu);
+    __syncthreads();
+    b.Bh = coded ? (msb < cbp - 1 ? msb : cbp - 1) : -1;
+    b.cRef = (uint32_t)a.g.cRef; b.cSig = (uint32_t)a.g.cSig; b.cSign = (uint32_t)a.g.cSign;
+    b.ref0 = (uint32_t)(grp * a.g.nBp * a.g.cRef);
+    b.sig0 = (uint32_t)(grp * a.g.nBp * a.g.cSig + a.g.nRef);
+    b.sign0 = (uint32_t)(grp * a.g.nBp * a.g.cSign + a.g.nRef + a.g.nSig);
+    b.total = (uint32_t)total;
+    b.lds = lds_half;
+    return cbp;
+}
+
 #ifndef PICSONG_BPC_ENC_WAVES
 #define PICSONG_BPC_ENC_WAVES 4        // waves per SIMD the register allocator must leave room for
 #endif
+// BULK = the -k > 0 instantiation (bulk scan after the ordinary planes, table s of the bit-plane
+// LUT files, LDS copy of that table); the k = 0 instantiation compiles to the plain coder.
+template <bool BULK>
 __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(BpcArgs a)
 {
+    __shared__ uint8_t lds_lut[BULK ? 2 * kBulkLutMax : 4];
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
     const int cb = a.cb_base + 2 * (int)blockIdx.x + (int)half;
     const bool valid = cb < a.nCB;
     const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
     const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
     int32_t *st = a.staging + (size_t)(valid ? cb : a.cb_base) * 4096u;
-    const int lut_total = a.g.nRef + a.g.nSig + a.g.nSign;
+    const int lut_total = (a.g.nRef + a.g.nSig + a.g.nSign) * (BULK ? a.n_tables : 1);
     const uint32_t prec = (uint32_t)a.g.prec;
 
     uint32_t PLlo[kMaxPlanes], PLhi[kMaxPlanes], PRlo[kMaxPlanes], PRhi[kMaxPlanes];
@@ -340,7 +512,14 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
     if (valid && msb != 32 && msb > kMaxPlanes - 1) { *a.range_flag = 1; msb = kMaxPlanes - 1; }
     const bool coded = valid && msb != 32;
 
-    int np = coded ? msb + 1 : 0;
+    int level, sb;
+    find_subband(cbx * 64 + 2 * (int)t, cby * 64, a.AW, a.AH, a.wl, level, sb);
+    const int grp = level * a.g.nSub + sb;
+    int cbp = 0, loff = 0;                                   // planes >= cbp take the two passes
+    BulkLane bl;
+    if constexpr (BULK) cbp = bulk_setup(a, coded, msb, cbx, cby, grp, t, lds_lut + half * kBulkLutMax, bl, loff);
+
+    int np = coded ? (msb + 1 - cbp > 0 ? msb + 1 - cbp : 0) : 0;
     { int o = __shfl_xor(np, 32); np = np > o ? np : o; }
     np = (int)__builtin_amdgcn_readfirstlane((uint32_t)np);      // wave-uniform: keep it scalar
 
@@ -377,10 +556,6 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
         }
     }
 
-    int level, sb;
-    find_subband(cbx * 64 + 2 * (int)t, cby * 64, a.AW, a.AH, a.wl, level, sb);
-    const int grp = level * a.g.nSub + sb;
-
     Coder c = { 0u, 0u, 0u, 0u, 0u };
     const uint32_t upper_mask = half ? 0xFFFFFFFFu : 0u, lower_mask = ~upper_mask;
     U64 AL = { 0u, 0u }, AR = { 0u, 0u };                 // significant before the current plane
@@ -388,13 +563,13 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
 
     for (int p = 0; p < np; p++) {
         const int bp = msb - p;
-        const bool act = coded && bp >= 0;
+        const bool act = coded && bp >= cbp;
 
         PlaneLut pl = { 0u, 0u, 0u, 0u, 0u };
         if (act) {
-            int ri = (grp * a.g.nBp + bp) * a.g.cRef;
-            int si = (grp * a.g.nBp + bp) * a.g.cSig + a.g.nRef;
-            int gi = (grp * a.g.nBp + bp) * a.g.cSign + a.g.nRef + a.g.nSig;
+            int ri = (grp * a.g.nBp + bp) * a.g.cRef + loff;
+            int si = (grp * a.g.nBp + bp) * a.g.cSig + a.g.nRef + loff;
+            int gi = (grp * a.g.nBp + bp) * a.g.cSign + a.g.nRef + a.g.nSig + loff;
             pl.ref = lut_at(a.lut, ri, lut_total);
             pl.sig0 = lut_at(a.lut, si + 0, lut_total) | (lut_at(a.lut, si + 1, lut_total) << 8) |
                       (lut_at(a.lut, si + 2, lut_total) << 16) | (lut_at(a.lut, si + 3, lut_total) << 24);
@@ -452,6 +627,43 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
         for (int k = 0; k < kMaxPlanes - 1; k++) {
             PLlo[k] = PLlo[k + 1]; PLhi[k] = PLhi[k + 1];
             PRlo[k] = PRlo[k + 1]; PRhi[k] = PRhi[k + 1];
+        }
+    }
+
+    // ---- bulk scan of the planes below cbp (encodeBulkMode :1640-1648): the rows are read again
+    // from the coefficient array (L2-resident), three at a time in flight
+    if constexpr (BULK) {
+        int Bmax = bl.Bh;
+        { int o = __shfl_xor(Bmax, 32); Bmax = Bmax > o ? Bmax : o; }
+        Bmax = (int)__builtin_amdgcn_readfirstlane((uint32_t)Bmax);
+        if (Bmax >= 0) {
+            const uint32_t lowmask = bl.Bh >= 0 ? ((2u << bl.Bh) - 1u) : 0u;
+            const uint32_t magmask = coded ? ((2u << msb) - 1u) : 0u;
+            const uint32_t sbsh = (uint32_t)(bl.Bh + 2);            // word >> (Bh+2) = magnitude >> (Bh+1)
+            auto row_words = [&](int i, uint32_t &w0, uint32_t &w1) {
+                int32_t v0, v1;
+                size_t idx = cbase + (size_t)i * (size_t)a.AW;
+                if (a.is_float) {
+                    float2 f = *reinterpret_cast<const float2 *>((const float *)a.coeffs_in + idx);
+                    v0 = (int32_t)f.x; v1 = (int32_t)f.y;
+                } else {
+                    int2 q = *reinterpret_cast<const int2 *>((const int32_t *)a.coeffs_in + idx);
+                    v0 = q.x; v1 = q.y;
+                }
+                w0 = ((((uint32_t)(v0 < 0 ? -v0 : v0)) & magmask) << 1) | (uint32_t)(v0 < 0);
+                w1 = ((((uint32_t)(v1 < 0 ? -v1 : v1)) & magmask) << 1) | (uint32_t)(v1 < 0);
+            };
+            // unprocessed word: sign | significant-before-the-scan << 1
+            auto unp = [&](uint32_t w) -> uint32_t { return (w & 1u) | ((w >> sbsh) != 0u ? 2u : 0u); };
+            uint32_t pUL = 0u, pUR = 0u, c0, c1, n0 = 0u, n1 = 0u;
+            row_words(0, c0, c1);
+            for (int i = 0; i < 64; i++) {
+                if (i < 63) row_words(i + 1, n0, n1); else { n0 = 0u; n1 = 0u; }
+                bulk_row<false>(c, t, unp(c0), unp(c1), (c0 >> 1) & lowmask, (c1 >> 1) & lowmask,
+                                i < 63 ? unp(n0) : 0u, i < 63 ? unp(n1) : 0u, pUL, pUR, bl, Bmax, prec,
+                                lower_mask, upper_mask, st);
+                c0 = n0; c1 = n1;
+            }
         }
     }
 
@@ -549,15 +761,17 @@ __device__ __forceinline__ uint32_t dec_spp_coeff(Coder &c, uint32_t idle, uint3
 }
 
 // One wave64 per workgroup; codeblocks cb_base + 2*blockIdx.x (lanes 0-31) and +1 (lanes 32-63).
+template <bool BULK>
 __global__ __launch_bounds__(64, 4) void bpc_decode_kernel(BpcArgs a)
 {
+    __shared__ uint8_t lds_lut[BULK ? 2 * kBulkLutMax : 4];
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
     const int cb = a.cb_base + 2 * (int)blockIdx.x + (int)half;
     const bool valid = cb < a.nCB;
     const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
     const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
     const int32_t *stage = a.staging + (size_t)(valid ? cb : a.cb_base) * 4096u;
-    const int lut_total = a.g.nRef + a.g.nSig + a.g.nSign;
+    const int lut_total = (a.g.nRef + a.g.nSig + a.g.nSign) * (BULK ? a.n_tables : 1);
     const uint32_t prec = (uint32_t)a.g.prec;
     const uint32_t upper_mask = half ? 0xFFFFFFFFu : 0u, lower_mask = ~upper_mask;
 
@@ -581,13 +795,17 @@ __global__ __launch_bounds__(64, 4) void bpc_decode_kernel(BpcArgs a)
     Coder c = { 0u, 0u, 0u, 0u, 0u };
     M64 sigL = { 0u, 0u }, sigR = { 0u, 0u }, refL = { 0u, 0u }, refR = { 0u, 0u };
 
-    int np = coded ? msb + 1 : 0;
+    int cbp = 0, loff = 0;
+    BulkLane bl;
+    if constexpr (BULK) cbp = bulk_setup(a, coded, msb, cbx, cby, grp, t, lds_lut + half * kBulkLutMax, bl, loff);
+
+    int np = coded ? (msb + 1 - cbp > 0 ? msb + 1 - cbp : 0) : 0;
     { int o = __shfl_xor(np, 32); np = np > o ? np : o; }
     np = (int)__builtin_amdgcn_readfirstlane((uint32_t)np);
 
     for (int p = 0; p < np; p++) {
         const int bp = msb - p;
-        const bool act = coded && bp >= 0;
+        const bool act = coded && bp >= cbp;
         const uint32_t idle = act ? 0u : 1u;
 
         // make room: plane registers move up so that after the last plane index k = plane k
@@ -602,9 +820,9 @@ __global__ __launch_bounds__(64, 4) void bpc_decode_kernel(BpcArgs a)
 
         PlaneLut pl = { 0u, 0u, 0u, 0u, 0u };
         if (act) {
-            int ri = (grp * a.g.nBp + bp) * a.g.cRef;
-            int si = (grp * a.g.nBp + bp) * a.g.cSig + a.g.nRef;
-            int gi = (grp * a.g.nBp + bp) * a.g.cSign + a.g.nRef + a.g.nSig;
+            int ri = (grp * a.g.nBp + bp) * a.g.cRef + loff;
+            int si = (grp * a.g.nBp + bp) * a.g.cSig + a.g.nRef + loff;
+            int gi = (grp * a.g.nBp + bp) * a.g.cSign + a.g.nRef + a.g.nSig + loff;
             pl.ref = lut_at(a.lut, ri, lut_total);
             pl.sig0 = lut_at(a.lut, si + 0, lut_total) | (lut_at(a.lut, si + 1, lut_total) << 8) |
                       (lut_at(a.lut, si + 2, lut_total) << 16) | (lut_at(a.lut, si + 3, lut_total) << 24);
@@ -675,7 +893,47 @@ __global__ __launch_bounds__(64, 4) void bpc_decode_kernel(BpcArgs a)
         refL = sigL; refR = sigR;
     }
 
-    if (valid) {
+    if constexpr (BULK) {
+        // ---- bulk scan (decodeBulkMode :1653-1662) fused with writeCoefficients: plane register k
+        // holds plane Bh+1+k here, the scan delivers the Bh+1 low bits and the missing signs row by row
+        int Bmax = bl.Bh;
+        { int o = __shfl_xor(Bmax, 32); Bmax = Bmax > o ? Bmax : o; }
+        Bmax = (int)__builtin_amdgcn_readfirstlane((uint32_t)Bmax);
+        auto unp = [&](const M64 &sg, const M64 &sn, int r) -> uint32_t {
+            if (r > 63) return 0u;
+            const uint32_t g = ((r < 32 ? sg.lo : sg.hi) >> (r & 31)) & 1u, n = ((r < 32 ? sn.lo : sn.hi) >> (r & 31)) & 1u;
+            return (g << 1) | (g & n);
+        };
+        uint32_t pUL = 0u, pUR = 0u;
+        for (int i = 0; i < 64; i++) {
+            const uint32_t uL = unp(sigL, sgnL, i), uR = unp(sigR, sgnR, i);
+            if (Bmax >= 0)
+                bulk_row<true>(c, t, uL, uR, 0u, 0u, unp(sigL, sgnL, i + 1), unp(sigR, sgnR, i + 1), pUL, pUR, bl,
+                               Bmax, prec, lower_mask, upper_mask, const_cast<int32_t *>(stage));
+            else { pUL = uL; pUR = uR; }
+            if (!valid) continue;
+            int32_t v0, v1;
+            if (sz == 4096) {
+                int2 w = *reinterpret_cast<const int2 *>(stage + t * 128u + 2u * (uint32_t)i);
+                v0 = (int32_t)(((uint32_t)w.x & 0xFFFFFFu) >> 1); if (w.x & 1) v0 = -v0;
+                v1 = (int32_t)(((uint32_t)w.y & 0xFFFFFFu) >> 1); if (w.y & 1) v1 = -v1;
+            } else {
+                const uint32_t ii = (uint32_t)i & 31u, hs = (uint32_t)(bl.Bh + 1);
+                uint32_t m0 = 0u, m1 = 0u;
+#pragma unroll
+                for (int k = 0; k < kMaxPlanes; k++) {
+                    uint32_t l = i < 32 ? PLlo[k] : PLhi[k], r = i < 32 ? PRlo[k] : PRhi[k];
+                    m0 |= ((l >> ii) & 1u) << k;
+                    m1 |= ((r >> ii) & 1u) << k;
+                }
+                m0 = (m0 << hs) | (pUL >> 2);
+                m1 = (m1 << hs) | (pUR >> 2);
+                v0 = (pUL & 1u) ? -(int32_t)m0 : (int32_t)m0;
+                v1 = (pUR & 1u) ? -(int32_t)m1 : (int32_t)m1;
+            }
+            *reinterpret_cast<int2 *>(a.coeffs_out + cbase + (size_t)i * (size_t)a.AW) = make_int2(v0, v1);
+        }
+    } else if (valid) {
         // writeCoefficients BPCEngine.cu:94-111 / copyEntireCodeblock :1915-1922
         for (int i = 0; i < 64; i++) {
             int32_t v0, v1;

@@ -166,11 +166,11 @@ int picsong_header_unpack(const uint16_t e[PICSONG_HDR_SHORTS], picsong_params *
 // ---------------------------------------------------------------------------------------------
 // LUT text parser
 // ---------------------------------------------------------------------------------------------
-static int lut_section(const std::string &folder, const char *stem, int component, int C, int nBp,
+static int lut_section(const std::string &folder, const char *stem, int component, int file_index, int C, int nBp,
                        int wl, int32_t *T, int base, size_t cap)
 {
     static const char *suffix[4] = { ".txt_", "R.txt_", "G.txt_", "B.txt_" };
-    std::string path = folder + stem + suffix[component & 3] + "0";
+    std::string path = folder + stem + suffix[component & 3] + std::to_string(file_index);
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) return fail(PICSONG_ERR_IO, "cannot open LUT file %s", path.c_str());
     int i = base, prev = -1, lvl, sb, bp, v[16];
@@ -202,6 +202,12 @@ static int lut_section(const std::string &folder, const char *stem, int componen
 int picsong_lut_load(const char *folder_c, int component, int wl, int fill, picsong_lut_info *info,
                      int32_t *table, size_t cap)
 {
+    return picsong_lut_load_k(folder_c, component, wl, fill, 1, info, table, cap);
+}
+
+int picsong_lut_load_k(const char *folder_c, int component, int wl, int fill, int n_tables, picsong_lut_info *info,
+                       int32_t *table, size_t cap)
+{
     if (!folder_c || !info) return fail(PICSONG_ERR_ARG, "lut_load: null argument");
     if (wl < 1 || wl > 10) return fail(PICSONG_ERR_ARG, "lut_load: wl %d out of range", wl);
     std::string folder(folder_c);
@@ -223,17 +229,27 @@ int picsong_lut_load(const char *folder_c, int component, int wl, int fill, pics
     info->n_ref = nS * nBp * info->ctx_ref * wl + nBp * info->ctx_ref;
     info->n_sig = nS * nBp * info->ctx_sig * wl + nBp * info->ctx_sig;
     info->n_sign = nS * nBp * info->ctx_sign * wl + nBp * info->ctx_sign;
+    if (n_tables <= 0) n_tables = info->n_bp_files;
+    if (n_tables < 1) n_tables = 1;
+    info->n_tables = n_tables;
     if (!table) return PICSONG_OK;
     const size_t total = (size_t)info->n_ref + info->n_sig + info->n_sign;
-    if (cap < total) return fail(PICSONG_ERR_ARG, "lut_load: table capacity %zu < %zu", cap, total);
+    if (cap < total * (size_t)n_tables)
+        return fail(PICSONG_ERR_ARG, "lut_load: table capacity %zu < %zu", cap, total * (size_t)n_tables);
     if (info->ctx_ref > 16 || info->ctx_sig > 16 || info->ctx_sign > 16)
         return fail(PICSONG_ERR_ARG, "lut_load: context counts above 16 are not supported");
-    for (size_t i = 0; i < total; i++) table[i] = fill;
-    int rc;
-    if ((rc = lut_section(folder, "ref", component, info->ctx_ref, nBp, wl, table, 0, total))) return rc;
-    if ((rc = lut_section(folder, "sig", component, info->ctx_sig, nBp, wl, table, info->n_ref, total))) return rc;
-    if ((rc = lut_section(folder, "sign", component, info->ctx_sign, nBp, wl, table,
-                          info->n_ref + info->n_sig, total))) return rc;
+    for (size_t i = 0; i < total * (size_t)n_tables; i++) table[i] = fill;
+    for (int j = 0; j < n_tables; j++) {
+        int32_t *T = table + (size_t)j * total;
+        // a group-change fill may reach past its table: inside the array it lands in the next table
+        // (which is parsed afterwards), at the very end it is dropped -- as in the oracle
+        const size_t room = total * (size_t)(n_tables - j);
+        int rc;
+        if ((rc = lut_section(folder, "ref", component, j, info->ctx_ref, nBp, wl, T, 0, room))) return rc;
+        if ((rc = lut_section(folder, "sig", component, j, info->ctx_sig, nBp, wl, T, info->n_ref, room))) return rc;
+        if ((rc = lut_section(folder, "sign", component, j, info->ctx_sign, nBp, wl, T, info->n_ref + info->n_sig,
+                              room))) return rc;
+    }
     return PICSONG_OK;
 }
 
@@ -248,7 +264,7 @@ int picsong_ctx_create(const picsong_params *p, int device, picsong_ctx **out)
     if (p->width <= 0 || p->height <= 0) return fail(PICSONG_ERR_ARG, "xSize/ySize must be positive");
     if (p->wl < 1 || p->wl > 7) return fail(PICSONG_ERR_ARG, "wl %d outside 1..7", p->wl);
     if (p->cp != 2) return fail(PICSONG_ERR_ARG, "only -cp 2 is implemented (got %d)", p->cp);
-    if (p->k != 0.0f) return fail(PICSONG_ERR_ARG, "only -k 0 is implemented");
+    if (!(p->k >= 0.0f && p->k <= 65.535f)) return fail(PICSONG_ERR_ARG, "k %g outside [0, 65.535]", p->k);
     if (p->lossy && !(p->qs > 0.0f && p->qs <= 1.0f)) return fail(PICSONG_ERR_ARG, "qs %g outside (0,1]", p->qs);
     if (p->bit_depth != 8) return fail(PICSONG_ERR_ARG, "only 8-bit samples are implemented");
     if (!((p->components == 1 && !p->is_rgb) || (p->components == 3 && p->is_rgb)))
@@ -317,7 +333,12 @@ int picsong_ctx_set_lut_component(picsong_ctx *c, int comp, const picsong_lut_in
         return fail(PICSONG_ERR_ARG, "LUT contexts must be 9/4/1 (sig/sign/ref), got %d/%d/%d", info->ctx_sig,
                     info->ctx_sign, info->ctx_ref);
     if (info->precision < 1 || info->precision > 8) return fail(PICSONG_ERR_ARG, "LUT precision %d", info->precision);
-    const size_t total = (size_t)info->n_ref + info->n_sig + info->n_sign;
+    const size_t one = (size_t)info->n_ref + info->n_sig + info->n_sign;
+    const int n_tables = info->n_tables > 0 ? info->n_tables : 1;
+    if (c->p.k > 0.0f && one > (size_t)kBulkLutMax)
+        return fail(PICSONG_ERR_ARG, "LUT table of %zu entries exceeds the %d the -k > 0 kernels hold in LDS", one,
+                    kBulkLutMax);
+    const size_t total = one * (size_t)n_tables;
     for (size_t i = 0; i < total; i++)
         if (host_table[i] < 0 || host_table[i] > 255)
             return fail(PICSONG_ERR_ARG, "LUT entry %zu = %d outside 0..255", i, host_table[i]);
@@ -326,6 +347,7 @@ int picsong_ctx_set_lut_component(picsong_ctx *c, int comp, const picsong_lut_in
     HIP_TRY(hipMalloc(&c->d_lut[comp], total * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(c->d_lut[comp], host_table, total * sizeof(int32_t), hipMemcpyHostToDevice));
     c->li[comp] = *info;
+    c->li[comp].n_tables = n_tables;
     c->has_lut[comp] = true;
     return PICSONG_OK;
 }
@@ -432,6 +454,7 @@ static int bpc_args(picsong_ctx *c, BpcArgs &a, int comp = 0)
     a.g.cSign = li.ctx_sign; a.g.cSig = li.ctx_sig; a.g.prec = li.precision;
     a.g.nRef = li.n_ref; a.g.nSig = li.n_sig; a.g.nSign = li.n_sign;
     a.range_flag = c->d_flag;
+    a.k = c->p.k; a.n_tables = li.n_tables > 0 ? li.n_tables : 1;
     return PICSONG_OK;
 }
 
@@ -449,7 +472,9 @@ static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_stag
     // BPCEngine::deviceMemoryAllocator BPCEngine.cu:2429-2441.  Slots beyond a codeblock's length
     // are never read downstream, so the fused frame path skips this 4*AW*AH-byte fill.
     if (memset_staging) HIP_TRY(hipMemsetAsync(d_staging, 0xFF, c->P * sizeof(int32_t), s));
-    bpc_encode_kernel<<<(unsigned)((cb_count + 1) / 2), 64, 0, s>>>(a);
+    // -k > 0: the BULK instantiation (bulk scan below the consecutive bit-planes, table s in LDS)
+    if (a.k > 0.0f) bpc_encode_kernel<true><<<(unsigned)((cb_count + 1) / 2), 64, 0, s>>>(a);
+    else bpc_encode_kernel<false><<<(unsigned)((cb_count + 1) / 2), 64, 0, s>>>(a);
     HIP_TRY(hipGetLastError());
     return PICSONG_OK;
 }
@@ -469,7 +494,8 @@ static int bpc_decode_impl(picsong_ctx *c, const int32_t *d_staging, const int32
     a.coeffs_out = d_coeffs;
     a.staging = const_cast<int32_t *>(d_staging);
     a.sizes = const_cast<int32_t *>(d_sizes);
-    bpc_decode_kernel<<<(unsigned)((c->ncb + 1) / 2), 64, 0, s>>>(a);
+    if (a.k > 0.0f) bpc_decode_kernel<true><<<(unsigned)((c->ncb + 1) / 2), 64, 0, s>>>(a);
+    else bpc_decode_kernel<false><<<(unsigned)((c->ncb + 1) / 2), 64, 0, s>>>(a);
     HIP_TRY(hipGetLastError());
     return PICSONG_OK;
 }

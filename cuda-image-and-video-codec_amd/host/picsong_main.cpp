@@ -2,7 +2,8 @@
 // of include/picsong_hip.h.  It keeps the reference's flags, defaults, validation, file formats and
 // console vocabulary (Launcher.cu:8-29,36-163; IO/IOManager.ipp:72-112,176-231,267-344,615-620) so
 // it is a drop-in for the greyscale and RGB (planar R,G,B; RCT / ICT) image / video encode + decode
-// paths.  The reference's -cp 3 (deprecated, LUT files not shipped) and -k > 0 modes are not built
+// paths, including the complexity-scalable mode -k > 0.  The reference's -cp 3 (deprecated, LUT files
+// not shipped) is not built
 // and are refused with a message instead of being silently ignored.
 //
 // Pipeline (video): `-numberOfStreams N` HIP streams, each with its own picsong_ctx, pinned host
@@ -80,7 +81,7 @@ void help()
         " -LUTFolder <dir>    probability tables (header.txt, {ref,sig,sign}R.txt_0)\n"
         " -numberOfStreams N  frames in flight (default 2)\n"
         " -isRGB 1 -components 3  planar R,G,B planes per frame (RCT lossless / ICT lossy)\n"
-        " -k 0                complexity-scalable mode is not built here\n"
+        " -k 0..65.535        complexity-scalable factor (needs the bit-plane LUT files _0.._14)\n"
         " -device D           GPU index (default 0);  --metrics <file>  JSON stage timings\n"
         " --lut-fill V        value of LUT entries the loader never writes (default 0)\n";
 }
@@ -150,15 +151,17 @@ struct Worker {
     long frame = -1;
 };
 
-// component c uses the {ref,sig,sign}{R,G,B}.txt_0 files (Engine::initLUT Engines/Engine.cu:124-136)
-void load_lut(picsong_ctx *ctx, const Options &o, int wl, int components = 1)
+// component c uses the {ref,sig,sign}{R,G,B}.txt_0 files (Engine::initLUT Engines/Engine.cu:124-136);
+// with k > 0 every bit-plane file _0 .. _(AMOUNT_OF_BITPLANE_FILES-1) (Engines/Engine.cu:12-56)
+void load_lut(picsong_ctx *ctx, const Options &o, int wl, int components = 1, float k = 0.0f)
 {
     if (o.lut_folder.empty()) die("Incorrect parameters. Please choose valid values. (-LUTFolder is required)");
+    const int n_tables = k > 0.0f ? 0 : 1;
     for (int c = 0; c < components; c++) {
         picsong_lut_info info;
-        CK(picsong_lut_load(o.lut_folder.c_str(), c + 1, wl, o.lut_fill, &info, nullptr, 0));
-        std::vector<int32_t> table((size_t)info.n_ref + info.n_sig + info.n_sign);
-        CK(picsong_lut_load(o.lut_folder.c_str(), c + 1, wl, o.lut_fill, &info, table.data(), table.size()));
+        CK(picsong_lut_load_k(o.lut_folder.c_str(), c + 1, wl, o.lut_fill, n_tables, &info, nullptr, 0));
+        std::vector<int32_t> table(((size_t)info.n_ref + info.n_sig + info.n_sign) * (size_t)info.n_tables);
+        CK(picsong_lut_load_k(o.lut_folder.c_str(), c + 1, wl, o.lut_fill, n_tables, &info, table.data(), table.size()));
         CK(picsong_ctx_set_lut_component(ctx, c, &info, table.data()));
     }
 }
@@ -198,7 +201,7 @@ int run_encode_rgb(const Options &o, size_t file_base, long nframes)
     picsong_params params = make_params(o);
     picsong_ctx *ctx = nullptr;
     CK(picsong_ctx_create(&params, o.device, &ctx));
-    load_lut(ctx, o, o.wl, 3);
+    load_lut(ctx, o, o.wl, 3, o.k);
     hipStream_t s;
     HIPCK(hipStreamCreate(&s));
     uint8_t *h_in, *d_in[3];
@@ -261,7 +264,6 @@ int run_encode(Options o)
     if (!((o.is_rgb && o.components == 3) || (!o.is_rgb && o.components == 1)))
         die("Incorrect parameters. Use -components 1, or -isRGB 1 -components 3 (planar R,G,B planes).");
     if (o.cp != 2) die("-cp 3 (deprecated in the reference) is not built in this MI355X hot-path build.");
-    if (o.k != 0) die("-k > 0 (complexity-scalable mode) is not built in this MI355X hot-path build.");
     if (o.signed_or_unsigned != 0 || o.bps != 8) die("Only unsigned 8-bit samples are built in this MI355X hot-path build.");
     const long nframes = o.video ? o.frames : 1;
     if (nframes <= 0) die("Incorrect parameters. Please choose valid values. (-frames)");
@@ -275,7 +277,7 @@ int run_encode(Options o)
     std::vector<Worker> w((size_t)nstreams);
     for (auto &k : w) {
         CK(picsong_ctx_create(&params, o.device, &k.ctx));
-        load_lut(k.ctx, o, o.wl);
+        load_lut(k.ctx, o, o.wl, 1, o.k);
         HIPCK(hipStreamCreate(&k.stream));
         HIPCK(hipHostMalloc(&k.h_in, P));
         HIPCK(hipMalloc(&k.d_in, P));
@@ -411,8 +413,8 @@ int run_decode(const Options &o)
     if ((size_t)in.gcount() != sizeof hdr) die("Input file too short for a PICSONG header.");
     picsong_params p;
     CK(picsong_header_unpack(hdr, &p));
-    if (p.cp != 2 || p.k != 0 || !((p.components == 1 && !p.is_rgb) || (p.components == 3 && p.is_rgb)))
-        die("This stream uses -cp 3 / -k / a component layout not built here.");
+    if (p.cp != 2 || !((p.components == 1 && !p.is_rgb) || (p.components == 3 && p.is_rgb)))
+        die("This stream uses -cp 3 / a component layout not built here.");
     const long nframes = o.video ? p.frames : 1;
     std::vector<long> frame_shorts;
     if (o.video || p.is_rgb) {
@@ -430,7 +432,7 @@ int run_decode(const Options &o)
     picsong_ctx *ctx = nullptr;
     CK(picsong_ctx_create(&p, o.device, &ctx));
     Options lo = o;
-    load_lut(ctx, lo, p.wl, p.components);
+    load_lut(ctx, lo, p.wl, p.components, p.k);
     int aw, ah, ncb;
     CK(picsong_ctx_padded_dims(ctx, &aw, &ah, &ncb));
     if (p.is_rgb) return run_decode_rgb(o, p, ctx, in, frame_shorts, nframes, aw, ah);

@@ -24,12 +24,14 @@ class Params(C.Structure):
 
 class LutInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("n_bitplanes", "n_subbands", "ctx_ref", "ctx_sign", "ctx_sig",
-                                       "precision", "n_files", "n_bp_files", "n_ref", "n_sig", "n_sign")]
+                                       "precision", "n_files", "n_bp_files", "n_ref", "n_sig", "n_sign",
+                                       "n_tables")]
 
 
 EXPORTS = [
     "picsong_last_error", "picsong_version", "picsong_pad_dim", "picsong_dwt_extra",
     "picsong_max_stream_shorts", "picsong_header_pack", "picsong_header_unpack", "picsong_lut_load",
+    "picsong_lut_load_k",
     "picsong_ctx_create", "picsong_ctx_destroy", "picsong_ctx_set_lut", "picsong_ctx_padded_dims",
     "picsong_level_shift_fwd", "picsong_level_shift_inv", "picsong_dwt_forward", "picsong_dwt_inverse",
     "picsong_dwt_forward_u8", "picsong_bpc_encode", "picsong_bpc_decode", "picsong_bitstream_pack",
@@ -66,6 +68,7 @@ def load():
     L.picsong_header_pack.argtypes = [C.POINTER(Params), vp]
     L.picsong_header_unpack.argtypes = [vp, C.POINTER(Params)]
     L.picsong_lut_load.argtypes = [C.c_char_p, i, i, i, C.POINTER(LutInfo), vp, C.c_size_t]
+    L.picsong_lut_load_k.argtypes = [C.c_char_p, i, i, i, i, C.POINTER(LutInfo), vp, C.c_size_t]
     L.picsong_ctx_create.argtypes = [C.POINTER(Params), i, C.POINTER(vp)]
     L.picsong_ctx_destroy.argtypes = [vp]
     L.picsong_ctx_destroy.restype = None
@@ -114,19 +117,20 @@ def dwt_extra(aw, ah, wl):
     return load().picsong_dwt_extra(aw, ah, wl)
 
 
-def lut_load(folder, wl, component=1, fill=0):
-    """Returns (LutInfo, np.int32 table) parsed by the library's own host parser."""
+def lut_load(folder, wl, component=1, fill=0, n_tables=1):
+    """Returns (LutInfo, np.int32 table) parsed by the library's own host parser.
+    n_tables = 1: file _0 (k = 0); n_tables = 0: every bit-plane file (the -k > 0 layout)."""
     L = load()
     info = LutInfo()
-    _check(L.picsong_lut_load(folder.encode(), component, wl, fill, C.byref(info), None, 0))
-    table = np.empty(info.n_ref + info.n_sig + info.n_sign, np.int32)
-    _check(L.picsong_lut_load(folder.encode(), component, wl, fill, C.byref(info),
-                              table.ctypes.data_as(C.c_void_p), table.size))
+    _check(L.picsong_lut_load_k(folder.encode(), component, wl, fill, n_tables, C.byref(info), None, 0))
+    table = np.empty((info.n_ref + info.n_sig + info.n_sign) * info.n_tables, np.int32)
+    _check(L.picsong_lut_load_k(folder.encode(), component, wl, fill, n_tables, C.byref(info),
+                                table.ctypes.data_as(C.c_void_p), table.size))
     return info, table
 
 
-def make_params(width, height, wl=5, lossy=False, qs=1.0, frames=0, rgb=False):
-    return Params(width=width, height=height, wl=wl, cp=2, lossy=int(lossy), qs=qs, k=0.0,
+def make_params(width, height, wl=5, lossy=False, qs=1.0, frames=0, rgb=False, k=0.0):
+    return Params(width=width, height=height, wl=wl, cp=2, lossy=int(lossy), qs=qs, k=k,
                   cb_width=64, cb_height=18, bit_depth=8, frames=frames, components=3 if rgb else 1,
                   is_rgb=int(rgb))
 
@@ -149,13 +153,13 @@ class Codec:
     objects + the LUT upload of Engine::initLUT).  All tensor arguments are torch CUDA tensors."""
 
     def __init__(self, width, height, wl=5, lossy=False, qs=1.0, lut_folder=None, lut_fill=0,
-                 device=0, frames=0, rgb=False):
+                 device=0, frames=0, rgb=False, k=0.0):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("no GPU visible: the picsong HIP path has no CPU fallback")
         self.torch = torch
         self.L = load()
-        self.params = make_params(width, height, wl, lossy, qs, frames, rgb)
+        self.params = make_params(width, height, wl, lossy, qs, frames, rgb, k)
         self.rgb = bool(rgb)
         self.device = device
         h = C.c_void_p()
@@ -171,7 +175,8 @@ class Codec:
         self.dev = torch.device("cuda", device)
         if lut_folder is not None:
             for comp in range(3 if rgb else 1):
-                info, table = lut_load(lut_folder, wl, comp + 1, lut_fill)     # files ...R/G/B.txt_0
+                # files ...R/G/B.txt_0 (k = 0) or every bit-plane file ...txt_0.._14 (k > 0)
+                info, table = lut_load(lut_folder, wl, comp + 1, lut_fill, 0 if k > 0 else 1)
                 self.set_lut(info, table, comp)
 
     def close(self):

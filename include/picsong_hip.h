@@ -58,6 +58,8 @@ typedef struct picsong_params {
 typedef struct picsong_lut_info {
     int n_bitplanes, n_subbands, ctx_ref, ctx_sign, ctx_sig, precision, n_files, n_bp_files;
     int n_ref, n_sig, n_sign;       /* section sizes in ints; table = [ref | sig | sign] */
+    int n_tables;                   /* tables laid back to back: 1 (k = 0, file _0) or the bit-plane
+                                     * files _0.._(n-1) of -k > 0 (Engines/Engine.cu:12-56); 0 == 1 */
 } picsong_lut_info;
 
 typedef struct picsong_ctx picsong_ctx;
@@ -82,6 +84,12 @@ int picsong_header_unpack(const uint16_t in[PICSONG_HDR_SHORTS], picsong_params 
  *      SURVEY fact 5).  table may be NULL to query info->n_* first. ---- */
 int picsong_lut_load(const char *folder, int component, int wl, int fill,
                      picsong_lut_info *info, int32_t *table, size_t table_capacity);
+/* -k > 0 (Engine::initLUT's multi-file branch, Engines/Engine.cu:12-56): the tables of files
+ * _0 .. _(n_tables-1), table j at offset j * (n_ref + n_sig + n_sign); n_tables <= 0 = all
+ * AMOUNT_OF_BITPLANE_FILES.  table needs n_tables * (n_ref + n_sig + n_sign) ints
+ * (query with table == NULL: info->n_tables is filled in). */
+int picsong_lut_load_k(const char *folder, int component, int wl, int fill, int n_tables,
+                       picsong_lut_info *info, int32_t *table, size_t table_capacity);
 
 /* ---- context: replaces `new DWT<T,Y>(...)` / `new BPCCuda<T>(...)` + Engine::initLUT's
  *      cudaMalloc/cudaMemcpy of the table (Engines/Engine.cu:111-136).  Owns only the LUT copy

@@ -104,7 +104,7 @@ def level_shift_fwd(u8, lossy):
     return out
 
 
-def bpc_encode(coef, wl, lut):
+def bpc_encode(coef, wl, lut, k=0.0):
     AH, AW = coef.shape
     coef = np.ascontiguousarray(coef)
     staging = np.empty(AW * AH, np.int32)
@@ -113,18 +113,19 @@ def bpc_encode(coef, wl, lut):
     tab = np.ascontiguousarray(lut.table, np.int32)
     geo = _geo(lut)
     lib().emu_bpc_encode(_p(coef), int(coef.dtype == np.float32), AW, AH, wl, _p(tab), _p(geo),
-                         _p(staging), _p(sizes), _p(flag))
+                         _p(staging), _p(sizes), _p(flag), C.c_float(k), int(getattr(lut, "n_tables", 1)))
     return staging, sizes, int(flag[0])
 
 
-def bpc_decode(staging, sizes, AW, AH, wl, lut):
+def bpc_decode(staging, sizes, AW, AH, wl, lut, k=0.0):
     staging = np.ascontiguousarray(staging, np.int32)
     sizes = np.ascontiguousarray(sizes, np.int32)
     coef = np.empty((AH, AW), np.int32)
     flag = np.zeros(1, np.int32)
     tab = np.ascontiguousarray(lut.table, np.int32)
     geo = _geo(lut)
-    lib().emu_bpc_decode(_p(staging), _p(sizes), AW, AH, wl, _p(tab), _p(geo), _p(coef), _p(flag))
+    lib().emu_bpc_decode(_p(staging), _p(sizes), AW, AH, wl, _p(tab), _p(geo), _p(coef), _p(flag),
+                         C.c_float(k), int(getattr(lut, "n_tables", 1)))
     return coef
 
 

@@ -115,21 +115,26 @@ static BpcArgs mk(int aw, int ah, int wl, const int32_t *lut, const int *geo, in
     return a;
 }
 
+// k > 0 (n_tables bit-plane tables in lut) runs the BULK instantiations, like picsong_hip.hip
 void emu_bpc_encode(const void *coeffs, int is_float, int aw, int ah, int wl, const int32_t *lut, const int *geo,
-                    int32_t *staging, int32_t *sizes, int *flag)
+                    int32_t *staging, int32_t *sizes, int *flag, float k, int n_tables)
 {
     BpcArgs a = mk(aw, ah, wl, lut, geo, staging, sizes, flag);
     a.coeffs_in = coeffs; a.is_float = is_float;
+    a.k = k; a.n_tables = n_tables;
     memset(staging, 0xFF, (size_t)aw * ah * 4);
-    emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_encode_kernel(a); });
+    if (k > 0.0f) emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_encode_kernel<true>(a); });
+    else emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_encode_kernel<false>(a); });
 }
 
 void emu_bpc_decode(const int32_t *staging, const int32_t *sizes, int aw, int ah, int wl, const int32_t *lut,
-                    const int *geo, int32_t *coeffs, int *flag)
+                    const int *geo, int32_t *coeffs, int *flag, float k, int n_tables)
 {
     BpcArgs a = mk(aw, ah, wl, lut, geo, const_cast<int32_t *>(staging), const_cast<int32_t *>(sizes), flag);
     a.coeffs_out = coeffs;
-    emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_decode_kernel(a); });
+    a.k = k; a.n_tables = n_tables;
+    if (k > 0.0f) emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_decode_kernel<true>(a); });
+    else emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_decode_kernel<false>(a); });
 }
 
 int emu_pack(const int32_t *staging, const int32_t *sizes, int ncb, const uint16_t *header, uint16_t *out)

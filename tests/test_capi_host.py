@@ -53,6 +53,16 @@ def test_lut_parser_matches_oracle(oracle, folder, wl):
     assert np.array_equal(table, ref.table)
 
 
+def test_lut_parser_bit_plane_tables_match_oracle(oracle):
+    path = os.path.join(oracle.LUT_DIR, "n1_lossless")
+    info, table = pa.lut_load(path, 4, component=1, fill=0, n_tables=0)      # the -k > 0 layout
+    ref = oracle.lut_for_k(False, 4)
+    assert info.n_tables == ref.n_tables == 15
+    assert np.array_equal(table, ref.table)
+    info1, table1 = pa.lut_load(path, 4, component=1, fill=0)
+    assert info1.n_tables == 1 and np.array_equal(table1, table[:table1.size])
+
+
 def test_lut_missing_folder_reports_error():
     info = pa.LutInfo()
     rc = pa.load().picsong_lut_load(b"/nonexistent/", 1, 5, 0, C.byref(info), None, 0)

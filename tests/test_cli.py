@@ -29,7 +29,8 @@ def test_help_and_validation():
     for extra, msg in ((("-wl", 11), "Incorrect parameters"), (("-cbWidth", 65), "Incorrect parameters"),
                        (("-cbHeight", 21), "Incorrect parameters"), (("-qs", 1.5), "Incorrect parameters"),
                        (("-isRGB", 1), "Incorrect parameters"), (("-components", 3), "Incorrect parameters"),
-                       (("-cp", 3), "not built"), (("-k", 0.5), "not built")):
+                       (("-cp", 3), "not built"), (("-k", 70), "Incorrect parameters"),
+                       (("-k", -1), "Incorrect parameters")):
         base = () if extra[0] == "-wl" else ("-wl", 1)
         r = _run("-cd", 0, "-i", "/etc/hostname", "-o", "/tmp/x", "-xSize", 64, "-ySize", 64, *base, *extra)
         assert r.returncode == 255 and msg in r.stdout, (extra, r.stdout)
@@ -123,3 +124,32 @@ def test_rgb_files_roundtrip_and_oracle_parity(oracle, tmp_path, lossy, video):
             else:
                 mse = np.mean((got[f, c].astype(np.float64) - planes[f][c]) ** 2)
                 assert 10 * np.log10(255 ** 2 / mse) > 35.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lossy,k", [(False, 0.3), (False, 2.0), (True, 0.5)])
+def test_complexity_scalable_files_roundtrip_and_oracle_parity(oracle, tmp_path, lossy, k):
+    """-k > 0: bit-plane LUT files, header word 8, decoder takes k from the stream."""
+    W, H, wl, qs = 520, 390, 3, 0.5
+    img = oracle.gen_frame(W, H, 9)
+    lutdir = os.path.join(oracle.LUT_DIR, "n1_lossy" if lossy else "n1_lossless")
+    raw, enc, dec = tmp_path / "in.raw", tmp_path / "out.enc", tmp_path / "out.pgm"
+    img.tofile(raw)
+    r = _run("-cd", 0, "-i", raw, "-o", enc, "-xSize", W, "-ySize", H, "-wl", wl, "-type", int(lossy), "-qs", qs,
+             "-k", k, "-LUTFolder", lutdir)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"User entered -k command" in r.stdout
+    lut = oracle.lut_for_k(lossy, wl)
+    ref = oracle.encode_frame(img, wl, lossy, qs, lut, 0, 0, k=k)      # the header carries -qs as given
+    got = np.fromfile(enc, np.uint16)
+    assert np.array_equal(got, ref)
+    assert oracle.header_unpack(got[:9])["k_1e3"] == int(np.float32(k) * np.float32(1000))
+    r = _run("-cd", 1, "-i", enc, "-o", dec, "-LUTFolder", lutdir)
+    assert r.returncode == 0, r.stdout + r.stderr
+    data = open(dec, "rb").read()
+    head = f"P5\n{W} {H}\n255\n".encode()
+    out = np.frombuffer(data[len(head):], np.uint8).reshape(H, W)
+    kdec = np.float32(oracle.header_unpack(got[:9])["k_1e3"] / 1000.0)
+    assert np.array_equal(out, oracle.decode_frame(ref, W, H, wl, lossy, qs, lut, k=float(kdec)))
+    if not lossy:
+        assert np.array_equal(out, img)

@@ -290,3 +290,32 @@ def test_rgb_components_parity(oracle, pa, torch, lossy, qs):
         if not lossy:
             assert np.array_equal(back[k].cpu().numpy(), planes[k])
     c.close()
+
+
+# ---- complexity-scalable mode -k > 0 -------------------------------------------
+@pytest.mark.parametrize("W,H,wl,lossy,qs,k", [(512, 512, 3, False, 1.0, 0.3), (700, 500, 4, False, 1.0, 1.5),
+                                               (512, 384, 3, False, 1.0, 65.0), (640, 384, 3, True, 0.5, 0.7)])
+def test_complexity_scalable_codestream_identical_to_oracle(oracle, pa, torch, W, H, wl, lossy, qs, k):
+    img = oracle.gen_frame(W, H, 4)
+    lut = oracle.lut_for_k(lossy, wl)
+    ref = oracle.encode_frame(img, wl, lossy, qs, lut, 0, 0, k=k)
+    c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=_lutdir(oracle, lossy), k=k)
+    got = c.encode_frame(_dev(torch, oracle.pad_frame(img)), 0).cpu().numpy().view(np.uint16)
+    assert np.array_equal(got, ref)
+    dec = c.decode_frame(_dev(torch, ref.view(np.int16))).cpu().numpy()[:H, :W]
+    assert np.array_equal(dec, oracle.decode_frame(ref, W, H, wl, lossy, qs, lut, k=k))
+    if not lossy:
+        assert np.array_equal(dec, img)
+    c.close()
+
+
+def test_complexity_scalable_full_size_roundtrip(oracle, pa, torch):
+    """8K, k = 0.5: size-independent property (decode(encode(x)) == x) + the stream differs from k = 0."""
+    W, H, wl = 7680, 4320, 5
+    frame = _dev(torch, oracle.pad_frame(oracle.gen_frame(W, H, 0)))
+    c = pa.Codec(W, H, wl=wl, lut_folder=_lutdir(oracle, False), k=0.5)
+    s = c.encode_frame(frame, 0)
+    assert torch.equal(c.decode_frame(s), frame.view(c.ah, c.aw))
+    c0 = pa.Codec(W, H, wl=wl, lut_folder=_lutdir(oracle, False))
+    assert c0.encode_frame(frame, 0).numel() != s.numel()
+    c.close(); c0.close()

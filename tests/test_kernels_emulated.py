@@ -236,3 +236,55 @@ def test_rgb_colour_transform_kernels(oracle, E, lossy):
     big = [np.full((64, 128), v, np.float32 if lossy else np.int32) for v in (300, -300, 50)]
     for x, y in zip(E.rgb_inverse(*big), oracle.rgb_inverse(*big)):
         assert np.array_equal(x, y)
+
+
+# ---- complexity-scalable mode -k > 0: BULK kernel instantiations vs the oracle -------------------
+
+def _bulk_coeffs(oracle, W, H, wl, lossy, seed):
+    rng = np.random.default_rng(seed)
+    img = np.clip(rng.normal(120, 45, (H, W)), 0, 255).astype(np.uint8)
+    img[H // 4:H // 2, W // 8:W // 2] = 230
+    img[:, W // 2:] = (img[:, W // 2:] // 8) * 8
+    x = oracle.level_shift_fwd(img, lossy)
+    f = oracle.dwt_forward(x, wl, 0.5) if lossy else oracle.dwt_forward(x, wl)
+    return f[:W * H].reshape(H, W)
+
+
+@pytest.mark.parametrize("W,H,wl,k", [(256, 128, 2, 0.3), (256, 128, 2, 1.0), (128, 192, 1, 4.0),
+                                      (192, 128, 2, 65.0), (128, 128, 3, 0.7)])
+def test_bulk_mode_kernels_bit_exact(oracle, E, W, H, wl, k):
+    coef = _bulk_coeffs(oracle, W, H, wl, False, 11)
+    lut = oracle.lut_for_k(False, wl)
+    st_o, sz_o = oracle.bpc_encode(coef, wl, lut, k=k)
+    st_e, sz_e, flag = E.bpc_encode(coef, wl, lut, k=k)
+    assert flag == 0
+    assert np.array_equal(sz_e, sz_o)
+    for cb in range(sz_o.size):
+        n = sz_o[cb]
+        assert np.array_equal(st_e[cb * 4096:cb * 4096 + n], st_o[cb * 4096:cb * 4096 + n]), cb
+    back = E.bpc_decode(st_o, sz_o, W, H, wl, lut, k=k)
+    assert np.array_equal(back, coef)
+
+
+def test_bulk_mode_kernels_float_input_and_odd_block_count(oracle, E):
+    W, H, wl, k = 192, 64, 1, 0.9            # 3 codeblocks: the last wave has an idle half
+    coef = _bulk_coeffs(oracle, W, H, wl, True, 3)
+    lut = oracle.lut_for_k(True, wl)
+    st_o, sz_o = oracle.bpc_encode(coef, wl, lut, k=k)
+    st_e, sz_e, _ = E.bpc_encode(coef, wl, lut, k=k)
+    assert np.array_equal(sz_e, sz_o)
+    for cb in range(sz_o.size):
+        n = sz_o[cb]
+        assert np.array_equal(st_e[cb * 4096:cb * 4096 + n], st_o[cb * 4096:cb * 4096 + n]), cb
+    assert np.array_equal(E.bpc_decode(st_o, sz_o, W, H, wl, lut, k=k), oracle.bpc_decode(st_o, sz_o, W, H, wl, lut, k=k))
+
+
+def test_bulk_mode_k0_tables_unchanged(oracle, E):
+    # the BULK build path is only taken for k > 0; with the multi-table LUT and k = 0 the plain
+    # kernels must still see table 0
+    W, H, wl = 128, 128, 2
+    coef = _bulk_coeffs(oracle, W, H, wl, False, 7)
+    lutk = oracle.lut_for_k(False, wl)
+    st_o, sz_o = oracle.bpc_encode(coef, wl, oracle.lut_for(False, wl))
+    st_e, sz_e, _ = E.bpc_encode(coef, wl, lutk, k=0.0)
+    assert np.array_equal(sz_e, sz_o)
