@@ -71,9 +71,34 @@ def pmc_traffic(workload):
     return (int(bpc) if bpc else None), (int(dwt) if dwt else None)
 
 
+def pmc_valu(workload):
+    """VALU wave-instructions per launch of the BPC encoder from the committed SQ counter pass
+    (profiles/*_pmc_sq.csv, SQ_INSTS_VALU): the kernel's real bound is vector-instruction issue."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01_final_pmc_sq.csv")
+    if workload != "8k_lossless" or not os.path.exists(path):
+        return None
+    for r in csv.DictReader(open(path)):
+        if "bpc_encode_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "SQ_INSTS_VALU":
+            return float(r["MeanValue"])
+    return None
+
+
 def dwt_bytes(P, wl, s0):
     """P*(s0+4) + 8*P*sum_{l=1}^{wl-1} 4^-l."""
     return P * (s0 + 4) + 8 * P * sum(4.0 ** -l for l in range(1, wl))
+
+
+def valu_issue(insts, step_s, iso_s):
+    """The encoder is bound by vector-instruction issue: one wave64 VALU instruction occupies a SIMD
+    for 4 cycles; 256 CUs x 4 SIMDs at the 2.4 GHz peak clock.  Fractions: in isolation (one kernel
+    on the GPU) and in the pipelined bench (one BPC launch per step, other kernels ignored)."""
+    if not insts:
+        return None
+    peak = 256 * 4 * 2.4e9 / 4.0                       # wave-instructions per second
+    return {"valu_wave_insts_per_launch": int(insts), "peak_wave_insts_per_s": peak,
+            "frac_single_stream": round(insts / iso_s / peak, 4), "frac_pipelined": round(insts / step_s / peak, 4),
+            "source": "profiles/r01_final_pmc_sq.csv (SQ_INSTS_VALU, rocprofv3 --pmc pass)"}
 
 
 def main():
@@ -236,6 +261,7 @@ def main():
                 "codeblocks_per_s": round(nCB / (bpc_ms * 1e-3), 1),
                 "single_stream": {"avg_launch_ms": round(float(iso_ms[1]), 4),
                                   "codeblocks_per_s": round(nCB / (float(iso_ms[1]) * 1e-3), 1)},
+                "valu_issue": valu_issue(pmc_valu(args.workload), dt / args.steps, float(iso_ms[1]) * 1e-3),
                 "note": "BPC is integer/latency-bound, not HBM-bound (SURVEY 8d): codeblocks/s is "
                         "the figure of merit; the HBM fraction is reported for completeness"}
     roofline_dwt = {"kernel": "dwt_fwd_kernel (all levels, u8 ingest fused)", "bound": "hbm",

@@ -128,11 +128,47 @@ struct Coder {
     uint32_t L, S;      // interval lower bound / size
     uint32_t slot;      // reserved codeword slot (staging index = 1 + slot)
     uint32_t cw;        // decoder: current codeword
-    uint32_t count;     // per-half codeword counter (codeStreamShared), uniform across the half
+    uint32_t cnt_lo, cnt_hi;   // codeword counters (codeStreamShared) of the codeblocks in lanes 0-31 /
+                               // 32-63: wave-uniform, they live in SGPRs and are updated by SALU
 };
 
 // significance probabilities for contexts 0..8 packed as bytes: w0 = ctx 0-3, w1 = ctx 4-7, p8.
 struct PlaneLut { uint32_t sig0, sig1, sig8, sign, ref; };
+
+// The probability table of a codeblock sits in LDS as bytes (3360 at wl = 5): a plane's 14 entries
+// are read with LDS latency.  Read from global memory instead, every plane would wait behind the
+// codeword stores the wave has in flight (loads and stores drain through ONE in-order vmcnt).
+constexpr int kLutLdsMax = 4672;       // bytes of one table: wl <= 7 -> 15 * (3*7 + 1) * 14 = 4620
+
+struct LutView {
+    const uint8_t *lds;            // this codeblock's table (table s of the bit-plane files when k > 0)
+    const int32_t *glob;           // the whole table array, for indices outside the table (as lut_at)
+    int total, glob_total, loff;   // entries of one table / of the array / offset of table s
+};
+__device__ __forceinline__ uint32_t lut_get(const LutView &v, int idx)
+{
+    if (idx >= 0 && idx < v.total) return v.lds[idx];
+    return lut_at(v.glob, v.loff + idx, v.glob_total);
+}
+__device__ __forceinline__ PlaneLut plane_lut(const LutView &v, const LutGeo &g, int grp, int bp)
+{
+    PlaneLut pl;
+    const int ri = (grp * g.nBp + bp) * g.cRef;
+    const int si = (grp * g.nBp + bp) * g.cSig + g.nRef;
+    const int gi = (grp * g.nBp + bp) * g.cSign + g.nRef + g.nSig;
+    pl.ref = lut_get(v, ri);
+    pl.sig0 = lut_get(v, si + 0) | (lut_get(v, si + 1) << 8) | (lut_get(v, si + 2) << 16) | (lut_get(v, si + 3) << 24);
+    pl.sig1 = lut_get(v, si + 4) | (lut_get(v, si + 5) << 8) | (lut_get(v, si + 6) << 16) | (lut_get(v, si + 7) << 24);
+    pl.sig8 = lut_get(v, si + 8);
+    pl.sign = lut_get(v, gi + 0) | (lut_get(v, gi + 1) << 8) | (lut_get(v, gi + 2) << 16) | (lut_get(v, gi + 3) << 24);
+    return pl;
+}
+// k = 0: both codeblocks of the wave use table 0; every lane copies a 64th of it
+__device__ __forceinline__ void lut_to_lds(const int32_t *lut, int total, uint8_t *lds, uint32_t lane)
+{
+    for (int j = (int)lane; j < total; j += 64) lds[j] = (uint8_t)((uint32_t)lut[j] & 0xFFu);
+    __syncthreads();
+}
 
 // =============================================================================================
 // Encoder, second formulation: contexts without neighbour exchange.
@@ -235,43 +271,48 @@ __device__ __forceinline__ uint32_t wave_or32(uint32_t v)
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-// Slot reservation for the encoder: m = ballot of the lanes that need a codeword.
-// lower_mask / upper_mask are per-lane constants (all ones in lanes 0-31 / 32-63).  The lower
-// half's ballot word is masked per lane and handed to v_mbcnt_lo as a VGPR, so lanes 32-63 start
-// their rank at their own counter; v_mbcnt_hi then adds the upper half's rank (0 in lanes 0-31).
-// `count` is a VGPR that is uniform across each half; v_bcnt adds the half's population to it.
-__device__ __forceinline__ void reserve_enc(Coder &c, bool need, uint64_t m, uint32_t lower_mask, uint32_t upper_mask)
+// Slot reservation: m = ballot of the lanes that need a codeword.  The rank of a lane among the
+// requesting lanes of ITS codeblock is v_mbcnt over the two ballot words; v_mbcnt_lo counts all of the
+// lower word for lanes 32-63, so those start at (their counter - popcount(lower word)).  The counters
+// are scalars: the ballot, its popcounts, the counter updates and their clamps are all SALU work.
+__device__ __forceinline__ void reserve_enc(Coder &c, bool need, uint64_t m, uint32_t upper_mask)
 {
     const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
-    const uint32_t vlo = mlo & lower_mask;                 // lower half's needs, 0 in the upper lanes
-    const uint32_t vhalf = (mhi & upper_mask) | vlo;       // this lane's half's needs
-    uint32_t s = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(vlo, c.count));
+    const uint32_t nlo = (uint32_t)__builtin_popcount(mlo), nhi = (uint32_t)__builtin_popcount(mhi);
+    const uint32_t base = upper_mask ? c.cnt_hi - nlo : c.cnt_lo;
+    uint32_t s = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, base));
     s = s > 4094u ? 4094u : s;
-    c.L = need ? 0u : c.L;
-    c.S = need ? 0xFFFFu : c.S;
-    c.slot = need ? s : c.slot;
-    const uint32_t n = (uint32_t)__builtin_popcount(vhalf) + c.count;
-    c.count = n > 4095u ? 4095u : n;
+    if (need) { c.L = 0u; c.S = 0xFFFFu; c.slot = s; }
+    const uint32_t a = c.cnt_lo + nlo, b = c.cnt_hi + nhi;
+    c.cnt_lo = a > 4095u ? 4095u : a;
+    c.cnt_hi = b > 4095u ? 4095u : b;
 }
 
 // arithmeticEncoder BPCEngine.cu:371-399, one call site; `inact` = 1 for lanes that sit this call
-// site out.  VALU instructions are what this kernel is bound by (SALU issues beside them), so:
-// the need-ballot is ONE compare ((S | inact) == 0), the state update runs inside an exec-masked
-// region (no selects for idle lanes), and the interval update uses 24-bit mads:
+// site out.  VALU instructions are what this kernel is bound by (SALU issues beside them), so: the
+// need-ballot is two compares whose masks are ANDed by SALU (the inact compare is the one the exec
+// region below needs anyway), the state update runs inside an exec-masked region (no selects for
+// idle lanes), and the interval update uses 24-bit mads:
 //   a = ((S*p) >> prec) + sym;  S' = sym ? S - a : a = a + sym*(S - 2a);  L' = L + sym*a.
-__device__ __forceinline__ void enc_site(Coder &c, uint32_t inact, uint32_t sym, uint32_t p, uint32_t prec,
-                                         uint32_t lower_mask, uint32_t upper_mask, int32_t *st)
+__device__ __forceinline__ void enc_site_on(Coder &c, bool on, uint32_t sym, uint32_t p, uint32_t prec,
+                                            uint32_t upper_mask, int32_t *st)
 {
-    const bool need = (c.S | inact) == 0u;
-    const uint64_t m = __builtin_amdgcn_ballot_w64(need);
-    if (m != 0ull) reserve_enc(c, need, m, lower_mask, upper_mask);
-    if (inact == 0u) {
+    const bool empty = c.S == 0u;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(empty) & __builtin_amdgcn_ballot_w64(on);
+    if (m != 0ull) reserve_enc(c, on && empty, m, upper_mask);
+    if (on) {
         const uint32_t a = (__umul24(c.S, p) >> prec) + sym;
         const int32_t t = (int32_t)(c.S - a) - (int32_t)a;                  // S - 2a, |t| < 2^17
         c.S = (uint32_t)(__mul24((int32_t)sym, t) + (int32_t)a);
         c.L = __umul24(sym, a) + c.L;
         if (c.S == 0u) st[1u + c.slot] = (int32_t)c.L;
     }
+}
+__device__ __forceinline__ void enc_site(Coder &c, uint32_t inact, uint32_t sym, uint32_t p, uint32_t prec,
+                                         uint32_t lower_mask, uint32_t upper_mask, int32_t *st)
+{
+    (void)lower_mask;
+    enc_site_on(c, inact == 0u, sym, p, prec, upper_mask, st);
 }
 
 // Context masks are kept pre-rotated (n1 by 1, n2 and n3 by 2 bits; sign bits c1 by 3, c2 by 4) so
@@ -284,7 +325,7 @@ __device__ __forceinline__ void enc_spp_coeff(Coder &c, uint32_t ii, uint32_t A,
                                               const PlaneLut &pl, uint32_t prec, uint32_t lower_mask,
                                               uint32_t upper_mask, int32_t *st)
 {
-    const uint32_t inact = (A >> ii) & 1u;
+    const bool on = ((A >> ii) & 1u) == 0u;
     const uint32_t sym = (B >> ii) & 1u;
     // byte selector of v_perm: bits 0..2 = context 0..7, other selector bytes = 0x0C (constant 0)
     uint32_t sel = (rotr32(cp.n0, ii) & 1u) | 0x0C0C0C00u;
@@ -293,13 +334,14 @@ __device__ __forceinline__ void enc_spp_coeff(Coder &c, uint32_t ii, uint32_t A,
     const uint32_t p07 = __builtin_amdgcn_perm(pl.sig1, pl.sig0, sel);
     // context 8 (n3 set => n0 = n1 = n2 = 0): a second byte select takes p8 (byte 4) instead of p07
     const uint32_t p = __builtin_amdgcn_perm(pl.sig8, p07, (rotr32(cp.n3, ii) & 4u) | 0x0C0C0C00u);
-    enc_site(c, inact, sym, p, prec, lower_mask, upper_mask, st);
-    const uint32_t inact2 = inact | (sym ^ 1u);
-    if (__builtin_amdgcn_ballot_w64(inact2 == 0u) != 0ull) {
+    (void)lower_mask;
+    enc_site_on(c, on, sym, p, prec, upper_mask, st);
+    const bool on2 = on && sym != 0u;                       // one compare; the AND of the masks is SALU
+    if (__builtin_amdgcn_ballot_w64(on2) != 0ull) {
         // bit offset of the sign probability inside pl.sign = 8 * (c >> 1)
         const uint32_t off = (rotr32(cp.c2, ii) & 16u) | (rotr32(cp.c1, ii) & 8u);
         const uint32_t p2 = (pl.sign >> off) & 0xFFu;
-        enc_site(c, inact2, (cp.s2 >> ii) & 1u, p2, prec, lower_mask, upper_mask, st);
+        enc_site_on(c, on2, (cp.s2 >> ii) & 1u, p2, prec, upper_mask, st);
     }
 }
 
@@ -326,7 +368,7 @@ __device__ __forceinline__ uint32_t dec_site(Coder &c, uint32_t inact, uint32_t 
 // unprocessed by construction.  The plane-q probabilities are read from an LDS copy of table s.
 // =============================================================================================
 
-constexpr int kBulkLutMax = 4672;      // bytes of one table held in LDS per codeblock (wl <= 7: 15*22*14 = 4620)
+constexpr int kBulkLutMax = kLutLdsMax;
 
 // L2Norm, BPC/BPCEngine.cuh:158-169
 __device__ __forceinline__ float l2norm(int level, int col)
@@ -353,14 +395,10 @@ struct BulkLane {
     int Bh;                        // first (highest) bulk plane of this lane's codeblock, -1 = none
     uint32_t ref0, sig0, sign0;    // LDS byte index of the plane-0 entries of the lane's LUT group
     uint32_t cRef, cSig, cSign;    // contexts per plane
-    uint32_t total;                // entries of one table (index clamp, as lut_at)
-    const uint8_t *lds;            // this half's table
+    LutView v;                     // this codeblock's table
 };
 
-__device__ __forceinline__ uint32_t bulk_lut(const BulkLane &b, uint32_t idx)
-{
-    return b.lds[idx >= b.total ? b.total - 1u : idx];
-}
+__device__ __forceinline__ uint32_t bulk_lut(const BulkLane &b, uint32_t idx) { return lut_get(b.v, (int)idx); }
 // computeContextBulk / computeContext term of one neighbour word
 __device__ __forceinline__ uint32_t bulk_cc(uint32_t pw, uint32_t sh) { return ((pw >> 1) | (pw >> sh)) & 1u; }
 // computeSignContextBulk term of one neighbour word at plane q: -1 / 0 / +1
@@ -463,8 +501,7 @@ __device__ __forceinline__ int bulk_setup(const BpcArgs &a, bool coded, int msb,
     b.ref0 = (uint32_t)(grp * a.g.nBp * a.g.cRef);
     b.sig0 = (uint32_t)(grp * a.g.nBp * a.g.cSig + a.g.nRef);
     b.sign0 = (uint32_t)(grp * a.g.nBp * a.g.cSign + a.g.nRef + a.g.nSig);
-    b.total = (uint32_t)total;
-    b.lds = lds_half;
+    b.v.lds = lds_half; b.v.glob = a.lut; b.v.total = total; b.v.glob_total = total * a.n_tables; b.v.loff = loff;
     return cbp;
 }
 
@@ -476,14 +513,13 @@ __device__ __forceinline__ int bulk_setup(const BpcArgs &a, bool coded, int msb,
 template <bool BULK>
 __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(BpcArgs a)
 {
-    __shared__ uint8_t lds_lut[BULK ? 2 * kBulkLutMax : 4];
+    __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
     const int cb = a.cb_base + 2 * (int)blockIdx.x + (int)half;
     const bool valid = cb < a.nCB;
     const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
     const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
     int32_t *st = a.staging + (size_t)(valid ? cb : a.cb_base) * 4096u;
-    const int lut_total = (a.g.nRef + a.g.nSig + a.g.nSign) * (BULK ? a.n_tables : 1);
     const uint32_t prec = (uint32_t)a.g.prec;
 
     uint32_t PLlo[kMaxPlanes], PLhi[kMaxPlanes], PRlo[kMaxPlanes], PRhi[kMaxPlanes];
@@ -517,7 +553,10 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
     const int grp = level * a.g.nSub + sb;
     int cbp = 0, loff = 0;                                   // planes >= cbp take the two passes
     BulkLane bl;
-    if constexpr (BULK) cbp = bulk_setup(a, coded, msb, cbx, cby, grp, t, lds_lut + half * kBulkLutMax, bl, loff);
+    if constexpr (BULK) cbp = bulk_setup(a, coded, msb, cbx, cby, grp, t, lds_lut + half * kLutLdsMax, bl, loff);
+    else lut_to_lds(a.lut, a.g.nRef + a.g.nSig + a.g.nSign, lds_lut, lane);
+    const LutView lv = { lds_lut + (BULK ? half * kLutLdsMax : 0u), a.lut, a.g.nRef + a.g.nSig + a.g.nSign,
+                         (a.g.nRef + a.g.nSig + a.g.nSign) * (BULK ? a.n_tables : 1), loff };
 
     int np = coded ? (msb + 1 - cbp > 0 ? msb + 1 - cbp : 0) : 0;
     { int o = __shfl_xor(np, 32); np = np > o ? np : o; }
@@ -556,7 +595,7 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
         }
     }
 
-    Coder c = { 0u, 0u, 0u, 0u, 0u };
+    Coder c = { 0u, 0u, 0u, 0u, 0u, 0u };
     const uint32_t upper_mask = half ? 0xFFFFFFFFu : 0u, lower_mask = ~upper_mask;
     U64 AL = { 0u, 0u }, AR = { 0u, 0u };                 // significant before the current plane
     const U64 sgPL = u_prev(sgR, t), sgNL = u_next(sgL, t);     // neighbour sign columns
@@ -566,19 +605,7 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
         const bool act = coded && bp >= cbp;
 
         PlaneLut pl = { 0u, 0u, 0u, 0u, 0u };
-        if (act) {
-            int ri = (grp * a.g.nBp + bp) * a.g.cRef + loff;
-            int si = (grp * a.g.nBp + bp) * a.g.cSig + a.g.nRef + loff;
-            int gi = (grp * a.g.nBp + bp) * a.g.cSign + a.g.nRef + a.g.nSig + loff;
-            pl.ref = lut_at(a.lut, ri, lut_total);
-            pl.sig0 = lut_at(a.lut, si + 0, lut_total) | (lut_at(a.lut, si + 1, lut_total) << 8) |
-                      (lut_at(a.lut, si + 2, lut_total) << 16) | (lut_at(a.lut, si + 3, lut_total) << 24);
-            pl.sig1 = lut_at(a.lut, si + 4, lut_total) | (lut_at(a.lut, si + 5, lut_total) << 8) |
-                      (lut_at(a.lut, si + 6, lut_total) << 16) | (lut_at(a.lut, si + 7, lut_total) << 24);
-            pl.sig8 = lut_at(a.lut, si + 8, lut_total);
-            pl.sign = lut_at(a.lut, gi + 0, lut_total) | (lut_at(a.lut, gi + 1, lut_total) << 8) |
-                      (lut_at(a.lut, gi + 2, lut_total) << 16) | (lut_at(a.lut, gi + 3, lut_total) << 24);
-        }
+        if (act) pl = plane_lut(lv, a.g, grp, bp);
 
         const U64 BL = { PLlo[0], PLhi[0] }, BR = { PRlo[0], PRhi[0] };
         const U64 NL = u_andn(BL, AL), NR = u_andn(BR, AR);          // become significant in this plane
@@ -617,9 +644,9 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
             while (rows) {
                 const uint32_t ii = (uint32_t)__builtin_ctz(rows);
                 rows &= rows - 1u;
-                const uint32_t iL = ((ml >> ii) & 1u) ^ 1u, iR = ((mr >> ii) & 1u) ^ 1u;
-                if (__builtin_amdgcn_ballot_w64(iL == 0u) != 0ull) enc_site(c, iL, (bl >> ii) & 1u, pl.ref, prec, lower_mask, upper_mask, st);
-                if (__builtin_amdgcn_ballot_w64(iR == 0u) != 0ull) enc_site(c, iR, (br >> ii) & 1u, pl.ref, prec, lower_mask, upper_mask, st);
+                const bool oL = ((ml >> ii) & 1u) != 0u, oR = ((mr >> ii) & 1u) != 0u;
+                if (__builtin_amdgcn_ballot_w64(oL) != 0ull) enc_site_on(c, oL, (bl >> ii) & 1u, pl.ref, prec, upper_mask, st);
+                if (__builtin_amdgcn_ballot_w64(oR) != 0ull) enc_site_on(c, oR, (br >> ii) & 1u, pl.ref, prec, upper_mask, st);
             }
         }
         AL = AL2; AR = AR2;
@@ -669,7 +696,7 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
 
     // flush (Encode BPCEngine.cu:1719) + sizeArray (:2010) + MSB slot (:1998)
     if (coded) st[1u + c.slot] = (int32_t)c.L;
-    const uint32_t size = c.count + 1u;
+    const uint32_t size = (half ? c.cnt_hi : c.cnt_lo) + 1u;
     if (valid && t == 0u) { a.sizes[cb] = (int32_t)size; st[0] = msb; }
     // expansionFix :1905-1912 overwrites the whole block and must land after every codeword store
     // of the block (they come from other lanes): drain the wave's stores first.
@@ -708,14 +735,15 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
 __device__ __forceinline__ uint32_t dec_site(Coder &c, uint32_t inact, uint32_t p, uint32_t prec,
                                              uint32_t lower_mask, uint32_t upper_mask, const int32_t *stage)
 {
-    const bool need = (c.S | inact) == 0u;
-    const uint64_t m = __builtin_amdgcn_ballot_w64(need);
+    (void)lower_mask;
+    const bool on = inact == 0u, empty = c.S == 0u;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(empty) & __builtin_amdgcn_ballot_w64(on);
     if (m != 0ull) {
-        reserve_enc(c, need, m, lower_mask, upper_mask);
-        if (need) c.cw = (uint32_t)stage[1u + c.slot];
+        reserve_enc(c, on && empty, m, upper_mask);
+        if (on && empty) c.cw = (uint32_t)stage[1u + c.slot];
     }
     uint32_t sym = 0u;
-    if (inact == 0u) {
+    if (on) {
         const uint32_t a = (__umul24(c.S, p) >> prec) + 1u;
         const uint32_t a2 = c.L + a;
         const bool ge = c.cw >= a2;
@@ -764,14 +792,13 @@ __device__ __forceinline__ uint32_t dec_spp_coeff(Coder &c, uint32_t idle, uint3
 template <bool BULK>
 __global__ __launch_bounds__(64, 4) void bpc_decode_kernel(BpcArgs a)
 {
-    __shared__ uint8_t lds_lut[BULK ? 2 * kBulkLutMax : 4];
+    __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
     const int cb = a.cb_base + 2 * (int)blockIdx.x + (int)half;
     const bool valid = cb < a.nCB;
     const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
     const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
     const int32_t *stage = a.staging + (size_t)(valid ? cb : a.cb_base) * 4096u;
-    const int lut_total = (a.g.nRef + a.g.nSig + a.g.nSign) * (BULK ? a.n_tables : 1);
     const uint32_t prec = (uint32_t)a.g.prec;
     const uint32_t upper_mask = half ? 0xFFFFFFFFu : 0u, lower_mask = ~upper_mask;
 
@@ -792,12 +819,15 @@ __global__ __launch_bounds__(64, 4) void bpc_decode_kernel(BpcArgs a)
     find_subband(cbx * 64 + 2 * (int)t, cby * 64, a.AW, a.AH, a.wl, level, sb);
     const int grp = level * a.g.nSub + sb;
 
-    Coder c = { 0u, 0u, 0u, 0u, 0u };
+    Coder c = { 0u, 0u, 0u, 0u, 0u, 0u };
     M64 sigL = { 0u, 0u }, sigR = { 0u, 0u }, refL = { 0u, 0u }, refR = { 0u, 0u };
 
     int cbp = 0, loff = 0;
     BulkLane bl;
-    if constexpr (BULK) cbp = bulk_setup(a, coded, msb, cbx, cby, grp, t, lds_lut + half * kBulkLutMax, bl, loff);
+    if constexpr (BULK) cbp = bulk_setup(a, coded, msb, cbx, cby, grp, t, lds_lut + half * kLutLdsMax, bl, loff);
+    else lut_to_lds(a.lut, a.g.nRef + a.g.nSig + a.g.nSign, lds_lut, lane);
+    const LutView lv = { lds_lut + (BULK ? half * kLutLdsMax : 0u), a.lut, a.g.nRef + a.g.nSig + a.g.nSign,
+                         (a.g.nRef + a.g.nSig + a.g.nSign) * (BULK ? a.n_tables : 1), loff };
 
     int np = coded ? (msb + 1 - cbp > 0 ? msb + 1 - cbp : 0) : 0;
     { int o = __shfl_xor(np, 32); np = np > o ? np : o; }
@@ -819,19 +849,7 @@ __global__ __launch_bounds__(64, 4) void bpc_decode_kernel(BpcArgs a)
         }
 
         PlaneLut pl = { 0u, 0u, 0u, 0u, 0u };
-        if (act) {
-            int ri = (grp * a.g.nBp + bp) * a.g.cRef + loff;
-            int si = (grp * a.g.nBp + bp) * a.g.cSig + a.g.nRef + loff;
-            int gi = (grp * a.g.nBp + bp) * a.g.cSign + a.g.nRef + a.g.nSig + loff;
-            pl.ref = lut_at(a.lut, ri, lut_total);
-            pl.sig0 = lut_at(a.lut, si + 0, lut_total) | (lut_at(a.lut, si + 1, lut_total) << 8) |
-                      (lut_at(a.lut, si + 2, lut_total) << 16) | (lut_at(a.lut, si + 3, lut_total) << 24);
-            pl.sig1 = lut_at(a.lut, si + 4, lut_total) | (lut_at(a.lut, si + 5, lut_total) << 8) |
-                      (lut_at(a.lut, si + 6, lut_total) << 16) | (lut_at(a.lut, si + 7, lut_total) << 24);
-            pl.sig8 = lut_at(a.lut, si + 8, lut_total);
-            pl.sign = lut_at(a.lut, gi + 0, lut_total) | (lut_at(a.lut, gi + 1, lut_total) << 8) |
-                      (lut_at(a.lut, gi + 2, lut_total) << 16) | (lut_at(a.lut, gi + 3, lut_total) << 24);
-        }
+        if (act) pl = plane_lut(lv, a.g, grp, bp);
 
         // ---- significance propagation pass (SPPDecoderLauncher), rows with an insignificant coeff
 #pragma unroll

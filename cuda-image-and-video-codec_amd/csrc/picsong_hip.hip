@@ -335,9 +335,9 @@ int picsong_ctx_set_lut_component(picsong_ctx *c, int comp, const picsong_lut_in
     if (info->precision < 1 || info->precision > 8) return fail(PICSONG_ERR_ARG, "LUT precision %d", info->precision);
     const size_t one = (size_t)info->n_ref + info->n_sig + info->n_sign;
     const int n_tables = info->n_tables > 0 ? info->n_tables : 1;
-    if (c->p.k > 0.0f && one > (size_t)kBulkLutMax)
-        return fail(PICSONG_ERR_ARG, "LUT table of %zu entries exceeds the %d the -k > 0 kernels hold in LDS", one,
-                    kBulkLutMax);
+    if (one > (size_t)kLutLdsMax)
+        return fail(PICSONG_ERR_ARG, "LUT table of %zu entries exceeds the %d the coder kernels hold in LDS", one,
+                    kLutLdsMax);
     const size_t total = one * (size_t)n_tables;
     for (size_t i = 0; i < total; i++)
         if (host_table[i] < 0 || host_table[i] > 255)
