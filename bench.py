@@ -104,7 +104,7 @@ def valu_issue(insts, step_s, iso_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="8k_lossless", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=2,
@@ -156,20 +156,29 @@ def main():
                        for _ in range(world - 1)]
     dev = torch.device("cuda", local_rank)
 
+    dx = pdist.DeferredExchange() if world > 1 else None
+
     def step(it):
         # consecutive frames alternate over the streams: frame i's BPC tail overlaps frame i+1's
         # DWT/BPC head (each stream has its own context = its own workspace)
         k = it % nstreams
         with torch.cuda.stream(streams[k]):
             codecs[k].encode_frame_async(frame, outs[k], 0 if it == 0 else 1)
-            if world > 1:
-                # the only exchange of the frame-sharded path (picsong_dist.gather_round, covered by
-                # the gloo tests): lengths all-gathered, then payload gatherv to rank 0 over RCCL
-                total = codecs[k].last_total()
-                pdist.gather_round(outs[k][:total], rank, world, dev, recv_bufs=gather_bufs)
+        if world > 1:
+            # the only exchange of the frame-sharded path (picsong_dist.gather_round, covered by
+            # the gloo tests): lengths all-gathered, then payload gatherv to rank 0 over RCCL.  It
+            # needs the length on the host, so it is run one step late (DeferredExchange): the host
+            # waits for frame i only after frame i+1 is queued, and the payload crosses xGMI while
+            # frame i+1 is being coded.  Every step's exchange is inside the timed region (flush).
+            def exchange(k=k):
+                with torch.cuda.stream(streams[k]):
+                    total = codecs[k].last_total()
+                    return pdist.gather_round(outs[k][:total], rank, world, dev, recv_bufs=gather_bufs)
+            dx.submit(exchange)
 
     def sync_all():
         if world > 1:
+            dx.flush()
             dist.barrier()
         torch.cuda.synchronize()
 

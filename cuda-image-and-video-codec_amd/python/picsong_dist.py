@@ -55,27 +55,74 @@ def gather_round(local_stream, rank, world, device, recv_bufs=None, group=None):
     return None
 
 
-def encode_video_distributed(n_frames, encode_fn, rank, world, device, on_frame=None, group=None):
+class DeferredExchange:
+    """Software-pipelines the per-round exchange by one frame.
+
+    The exchange needs the codestream length on the host (send / recv counts), i.e. a wait for the
+    frame.  Done right after launching the frame it would stall the launch of the next one; so the
+    exchange of round i is submitted as a callable and RUN when round i + 1 has been launched (or at
+    `flush`).  The GPU then always has the next frame queued while the host waits for the previous
+    one, and the payload moves over xGMI while the next frame is being coded.  Results come back
+    one round late, in order."""
+
+    def __init__(self):
+        self._pending = None
+
+    def submit(self, exchange_fn):
+        """`exchange_fn()` performs one round's exchange (e.g. a `gather_round` call) and returns
+        its result.  Returns the result of the PREVIOUS submission (None for the first)."""
+        prev, self._pending = self._pending, exchange_fn
+        return prev() if prev is not None else None
+
+    def flush(self):
+        prev, self._pending = self._pending, None
+        return prev() if prev is not None else None
+
+
+def encode_video_distributed(n_frames, encode_fn, rank, world, device, on_frame=None, group=None,
+                             pipelined=False):
     """Encode `n_frames` frames sharded f mod world; rank 0 receives every codestream in frame
     order and hands it to `on_frame(frame_index, stream_tensor)`.  Returns the per-frame lengths
-    (shorts) on rank 0, None elsewhere."""
+    (shorts) on rank 0, None elsewhere.  `pipelined`: see DeferredExchange (then `encode_fn`
+    launches the frame and returns a zero-argument callable that waits for and returns its stream)."""
     sizes = []
     rounds = (n_frames + world - 1) // world
+
+    def deliver(rd, got):
+        if rank != 0 or got is None:
+            return
+        for r, s in enumerate(got):
+            fr = rd * world + r
+            if fr >= n_frames:
+                continue
+            assert s is not None, f"missing stream for frame {fr}"
+            sizes.append(int(s.numel()))
+            if on_frame is not None:
+                on_frame(fr, s)
+
+    if not pipelined:
+        for rd in range(rounds):
+            f = rd * world + rank
+            local = encode_fn(f, 0 if f == 0 else 1) if f < n_frames else None
+            deliver(rd, gather_round(local, rank, world, device, group=group))
+        return sizes if rank == 0 else None
+
+    # pipelined: `encode_fn` only LAUNCHES the frame and returns a callable that yields its stream
+    # (waiting for it); the exchange of round rd runs after round rd + 1 has been launched
+    dx = DeferredExchange()
     for rd in range(rounds):
         f = rd * world + rank
-        local = None
-        if f < n_frames:
-            local = encode_fn(f, 0 if f == 0 else 1)
-        got = gather_round(local, rank, world, device, group=group)
-        if rank == 0:
-            for r, s in enumerate(got):
-                fr = rd * world + r
-                if fr >= n_frames:
-                    continue
-                assert s is not None, f"missing stream for frame {fr}"
-                sizes.append(int(s.numel()))
-                if on_frame is not None:
-                    on_frame(fr, s)
+        fetch = encode_fn(f, 0 if f == 0 else 1) if f < n_frames else None
+
+        def exchange(rd=rd, fetch=fetch):
+            local = fetch() if fetch is not None else None
+            return rd, gather_round(local, rank, world, device, group=group)
+        prev = dx.submit(exchange)
+        if prev is not None:
+            deliver(*prev)
+    prev = dx.flush()
+    if prev is not None:
+        deliver(*prev)
     return sizes if rank == 0 else None
 
 

@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, pipelined=False):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(ROOT, "cuda-image-and-video-codec_amd", "python"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -35,14 +35,31 @@ def _worker(rank, world, port, outdir):
     lut = orc.lut_for(False, WL)
     encoded = []
 
-    def encode_fn(f, it):
-        encoded.append(f)
+    fetched = []
+
+    def encode_now(f, it):
         s = orc.encode_frame(orc.gen_frame(W, H, f), WL, False, 1.0, lut, it, NF)
         return torch.from_numpy(s.view(np.int16).copy())
 
+    def encode_fn(f, it):
+        encoded.append(f)
+        if not pipelined:
+            return encode_now(f, it)
+
+        def fetch():                                   # "wait for the frame" of the pipelined form
+            fetched.append((f, len(encoded)))
+            return encode_now(f, it)
+        return fetch
+
     chunks = {}
     sizes = pd.encode_video_distributed(NF, encode_fn, rank, world, torch.device("cpu"),
-                                        on_frame=lambda f, s: chunks.__setitem__(f, s.numpy().view(np.uint16).copy()))
+                                        on_frame=lambda f, s: chunks.__setitem__(f, s.numpy().view(np.uint16).copy()),
+                                        pipelined=pipelined)
+    if pipelined and len(encoded) > 1:
+        # the exchange (and with it the wait) of a frame ran only after the NEXT frame was launched
+        mine = pd.shard_frames(NF, rank, world)
+        for (f, launched) in fetched[:-1]:
+            assert launched >= mine.index(f) + 2, (f, launched)
     assert encoded == pd.shard_frames(NF, rank, world)
     if rank == 0:
         assert sorted(chunks) == list(range(NF))
@@ -55,10 +72,10 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_frame_sharding_gather_matches_single_process(oracle, tmp_path, world):
+@pytest.mark.parametrize("world,pipelined", [(2, False), (3, False), (2, True), (3, True)])
+def test_frame_sharding_gather_matches_single_process(oracle, tmp_path, world, pipelined):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), pipelined), nprocs=world, join=True)
     lut = oracle.lut_for(False, WL)
     ref = [oracle.encode_frame(oracle.gen_frame(W, H, f), WL, False, 1.0, lut, 0 if f == 0 else 1, NF)
            for f in range(NF)]
@@ -71,6 +88,15 @@ def test_frame_sharding_gather_matches_single_process(oracle, tmp_path, world):
     # every frame decodes back to its input
     for f in (0, NF - 1):
         assert np.array_equal(oracle.decode_frame(ref[f], W, H, WL, False, 1.0, lut), oracle.gen_frame(W, H, f))
+
+
+def test_deferred_exchange_order():
+    sys.path.insert(0, os.path.join(ROOT, "cuda-image-and-video-codec_amd", "python"))
+    import picsong_dist as pd
+    dx, log = pd.DeferredExchange(), []
+    assert dx.submit(lambda: log.append("a") or "A") is None and log == []
+    assert dx.submit(lambda: log.append("b") or "B") == "A" and log == ["a"]
+    assert dx.flush() == "B" and log == ["a", "b"] and dx.flush() is None
 
 
 def test_shard_helpers():
