@@ -144,6 +144,7 @@ static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v)
 static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 static inline int __mul24(int a, int b) { return (int)(((a << 8) >> 8) * (long long)((b << 8) >> 8)); }
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
+static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __syncthreads() { emu::barrier(); }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
