@@ -103,8 +103,8 @@ __device__ __forceinline__ uint32_t sign_ctx(int h, int v)
 {
     const uint32_t K = 7u | (5u << 3) | (1u << 6) | (3u << 9) | (0u << 12) | (2u << 15) |
                        (0u << 18) | (4u << 21) | (6u << 24);
-    int hs = (h > 0) - (h < 0), vs = (v > 0) - (v < 0);
-    return (K >> (3 * ((hs + 1) * 3 + (vs + 1)))) & 7u;
+    const int hs = h < -1 ? -1 : (h > 1 ? 1 : h), vs = v < -1 ? -1 : (v > 1 ? 1 : v);   // v_med3_i32
+    return (K >> (3 * (hs * 3 + vs + 4))) & 7u;
 }
 
 // findSubband BPCEngine.cu:143-170
@@ -309,9 +309,8 @@ __device__ __forceinline__ void enc_site_on(Coder &c, bool on, uint32_t sym, uin
     }
 }
 __device__ __forceinline__ void enc_site(Coder &c, uint32_t inact, uint32_t sym, uint32_t p, uint32_t prec,
-                                         uint32_t lower_mask, uint32_t upper_mask, int32_t *st)
+                                         uint32_t upper_mask, int32_t *st)
 {
-    (void)lower_mask;
     enc_site_on(c, inact == 0u, sym, p, prec, upper_mask, st);
 }
 
@@ -322,8 +321,7 @@ __device__ __forceinline__ uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b)
 
 // A: significant-before mask of the column's 32 rows (all ones for an idle half): a set bit = skip.
 __device__ __forceinline__ void enc_spp_coeff(Coder &c, uint32_t ii, uint32_t A, uint32_t B, const ColHalf &cp,
-                                              const PlaneLut &pl, uint32_t prec, uint32_t lower_mask,
-                                              uint32_t upper_mask, int32_t *st)
+                                              const PlaneLut &pl, uint32_t prec,                                               uint32_t upper_mask, int32_t *st)
 {
     const bool on = ((A >> ii) & 1u) == 0u;
     const uint32_t sym = (B >> ii) & 1u;
@@ -334,7 +332,6 @@ __device__ __forceinline__ void enc_spp_coeff(Coder &c, uint32_t ii, uint32_t A,
     const uint32_t p07 = __builtin_amdgcn_perm(pl.sig1, pl.sig0, sel);
     // context 8 (n3 set => n0 = n1 = n2 = 0): a second byte select takes p8 (byte 4) instead of p07
     const uint32_t p = __builtin_amdgcn_perm(pl.sig8, p07, (rotr32(cp.n3, ii) & 4u) | 0x0C0C0C00u);
-    (void)lower_mask;
     enc_site_on(c, on, sym, p, prec, upper_mask, st);
     const bool on2 = on && sym != 0u;                       // one compare; the AND of the masks is SALU
     if (__builtin_amdgcn_ballot_w64(on2) != 0ull) {
@@ -346,7 +343,7 @@ __device__ __forceinline__ void enc_spp_coeff(Coder &c, uint32_t ii, uint32_t A,
 }
 
 __device__ __forceinline__ uint32_t dec_site(Coder &c, uint32_t inact, uint32_t p, uint32_t prec,
-                                             uint32_t lower_mask, uint32_t upper_mask, const int32_t *stage);
+                                             uint32_t upper_mask, const int32_t *stage);
 
 // =============================================================================================
 // Complexity-scalable mode, -k > 0 (Encode BPCEngine.cu:1684-1716, Decode :1794-1835,
@@ -414,7 +411,7 @@ __device__ __forceinline__ int bulk_sc(uint32_t pw, uint32_t q)
 template <bool DEC>
 __device__ __forceinline__ uint32_t bulk_coeff(Coder &c, uint32_t u, uint32_t low, uint32_t ctx, uint32_t up,
                                                uint32_t lf, uint32_t rt, uint32_t dn, const BulkLane &b, int Bmax,
-                                               uint32_t prec, uint32_t lower_mask, uint32_t upper_mask,
+                                               uint32_t prec, uint32_t upper_mask,
                                                int32_t *st)
 {
     uint32_t sig = (u >> 1) & 1u, neg = u & 1u;
@@ -426,16 +423,16 @@ __device__ __forceinline__ uint32_t bulk_coeff(Coder &c, uint32_t u, uint32_t lo
         const uint32_t iA = (on & sig) ^ 1u;
         if (__builtin_amdgcn_ballot_w64(iA == 0u) != 0ull) {
             const uint32_t p = bulk_lut(b, b.ref0 + (uint32_t)q * b.cRef);
-            if (DEC) low |= dec_site(c, iA, p, prec, lower_mask, upper_mask, st) << q;
-            else enc_site(c, iA, bit, p, prec, lower_mask, upper_mask, st);
+            if (DEC) low |= dec_site(c, iA, p, prec, upper_mask, st) << q;
+            else enc_site(c, iA, bit, p, prec, upper_mask, st);
         }
         // significance call site: the others
         const uint32_t iB = (on & (sig ^ 1u)) ^ 1u;
         uint32_t ns = 0u;
         if (__builtin_amdgcn_ballot_w64(iB == 0u) != 0ull) {
             const uint32_t p = bulk_lut(b, b.sig0 + (uint32_t)q * b.cSig + ctx);
-            if (DEC) { ns = dec_site(c, iB, p, prec, lower_mask, upper_mask, st); low |= ns << q; }
-            else { enc_site(c, iB, bit, p, prec, lower_mask, upper_mask, st); ns = (iB ^ 1u) & bit; }
+            if (DEC) { ns = dec_site(c, iB, p, prec, upper_mask, st); low |= ns << q; }
+            else { enc_site(c, iB, bit, p, prec, upper_mask, st); ns = (iB ^ 1u) & bit; }
         }
         // sign call site: coefficients that just became significant
         if (__builtin_amdgcn_ballot_w64(ns != 0u) != 0ull) {
@@ -443,10 +440,10 @@ __device__ __forceinline__ uint32_t bulk_coeff(Coder &c, uint32_t u, uint32_t lo
                                          bulk_sc(up, (uint32_t)q) + bulk_sc(dn, (uint32_t)q));
             const uint32_t p = bulk_lut(b, b.sign0 + (uint32_t)q * b.cSign + (sc >> 1));
             if (DEC) {
-                const uint32_t s2 = dec_site(c, ns ^ 1u, p, prec, lower_mask, upper_mask, st);
+                const uint32_t s2 = dec_site(c, ns ^ 1u, p, prec, upper_mask, st);
                 if (ns) neg = s2 ^ (sc & 1u);                  // :1488-1490
             } else {
-                enc_site(c, ns ^ 1u, neg ^ (sc & 1u), p, prec, lower_mask, upper_mask, st);   // :1308
+                enc_site(c, ns ^ 1u, neg ^ (sc & 1u), p, prec, upper_mask, st);   // :1308
             }
             sig |= ns;
         }
@@ -459,7 +456,7 @@ __device__ __forceinline__ uint32_t bulk_coeff(Coder &c, uint32_t u, uint32_t lo
 template <bool DEC>
 __device__ __forceinline__ void bulk_row(Coder &c, uint32_t t, uint32_t uL, uint32_t uR, uint32_t lowL, uint32_t lowR,
                                          uint32_t dL, uint32_t dR, uint32_t &pUL, uint32_t &pUR, const BulkLane &b,
-                                         int Bmax, uint32_t prec, uint32_t lower_mask, uint32_t upper_mask,
+                                         int Bmax, uint32_t prec, uint32_t upper_mask,
                                          int32_t *st)
 {
     const uint32_t sh = 2u + (uint32_t)(b.Bh < 0 ? 0 : b.Bh);
@@ -469,12 +466,12 @@ __device__ __forceinline__ void bulk_row(Coder &c, uint32_t t, uint32_t uL, uint
     // left coefficients of all lanes (encodeLeftCoefficients :1320-1381)
     const uint32_t ctxL = bulk_cc(P_ur, sh) + bulk_cc(pUL, sh) + bulk_cc(pUR, sh) + bulk_cc(P_r, sh) +
                           bulk_cc(uR, sh) + bulk_cc(P_dr, sh) + bulk_cc(dL, sh) + bulk_cc(dR, sh);
-    const uint32_t nL = bulk_coeff<DEC>(c, uL, lowL, ctxL, pUL, P_r, uR, dL, b, Bmax, prec, lower_mask, upper_mask, st);
+    const uint32_t nL = bulk_coeff<DEC>(c, uL, lowL, ctxL, pUL, P_r, uR, dL, b, Bmax, prec, upper_mask, st);
     // right coefficients (encodeRightCoefficients :1387-1448): the left ones of this row are done
     const uint32_t N_l = from_next32(nL, t);
     const uint32_t ctxR = bulk_cc(pUL, sh) + bulk_cc(pUR, sh) + bulk_cc(N_ul, sh) + bulk_cc(nL, sh) +
                           bulk_cc(N_l, sh) + bulk_cc(dL, sh) + bulk_cc(dR, sh) + bulk_cc(N_dl, sh);
-    const uint32_t nR = bulk_coeff<DEC>(c, uR, lowR, ctxR, pUR, nL, N_l, dR, b, Bmax, prec, lower_mask, upper_mask, st);
+    const uint32_t nR = bulk_coeff<DEC>(c, uR, lowR, ctxR, pUR, nL, N_l, dR, b, Bmax, prec, upper_mask, st);
     pUL = nL; pUR = nR;
 }
 
@@ -596,7 +593,7 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
     }
 
     Coder c = { 0u, 0u, 0u, 0u, 0u, 0u };
-    const uint32_t upper_mask = half ? 0xFFFFFFFFu : 0u, lower_mask = ~upper_mask;
+    const uint32_t upper_mask = half ? 0xFFFFFFFFu : 0u;
     U64 AL = { 0u, 0u }, AR = { 0u, 0u };                 // significant before the current plane
     const U64 sgPL = u_prev(sgR, t), sgNL = u_next(sgL, t);     // neighbour sign columns
 
@@ -631,8 +628,8 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
             while (rows) {
                 const uint32_t ii = (uint32_t)__builtin_ctz(rows);
                 rows &= rows - 1u;
-                enc_spp_coeff(c, ii, al, bl, cpL, pl, prec, lower_mask, upper_mask, st);
-                enc_spp_coeff(c, ii, ar, br, cpR, pl, prec, lower_mask, upper_mask, st);
+                enc_spp_coeff(c, ii, al, bl, cpL, pl, prec, upper_mask, st);
+                enc_spp_coeff(c, ii, ar, br, cpR, pl, prec, upper_mask, st);
             }
         }
         // ---- magnitude refinement pass: coefficients significant before this plane
@@ -688,7 +685,7 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
                 if (i < 63) row_words(i + 1, n0, n1); else { n0 = 0u; n1 = 0u; }
                 bulk_row<false>(c, t, unp(c0), unp(c1), (c0 >> 1) & lowmask, (c1 >> 1) & lowmask,
                                 i < 63 ? unp(n0) : 0u, i < 63 ? unp(n1) : 0u, pUL, pUR, bl, Bmax, prec,
-                                lower_mask, upper_mask, st);
+                                upper_mask, st);
                 c0 = n0; c1 = n1;
             }
         }
@@ -733,9 +730,8 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
 
 // arithmeticDecoder BPCEngine.cu:405-442, one call site
 __device__ __forceinline__ uint32_t dec_site(Coder &c, uint32_t inact, uint32_t p, uint32_t prec,
-                                             uint32_t lower_mask, uint32_t upper_mask, const int32_t *stage)
+                                             uint32_t upper_mask, const int32_t *stage)
 {
-    (void)lower_mask;
     const bool on = inact == 0u, empty = c.S == 0u;
     const uint64_t m = __builtin_amdgcn_ballot_w64(empty) & __builtin_amdgcn_ballot_w64(on);
     if (m != 0ull) {
@@ -760,7 +756,7 @@ __device__ __forceinline__ uint32_t dec_site(Coder &c, uint32_t inact, uint32_t 
 __device__ __forceinline__ uint32_t dec_spp_coeff(Coder &c, uint32_t idle, uint32_t ii, M64 &wo, const M64 &wl,
                                                   const M64 &wr, M64 &so, const M64 &sl, const M64 &sr,
                                                   uint32_t &cur, const PlaneLut &pl, uint32_t prec,
-                                                  uint32_t lower_mask, uint32_t upper_mask, const int32_t *stage)
+                                                  uint32_t upper_mask, const int32_t *stage)
 {
     const uint32_t to = triple(wo, ii), tl = triple(wl, ii), tr = triple(wr, ii);
     const uint32_t inact = idle | ((to >> 1) & 1u);
@@ -768,17 +764,19 @@ __device__ __forceinline__ uint32_t dec_spp_coeff(Coder &c, uint32_t idle, uint3
     const uint32_t ctx = (uint32_t)__builtin_popcount(to) + (uint32_t)__builtin_popcount(tl) +
                          (uint32_t)__builtin_popcount(tr);
     const uint32_t p07 = __builtin_amdgcn_perm(pl.sig1, pl.sig0, ctx | 0x0C0C0C00u);
-    const uint32_t sym = dec_site(c, inact, ctx >= 8u ? pl.sig8 : p07, prec, lower_mask, upper_mask, stage);
+    const uint32_t sym = dec_site(c, inact, ctx >= 8u ? pl.sig8 : p07, prec, upper_mask, stage);
     if (__builtin_amdgcn_ballot_w64(sym != 0u) != 0ull) {
         const uint32_t xo = triple(so, ii), xl = triple(sl, ii), xr = triple(sr, ii);
-        // computeSignContext BPCEngine.cu:296-308: 0 if not significant, -1 if sign bit set, else +1
-        const int up = (to & 1u) ? ((xo & 1u) ? -1 : 1) : 0;
-        const int dn = (to & 4u) ? ((xo & 4u) ? -1 : 1) : 0;
-        const int lf = (tl & 2u) ? ((xl & 2u) ? -1 : 1) : 0;
-        const int rt = (tr & 2u) ? ((xr & 2u) ? -1 : 1) : 0;
+        // computeSignContext BPCEngine.cu:296-308: 0 if not significant, -1 if sign bit set, else +1.
+        // A sign bit is only ever set on a significant coefficient, so the contribution is
+        // significance - 2 * sign: three instructions per neighbour, no selects.
+        const int up = (int)(to & 1u) - (int)((xo & 1u) << 1);
+        const int dn = (int)((to >> 2) & 1u) - (int)((xo >> 1) & 2u);
+        const int lf = (int)((tl >> 1) & 1u) - (int)(xl & 2u);
+        const int rt = (int)((tr >> 1) & 1u) - (int)(xr & 2u);
         const uint32_t sc = sign_ctx(lf + rt, up + dn);
         const uint32_t p2 = (pl.sign >> (8u * (sc >> 1))) & 0xFFu;
-        const uint32_t s2 = dec_site(c, sym ^ 1u, p2, prec, lower_mask, upper_mask, stage);
+        const uint32_t s2 = dec_site(c, sym ^ 1u, p2, prec, upper_mask, stage);
         if (sym) {
             w_set(so, ii, s2 ^ (sc & 1u));          // :587-589
             w_set(wo, ii, 1u);
@@ -800,7 +798,7 @@ __global__ __launch_bounds__(64, 4) void bpc_decode_kernel(BpcArgs a)
     const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
     const int32_t *stage = a.staging + (size_t)(valid ? cb : a.cb_base) * 4096u;
     const uint32_t prec = (uint32_t)a.g.prec;
-    const uint32_t upper_mask = half ? 0xFFFFFFFFu : 0u, lower_mask = ~upper_mask;
+    const uint32_t upper_mask = half ? 0xFFFFFFFFu : 0u;
 
     uint32_t PLlo[kMaxPlanes], PLhi[kMaxPlanes], PRlo[kMaxPlanes], PRhi[kMaxPlanes];
 #pragma unroll
@@ -867,16 +865,14 @@ __global__ __launch_bounds__(64, 4) void bpc_decode_kernel(BpcArgs a)
                 const uint32_t ii = (uint32_t)__builtin_ctz(rows);
                 rows &= rows - 1u;
                 // all lanes: left column, neighbours = lane-1's right column | own right column
-                const uint32_t bL = dec_spp_coeff(c, idle, ii, wL, wPR, wR, sL, sPR, sR, curL, pl, prec, lower_mask,
-                                                  upper_mask, stage);
+                const uint32_t bL = dec_spp_coeff(c, idle, ii, wL, wPR, wR, sL, sPR, sR, curL, pl, prec, upper_mask, stage);
                 // lane+1's left column as it is after this row's left phase (:791, shfl_down)
                 if (__builtin_amdgcn_ballot_w64(bL != 0u) != 0ull) {
                     wNL.lo = from_next32(wL.lo, t); wNL.hi = from_next32(wL.hi, t);
                     sNL.lo = from_next32(sL.lo, t); sNL.hi = from_next32(sL.hi, t);
                 }
                 // all lanes: right column, neighbours = own left column | lane+1's left column
-                const uint32_t bR = dec_spp_coeff(c, idle, ii, wR, wL, wNL, sR, sL, sNL, curR, pl, prec, lower_mask,
-                                                  upper_mask, stage);
+                const uint32_t bR = dec_spp_coeff(c, idle, ii, wR, wL, wNL, sR, sL, sNL, curR, pl, prec, upper_mask, stage);
                 // lane-1's right column as it is after this row's right phase (:804, shfl_up)
                 if (__builtin_amdgcn_ballot_w64(bR != 0u) != 0ull) {
                     wPR.lo = from_prev32(wR.lo, t); wPR.hi = from_prev32(wR.hi, t);
@@ -902,9 +898,9 @@ __global__ __launch_bounds__(64, 4) void bpc_decode_kernel(BpcArgs a)
                 rows &= rows - 1u;
                 const uint32_t iL = ((rL >> ii) & 1u) ^ 1u, iR = ((rR >> ii) & 1u) ^ 1u;
                 if (__builtin_amdgcn_ballot_w64(iL == 0u) != 0ull)
-                    curL |= dec_site(c, iL, pl.ref, prec, lower_mask, upper_mask, stage) << ii;
+                    curL |= dec_site(c, iL, pl.ref, prec, upper_mask, stage) << ii;
                 if (__builtin_amdgcn_ballot_w64(iR == 0u) != 0ull)
-                    curR |= dec_site(c, iR, pl.ref, prec, lower_mask, upper_mask, stage) << ii;
+                    curR |= dec_site(c, iR, pl.ref, prec, upper_mask, stage) << ii;
             }
             if (hw == 0) { PLlo[0] = curL; PRlo[0] = curR; } else { PLhi[0] = curL; PRhi[0] = curR; }
         }
@@ -927,7 +923,7 @@ __global__ __launch_bounds__(64, 4) void bpc_decode_kernel(BpcArgs a)
             const uint32_t uL = unp(sigL, sgnL, i), uR = unp(sigR, sgnR, i);
             if (Bmax >= 0)
                 bulk_row<true>(c, t, uL, uR, 0u, 0u, unp(sigL, sgnL, i + 1), unp(sigR, sgnR, i + 1), pUL, pUR, bl,
-                               Bmax, prec, lower_mask, upper_mask, const_cast<int32_t *>(stage));
+                               Bmax, prec, upper_mask, const_cast<int32_t *>(stage));
             else { pUL = uL; pUR = uR; }
             if (!valid) continue;
             int32_t v0, v1;
