@@ -81,6 +81,8 @@ struct DwtInvArgs {
     void *dst;              // packed output T[H x W]
     float qs;
     float q[4];
+    uint8_t *dst_u8;        // U8OUT kernels (finest level of the frame path): pixels, row stride W
+    int off;                // level shift to add back (128 for 8-bit)
 };
 
 __device__ __forceinline__ int reflect(int i, int n)
@@ -472,7 +474,32 @@ __device__ __forceinline__ void store_row4(const DwtInvArgs &a, int y, int c0, c
     }
 }
 
-template <typename T, bool LOSSY, int BAND, bool VEC>
+// removeOffsetAndApplyMaxMin / ...Lossy (Engines/DecodingEngine.cu:706-729) + the u8 conversion of
+// IOManager::writeImage (IO/IOManager.ipp:332-335) fused into the finest level's store: 4 pixels per
+// lane, one dword.  Same arithmetic as clamp_to_u8_i32_kernel / clamp_to_u8_f32_kernel.
+__device__ __forceinline__ uint32_t to_pixel(int v, int off)
+{
+    const int t = v + off;
+    return (uint32_t)(t > 255 ? 255 : (t < 0 ? 0 : t));
+}
+__device__ __forceinline__ uint32_t to_pixel(float v, int off)
+{
+    float t = v + (float)off;
+    t = t + 0.01f;
+    float r = rintf(t);                      // __float2int_rn
+    r = r > 255.0f ? 255.0f : r;
+    r = r < 0.0f ? 0.0f : r;
+    return (uint32_t)(int)r;
+}
+template <typename T>
+__device__ __forceinline__ void store_row4_u8(const DwtInvArgs &a, int y, int c0, const T v[4])
+{
+    const uint32_t w = to_pixel(v[0], a.off) | (to_pixel(v[1], a.off) << 8) | (to_pixel(v[2], a.off) << 16) |
+                       (to_pixel(v[3], a.off) << 24);
+    *reinterpret_cast<uint32_t *>(a.dst_u8 + (size_t)y * (size_t)a.W + (uint32_t)c0) = w;
+}
+
+template <typename T, bool LOSSY, int BAND, bool VEC, bool U8OUT = false>
 __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
 {
     constexpr int kInvBandRows = BAND;
@@ -511,8 +538,13 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
                 sp[k] = s; Hp[k] = Hr[k];
             }
             if (j - 1 >= m0 && wr) {
-                store_row4<T, VEC>(a, 2 * (j - 1), c0, ev);
-                store_row4<T, VEC>(a, 2 * (j - 1) + 1, c0, od);
+                if constexpr (U8OUT) {
+                    store_row4_u8<T>(a, 2 * (j - 1), c0, ev);
+                    store_row4_u8<T>(a, 2 * (j - 1) + 1, c0, od);
+                } else {
+                    store_row4<T, VEC>(a, 2 * (j - 1), c0, ev);
+                    store_row4<T, VEC>(a, 2 * (j - 1) + 1, c0, od);
+                }
             }
         }
     } else {
@@ -540,8 +572,13 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
                 ddp[k] = (T)dd; s1p[k] = (T)s1; d1p[k] = (T)d1; s0p[k] = (T)s0;
             }
             if (j - 2 >= m0 && wr) {
-                store_row4<T, VEC>(a, 2 * (j - 2), c0, ev);
-                store_row4<T, VEC>(a, 2 * (j - 2) + 1, c0, od);
+                if constexpr (U8OUT) {
+                    store_row4_u8<T>(a, 2 * (j - 2), c0, ev);
+                    store_row4_u8<T>(a, 2 * (j - 2) + 1, c0, od);
+                } else {
+                    store_row4<T, VEC>(a, 2 * (j - 2), c0, ev);
+                    store_row4<T, VEC>(a, 2 * (j - 2) + 1, c0, od);
+                }
             }
         }
     }

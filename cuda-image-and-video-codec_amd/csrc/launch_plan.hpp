@@ -106,6 +106,7 @@ inline std::vector<InvLaunch> plan_dwt_inverse(const int32_t *d_in, void *d_out,
         a.first = first ? 1 : 0;
         a.W = W; a.H = H;
         a.dst = (char *)d_out + write_off * 4;
+        a.dst_u8 = nullptr; a.off = 0;
         a.qs = qs;
         for (int k = 0; k < 4; k++) a.q[k] = kQSteps[l][k];
         const int strips = (W + kStripUseful - 1) / kStripUseful;

@@ -72,7 +72,10 @@ template <int BAND>
 static void launch_inv(const picsong_ctx *c, const InvLaunch &f, hipStream_t s)
 {
     dim3 grid(f.gx, f.gy);
-    if (f.vec) {
+    if (f.vec && f.a.dst_u8) {          // finest level of the frame path: pixels out, clamp fused
+        if (c->p.lossy) dwt_inv_kernel<float, true, BAND, true, true><<<grid, 256, 0, s>>>(f.a);
+        else dwt_inv_kernel<int, false, BAND, true, true><<<grid, 256, 0, s>>>(f.a);
+    } else if (f.vec) {
         if (c->p.lossy) dwt_inv_kernel<float, true, BAND, true><<<grid, 256, 0, s>>>(f.a);
         else dwt_inv_kernel<int, false, BAND, true><<<grid, 256, 0, s>>>(f.a);
     } else {
@@ -423,6 +426,30 @@ int picsong_dwt_forward_u8(picsong_ctx *c, const uint8_t *d_in, void *d_out, voi
     return dwt_forward_impl(c, d_in, true, d_out, (hipStream_t)stream);
 }
 
+// d_pixels != nullptr: the finest level writes clamped u8 pixels there (level shift + clamp fused,
+// when its vector kernel applies) instead of T samples into d_out; returns 1 in *fused then.
+static int dwt_inverse_impl(picsong_ctx *c, const int32_t *d_in, void *d_out, uint8_t *d_pixels, bool *fused,
+                            hipStream_t s)
+{
+    if (fused) *fused = false;
+    std::vector<InvLaunch> plan = plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs);
+    if (d_pixels && !plan.empty() && plan.back().vec && (((uintptr_t)d_pixels) & 3u) == 0) {
+        plan.back().a.dst_u8 = d_pixels;
+        plan.back().a.off = 1 << (c->p.bit_depth - 1);
+        if (fused) *fused = true;
+    }
+    for (const InvLaunch &f : plan) {
+        switch (f.band) {
+        case 32: launch_inv<32>(c, f, s); break;
+        case 16: launch_inv<16>(c, f, s); break;
+        case 8: launch_inv<8>(c, f, s); break;
+        default: launch_inv<4>(c, f, s); break;
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    return PICSONG_OK;
+}
+
 int picsong_dwt_inverse(picsong_ctx *c, const int32_t *d_in, void *d_out, void *stream)
 {
     if (!c || !d_in || !d_out) return fail(PICSONG_ERR_ARG, "dwt_inverse: null argument");
@@ -644,7 +671,9 @@ int picsong_decode_frame(picsong_ctx *c, const uint16_t *d_stream, uint8_t *d_fr
     hipStream_t s = (hipStream_t)stream;
     if ((rc = unpack_impl(c, d_stream, c->d_staging, c->d_sizes, false, s))) return rc;
     if ((rc = picsong_bpc_decode(c, c->d_staging, c->d_sizes, c->d_coef_i, stream))) return rc;
-    if ((rc = picsong_dwt_inverse(c, c->d_coef_i, c->d_coef, stream))) return rc;
+    bool fused = false;
+    if ((rc = dwt_inverse_impl(c, c->d_coef_i, c->d_coef, d_frame_out, &fused, s))) return rc;
+    if (fused) return PICSONG_OK;            // the finest level wrote the pixels itself
     const void *img = (const char *)c->d_coef + c->extra * 4;
     const size_t n4 = c->P / 4;
     const int off = 1 << (c->p.bit_depth - 1);

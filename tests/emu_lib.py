@@ -69,6 +69,16 @@ def dwt_inverse(coef, wl, lossy, qs=1.0, extra=0):
     return out
 
 
+def dwt_inverse_u8(coef, wl, lossy, qs=1.0, extra=0):
+    """Frame-path inverse: returns (pixels u8 (AH, AW), fused flag)."""
+    AH, AW = coef.shape
+    coef = aligned_copy(np.ascontiguousarray(coef, np.int32))
+    scratch = aligned_zeros(AW * AH + extra, np.float32 if lossy else np.int32)
+    pix = aligned_zeros(AW * AH, np.uint8)
+    fused = lib().emu_dwt_inverse_u8(_p(coef), _p(scratch), _p(pix), AW, AH, wl, int(lossy), C.c_float(qs))
+    return pix.reshape(AH, AW), bool(fused)
+
+
 def level_shift_inv(x):
     x = np.ascontiguousarray(x).copy()
     lib().emu_level_shift_inv(_p(x), C.c_size_t(x.size), int(x.dtype == np.float32))

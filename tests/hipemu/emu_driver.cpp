@@ -18,7 +18,12 @@ template <int BAND, bool VEC> static void emu_inv_v(const InvLaunch &f, int loss
 }
 template <int BAND> static void emu_inv(const InvLaunch &f, int lossy)
 {
-    if (f.vec) emu_inv_v<BAND, true>(f, lossy); else emu_inv_v<BAND, false>(f, lossy);
+    DwtInvArgs a = f.a;
+    if (f.vec && a.dst_u8) {            // finest level of the frame path: pixels out, clamp fused
+        if (lossy) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<float, true, BAND, true, true>(a); });
+        else emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<int, false, BAND, true, true>(a); });
+    } else if (f.vec) emu_inv_v<BAND, true>(f, lossy);
+    else emu_inv_v<BAND, false>(f, lossy);
 }
 
 template <int BAND, bool VEC> static void emu_fwd_v(const FwdLaunch &f, int lossy)
@@ -70,6 +75,24 @@ void emu_dwt_inverse(const int32_t *in, void *out, int aw, int ah, int wl, int l
         default: emu_inv<4>(f, lossy); break;
         }
     }
+}
+
+// the frame path's inverse: the finest level writes clamped pixels (mirrors dwt_inverse_impl);
+// returns 1 when that fused kernel applied
+int emu_dwt_inverse_u8(const int32_t *in, void *scratch, uint8_t *pixels, int aw, int ah, int wl, int lossy, float qs)
+{
+    std::vector<InvLaunch> plan = plan_dwt_inverse(in, scratch, aw, ah, wl, qs);
+    const bool fused = !plan.empty() && plan.back().vec && (((uintptr_t)pixels) & 3u) == 0;
+    if (fused) { plan.back().a.dst_u8 = pixels; plan.back().a.off = 128; }
+    for (const InvLaunch &f : plan) {
+        switch (f.band) {
+        case 32: emu_inv<32>(f, lossy); break;
+        case 16: emu_inv<16>(f, lossy); break;
+        case 8: emu_inv<8>(f, lossy); break;
+        default: emu_inv<4>(f, lossy); break;
+        }
+    }
+    return fused ? 1 : 0;
 }
 
 void emu_level_shift_inv(void *data, size_t n, int lossy)

@@ -72,6 +72,23 @@ def test_dwt97_forward_inverse_bit_exact(oracle, E, dwt_path, W, H, wl, qs):
     assert np.array_equal(E.level_shift_inv(gi[extra:]), oracle.level_shift_inv(ri[ex:]))
 
 
+@pytest.mark.parametrize("W,H,wl,lossy,qs", [(320, 192, 3, False, 1.0), (256, 128, 2, True, 0.5), (64, 64, 1, False, 1.0)])
+def test_dwt_inverse_fused_pixel_output(oracle, E, W, H, wl, lossy, qs):
+    """Finest inverse level with level shift + clamp + u8 conversion fused == inverse, shift, clamp."""
+    rng = np.random.default_rng(17)
+    img = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    x = oracle.level_shift_fwd(img, lossy)
+    extra = oracle.dwt_extra(W, H, wl)
+    f = oracle.dwt_forward(x, wl, qs) if lossy else oracle.dwt_forward(x, wl)
+    coef = f[:W * H].astype(np.int32).reshape(H, W)
+    coef[3, 5] += 4000                                   # force clamping on both ends
+    coef[9, 70 % W] -= 4000
+    ref, ex = oracle.dwt_inverse(coef, wl, lossy, qs)
+    want = oracle.level_shift_inv(ref[ex:]).reshape(H, W).astype(np.uint8)
+    got, fused = E.dwt_inverse_u8(coef, wl, lossy, qs, extra=extra)
+    assert fused and np.array_equal(got, want)
+
+
 def test_dwt_odd_half_width_scalar_paths(oracle, E):
     """(AW >> l) / 2 odd at the last level: 8-byte vector stores are illegal, scalar path used."""
     W, H, wl = 192, 64, 2            # level 1: 96x32, half width 48 (even); level... use wl where odd
