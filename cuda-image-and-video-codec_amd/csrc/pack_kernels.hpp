@@ -63,11 +63,17 @@ __global__ __launch_bounds__(256) void pack_kernel(const int32_t *staging, const
     }
 }
 
-// retrieveSizeArray BitStreamBuilder.cpp:119-129 on the device
-__global__ __launch_bounds__(256) void read_sizes_kernel(const uint16_t *stream, int n, int32_t *sizes)
+// retrieveSizeArray BitStreamBuilder.cpp:119-129 on the device.  A length outside 1..4096 cannot
+// come from the encoder; it is clamped (and flagged) so that a damaged stream can neither write
+// outside a codeblock's staging nor read past 9 + 2n + 4095n + 1 shorts of the stream buffer.
+__global__ __launch_bounds__(256) void read_sizes_kernel(const uint16_t *stream, int n, int32_t *sizes, int *flag)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) sizes[i] = stream[10 + 2 * i];
+    if (i < n) {
+        int v = stream[10 + 2 * i];
+        if (v < 1 || v > 4096) { *flag = 1; v = v < 1 ? 1 : 4096; }
+        sizes[i] = v;
+    }
 }
 
 // buildCodeStreamLUTBS BitStreamBuilder.cu:142-171 layout

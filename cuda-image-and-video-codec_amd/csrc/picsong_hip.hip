@@ -586,7 +586,7 @@ static int unpack_impl(picsong_ctx *c, const uint16_t *d_stream, int32_t *d_stag
     // BSEngine::deviceMemoryAllocator BitStreamBuilder.cu:281-284.  Slots beyond a codeblock's length
     // are never read by the decoder, so the frame path skips this 4*AW*AH-byte fill.
     if (memset_staging) HIP_TRY(hipMemsetAsync(d_staging, 0xFF, c->P * sizeof(int32_t), s));
-    read_sizes_kernel<<<(unsigned)((c->ncb + 255) / 256), 256, 0, s>>>(d_stream, c->ncb, d_sizes);
+    read_sizes_kernel<<<(unsigned)((c->ncb + 255) / 256), 256, 0, s>>>(d_stream, c->ncb, d_sizes, c->d_flag);
     HIP_TRY(hipGetLastError());
     scan_sizes_kernel<<<1, 1024, 0, s>>>(d_sizes, c->ncb, c->d_offsets, c->d_total);
     HIP_TRY(hipGetLastError());

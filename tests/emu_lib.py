@@ -153,5 +153,5 @@ def unpack(stream, n_cb):
     stream = np.ascontiguousarray(stream, np.uint16)
     staging = np.empty(n_cb * 4096, np.int32)
     sizes = np.empty(n_cb, np.int32)
-    lib().emu_unpack(_p(stream), n_cb, _p(staging), _p(sizes))
+    unpack.last_flag = int(lib().emu_unpack(_p(stream), n_cb, _p(staging), _p(sizes)))
     return staging, sizes

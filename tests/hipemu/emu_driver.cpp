@@ -172,14 +172,16 @@ int emu_pack(const int32_t *staging, const int32_t *sizes, int ncb, const uint16
     return total;
 }
 
-void emu_unpack(const uint16_t *stream, int ncb, int32_t *staging, int32_t *sizes)
+int emu_unpack(const uint16_t *stream, int ncb, int32_t *staging, int32_t *sizes)
 {
     std::vector<int32_t> offsets(ncb);
     int32_t total = 0;
+    int flag = 0;
     memset(staging, 0xFF, (size_t)ncb * 4096 * 4);
-    emu::launch(dim3((unsigned)((ncb + 255) / 256)), dim3(256), [&] { read_sizes_kernel(stream, ncb, sizes); });
+    emu::launch(dim3((unsigned)((ncb + 255) / 256)), dim3(256), [&] { read_sizes_kernel(stream, ncb, sizes, &flag); });
     emu::launch(dim3(1), dim3(1024), [&] { scan_sizes_kernel(sizes, ncb, offsets.data(), &total); });
     emu::launch(dim3((unsigned)ncb), dim3(256), [&] { unpack_kernel(stream, sizes, offsets.data(), ncb, staging); });
+    return flag;
 }
 
 }  // extern "C"

@@ -153,3 +153,18 @@ def test_complexity_scalable_files_roundtrip_and_oracle_parity(oracle, tmp_path,
     assert np.array_equal(out, oracle.decode_frame(ref, W, H, wl, lossy, qs, lut, k=float(kdec)))
     if not lossy:
         assert np.array_equal(out, img)
+
+
+FACADE = os.path.join(ROOT, "tests", "facade", "facade_demo")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lossy", [0, 1])
+def test_facade_classes_drive_the_library(oracle, lossy):
+    """include/picsong_facade.hpp: the reference's DWT<T,Y> / BPCCuda<T> classes over the C ABI, called
+    in the reference engines' order, give picsong_encode_frame's codestream and reconstruct the frame."""
+    if not os.path.exists(FACADE):
+        subprocess.check_call(["make", "-C", os.path.dirname(FACADE)])
+    lutdir = os.path.join(oracle.LUT_DIR, "n1_lossy" if lossy else "n1_lossless")
+    r = subprocess.run([FACADE, "600", "410", "4", str(lossy), "0.5", lutdir], capture_output=True, text=True)
+    assert r.returncode == 0 and "FACADE OK" in r.stdout, r.stdout + r.stderr

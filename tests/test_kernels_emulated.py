@@ -213,6 +213,26 @@ def test_pack_unpack_kernels(oracle, E):
     assert np.array_equal(sz2, sizes) and np.array_equal(st2, staging)
 
 
+def test_unpack_clamps_damaged_lengths(oracle, E):
+    """A codeblock length outside 1..4096 is clamped and flagged: nothing is written outside the
+    codeblock's own 4096 staging words."""
+    n_cb = 3
+    st = np.full(n_cb * 4096, -1, np.int32)
+    sz = np.array([5, 9, 3], np.int32)
+    for cb in range(n_cb):
+        st[cb * 4096] = 7
+        st[cb * 4096 + 1:cb * 4096 + sz[cb]] = np.arange(1, sz[cb]) + 100 * cb
+    stream = np.concatenate([oracle.bitstream_pack(st, sz), np.zeros(3 * 4096, np.uint16)])
+    good, gsz = E.unpack(stream, n_cb)
+    assert E.unpack.last_flag == 0 and np.array_equal(gsz, sz)
+    bad = stream.copy()
+    bad[10 + 2 * 1] = 60000                               # block 1 claims 60000 words
+    bad[10 + 2 * 2] = 0                                   # block 2 claims none
+    got, bsz = E.unpack(bad, n_cb)
+    assert E.unpack.last_flag == 1 and bsz.tolist() == [5, 4096, 1]
+    assert np.array_equal(got[:4096][:5], good[:5])       # block 0 untouched by its neighbours
+
+
 def test_whole_frame_codestream_identical_to_oracle(oracle, E):
     """u8 frame -> fused DWT -> BPC -> pack on the emulated kernels == oracle codestream, and the
     emulated decode path returns the input."""
