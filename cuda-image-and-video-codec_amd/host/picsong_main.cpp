@@ -6,22 +6,31 @@
 // not shipped) is not built
 // and are refused with a message instead of being silently ignored.
 //
-// Pipeline (video): `-numberOfStreams N` HIP streams, each with its own picsong_ctx, pinned host
-// frame buffer and device buffers; frame f runs on stream f mod N; while the GPU works on up to N
-// frames the host thread reads and pads the next one.  No spin-wait flag arrays (the reference's
-// _doubleBufferInput/_doubleBufferOutput, CodingEngine.cu:233-239): ordering comes from the
-// streams, completion from picsong_last_total()'s stream synchronisation.
+// Pipeline (video encode): the reference's reader / worker / writer structure
+// (CodingEngine.cu:212-262,463-498,758-1069) with condition variables instead of its spin-wait flag
+// arrays (_doubleBufferInput/_doubleBufferOutput, :233-239).  A ring of slots, each with its own
+// picsong_ctx, HIP stream, pinned host buffers and device buffers; frame f lives in slot f mod S
+// (S = max(-numberOfStreams, 3) + 3).  Two reader threads fill the pinned input buffers straight from
+// the file (pread), the main thread launches H2D copy + encode on the slot's stream, a collector
+// thread waits for the streams in frame order, copies the codestream back and fixes its file offset,
+// two writer threads pwrite the payloads; the _SIZE entries are appended in frame order at the end.
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <chrono>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/picsong_hip.h"
@@ -268,11 +277,14 @@ int run_encode(Options o)
     const long nframes = o.video ? o.frames : 1;
     if (nframes <= 0) die("Incorrect parameters. Please choose valid values. (-frames)");
     if (o.is_rgb) return run_encode_rgb(o, pgm.is_pgm ? pgm.offset : 0, nframes);
-    const int nstreams = o.video ? (o.streams < 1 ? 1 : o.streams) : 1;
+    // slots of the pipeline: at least 6 for a video (2 readers | launch | run | collect | 2 writers overlap)
+    const int nstreams = o.video ? ((o.streams < 3 ? 3 : o.streams) + 3) : 1;
 
     HIPCK(hipSetDevice(o.device));
     const int aw = picsong_pad_dim(o.x), ah = picsong_pad_dim(o.y);
     const size_t P = (size_t)aw * ah, max_shorts = picsong_max_stream_shorts(aw, ah);
+    const size_t frame_bytes = (size_t)o.x * o.y, file_base = pgm.is_pgm ? pgm.offset : 0;
+    const bool padded_already = (o.x == aw && o.y == ah);
     picsong_params params = make_params(o);
     std::vector<Worker> w((size_t)nstreams);
     for (auto &k : w) {
@@ -283,41 +295,173 @@ int run_encode(Options o)
         HIPCK(hipMalloc(&k.d_in, P));
         HIPCK(hipHostMalloc(&k.h_out, max_shorts * 2));
         HIPCK(hipMalloc(&k.d_out, max_shorts * 2));
-        k.h_raw = (uint8_t *)malloc((size_t)o.x * o.y);
+        k.h_raw = (uint8_t *)malloc(frame_bytes);
         CK(picsong_profile_begin(k.ctx, (int)((nframes + nstreams - 1) / nstreams)));
     }
-    std::ifstream in(o.input, std::ios::binary);
-    if (!in) die("Cannot open input file " + o.input);
+    const int fd = open(o.input.c_str(), O_RDONLY);
+    if (fd < 0) die("Cannot open input file " + o.input);
     // image: one truncating write (IOManager.ipp:615-620); video: append + _SIZE (:176-190)
-    std::ofstream out(o.output, std::ios::binary | (o.video ? std::ios::app : std::ios::trunc));
-    std::ofstream sizes;
-    if (o.video) sizes.open(o.output + "_SIZE", std::ios::binary | std::ios::app);
+    const int ofd = open(o.output.c_str(), O_WRONLY | O_CREAT | (o.video ? 0 : O_TRUNC), 0644);
+    if (ofd < 0) die("Cannot open output file " + o.output);
+    const off_t out_base = o.video ? lseek(ofd, 0, SEEK_END) : 0;
     long total_shorts = 0;
+    std::vector<int> frame_totals((size_t)nframes, 0);
     auto t0 = std::chrono::steady_clock::now();
 
-    auto finish = [&](Worker &k) {
-        if (k.frame < 0) return;
-        int total = 0;
-        CK(picsong_last_total(k.ctx, k.stream, &total));
-        HIPCK(hipMemcpyAsync(k.h_out, k.d_out, (size_t)total * 2, hipMemcpyDeviceToHost, k.stream));
-        HIPCK(hipStreamSynchronize(k.stream));
-        out.write(reinterpret_cast<const char *>(k.h_out), (std::streamsize)total * 2);
-        if (o.video) { if (k.frame == 0) sizes << total; else sizes << "," << total; }
-        total_shorts += total;
-        k.frame = -1;
+    // slot state machine: FREE -(reader)-> FILLED -(main)-> LAUNCHED -(collector)-> COLLECTED
+    // -(writer)-> FREE; `expect` is the frame the slot takes next, so frames f and f + S never race
+    enum { FREE = 0, FILLED = 1, LAUNCHED = 2, COLLECTED = 3 };
+    struct SlotState { int state = FREE; long expect = 0; off_t offset = 0; int total = 0; };
+    std::vector<SlotState> st((size_t)nstreams);
+    for (int i = 0; i < nstreams; i++) st[(size_t)i].expect = i;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::string failure;                      // first error of a helper thread (reported by main)
+    // where the host threads spend their time (reported with --metrics)
+    std::vector<double> t_read(16, 0.0);
+    double t_wait_gpu = 0.0, t_write = 0.0, t_main_wait = 0.0, t_launch = 0.0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double>(b - a).count(); };
+
+    auto reader = [&](int r, int nreaders) {
+        for (long f = r; f < nframes; f += nreaders) {
+            const size_t si = (size_t)(f % nstreams);
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !failure.empty() || (st[si].state == FREE && st[si].expect == f); });
+                if (!failure.empty()) return;
+            }
+            Worker &k = w[si];
+            uint8_t *dst = padded_already ? k.h_in : k.h_raw;
+            const auto tr0 = now();
+            size_t got = 0;
+            while (got < frame_bytes) {
+                ssize_t n = pread(fd, dst + got, frame_bytes - got, (off_t)(file_base + (size_t)f * frame_bytes + got));
+                if (n <= 0) break;
+                got += (size_t)n;
+            }
+            std::string err;
+            if (got != frame_bytes) err = "Input file is shorter than the requested frames.";
+            else if (!padded_already && picsong_pad_frame_host(k.h_raw, o.x, o.y, k.h_in, aw, ah) != PICSONG_OK)
+                err = picsong_last_error();
+            t_read[(size_t)r] += secs(tr0, now());
+            std::lock_guard<std::mutex> lk(mu);
+            if (!err.empty() && failure.empty()) failure = err;
+            st[si].state = FILLED;
+            cv.notify_all();
+        }
     };
+    // collector (one thread, frame order): waits for the frame's length and fixes its place in the
+    // file; writers (any order): copy the codestream back, pwrite it there and free the slot
+    auto collector = [&] {
+        (void)hipSetDevice(o.device);
+        off_t offset = out_base;
+        for (long f = 0; f < nframes; f++) {
+            const size_t si = (size_t)(f % nstreams);
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !failure.empty() || (st[si].state == LAUNCHED && st[si].expect == f); });
+                if (!failure.empty()) return;
+            }
+            Worker &k = w[si];
+            int total = 0;
+            std::string err;
+            const auto tw0 = now();
+            if (picsong_last_total(k.ctx, k.stream, &total) != PICSONG_OK) err = picsong_last_error();
+            t_wait_gpu += secs(tw0, now());
+            std::lock_guard<std::mutex> lk(mu);
+            if (!err.empty() && failure.empty()) failure = err;
+            frame_totals[(size_t)f] = total;
+            total_shorts += total;
+            st[si].offset = offset;
+            st[si].total = total;
+            st[si].state = COLLECTED;
+            offset += (off_t)total * 2;
+            cv.notify_all();
+        }
+    };
+    std::vector<double> t_write_v(8, 0.0);
+    auto writer = [&](int r, int nwriters) {
+        (void)hipSetDevice(o.device);
+        for (long f = r; f < nframes; f += nwriters) {
+            const size_t si = (size_t)(f % nstreams);
+            off_t offset;
+            int total;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !failure.empty() || (st[si].state == COLLECTED && st[si].expect == f); });
+                if (!failure.empty()) return;
+                offset = st[si].offset; total = st[si].total;
+            }
+            const auto tw1 = now();
+            const char *src = reinterpret_cast<const char *>(w[si].h_out);
+            size_t left = (size_t)total * 2, done = 0;
+            std::string err;
+            if (hipMemcpyAsync(w[si].h_out, w[si].d_out, left, hipMemcpyDeviceToHost, w[si].stream) != hipSuccess ||
+                hipStreamSynchronize(w[si].stream) != hipSuccess) {
+                err = "HIP error while copying a codestream back";
+                left = 0;
+            }
+            while (left) {
+                ssize_t n = pwrite(ofd, src + done, left, offset + (off_t)done);
+                if (n <= 0) { err = "Cannot write the output file " + o.output; break; }
+                done += (size_t)n; left -= (size_t)n;
+            }
+            t_write_v[(size_t)r] += secs(tw1, now());
+            std::lock_guard<std::mutex> lk(mu);
+            if (!err.empty() && failure.empty()) failure = err;
+            st[si].state = FREE;
+            st[si].expect = f + nstreams;
+            cv.notify_all();
+        }
+    };
+    int nreaders = nframes > 1 ? 2 : 1;
+    if (const char *e = getenv("PICSONG_READERS")) { int v = atoi(e); if (v >= 1 && v <= 16) nreaders = v; }
+    if (nreaders > nstreams - 1 && nstreams > 1) nreaders = nstreams - 1;
+    std::vector<std::thread> threads;
+    for (int r = 0; r < nreaders; r++) threads.emplace_back(reader, r, nreaders);
+    int nwriters = nframes > 1 ? 2 : 1;
+    if (const char *e = getenv("PICSONG_WRITERS")) { int v = atoi(e); if (v >= 1 && v <= 8) nwriters = v; }
+    threads.emplace_back(collector);
+    for (int r = 0; r < nwriters; r++) threads.emplace_back(writer, r, nwriters);
     for (long f = 0; f < nframes; f++) {
-        Worker &k = w[(size_t)(f % nstreams)];
-        finish(k);
-        if (!read_frame(in, pgm.is_pgm ? pgm.offset : 0, (size_t)f, o.x, o.y, k.h_raw)) die("Input file is shorter than the requested frames.");
-        CK(picsong_pad_frame_host(k.h_raw, o.x, o.y, k.h_in, aw, ah));
-        HIPCK(hipMemcpyAsync(k.d_in, k.h_in, P, hipMemcpyHostToDevice, k.stream));
-        CK(picsong_encode_frame(k.ctx, k.d_in, f == 0 ? 0 : 1, k.d_out, k.stream));
-        k.frame = f;
+        const size_t si = (size_t)(f % nstreams);
+        const auto tm0 = now();
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !failure.empty() || (st[si].state == FILLED && st[si].expect == f); });
+            if (!failure.empty()) break;
+        }
+        const auto tm1 = now();
+        t_main_wait += secs(tm0, tm1);
+        Worker &k = w[si];
+        std::string err;
+        if (hipMemcpyAsync(k.d_in, k.h_in, P, hipMemcpyHostToDevice, k.stream) != hipSuccess) err = "HIP error in the frame upload";
+        else if (picsong_encode_frame(k.ctx, k.d_in, f == 0 ? 0 : 1, k.d_out, k.stream) != PICSONG_OK) err = picsong_last_error();
+        t_launch += secs(tm1, now());
+        std::lock_guard<std::mutex> lk(mu);
+        if (!err.empty() && failure.empty()) failure = err;
+        st[si].state = LAUNCHED;
+        cv.notify_all();
     }
-    // drain in frame order
-    for (long f = nframes - nstreams < 0 ? 0 : nframes - nstreams; f < nframes; f++) finish(w[(size_t)(f % nstreams)]);
+    for (auto &t : threads) t.join();
+    close(fd);
+    close(ofd);
+    if (!failure.empty()) die(failure);
+    if (o.video) {
+        // IOManager.ipp:176-190: lengths in shorts, comma separated, appended in frame order
+        std::ofstream sizes(o.output + "_SIZE", std::ios::binary | std::ios::app);
+        for (long f = 0; f < nframes; f++) { if (f) sizes << ","; sizes << frame_totals[(size_t)f]; }
+    }
+    for (double v : t_write_v) t_write += v;
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!o.metrics.empty()) {
+        double rd = 0; for (double v : t_read) rd += v;
+        std::cout << "host pipeline seconds: read(sum of " << nreaders << " readers) " << rd << ", main waiting for frames "
+                  << t_main_wait << ", main launching " << t_launch << ", writer waiting for the GPU " << t_wait_gpu
+                  << ", writer writing " << t_write << std::endl;
+    }
 
     double dwt = 0, bpc = 0, pack = 0;
     long counted = 0;
