@@ -547,6 +547,142 @@ int run_decode_rgb(const Options &o, const picsong_params &p, picsong_ctx *ctx, 
     return 0;
 }
 
+// ---- video decode pipeline (DecodingEngine::runVideo, Engines/DecodingEngine.cu:866-1141: reader,
+// worker and writer threads).  Every offset is known up front (the _SIZE sidecar gives the stream
+// chunks, frames are W*H bytes), so: two reader threads pread chunks into pinned buffers, the main
+// thread launches H2D + decode + D2H on the slot's stream, two writer threads wait for their slot's
+// stream, crop and pwrite the frame at f * W * H (IOManager::writeDecodedFrame IO/IOManager.ipp:214-231
+// appends raw W*H bytes per frame).
+int run_decode_video(const Options &o, const picsong_params &p, const std::vector<long> &frame_shorts, long nframes)
+{
+    const int aw = picsong_pad_dim(p.width), ah = picsong_pad_dim(p.height);
+    const size_t P = (size_t)aw * ah, max_shorts = picsong_max_stream_shorts(aw, ah);
+    const size_t frame_bytes = (size_t)p.width * p.height;
+    const int nslots = (o.streams < 3 ? 3 : o.streams) + 3;
+    struct Slot {
+        picsong_ctx *ctx = nullptr; hipStream_t stream = nullptr;
+        uint16_t *h_in = nullptr, *d_in = nullptr; uint8_t *h_pix = nullptr, *d_pix = nullptr;
+        std::vector<uint8_t> crop;
+        int state = 0; long expect = 0;
+    };
+    enum { FREE = 0, FILLED = 1, LAUNCHED = 2 };
+    std::vector<Slot> sl((size_t)nslots);
+    for (int i = 0; i < nslots; i++) {
+        Slot &k = sl[(size_t)i];
+        CK(picsong_ctx_create(&p, o.device, &k.ctx));
+        load_lut(k.ctx, o, p.wl, 1, p.k);
+        HIPCK(hipStreamCreate(&k.stream));
+        HIPCK(hipHostMalloc(&k.h_in, max_shorts * 2));
+        HIPCK(hipMalloc(&k.d_in, max_shorts * 2));
+        HIPCK(hipHostMalloc(&k.h_pix, P));
+        HIPCK(hipMalloc(&k.d_pix, P));
+        if (aw != p.width) k.crop.resize(frame_bytes);
+        k.expect = i;
+    }
+    std::vector<size_t> in_off((size_t)nframes + 1, 0);
+    for (long f = 0; f < nframes; f++) {
+        if ((size_t)frame_shorts[(size_t)f] > max_shorts) die("Frame codestream longer than the maximum for this geometry.");
+        in_off[(size_t)f + 1] = in_off[(size_t)f] + (size_t)frame_shorts[(size_t)f];
+    }
+    const int ifd = open(o.input.c_str(), O_RDONLY);
+    if (ifd < 0) die("Cannot open input file " + o.input);
+    const int ofd = open(o.output.c_str(), O_WRONLY | O_CREAT, 0644);
+    if (ofd < 0) die("Cannot open output file " + o.output);
+    const off_t out_base = lseek(ofd, 0, SEEK_END);          // appended, like the reference
+    std::mutex mu;
+    std::condition_variable cv;
+    std::string failure;
+    auto t0 = std::chrono::steady_clock::now();
+
+    auto reader = [&](int r, int nreaders) {
+        for (long f = r; f < nframes; f += nreaders) {
+            Slot &k = sl[(size_t)(f % nslots)];
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !failure.empty() || (k.state == FREE && k.expect == f); });
+                if (!failure.empty()) return;
+            }
+            const size_t bytes = (size_t)frame_shorts[(size_t)f] * 2;
+            size_t got = 0;
+            while (got < bytes) {
+                ssize_t n = pread(ifd, reinterpret_cast<char *>(k.h_in) + got, bytes - got, (off_t)(in_off[(size_t)f] * 2 + got));
+                if (n <= 0) break;
+                got += (size_t)n;
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            if (got != bytes && failure.empty()) failure = "Input file is shorter than its _SIZE sidecar says.";
+            k.state = FILLED;
+            cv.notify_all();
+        }
+    };
+    auto writer = [&](int r, int nwriters) {
+        (void)hipSetDevice(o.device);
+        for (long f = r; f < nframes; f += nwriters) {
+            Slot &k = sl[(size_t)(f % nslots)];
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !failure.empty() || (k.state == LAUNCHED && k.expect == f); });
+                if (!failure.empty()) return;
+            }
+            std::string err;
+            if (hipStreamSynchronize(k.stream) != hipSuccess) err = "HIP error while decoding a frame";
+            const uint8_t *src = k.h_pix;
+            if (err.empty() && aw != p.width) {
+                for (int y = 0; y < p.height; y++) memcpy(&k.crop[(size_t)y * p.width], k.h_pix + (size_t)y * aw, (size_t)p.width);
+                src = k.crop.data();
+            }
+            size_t left = err.empty() ? frame_bytes : 0, done = 0;
+            while (left) {
+                ssize_t n = pwrite(ofd, src + done, left, out_base + (off_t)((size_t)f * frame_bytes + done));
+                if (n <= 0) { err = "Cannot write the output file " + o.output; break; }
+                done += (size_t)n; left -= (size_t)n;
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            if (!err.empty() && failure.empty()) failure = err;
+            k.state = FREE;
+            k.expect = f + nslots;
+            cv.notify_all();
+        }
+    };
+    const int nreaders = 2, nwriters = 2;
+    std::vector<std::thread> threads;
+    for (int r = 0; r < nreaders; r++) threads.emplace_back(reader, r, nreaders);
+    for (int r = 0; r < nwriters; r++) threads.emplace_back(writer, r, nwriters);
+    for (long f = 0; f < nframes; f++) {
+        Slot &k = sl[(size_t)(f % nslots)];
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !failure.empty() || (k.state == FILLED && k.expect == f); });
+            if (!failure.empty()) break;
+        }
+        std::string err;
+        if (hipMemcpyAsync(k.d_in, k.h_in, (size_t)frame_shorts[(size_t)f] * 2, hipMemcpyHostToDevice, k.stream) != hipSuccess)
+            err = "HIP error in the codestream upload";
+        else if (picsong_decode_frame(k.ctx, k.d_in, k.d_pix, k.stream) != PICSONG_OK) err = picsong_last_error();
+        else if (hipMemcpyAsync(k.h_pix, k.d_pix, P, hipMemcpyDeviceToHost, k.stream) != hipSuccess)
+            err = "HIP error in the frame download";
+        std::lock_guard<std::mutex> lk(mu);
+        if (!err.empty() && failure.empty()) failure = err;
+        k.state = LAUNCHED;
+        cv.notify_all();
+    }
+    for (auto &t : threads) t.join();
+    close(ifd);
+    close(ofd);
+    if (!failure.empty()) die(failure);
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::cout << "The time spent with the app without considering allocation periods and I/O is: " << sec << std::endl;
+    Options mo = o;
+    mo.x = p.width; mo.y = p.height;
+    write_metrics(mo, "decode", nframes, sec, 0, 0, 0, (long)in_off[(size_t)nframes]);
+    for (auto &k : sl) {
+        picsong_ctx_destroy(k.ctx);
+        (void)hipStreamDestroy(k.stream);
+        (void)hipHostFree(k.h_in); (void)hipFree(k.d_in); (void)hipHostFree(k.h_pix); (void)hipFree(k.d_pix);
+    }
+    return 0;
+}
+
 int run_decode(const Options &o)
 {
     if (o.input.empty() || o.output.empty()) die("Incorrect parameters. Please choose valid values.");
@@ -580,6 +716,11 @@ int run_decode(const Options &o)
     int aw, ah, ncb;
     CK(picsong_ctx_padded_dims(ctx, &aw, &ah, &ncb));
     if (p.is_rgb) return run_decode_rgb(o, p, ctx, in, frame_shorts, nframes, aw, ah);
+    if (o.video) {
+        picsong_ctx_destroy(ctx);
+        in.close();
+        return run_decode_video(lo, p, frame_shorts, nframes);
+    }
     const size_t P = (size_t)aw * ah, max_shorts = picsong_max_stream_shorts(aw, ah);
     hipStream_t s;
     HIPCK(hipStreamCreate(&s));
