@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void clamp_to_u8_i32_kernel(const int32_t *in,
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const uint4 w = reinterpret_cast<const uint4 *>(in)[i];
-        const int v[4] = { (int)w.x + off, (int)w.y + off, (int)w.z + off, (int)w.w + off };
+        int v[4] = { (int)w.x + off, (int)w.y + off, (int)w.z + off, (int)w.w + off };
         uint32_t o = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) o |= (uint32_t)(v[k] > 255 ? 255 : (v[k] < 0 ? 0 : v[k])) << (8 * k);
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256) void clamp_to_u8_f32_kernel(const float *in, u
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const uint4 w = reinterpret_cast<const uint4 *>(in)[i];
-        const float v[4] = { __uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w) };
+        float v[4] = { __uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w) };
         uint32_t o = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {

@@ -9,12 +9,19 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU_DIR = os.path.join(ROOT, "tests", "hipemu")
 SO_PATH = os.path.join(EMU_DIR, "_build", "libpicsong_emu.so")
+# PICSONG_EMU_SO: run the emulated tests on another build of the same sources (tools/sanitize_emu.sh:
+# -fsanitize=undefined / address builds, with the sanitizer runtime preloaded)
+SO_OVERRIDE = os.environ.get("PICSONG_EMU_SO")
 _lib = None
 
 
 def lib():
     global _lib
     if _lib is None:
+        if SO_OVERRIDE:
+            _lib = C.CDLL(SO_OVERRIDE)
+            _lib.emu_pack.restype = C.c_int
+            return _lib
         subprocess.check_call(["make", "-C", EMU_DIR, "-s"])
         _lib = C.CDLL(SO_PATH)
         _lib.emu_pack.restype = C.c_int

@@ -142,7 +142,8 @@ static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v)
     return (unsigned)emu::collective(emu::OP_READFIRST, v, 0, 0);
 }
 static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
-static inline int __mul24(int a, int b) { return (int)(((a << 8) >> 8) * (long long)((b << 8) >> 8)); }
+static inline int emu_sext24(int v) { return (int)((((unsigned)v & 0xFFFFFFu) ^ 0x800000u)) - 0x800000; }
+static inline int __mul24(int a, int b) { return (int)(unsigned)((long long)emu_sext24(a) * (long long)emu_sext24(b)); }
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __syncthreads() { emu::barrier(); }
