@@ -123,6 +123,20 @@ __device__ __forceinline__ uint32_t lut_at(const int32_t *lut, int idx, int tota
     return (uint32_t)lut[idx] & 0xFFu;
 }
 
+// S * p of the interval update: S < 2^16, p < 2^8.  Spelled as the instruction because the optimiser,
+// once it knows p is a byte (refinement probability straight from the LDS table), rewrites the 24-bit
+// multiply intrinsic into a generic 32-bit multiply and then selects the quarter-rate v_mul_lo_u32.
+__device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b)
+{
+#if defined(__AMDGCN__)
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return __umul24(a, b);          // CPU wave-emulator build of this header (tests/hipemu)
+#endif
+}
+
 // Per-lane arithmetic coder state (arithmeticEncoder/Decoder BPCEngine.cu:371-442).
 struct Coder {
     uint32_t L, S;      // interval lower bound / size
@@ -279,7 +293,7 @@ __device__ __forceinline__ void reserve_enc(Coder &c, bool need, uint64_t m, uin
 {
     const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
     const uint32_t nlo = (uint32_t)__builtin_popcount(mlo), nhi = (uint32_t)__builtin_popcount(mhi);
-    const uint32_t base = upper_mask ? c.cnt_hi - nlo : c.cnt_lo;
+    const uint32_t base = c.cnt_lo + (upper_mask & (c.cnt_hi - nlo - c.cnt_lo));      // v_and + v_add, scalars folded by SALU
     uint32_t s = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, base));
     s = s > 4094u ? 4094u : s;
     if (need) { c.L = 0u; c.S = 0xFFFFu; c.slot = s; }
@@ -292,26 +306,27 @@ __device__ __forceinline__ void reserve_enc(Coder &c, bool need, uint64_t m, uin
 // site out.  VALU instructions are what this kernel is bound by (SALU issues beside them), so: the
 // need-ballot is two compares whose masks are ANDed by SALU (the inact compare is the one the exec
 // region below needs anyway), the state update runs inside an exec-masked region (no selects for
-// idle lanes), and the interval update uses 24-bit mads:
-//   a = ((S*p) >> prec) + sym;  S' = sym ? S - a : a = a + sym*(S - 2a);  L' = L + sym*a.
-__device__ __forceinline__ void enc_site_on(Coder &c, bool on, uint32_t sym, uint32_t p, uint32_t prec,
+// idle lanes):  a = ((S*p) >> prec) + sym;  S' = sym ? S - a : a;  L' = L + sym*a.
+// onm = ballot(on): the callers have it already (they skip the site when it is 0); handing it over
+// keeps `on` a lane mask in SGPRs instead of a 0/1 VGPR that has to be compared again.
+__device__ __forceinline__ void enc_site_on(Coder &c, bool on, uint64_t onm, uint32_t sym, uint32_t p, uint32_t prec,
                                             uint32_t upper_mask, int32_t *st)
 {
     const bool empty = c.S == 0u;
-    const uint64_t m = __builtin_amdgcn_ballot_w64(empty) & __builtin_amdgcn_ballot_w64(on);
+    const uint64_t m = __builtin_amdgcn_ballot_w64(empty) & onm;
     if (m != 0ull) reserve_enc(c, on && empty, m, upper_mask);
     if (on) {
-        const uint32_t a = (__umul24(c.S, p) >> prec) + sym;
-        const int32_t t = (int32_t)(c.S - a) - (int32_t)a;                  // S - 2a, |t| < 2^17
-        c.S = (uint32_t)(__mul24((int32_t)sym, t) + (int32_t)a);
+        const uint32_t a = (mul_u24(c.S, p) >> prec) + sym;
+        c.S = sym != 0u ? c.S - a : a;          // v_sub + v_cndmask (a 24-bit mad form costs two shifts more)
         c.L = __umul24(sym, a) + c.L;
-        if (c.S == 0u) st[1u + c.slot] = (int32_t)c.L;
+        if (c.S == 0u) st[c.slot] = (int32_t)c.L;         // st = the codeblock's codeword array (staging + 1)
     }
 }
 __device__ __forceinline__ void enc_site(Coder &c, uint32_t inact, uint32_t sym, uint32_t p, uint32_t prec,
                                          uint32_t upper_mask, int32_t *st)
 {
-    enc_site_on(c, inact == 0u, sym, p, prec, upper_mask, st);
+    const bool on = inact == 0u;
+    enc_site_on(c, on, __builtin_amdgcn_ballot_w64(on), sym, p, prec, upper_mask, st);
 }
 
 // Context masks are kept pre-rotated (n1 by 1, n2 and n3 by 2 bits; sign bits c1 by 3, c2 by 4) so
@@ -332,13 +347,15 @@ __device__ __forceinline__ void enc_spp_coeff(Coder &c, uint32_t ii, uint32_t A,
     const uint32_t p07 = __builtin_amdgcn_perm(pl.sig1, pl.sig0, sel);
     // context 8 (n3 set => n0 = n1 = n2 = 0): a second byte select takes p8 (byte 4) instead of p07
     const uint32_t p = __builtin_amdgcn_perm(pl.sig8, p07, (rotr32(cp.n3, ii) & 4u) | 0x0C0C0C00u);
-    enc_site_on(c, on, sym, p, prec, upper_mask, st);
-    const bool on2 = on && sym != 0u;                       // one compare; the AND of the masks is SALU
-    if (__builtin_amdgcn_ballot_w64(on2) != 0ull) {
+    const uint64_t onm = __builtin_amdgcn_ballot_w64(on);
+    enc_site_on(c, on, onm, sym, p, prec, upper_mask, st);
+    const bool one = sym != 0u, on2 = on && one;            // one compare; the masks are ANDed by SALU
+    const uint64_t on2m = onm & __builtin_amdgcn_ballot_w64(one);
+    if (on2m != 0ull) {
         // bit offset of the sign probability inside pl.sign = 8 * (c >> 1)
         const uint32_t off = (rotr32(cp.c2, ii) & 16u) | (rotr32(cp.c1, ii) & 8u);
         const uint32_t p2 = (pl.sign >> off) & 0xFFu;
-        enc_site_on(c, on2, (cp.s2 >> ii) & 1u, p2, prec, upper_mask, st);
+        enc_site_on(c, on2, on2m, (cp.s2 >> ii) & 1u, p2, prec, upper_mask, st);
     }
 }
 
@@ -517,6 +534,7 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
     const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
     const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
     int32_t *st = a.staging + (size_t)(valid ? cb : a.cb_base) * 4096u;
+    int32_t *cw = st + 1;                                   // codeword array: slot k lives at st[1 + k]
     const uint32_t prec = (uint32_t)a.g.prec;
 
     uint32_t PLlo[kMaxPlanes], PLhi[kMaxPlanes], PRlo[kMaxPlanes], PRhi[kMaxPlanes];
@@ -628,8 +646,8 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
             while (rows) {
                 const uint32_t ii = (uint32_t)__builtin_ctz(rows);
                 rows &= rows - 1u;
-                enc_spp_coeff(c, ii, al, bl, cpL, pl, prec, upper_mask, st);
-                enc_spp_coeff(c, ii, ar, br, cpR, pl, prec, upper_mask, st);
+                enc_spp_coeff(c, ii, al, bl, cpL, pl, prec, upper_mask, cw);
+                enc_spp_coeff(c, ii, ar, br, cpR, pl, prec, upper_mask, cw);
             }
         }
         // ---- magnitude refinement pass: coefficients significant before this plane
@@ -642,8 +660,9 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
                 const uint32_t ii = (uint32_t)__builtin_ctz(rows);
                 rows &= rows - 1u;
                 const bool oL = ((ml >> ii) & 1u) != 0u, oR = ((mr >> ii) & 1u) != 0u;
-                if (__builtin_amdgcn_ballot_w64(oL) != 0ull) enc_site_on(c, oL, (bl >> ii) & 1u, pl.ref, prec, upper_mask, st);
-                if (__builtin_amdgcn_ballot_w64(oR) != 0ull) enc_site_on(c, oR, (br >> ii) & 1u, pl.ref, prec, upper_mask, st);
+                const uint64_t mL = __builtin_amdgcn_ballot_w64(oL), mR = __builtin_amdgcn_ballot_w64(oR);
+                if (mL != 0ull) enc_site_on(c, oL, mL, (bl >> ii) & 1u, pl.ref, prec, upper_mask, cw);
+                if (mR != 0ull) enc_site_on(c, oR, mR, (br >> ii) & 1u, pl.ref, prec, upper_mask, cw);
             }
         }
         AL = AL2; AR = AR2;
@@ -685,7 +704,7 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
                 if (i < 63) row_words(i + 1, n0, n1); else { n0 = 0u; n1 = 0u; }
                 bulk_row<false>(c, t, unp(c0), unp(c1), (c0 >> 1) & lowmask, (c1 >> 1) & lowmask,
                                 i < 63 ? unp(n0) : 0u, i < 63 ? unp(n1) : 0u, pUL, pUR, bl, Bmax, prec,
-                                upper_mask, st);
+                                upper_mask, cw);
                 c0 = n0; c1 = n1;
             }
         }
@@ -736,11 +755,11 @@ __device__ __forceinline__ uint32_t dec_site(Coder &c, uint32_t inact, uint32_t 
     const uint64_t m = __builtin_amdgcn_ballot_w64(empty) & __builtin_amdgcn_ballot_w64(on);
     if (m != 0ull) {
         reserve_enc(c, on && empty, m, upper_mask);
-        if (on && empty) c.cw = (uint32_t)stage[1u + c.slot];
+        if (on && empty) c.cw = (uint32_t)stage[c.slot];   // stage = the codeword array (staging + 1)
     }
     uint32_t sym = 0u;
     if (on) {
-        const uint32_t a = (__umul24(c.S, p) >> prec) + 1u;
+        const uint32_t a = (mul_u24(c.S, p) >> prec) + 1u;
         const uint32_t a2 = c.L + a;
         const bool ge = c.cw >= a2;
         c.S = ge ? c.S - a : a - 1u;
@@ -797,6 +816,7 @@ __global__ __launch_bounds__(64, 4) void bpc_decode_kernel(BpcArgs a)
     const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
     const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
     const int32_t *stage = a.staging + (size_t)(valid ? cb : a.cb_base) * 4096u;
+    const int32_t *cw = stage + 1;                          // codeword array: slot k lives at stage[1 + k]
     const uint32_t prec = (uint32_t)a.g.prec;
     const uint32_t upper_mask = half ? 0xFFFFFFFFu : 0u;
 
@@ -865,14 +885,14 @@ __global__ __launch_bounds__(64, 4) void bpc_decode_kernel(BpcArgs a)
                 const uint32_t ii = (uint32_t)__builtin_ctz(rows);
                 rows &= rows - 1u;
                 // all lanes: left column, neighbours = lane-1's right column | own right column
-                const uint32_t bL = dec_spp_coeff(c, idle, ii, wL, wPR, wR, sL, sPR, sR, curL, pl, prec, upper_mask, stage);
+                const uint32_t bL = dec_spp_coeff(c, idle, ii, wL, wPR, wR, sL, sPR, sR, curL, pl, prec, upper_mask, cw);
                 // lane+1's left column as it is after this row's left phase (:791, shfl_down)
                 if (__builtin_amdgcn_ballot_w64(bL != 0u) != 0ull) {
                     wNL.lo = from_next32(wL.lo, t); wNL.hi = from_next32(wL.hi, t);
                     sNL.lo = from_next32(sL.lo, t); sNL.hi = from_next32(sL.hi, t);
                 }
                 // all lanes: right column, neighbours = own left column | lane+1's left column
-                const uint32_t bR = dec_spp_coeff(c, idle, ii, wR, wL, wNL, sR, sL, sNL, curR, pl, prec, upper_mask, stage);
+                const uint32_t bR = dec_spp_coeff(c, idle, ii, wR, wL, wNL, sR, sL, sNL, curR, pl, prec, upper_mask, cw);
                 // lane-1's right column as it is after this row's right phase (:804, shfl_up)
                 if (__builtin_amdgcn_ballot_w64(bR != 0u) != 0ull) {
                     wPR.lo = from_prev32(wR.lo, t); wPR.hi = from_prev32(wR.hi, t);
@@ -898,9 +918,9 @@ __global__ __launch_bounds__(64, 4) void bpc_decode_kernel(BpcArgs a)
                 rows &= rows - 1u;
                 const uint32_t iL = ((rL >> ii) & 1u) ^ 1u, iR = ((rR >> ii) & 1u) ^ 1u;
                 if (__builtin_amdgcn_ballot_w64(iL == 0u) != 0ull)
-                    curL |= dec_site(c, iL, pl.ref, prec, upper_mask, stage) << ii;
+                    curL |= dec_site(c, iL, pl.ref, prec, upper_mask, cw) << ii;
                 if (__builtin_amdgcn_ballot_w64(iR == 0u) != 0ull)
-                    curR |= dec_site(c, iR, pl.ref, prec, upper_mask, stage) << ii;
+                    curR |= dec_site(c, iR, pl.ref, prec, upper_mask, cw) << ii;
             }
             if (hw == 0) { PLlo[0] = curL; PRlo[0] = curR; } else { PLhi[0] = curL; PRhi[0] = curR; }
         }
@@ -923,7 +943,7 @@ __global__ __launch_bounds__(64, 4) void bpc_decode_kernel(BpcArgs a)
             const uint32_t uL = unp(sigL, sgnL, i), uR = unp(sigR, sgnR, i);
             if (Bmax >= 0)
                 bulk_row<true>(c, t, uL, uR, 0u, 0u, unp(sigL, sgnL, i + 1), unp(sigR, sgnR, i + 1), pUL, pUR, bl,
-                               Bmax, prec, upper_mask, const_cast<int32_t *>(stage));
+                               Bmax, prec, upper_mask, const_cast<int32_t *>(cw));
             else { pUL = uL; pUR = uR; }
             if (!valid) continue;
             int32_t v0, v1;
