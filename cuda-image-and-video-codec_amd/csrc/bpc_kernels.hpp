@@ -298,8 +298,10 @@ __device__ __forceinline__ void reserve_enc(Coder &c, bool need, uint64_t m, uin
     s = s > 4094u ? 4094u : s;
     if (need) { c.L = 0u; c.S = 0xFFFFu; c.slot = s; }
     const uint32_t a = c.cnt_lo + nlo, b = c.cnt_hi + nhi;
-    c.cnt_lo = a > 4095u ? 4095u : a;
-    c.cnt_hi = b > 4095u ? 4095u : b;
+    // (readfirstlane: states the uniformity; without it the decoder's counters ended up as per-lane
+    // VGPR values updated by a dozen vector instructions at every call site)
+    c.cnt_lo = __builtin_amdgcn_readfirstlane(a > 4095u ? 4095u : a);
+    c.cnt_hi = __builtin_amdgcn_readfirstlane(b > 4095u ? 4095u : b);
 }
 
 // arithmeticEncoder BPCEngine.cu:371-399, one call site; `inact` = 1 for lanes that sit this call
