@@ -521,8 +521,12 @@ __device__ __forceinline__ int bulk_setup(const BpcArgs &a, bool coded, int msb,
     return cbp;
 }
 
+// Waves per SIMD the register allocator must leave room for.  Measured on MI355X, 8K frames, frames
+// in flight on 2 / 3 streams: 4 waves (128 VGPRs, 14 spilled) 87 / 83 Gpixel/s and the shortest single
+// launch (0.45 ms); 5 waves (96 VGPRs) 87 / 91 Gpixel/s, single launch 0.52 ms; 6 and 8 waves lose to
+// spill traffic (84 / 83 at best).  The pipelined throughput is the figure of merit: 5.
 #ifndef PICSONG_BPC_ENC_WAVES
-#define PICSONG_BPC_ENC_WAVES 4        // waves per SIMD the register allocator must leave room for
+#define PICSONG_BPC_ENC_WAVES 5
 #endif
 // BULK = the -k > 0 instantiation (bulk scan after the ordinary planes, table s of the bit-plane
 // LUT files, LDS copy of that table); the k = 0 instantiation compiles to the plain coder.
