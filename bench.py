@@ -271,8 +271,11 @@ def main():
                 "single_stream": {"avg_launch_ms": round(float(iso_ms[1]), 4),
                                   "codeblocks_per_s": round(nCB / (float(iso_ms[1]) * 1e-3), 1)},
                 "valu_issue": valu_issue(pmc_valu(args.workload), dt / args.steps, float(iso_ms[1]) * 1e-3),
-                "note": "BPC is integer/latency-bound, not HBM-bound (SURVEY 8d): codeblocks/s is "
-                        "the figure of merit; the HBM fraction is reported for completeness"}
+                "note": "BPC is bound by vector-instruction issue, not HBM (SURVEY 8d): codeblocks/s and "
+                        "valu_issue are the figures of merit, the HBM fraction is reported for completeness; "
+                        "`traffic` (PMC) exceeds the algorithmic bytes because the coefficients are read twice "
+                        "(MSB search, then bit-plane transposition) and the 96-VGPR build (5 waves/SIMD, the "
+                        "faster one when frames are pipelined) spills ~50 dwords per lane to scratch"}
     roofline_dwt = {"kernel": "dwt_fwd_kernel (all levels, u8 ingest fused)", "bound": "hbm",
                     "achieved": round(dwt_b / (dwt_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(dwt_b / (dwt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
