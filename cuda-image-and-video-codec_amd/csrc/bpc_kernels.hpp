@@ -26,7 +26,13 @@
 
 namespace picsong {
 
-constexpr int kMaxPlanes = 16;     // bit-planes held per column: supports MSB <= 15
+constexpr int kMaxPlanes = 16;     // bit-planes a codeblock may have: supports MSB <= 15
+// The encoder keeps the 8 topmost planes of its two columns in registers (32 VGPRs); the planes below
+// them -- only codeblocks with MSB >= 8 have any -- wait in a scratch array in HBM (8 KB per wave,
+// written once after the transposition, one plane read back per plane step).  With all 16 in
+// registers the kernel needed 128 VGPRs (4 waves/SIMD) or spilled ~50 dwords per lane at 96.
+constexpr int kEncRegPlanes = 8;
+constexpr int kEncScratchDwordsPerWave = (kMaxPlanes - kEncRegPlanes) * 4 * 64;
 
 struct LutGeo {
     int nBp, nSub, cRef, cSign, cSig, prec;
@@ -44,6 +50,7 @@ struct BpcArgs {
     int32_t *staging;              // int32[nCB*4096]
     int32_t *sizes;                // int32[nCB]
     int *range_flag;               // set to 1 if a codeblock has MSB > 15
+    uint32_t *plane_scratch;       // encoder: kEncScratchDwordsPerWave dwords per workgroup of the launch
     float k;                       // complexity-scalability factor (-k); > 0 only in BULK kernels
     int n_tables;                  // bit-plane tables laid back to back in `lut` (1 when k = 0)
 };
@@ -543,9 +550,9 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
     int32_t *cw = st + 1;                                   // codeword array: slot k lives at st[1 + k]
     const uint32_t prec = (uint32_t)a.g.prec;
 
-    uint32_t PLlo[kMaxPlanes], PLhi[kMaxPlanes], PRlo[kMaxPlanes], PRhi[kMaxPlanes];
+    uint32_t PLlo[kEncRegPlanes], PLhi[kEncRegPlanes], PRlo[kEncRegPlanes], PRhi[kEncRegPlanes];
 #pragma unroll
-    for (int k = 0; k < kMaxPlanes; k++) { PLlo[k] = PLhi[k] = PRlo[k] = PRhi[k] = 0u; }
+    for (int k = 0; k < kEncRegPlanes; k++) { PLlo[k] = PLhi[k] = PRlo[k] = PRhi[k] = 0u; }
     U64 sgL = { 0u, 0u }, sgR = { 0u, 0u };
 
     // ---- findMSB (BPCEngine.cu:176-192)
@@ -604,7 +611,7 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
                 if (hw == 0) { sgL.lo |= n0 << ii; sgR.lo |= n1 << ii; }
                 else         { sgL.hi |= n0 << ii; sgR.hi |= n1 << ii; }
 #pragma unroll
-                for (int k = 0; k < kMaxPlanes; k++) {
+                for (int k = 0; k < kEncRegPlanes; k++) {
                     if (k < np) {
                         uint32_t b0 = (m0 >> (kMaxPlanes - 1 - k)) & 1u;
                         uint32_t b1 = (m1 >> (kMaxPlanes - 1 - k)) & 1u;
@@ -612,6 +619,48 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
                         else         { PLhi[k] |= b0 << ii; PRhi[k] |= b1 << ii; }
                     }
                 }
+            }
+        }
+    }
+    // planes below the 8 held in registers (a codeblock with MSB >= 8 in the wave): one more pass over
+    // the rows builds them in registers that are free until the plane loop, then parks them in HBM;
+    // slot j = plane kEncRegPlanes + j, layout [slot][4][lane] so that every access is a 256-byte row
+    uint32_t *const pscr = a.plane_scratch + (size_t)blockIdx.x * (size_t)kEncScratchDwordsPerWave + lane;
+    if (np > kEncRegPlanes) {
+        uint32_t Tl[kMaxPlanes - kEncRegPlanes][2], Tr[kMaxPlanes - kEncRegPlanes][2];
+#pragma unroll
+        for (int j = 0; j < kMaxPlanes - kEncRegPlanes; j++) { Tl[j][0] = Tl[j][1] = Tr[j][0] = Tr[j][1] = 0u; }
+        if (coded) {
+            const uint32_t up = (uint32_t)(kMaxPlanes - 1 - msb);
+#pragma unroll
+            for (int hw = 0; hw < 2; hw++) {
+                for (int ii = 0; ii < 32; ii++) {
+                    int32_t v0, v1;
+                    size_t idx = cbase + (size_t)(hw * 32 + ii) * (size_t)a.AW;
+                    if (a.is_float) {
+                        float2 f = *reinterpret_cast<const float2 *>((const float *)a.coeffs_in + idx);
+                        v0 = (int32_t)f.x; v1 = (int32_t)f.y;
+                    } else {
+                        int2 q = *reinterpret_cast<const int2 *>((const int32_t *)a.coeffs_in + idx);
+                        v0 = q.x; v1 = q.y;
+                    }
+                    const uint32_t m0 = ((uint32_t)(v0 < 0 ? -v0 : v0) << up) & 0xFFFFu;
+                    const uint32_t m1 = ((uint32_t)(v1 < 0 ? -v1 : v1) << up) & 0xFFFFu;
+#pragma unroll
+                    for (int j = 0; j < kMaxPlanes - kEncRegPlanes; j++) {
+                        if (kEncRegPlanes + j < np) {
+                            Tl[j][hw] |= ((m0 >> (kMaxPlanes - 1 - kEncRegPlanes - j)) & 1u) << ii;
+                            Tr[j][hw] |= ((m1 >> (kMaxPlanes - 1 - kEncRegPlanes - j)) & 1u) << ii;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxPlanes - kEncRegPlanes; j++) {
+            if (kEncRegPlanes + j < np) {
+                pscr[(j * 4 + 0) * 64] = Tl[j][0]; pscr[(j * 4 + 1) * 64] = Tl[j][1];
+                pscr[(j * 4 + 2) * 64] = Tr[j][0]; pscr[(j * 4 + 3) * 64] = Tr[j][1];
             }
         }
     }
@@ -673,9 +722,15 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
         }
         AL = AL2; AR = AR2;
 #pragma unroll
-        for (int k = 0; k < kMaxPlanes - 1; k++) {
+        for (int k = 0; k < kEncRegPlanes - 1; k++) {
             PLlo[k] = PLlo[k + 1]; PLhi[k] = PLhi[k + 1];
             PRlo[k] = PRlo[k + 1]; PRhi[k] = PRhi[k + 1];
+        }
+        // the plane that moves into the last register: slot p of the scratch (plane p + kEncRegPlanes)
+        PLlo[kEncRegPlanes - 1] = PLhi[kEncRegPlanes - 1] = PRlo[kEncRegPlanes - 1] = PRhi[kEncRegPlanes - 1] = 0u;
+        if (p + kEncRegPlanes < np) {
+            PLlo[kEncRegPlanes - 1] = pscr[(p * 4 + 0) * 64]; PLhi[kEncRegPlanes - 1] = pscr[(p * 4 + 1) * 64];
+            PRlo[kEncRegPlanes - 1] = pscr[(p * 4 + 2) * 64]; PRhi[kEncRegPlanes - 1] = pscr[(p * 4 + 3) * 64];
         }
     }
 

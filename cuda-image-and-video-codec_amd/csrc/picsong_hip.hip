@@ -55,6 +55,7 @@ struct picsong_ctx {
     bool has_lut[3];
     // small scratch
     int32_t *d_offsets;   // nCB
+    uint32_t *d_plane_scratch;   // encoder: planes below the 8 held in registers, 8 KB per wave (lazy)
     int32_t *d_total;     // 1
     int *d_flag;          // 1
     int32_t *h_pinned;    // [0] total, [1] flag
@@ -313,6 +314,7 @@ void picsong_ctx_destroy(picsong_ctx *c)
     for (int k = 0; k < 3; k++)
         if (c->d_lut[k]) (void)hipFree(c->d_lut[k]);
     if (c->d_offsets) (void)hipFree(c->d_offsets);
+    if (c->d_plane_scratch) (void)hipFree(c->d_plane_scratch);
     if (c->d_total) (void)hipFree(c->d_total);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -496,6 +498,11 @@ static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_stag
     a.nCB = cb_begin + cb_count;
     a.coeffs_in = d_coeffs; a.is_float = c->p.lossy ? 1 : 0;
     a.staging = d_staging; a.sizes = d_sizes;
+    if (!c->d_plane_scratch) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipMalloc(&c->d_plane_scratch, (size_t)((c->ncb + 1) / 2) * kEncScratchDwordsPerWave * sizeof(uint32_t)));
+    }
+    a.plane_scratch = c->d_plane_scratch;
     // BPCEngine::deviceMemoryAllocator BPCEngine.cu:2429-2441.  Slots beyond a codeblock's length
     // are never read downstream, so the fused frame path skips this 4*AW*AH-byte fill.
     if (memset_staging) HIP_TRY(hipMemsetAsync(d_staging, 0xFF, c->P * sizeof(int32_t), s));

@@ -145,6 +145,8 @@ void emu_bpc_encode(const void *coeffs, int is_float, int aw, int ah, int wl, co
     BpcArgs a = mk(aw, ah, wl, lut, geo, staging, sizes, flag);
     a.coeffs_in = coeffs; a.is_float = is_float;
     a.k = k; a.n_tables = n_tables;
+    std::vector<uint32_t> plane_scratch((size_t)((a.nCB + 1) / 2) * kEncScratchDwordsPerWave, 0xDEADBEEFu);
+    a.plane_scratch = plane_scratch.data();
     memset(staging, 0xFF, (size_t)aw * ah * 4);
     if (k > 0.0f) emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_encode_kernel<true>(a); });
     else emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_encode_kernel<false>(a); });

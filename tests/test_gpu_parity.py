@@ -319,3 +319,36 @@ def test_complexity_scalable_full_size_roundtrip(oracle, pa, torch):
     c0 = pa.Codec(W, H, wl=wl, lut_folder=_lutdir(oracle, False))
     assert c0.encode_frame(frame, 0).numel() != s.numel()
     c.close(); c0.close()
+
+
+@pytest.mark.parametrize("k", [0.0, 0.4])
+def test_deep_planes_beyond_the_register_file(oracle, pa, torch, k):
+    """Codeblocks with MSB 8..15: the encoder keeps 8 planes in registers, the deeper ones go through
+    its HBM scratch; paired in one wave with shallow and empty codeblocks."""
+    rng = np.random.default_rng(23)
+    W, H, wl = 256, 128, 1
+    peak = np.array([[6000, 5, 300, 0], [40000, 1000, 2, 200]])
+    coef = np.zeros((H, W), np.int32)
+    for by in range(2):
+        for bx in range(4):
+            s = int(peak[by, bx])
+            if not s:
+                continue
+            blk = rng.integers(-2, 3, (64, 64))
+            ys, xs = rng.integers(0, 64, 60), rng.integers(0, 64, 60)
+            blk[ys, xs] = rng.integers(-s, s + 1, 60)
+            coef[by * 64:by * 64 + 64, bx * 64:bx * 64 + 64] = blk
+    coef[70, 3] = 65535
+    lut = oracle.lut_for_k(False, wl) if k > 0 else oracle.lut_for(False, wl)
+    st_ref, sz_ref = oracle.bpc_encode(coef, wl, lut, k=k)
+    assert (sz_ref < 4096).all() and st_ref[::4096][st_ref[::4096] != 32].max() == 15
+    c = pa.Codec(W, H, wl=wl, lut_folder=_lutdir(oracle, False), k=k)
+    st, sz = c.bpc_encode(_dev(torch, coef))
+    st, sz = st.cpu().numpy(), sz.cpu().numpy()
+    assert np.array_equal(sz, sz_ref)
+    for cb in range(sz_ref.size):
+        n = sz_ref[cb]
+        assert np.array_equal(st[cb * 4096:cb * 4096 + n], st_ref[cb * 4096:cb * 4096 + n]), cb
+    back = c.bpc_decode(_dev(torch, st_ref), _dev(torch, sz_ref)).cpu().numpy().reshape(H, W)
+    assert np.array_equal(back, coef)
+    c.close()

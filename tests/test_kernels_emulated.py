@@ -325,3 +325,35 @@ def test_bulk_mode_k0_tables_unchanged(oracle, E):
     st_o, sz_o = oracle.bpc_encode(coef, wl, oracle.lut_for(False, wl))
     st_e, sz_e, _ = E.bpc_encode(coef, wl, lutk, k=0.0)
     assert np.array_equal(sz_e, sz_o)
+
+
+@pytest.mark.parametrize("k", [0.0, 0.4])
+def test_bpc_deep_planes_beyond_the_register_file(oracle, E, k):
+    """Codeblocks with MSB 8..15 (more planes than the encoder holds in registers: the lower ones take
+    the HBM scratch path), paired in one wave with shallow and with empty codeblocks."""
+    rng = np.random.default_rng(23)
+    W, H, wl = 256, 128, 1
+    peak = np.array([[6000, 5, 300, 0], [40000, 1000, 2, 200]])         # per 64x64 block; 40000 -> MSB 15
+    coef = np.zeros((H, W), np.int32)
+    for by in range(2):
+        for bx in range(4):
+            s = int(peak[by, bx])
+            if not s:
+                continue
+            blk = rng.integers(-2, 3, (64, 64))                          # compressible: small noise ...
+            ys, xs = rng.integers(0, 64, 60), rng.integers(0, 64, 60)
+            blk[ys, xs] = rng.integers(-s, s + 1, 60)                    # ... plus a few deep spikes
+            coef[by * 64:by * 64 + 64, bx * 64:bx * 64 + 64] = blk
+    coef[70, 3] = 65535                                                  # MSB 15 exactly
+    lut = oracle.lut_for_k(False, wl) if k > 0 else oracle.lut_for(False, wl)
+    st_o, sz_o = oracle.bpc_encode(coef, wl, lut, k=k)
+    st_e, sz_e, flag = E.bpc_encode(coef, wl, lut, k=k)
+    assert flag == 0 and np.array_equal(sz_e, sz_o)
+    assert (sz_o < 4096).all()                                          # none took the raw fallback
+    msbs = st_o[::4096]
+    coded = msbs[msbs != 32]                                             # 32 = all-zero codeblock
+    assert coded.max() == 15 and (coded >= 8).sum() >= 4 and (coded < 8).sum() >= 3
+    for cb in range(sz_o.size):
+        n = sz_o[cb]
+        assert np.array_equal(st_e[cb * 4096:cb * 4096 + n], st_o[cb * 4096:cb * 4096 + n]), cb
+    assert np.array_equal(E.bpc_decode(st_o, sz_o, W, H, wl, lut, k=k), oracle.bpc_decode(st_o, sz_o, W, H, wl, lut, k=k))
