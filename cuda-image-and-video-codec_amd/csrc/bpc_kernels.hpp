@@ -809,69 +809,92 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
 // =============================================================================================
 
 // arithmeticDecoder BPCEngine.cu:405-442, one call site
-__device__ __forceinline__ uint32_t dec_site(Coder &c, uint32_t inact, uint32_t p, uint32_t prec,
-                                             uint32_t upper_mask, const int32_t *stage)
+// `on` / onm = ballot(on): as enc_site_on.  Returns true in the lanes that decoded a 1.
+__device__ __forceinline__ bool dec_site_on(Coder &c, bool on, uint64_t onm, uint32_t p, uint32_t prec,
+                                            uint32_t upper_mask, const int32_t *stage)
 {
-    const bool on = inact == 0u, empty = c.S == 0u;
-    const uint64_t m = __builtin_amdgcn_ballot_w64(empty) & __builtin_amdgcn_ballot_w64(on);
+    const bool empty = c.S == 0u;
+    const uint64_t m = __builtin_amdgcn_ballot_w64(empty) & onm;
     if (m != 0ull) {
         reserve_enc(c, on && empty, m, upper_mask);
         if (on && empty) c.cw = (uint32_t)stage[c.slot];   // stage = the codeword array (staging + 1)
     }
-    uint32_t sym = 0u;
+    bool one = false;
     if (on) {
         const uint32_t a = (mul_u24(c.S, p) >> prec) + 1u;
         const uint32_t a2 = c.L + a;
-        const bool ge = c.cw >= a2;
-        c.S = ge ? c.S - a : a - 1u;
-        c.L = ge ? a2 : c.L;
-        sym = ge ? 1u : 0u;
+        one = c.cw >= a2;
+        c.S = one ? c.S - a : a - 1u;
+        c.L = one ? a2 : c.L;
     }
-    return sym;
+    return one;
+}
+__device__ __forceinline__ uint32_t dec_site(Coder &c, uint32_t inact, uint32_t p, uint32_t prec,
+                                             uint32_t upper_mask, const int32_t *stage)
+{
+    const bool on = inact == 0u;
+    return dec_site_on(c, on, __builtin_amdgcn_ballot_w64(on), p, prec, upper_mask, stage) ? 1u : 0u;
 }
 
-// One coefficient of the decoder's significance propagation pass; returns 1 in lanes whose
-// coefficient became significant.  wo/wl/wr: W-form significance of the own / left / right column,
-// so/sl/sr: W-form signs; cur: the plane's 32 rows being decoded (X-form dword).
-__device__ __forceinline__ uint32_t dec_spp_coeff(Coder &c, uint32_t idle, uint32_t ii, M64 &wo, const M64 &wl,
+// Sign context of the decoder by table: the four neighbours' (significant, sign) pairs make an 8-bit
+// index (up, down, left, right; bit 2n = significant, bit 2n+1 = sign), the LDS table holds for each
+// the context c of computeSignContext (BPCEngine.cu:252-308) in bits 0-2 and the bit offset
+// 8 * (c >> 1) of its probability inside PlaneLut::sign in bits 3-7.  Replaces ~30 compares / selects.
+__device__ __forceinline__ void sign_table_fill(uint8_t *tab, uint32_t lane)
+{
+    for (uint32_t idx = lane; idx < 256u; idx += 64u) {
+        const int up = (int)(idx & 1u) - (int)(idx & 2u), dn = (int)((idx >> 2) & 1u) - (int)((idx >> 2) & 2u);
+        const int lf = (int)((idx >> 4) & 1u) - (int)((idx >> 4) & 2u), rt = (int)((idx >> 6) & 1u) - (int)((idx >> 6) & 2u);
+        const uint32_t sc = sign_ctx(lf + rt, up + dn);
+        tab[idx] = (uint8_t)(sc | ((8u * (sc >> 1)) << 3));
+    }
+}
+
+// One coefficient of the decoder's significance propagation pass; returns the ballot of the lanes
+// whose coefficient became significant.  wo/wl/wr: W-form significance of the own / left / right
+// column, so/sl/sr: W-form signs; cur: the plane's 32 rows being decoded (X-form dword).
+__device__ __forceinline__ uint64_t dec_spp_coeff(Coder &c, bool idle, uint32_t ii, M64 &wo, const M64 &wl,
                                                   const M64 &wr, M64 &so, const M64 &sl, const M64 &sr,
                                                   uint32_t &cur, const PlaneLut &pl, uint32_t prec,
-                                                  uint32_t upper_mask, const int32_t *stage)
+                                                  uint32_t upper_mask, const int32_t *stage, const uint8_t *sgt)
 {
     const uint32_t to = triple(wo, ii), tl = triple(wl, ii), tr = triple(wr, ii);
-    const uint32_t inact = idle | ((to >> 1) & 1u);
+    const bool on = !idle && (to & 2u) == 0u;
+    const uint64_t onm = __builtin_amdgcn_ballot_w64(on);
     // computeContext BPCEngine.cu:222-230 -- the coefficient's own bit is 0 whenever it is visited
     const uint32_t ctx = (uint32_t)__builtin_popcount(to) + (uint32_t)__builtin_popcount(tl) +
                          (uint32_t)__builtin_popcount(tr);
     const uint32_t p07 = __builtin_amdgcn_perm(pl.sig1, pl.sig0, ctx | 0x0C0C0C00u);
-    const uint32_t sym = dec_site(c, inact, ctx >= 8u ? pl.sig8 : p07, prec, upper_mask, stage);
-    if (__builtin_amdgcn_ballot_w64(sym != 0u) != 0ull) {
+    const bool one = dec_site_on(c, on, onm, ctx >= 8u ? pl.sig8 : p07, prec, upper_mask, stage);
+    const uint64_t onem = __builtin_amdgcn_ballot_w64(one);
+    if (onem != 0ull) {
         const uint32_t xo = triple(so, ii), xl = triple(sl, ii), xr = triple(sr, ii);
-        // computeSignContext BPCEngine.cu:296-308: 0 if not significant, -1 if sign bit set, else +1.
-        // A sign bit is only ever set on a significant coefficient, so the contribution is
-        // significance - 2 * sign: three instructions per neighbour, no selects.
-        const int up = (int)(to & 1u) - (int)((xo & 1u) << 1);
-        const int dn = (int)((to >> 2) & 1u) - (int)((xo >> 1) & 2u);
-        const int lf = (int)((tl >> 1) & 1u) - (int)(xl & 2u);
-        const int rt = (int)((tr >> 1) & 1u) - (int)(xr & 2u);
-        const uint32_t sc = sign_ctx(lf + rt, up + dn);
-        const uint32_t p2 = (pl.sign >> (8u * (sc >> 1))) & 0xFFu;
-        const uint32_t s2 = dec_site(c, sym ^ 1u, p2, prec, upper_mask, stage);
-        if (sym) {
-            w_set(so, ii, s2 ^ (sc & 1u));          // :587-589
+        // index: up (to/xo bit 0) | down (bit 2) | left (tl/xl bit 1) | right (tr/xr bit 1)
+        uint32_t idx = (to & 5u) | ((xo & 5u) << 1);
+        idx |= ((tl & 2u) << 3) | ((xl & 2u) << 4) | ((tr & 2u) << 5) | ((xr & 2u) << 6);
+        const uint32_t tv = sgt[idx];
+        const uint32_t p2 = (pl.sign >> (tv >> 3)) & 0xFFu;
+        const bool s2 = dec_site_on(c, one, onem, p2, prec, upper_mask, stage);
+        if (one) {
+            w_set(so, ii, (s2 ? 1u : 0u) ^ (tv & 1u));          // :587-589
             w_set(wo, ii, 1u);
             cur |= 1u << ii;
         }
     }
-    return sym;
+    return onem;
 }
 
 // One wave64 per workgroup; codeblocks cb_base + 2*blockIdx.x (lanes 0-31) and +1 (lanes 32-63).
+#ifndef PICSONG_BPC_DEC_WAVES
+#define PICSONG_BPC_DEC_WAVES 4
+#endif
 template <bool BULK>
-__global__ __launch_bounds__(64, 4) void bpc_decode_kernel(BpcArgs a)
+__global__ __launch_bounds__(64, PICSONG_BPC_DEC_WAVES) void bpc_decode_kernel(BpcArgs a)
 {
     __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
+    __shared__ uint8_t sign_tab[256];
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
+    sign_table_fill(sign_tab, lane);                        // (the LUT copy below ends with the barrier)
     const int cb = a.cb_base + 2 * (int)blockIdx.x + (int)half;
     const bool valid = cb < a.nCB;
     const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
@@ -946,16 +969,16 @@ __global__ __launch_bounds__(64, 4) void bpc_decode_kernel(BpcArgs a)
                 const uint32_t ii = (uint32_t)__builtin_ctz(rows);
                 rows &= rows - 1u;
                 // all lanes: left column, neighbours = lane-1's right column | own right column
-                const uint32_t bL = dec_spp_coeff(c, idle, ii, wL, wPR, wR, sL, sPR, sR, curL, pl, prec, upper_mask, cw);
+                const uint64_t bL = dec_spp_coeff(c, idle != 0u, ii, wL, wPR, wR, sL, sPR, sR, curL, pl, prec, upper_mask, cw, sign_tab);
                 // lane+1's left column as it is after this row's left phase (:791, shfl_down)
-                if (__builtin_amdgcn_ballot_w64(bL != 0u) != 0ull) {
+                if (bL != 0ull) {
                     wNL.lo = from_next32(wL.lo, t); wNL.hi = from_next32(wL.hi, t);
                     sNL.lo = from_next32(sL.lo, t); sNL.hi = from_next32(sL.hi, t);
                 }
                 // all lanes: right column, neighbours = own left column | lane+1's left column
-                const uint32_t bR = dec_spp_coeff(c, idle, ii, wR, wL, wNL, sR, sL, sNL, curR, pl, prec, upper_mask, cw);
+                const uint64_t bR = dec_spp_coeff(c, idle != 0u, ii, wR, wL, wNL, sR, sL, sNL, curR, pl, prec, upper_mask, cw, sign_tab);
                 // lane-1's right column as it is after this row's right phase (:804, shfl_up)
-                if (__builtin_amdgcn_ballot_w64(bR != 0u) != 0ull) {
+                if (bR != 0ull) {
                     wPR.lo = from_prev32(wR.lo, t); wPR.hi = from_prev32(wR.hi, t);
                     sPR.lo = from_prev32(sR.lo, t); sPR.hi = from_prev32(sR.hi, t);
                 }
@@ -977,11 +1000,10 @@ __global__ __launch_bounds__(64, 4) void bpc_decode_kernel(BpcArgs a)
             while (rows) {
                 const uint32_t ii = (uint32_t)__builtin_ctz(rows);
                 rows &= rows - 1u;
-                const uint32_t iL = ((rL >> ii) & 1u) ^ 1u, iR = ((rR >> ii) & 1u) ^ 1u;
-                if (__builtin_amdgcn_ballot_w64(iL == 0u) != 0ull)
-                    curL |= dec_site(c, iL, pl.ref, prec, upper_mask, cw) << ii;
-                if (__builtin_amdgcn_ballot_w64(iR == 0u) != 0ull)
-                    curR |= dec_site(c, iR, pl.ref, prec, upper_mask, cw) << ii;
+                const bool oL = ((rL >> ii) & 1u) != 0u, oR = ((rR >> ii) & 1u) != 0u;
+                const uint64_t mL = __builtin_amdgcn_ballot_w64(oL), mR = __builtin_amdgcn_ballot_w64(oR);
+                if (mL != 0ull) curL |= dec_site_on(c, oL, mL, pl.ref, prec, upper_mask, cw) ? (1u << ii) : 0u;
+                if (mR != 0ull) curR |= dec_site_on(c, oR, mR, pl.ref, prec, upper_mask, cw) ? (1u << ii) : 0u;
             }
             if (hw == 0) { PLlo[0] = curL; PRlo[0] = curR; } else { PLhi[0] = curL; PRhi[0] = curR; }
         }

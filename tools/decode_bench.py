@@ -13,7 +13,11 @@ import torch
 import oracle_lib as orc
 import picsong_amd as pa
 
-lossy = len(sys.argv) > 1 and sys.argv[1] == "lossy"
+lossy = "lossy" in sys.argv[1:]
+nstreams = 1
+for a in sys.argv[1:]:
+    if a.startswith("--streams="):
+        nstreams = int(a.split("=")[1])
 W, H, wl, qs = (7680, 4320, 6, 0.5) if lossy else (7680, 4320, 5, 1.0)
 lut = os.path.join(orc.LUT_DIR, "n1_lossy" if lossy else "n1_lossless")
 c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=lut)
@@ -30,3 +34,20 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 ok = bool(torch.equal(d, frame.view(c.ah, c.aw))) if not lossy else None
 print(f"decode {W}x{H} lossy={lossy}: {dt * 1e3:.3f} ms/frame = {W * H / dt / 1e6:.0f} Mpixel/s, roundtrip_ok={ok}")
+if nstreams > 1:
+    # frames pipelined over several streams, each with its own context (like bench.py does for encode)
+    cs = [c] + [pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=lut) for _ in range(nstreams - 1)]
+    sts = [torch.cuda.Stream() for _ in range(nstreams)]
+    outs = [None] * nstreams
+    torch.cuda.synchronize()
+    n = 60
+    for rep in range(2):
+        t0 = time.perf_counter()
+        for i in range(n):
+            k = i % nstreams
+            with torch.cuda.stream(sts[k]):
+                outs[k] = cs[k].decode_frame(s)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+    okp = all(bool(torch.equal(o, frame.view(c.ah, c.aw))) for o in outs) if not lossy else None
+    print(f"decode pipelined over {nstreams} streams: {dt * 1e3:.3f} ms/frame = {W * H / dt / 1e6:.0f} Mpixel/s, roundtrip_ok={okp}")
