@@ -217,17 +217,8 @@ __device__ __forceinline__ U64 u_and(U64 a, U64 b) { return U64{ a.lo & b.lo, a.
 __device__ __forceinline__ U64 u_or(U64 a, U64 b) { return U64{ a.lo | b.lo, a.hi | b.hi }; }
 __device__ __forceinline__ U64 u_xor(U64 a, U64 b) { return U64{ a.lo ^ b.lo, a.hi ^ b.hi }; }
 __device__ __forceinline__ U64 u_andn(U64 a, U64 b) { return U64{ a.lo & ~b.lo, a.hi & ~b.hi }; }   // a & ~b
-__device__ __forceinline__ U64 u_up(U64 a) { return U64{ a.lo << 1, (a.hi << 1) | (a.lo >> 31) }; }    // row i-1 -> bit i
-__device__ __forceinline__ U64 u_dn(U64 a) { return U64{ (a.lo >> 1) | (a.hi << 31), a.hi >> 1 }; }    // row i+1 -> bit i
 __device__ __forceinline__ U64 u_prev(U64 a, uint32_t t) { return U64{ from_prev32(a.lo, t), from_prev32(a.hi, t) }; }
 __device__ __forceinline__ U64 u_next(U64 a, uint32_t t) { return U64{ from_next32(a.lo, t), from_next32(a.hi, t) }; }
-__device__ __forceinline__ void full_add(U64 a, U64 b, U64 c, U64 &s, U64 &cy)
-{
-    U64 x = u_xor(a, b);
-    s = u_xor(x, c);
-    cy = u_or(u_and(a, b), u_and(c, x));
-}
-__device__ __forceinline__ void half_add(U64 a, U64 b, U64 &s, U64 &cy) { s = u_xor(a, b); cy = u_and(a, b); }
 
 // per-column side information for the 32 rows of one half-pass, bit-sliced
 struct ColHalf {

@@ -647,15 +647,6 @@ __global__ __launch_bounds__(256) void clamp_to_u8_f32_kernel(const float *in, u
         reinterpret_cast<uint32_t *>(out)[i] = o;
     }
 }
-// final image (T, row stride AW, after the inverse level shift) -> u8 crop-free copy
-template <typename T>
-__global__ __launch_bounds__(256) void to_u8_kernel(const T *in, uint8_t *out, size_t n)
-{
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = (uint8_t)(int)in[i];
-}
-
-
 // ---- colour transforms of the RGB path (RGBTransformLossless / RGBTransformLossy, reference
 // Engines/CodingEngine.cu:357-403 and Engines/DecodingEngine.cu:599-650), level shift fused, four
 // samples per lane.  RCT: c0 = floor((R+2G+B)/4), c1 = B-G, c2 = R-G.  ICT: 3x3 matrix, evaluated
