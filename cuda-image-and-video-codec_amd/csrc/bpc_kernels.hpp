@@ -151,6 +151,7 @@ struct Coder {
     uint32_t cw;        // decoder: current codeword
     uint32_t cnt_lo, cnt_hi;   // codeword counters (codeStreamShared) of the codeblocks in lanes 0-31 /
                                // 32-63: wave-uniform, they live in SGPRs and are updated by SALU
+    uint64_t emptym;           // encoder: ballot(S == 0) as of the end of the previous call site
 };
 
 // significance probabilities for contexts 0..8 packed as bytes: w0 = ctx 0-3, w1 = ctx 4-7, p8.
@@ -312,15 +313,18 @@ __device__ __forceinline__ void reserve_enc(Coder &c, bool need, uint64_t m, uin
 __device__ __forceinline__ void enc_site_on(Coder &c, bool on, uint64_t onm, uint32_t sym, uint32_t p, uint32_t prec,
                                             uint32_t upper_mask, int32_t *st)
 {
-    const bool empty = c.S == 0u;
-    const uint64_t m = __builtin_amdgcn_ballot_w64(empty) & onm;
-    if (m != 0ull) reserve_enc(c, on && empty, m, upper_mask);
+    // which lanes have an exhausted interval is known from the end of the previous call site: the
+    // one compare per site (below) serves the codeword store of this site and the need-ballot of the next
+    const uint64_t m = c.emptym & onm;
+    if (m != 0ull) reserve_enc(c, on && c.S == 0u, m, upper_mask);
     if (on) {
         const uint32_t a = (mul_u24(c.S, p) >> prec) + sym;
         c.S = sym != 0u ? c.S - a : a;          // v_sub + v_cndmask (a 24-bit mad form costs two shifts more)
         c.L = __umul24(sym, a) + c.L;
-        if (c.S == 0u) st[c.slot] = (int32_t)c.L;         // st = the codeblock's codeword array (staging + 1)
     }
+    const bool z = c.S == 0u;
+    c.emptym = __builtin_amdgcn_ballot_w64(z);
+    if (on && z) st[c.slot] = (int32_t)c.L;               // st = the codeblock's codeword array (staging + 1)
 }
 __device__ __forceinline__ void enc_site(Coder &c, uint32_t inact, uint32_t sym, uint32_t p, uint32_t prec,
                                          uint32_t upper_mask, int32_t *st)
@@ -656,7 +660,7 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
         }
     }
 
-    Coder c = { 0u, 0u, 0u, 0u, 0u, 0u };
+    Coder c = { 0u, 0u, 0u, 0u, 0u, 0u, ~0ull };
     const uint32_t upper_mask = half ? 0xFFFFFFFFu : 0u;
     U64 AL = { 0u, 0u }, AR = { 0u, 0u };                 // significant before the current plane
     const U64 sgPL = u_prev(sgR, t), sgNL = u_next(sgL, t);     // neighbour sign columns
@@ -912,7 +916,7 @@ __global__ __launch_bounds__(64, PICSONG_BPC_DEC_WAVES) void bpc_decode_kernel(B
     find_subband(cbx * 64 + 2 * (int)t, cby * 64, a.AW, a.AH, a.wl, level, sb);
     const int grp = level * a.g.nSub + sb;
 
-    Coder c = { 0u, 0u, 0u, 0u, 0u, 0u };
+    Coder c = { 0u, 0u, 0u, 0u, 0u, 0u, ~0ull };
     M64 sigL = { 0u, 0u }, sigR = { 0u, 0u }, refL = { 0u, 0u }, refR = { 0u, 0u };
 
     int cbp = 0, loff = 0;
