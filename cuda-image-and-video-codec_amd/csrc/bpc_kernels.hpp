@@ -60,12 +60,12 @@ struct BpcArgs {
 // (== correctCBBorders, BPCEngine.cu:465-484).
 __device__ __forceinline__ uint32_t from_prev32(uint32_t v, uint32_t t)
 {
-    uint32_t r = __builtin_amdgcn_update_dpp(0u, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, false);
+    uint32_t r = __builtin_amdgcn_update_dpp(0u, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
     return t == 0u ? 0u : r;
 }
 __device__ __forceinline__ uint32_t from_next32(uint32_t v, uint32_t t)
 {
-    uint32_t r = __builtin_amdgcn_update_dpp(0u, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
+    uint32_t r = __builtin_amdgcn_update_dpp(0u, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
     return t == 31u ? 0u : r;
 }
 __device__ __forceinline__ uint32_t half_or(uint32_t v)
@@ -804,9 +804,12 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
 // =============================================================================================
 
 // arithmeticDecoder BPCEngine.cu:405-442, one call site
-// `on` / onm = ballot(on): as enc_site_on.  Returns true in the lanes that decoded a 1.
-__device__ __forceinline__ bool dec_site_on(Coder &c, bool on, uint64_t onm, uint32_t p, uint32_t prec,
-                                            uint32_t upper_mask, const int32_t *stage)
+// `on` / onm = ballot(on): as enc_site_on.  Returns the ballot of the lanes that decoded a 1 and
+// sets `one` in them.  The interval split and the compare run in every lane (the result of a lane
+// that is off is never used) so that the ballot is the compare's own mask: a bool that leaves an
+// exec-masked region costs a select and a second compare to get back into a mask.
+__device__ __forceinline__ uint64_t dec_site_m(Coder &c, bool on, uint64_t onm, uint32_t p, uint32_t prec,
+                                               uint32_t upper_mask, const int32_t *stage, bool &one)
 {
     const bool empty = c.S == 0u;
     const uint64_t m = __builtin_amdgcn_ballot_w64(empty) & onm;
@@ -814,14 +817,22 @@ __device__ __forceinline__ bool dec_site_on(Coder &c, bool on, uint64_t onm, uin
         reserve_enc(c, on && empty, m, upper_mask);
         if (on && empty) c.cw = (uint32_t)stage[c.slot];   // stage = the codeword array (staging + 1)
     }
-    bool one = false;
+    const uint32_t a = (mul_u24(c.S, p) >> prec) + 1u;
+    const uint32_t a2 = c.L + a;
+    const bool ge = c.cw >= a2;
+    const uint64_t gem = __builtin_amdgcn_ballot_w64(ge);
     if (on) {
-        const uint32_t a = (mul_u24(c.S, p) >> prec) + 1u;
-        const uint32_t a2 = c.L + a;
-        one = c.cw >= a2;
-        c.S = one ? c.S - a : a - 1u;
-        c.L = one ? a2 : c.L;
+        c.S = ge ? c.S - a : a - 1u;
+        c.L = ge ? a2 : c.L;
     }
+    one = ge && on;
+    return gem & onm;
+}
+__device__ __forceinline__ bool dec_site_on(Coder &c, bool on, uint64_t onm, uint32_t p, uint32_t prec,
+                                            uint32_t upper_mask, const int32_t *stage)
+{
+    bool one;
+    (void)dec_site_m(c, on, onm, p, prec, upper_mask, stage, one);
     return one;
 }
 __device__ __forceinline__ uint32_t dec_site(Coder &c, uint32_t inact, uint32_t p, uint32_t prec,
@@ -848,20 +859,21 @@ __device__ __forceinline__ void sign_table_fill(uint8_t *tab, uint32_t lane)
 // One coefficient of the decoder's significance propagation pass; returns the ballot of the lanes
 // whose coefficient became significant.  wo/wl/wr: W-form significance of the own / left / right
 // column, so/sl/sr: W-form signs; cur: the plane's 32 rows being decoded (X-form dword).
-__device__ __forceinline__ uint64_t dec_spp_coeff(Coder &c, bool idle, uint32_t ii, M64 &wo, const M64 &wl,
+__device__ __forceinline__ uint64_t dec_spp_coeff(Coder &c, bool idle, uint64_t actm, uint32_t ii, M64 &wo, const M64 &wl,
                                                   const M64 &wr, M64 &so, const M64 &sl, const M64 &sr,
                                                   uint32_t &cur, const PlaneLut &pl, uint32_t prec,
                                                   uint32_t upper_mask, const int32_t *stage, const uint8_t *sgt)
 {
     const uint32_t to = triple(wo, ii), tl = triple(wl, ii), tr = triple(wr, ii);
-    const bool on = !idle && (to & 2u) == 0u;
-    const uint64_t onm = __builtin_amdgcn_ballot_w64(on);
+    const bool insig = (to & 2u) == 0u;
+    const bool on = !idle && insig;
+    const uint64_t onm = __builtin_amdgcn_ballot_w64(insig) & actm;     // actm = ballot(!idle)
     // computeContext BPCEngine.cu:222-230 -- the coefficient's own bit is 0 whenever it is visited
     const uint32_t ctx = (uint32_t)__builtin_popcount(to) + (uint32_t)__builtin_popcount(tl) +
                          (uint32_t)__builtin_popcount(tr);
     const uint32_t p07 = __builtin_amdgcn_perm(pl.sig1, pl.sig0, ctx | 0x0C0C0C00u);
-    const bool one = dec_site_on(c, on, onm, ctx >= 8u ? pl.sig8 : p07, prec, upper_mask, stage);
-    const uint64_t onem = __builtin_amdgcn_ballot_w64(one);
+    bool one;
+    const uint64_t onem = dec_site_m(c, on, onm, ctx >= 8u ? pl.sig8 : p07, prec, upper_mask, stage, one);
     if (onem != 0ull) {
         const uint32_t xo = triple(so, ii), xl = triple(sl, ii), xr = triple(sr, ii);
         // index: up (to/xo bit 0) | down (bit 2) | left (tl/xl bit 1) | right (tr/xr bit 1)
@@ -877,6 +889,35 @@ __device__ __forceinline__ uint64_t dec_spp_coeff(Coder &c, bool idle, uint32_t 
         }
     }
     return onem;
+}
+
+// 32 rows of the decoder's output: bit ii of plane register k is bit k of row row0 + ii's magnitude
+template <int NP>
+__device__ __forceinline__ void write_rows(const uint32_t (&PL)[kMaxPlanes], const uint32_t (&PR)[kMaxPlanes],
+                                           uint32_t sgL, uint32_t sgR, int row0, bool valid, int32_t sz,
+                                           const int32_t *stage, uint32_t t, int32_t *out, int AW)
+{
+    if (!valid) return;
+#pragma unroll 1
+    for (int ii = 0; ii < 32; ii++) {
+        const int i = row0 + ii;
+        int32_t v0, v1;
+        if (sz == 4096) {
+            int2 w = *reinterpret_cast<const int2 *>(stage + t * 128u + 2u * (uint32_t)i);
+            v0 = (int32_t)(((uint32_t)w.x & 0xFFFFFFu) >> 1); if (w.x & 1) v0 = -v0;
+            v1 = (int32_t)(((uint32_t)w.y & 0xFFFFFFu) >> 1); if (w.y & 1) v1 = -v1;
+        } else {
+            uint32_t m0 = 0u, m1 = 0u;
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                m0 |= ((PL[k] >> ii) & 1u) << k;
+                m1 |= ((PR[k] >> ii) & 1u) << k;
+            }
+            v0 = ((sgL >> ii) & 1u) ? -(int32_t)m0 : (int32_t)m0;
+            v1 = ((sgR >> ii) & 1u) ? -(int32_t)m1 : (int32_t)m1;
+        }
+        *reinterpret_cast<int2 *>(out + (size_t)i * (size_t)AW) = make_int2(v0, v1);
+    }
 }
 
 // One wave64 per workgroup; codeblocks cb_base + 2*blockIdx.x (lanes 0-31) and +1 (lanes 32-63).
@@ -934,6 +975,7 @@ __global__ __launch_bounds__(64, PICSONG_BPC_DEC_WAVES) void bpc_decode_kernel(B
         const int bp = msb - p;
         const bool act = coded && bp >= cbp;
         const uint32_t idle = act ? 0u : 1u;
+        const uint64_t actm = __builtin_amdgcn_ballot_w64(act);
 
         // make room: plane registers move up so that after the last plane index k = plane k
         if (act && p > 0) {
@@ -964,14 +1006,14 @@ __global__ __launch_bounds__(64, PICSONG_BPC_DEC_WAVES) void bpc_decode_kernel(B
                 const uint32_t ii = (uint32_t)__builtin_ctz(rows);
                 rows &= rows - 1u;
                 // all lanes: left column, neighbours = lane-1's right column | own right column
-                const uint64_t bL = dec_spp_coeff(c, idle != 0u, ii, wL, wPR, wR, sL, sPR, sR, curL, pl, prec, upper_mask, cw, sign_tab);
+                const uint64_t bL = dec_spp_coeff(c, idle != 0u, actm, ii, wL, wPR, wR, sL, sPR, sR, curL, pl, prec, upper_mask, cw, sign_tab);
                 // lane+1's left column as it is after this row's left phase (:791, shfl_down)
                 if (bL != 0ull) {
                     wNL.lo = from_next32(wL.lo, t); wNL.hi = from_next32(wL.hi, t);
                     sNL.lo = from_next32(sL.lo, t); sNL.hi = from_next32(sL.hi, t);
                 }
                 // all lanes: right column, neighbours = own left column | lane+1's left column
-                const uint64_t bR = dec_spp_coeff(c, idle != 0u, ii, wR, wL, wNL, sR, sL, sNL, curR, pl, prec, upper_mask, cw, sign_tab);
+                const uint64_t bR = dec_spp_coeff(c, idle != 0u, actm, ii, wR, wL, wNL, sR, sL, sNL, curR, pl, prec, upper_mask, cw, sign_tab);
                 // lane-1's right column as it is after this row's right phase (:804, shfl_up)
                 if (bR != 0ull) {
                     wPR.lo = from_prev32(wR.lo, t); wPR.hi = from_prev32(wR.hi, t);
@@ -1045,29 +1087,15 @@ __global__ __launch_bounds__(64, PICSONG_BPC_DEC_WAVES) void bpc_decode_kernel(B
             }
             *reinterpret_cast<int2 *>(a.coeffs_out + cbase + (size_t)i * (size_t)a.AW) = make_int2(v0, v1);
         }
-    } else if (valid) {
-        // writeCoefficients BPCEngine.cu:94-111 / copyEntireCodeblock :1915-1922
-        for (int i = 0; i < 64; i++) {
-            int32_t v0, v1;
-            if (sz == 4096) {
-                int2 w = *reinterpret_cast<const int2 *>(stage + t * 128u + 2u * (uint32_t)i);
-                v0 = (int32_t)(((uint32_t)w.x & 0xFFFFFFu) >> 1); if (w.x & 1) v0 = -v0;
-                v1 = (int32_t)(((uint32_t)w.y & 0xFFFFFFu) >> 1); if (w.y & 1) v1 = -v1;
-            } else {
-                const uint32_t ii = (uint32_t)i & 31u;
-                uint32_t m0 = 0u, m1 = 0u;
-#pragma unroll
-                for (int k = 0; k < kMaxPlanes; k++) {
-                    uint32_t l = i < 32 ? PLlo[k] : PLhi[k], r = i < 32 ? PRlo[k] : PRhi[k];
-                    m0 |= ((l >> ii) & 1u) << k;
-                    m1 |= ((r >> ii) & 1u) << k;
-                }
-                uint32_t s0 = ((i < 32 ? sgnL.lo : sgnL.hi) >> ii) & 1u;
-                uint32_t s1 = ((i < 32 ? sgnR.lo : sgnR.hi) >> ii) & 1u;
-                v0 = s0 ? -(int32_t)m0 : (int32_t)m0;
-                v1 = s1 ? -(int32_t)m1 : (int32_t)m1;
-            }
-            *reinterpret_cast<int2 *>(a.coeffs_out + cbase + (size_t)i * (size_t)a.AW) = make_int2(v0, v1);
+    } else {
+        // writeCoefficients BPCEngine.cu:94-111 / copyEntireCodeblock :1915-1922.  Plane registers
+        // np.. are zero in both codeblocks of the wave: gather 8 planes unless some block has more.
+        if (np <= 8) {
+            write_rows<8>(PLlo, PRlo, sgnL.lo, sgnR.lo, 0, valid, sz, stage, t, a.coeffs_out + cbase, a.AW);
+            write_rows<8>(PLhi, PRhi, sgnL.hi, sgnR.hi, 32, valid, sz, stage, t, a.coeffs_out + cbase, a.AW);
+        } else {
+            write_rows<kMaxPlanes>(PLlo, PRlo, sgnL.lo, sgnR.lo, 0, valid, sz, stage, t, a.coeffs_out + cbase, a.AW);
+            write_rows<kMaxPlanes>(PLhi, PRhi, sgnL.hi, sgnR.hi, 32, valid, sz, stage, t, a.coeffs_out + cbase, a.AW);
         }
     }
 }
