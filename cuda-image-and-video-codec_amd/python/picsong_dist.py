@@ -34,9 +34,13 @@ def gather_round(local_stream, rank, world, device, recv_bufs=None, group=None):
     lens = torch.zeros(world, dtype=torch.int32, device=device)
     dist.all_gather_into_tensor(lens, mine, group=group)
     lens = lens.tolist()
+    # One grouped point-to-point batch per round: RCCL runs the 7 receives of the root as ONE kernel
+    # with every peer's payload on its own xGMI link at the same time (receives issued one by one
+    # would run one after the other on RCCL's stream).
+    out = None
+    ops = []
     if rank == 0:
         out = [local_stream if n else None]
-        reqs = []
         for r in range(1, world):
             if lens[r] == 0:
                 out.append(None)
@@ -46,13 +50,13 @@ def gather_round(local_stream, rank, world, device, recv_bufs=None, group=None):
             else:
                 buf = torch.empty(lens[r], dtype=torch.int16, device=device)
             out.append(buf)
-            reqs.append(dist.irecv(buf, src=r, group=group))
-        for q in reqs:
+            ops.append(dist.P2POp(dist.irecv, buf, r, group))
+    elif n:
+        ops.append(dist.P2POp(dist.isend, local_stream, 0, group))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
             q.wait()
-        return out
-    if n:
-        dist.send(local_stream, dst=0, group=group)
-    return None
+    return out
 
 
 class DeferredExchange:
