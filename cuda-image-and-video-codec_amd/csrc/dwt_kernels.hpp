@@ -49,6 +49,9 @@ namespace picsong {
 constexpr int kStripCols = 256;                 // columns held by one wave
 constexpr int kEdgeLanes = PICSONG_DWT_EDGE_LANES;          // recomputed, never-written lanes per side (>= 1)
 constexpr int kStripUseful = kStripCols - 8 * kEdgeLanes;   // lanes kEdgeLanes .. 63-kEdgeLanes write
+#ifndef PICSONG_DWT_INV_AHEAD
+#define PICSONG_DWT_INV_AHEAD 6       // inverse kernels: row pairs whose loads are in flight ahead of the math
+#endif
 #ifndef PICSONG_DWT_UNROLL
 #define PICSONG_DWT_UNROLL 4
 #endif
@@ -81,6 +84,7 @@ struct DwtInvArgs {
     void *dst;              // packed output T[H x W]
     float qs;
     float q[4];
+    float rqs, rq[4];       // correctly rounded reciprocals 1.0f / qs, 1.0f / q[k] (FAST kernels)
     uint8_t *dst_u8;        // U8OUT kernels (finest level of the frame path): pixels, row stride W
     int off;                // level shift to add back (128 for 8-bit)
 };
@@ -124,6 +128,55 @@ template <> __device__ __forceinline__ float dpp_prev<float>(float v)
 template <> __device__ __forceinline__ float dpp_next<float>(float v)
 { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x130, 0xf, 0xf, false)); }
 
+// ---- division by a constant ------------------------------------------------------------------
+// The 9/7 synthesis divides (the reference writes x / K, x / 0.812893066, (m / Q) / qs; the forward
+// transform multiplies), and a correctly rounded fp32 division is ~11 instructions.  With the
+// correctly rounded reciprocal rc = 1.0f / c at hand, q = x*rc; r = fma(-q, c, x); q + r*rc (one
+// Newton step on the residual, Markstein) is the SAME correctly rounded quotient in 3.  Where that is
+// used, it is checked, not assumed: for the two lifting constants exhaustively over every float
+// with exponent >= -96 (tools/div_check.c; below that the residual underflows, and such a value
+// takes the division: div_n1n2), for the quantisation steps over their whole input domain (|v| + 0.5,
+// |v| < 65536) and for the context's qs over every value that can reach it (dequant_fast_ok,
+// launch_plan.hpp, at context creation; a qs that fails selects the kernels that divide).
+__host__ __device__ __forceinline__ float div_rc(float x, float c, float rc)
+{
+    const float q = x * rc;
+    const float r = fmaf(-q, c, x);
+    return fmaf(r, rc, q);
+}
+#define PS_RN1 (1.0f / PS_N1)
+#define PS_RN2 (1.0f / PS_N2)
+// (bits << 1) - 1: 0xFFFFFFFF for +-0, small for a nonzero value of small magnitude
+__device__ __forceinline__ uint32_t tiny_key(float x) { return (__float_as_uint(x) << 1) - 1u; }
+constexpr uint32_t kTinyKey = ((uint32_t)(127 - 96) << 24) - 1u;       // keys below: 0 < |x| < 2^-96
+__device__ __forceinline__ void keep_in_branch(float &x)
+{   // the dividing path must stay a branch: if-converted, every lane would pay for both forms
+#if defined(__AMDGCN__)
+    asm volatile("" : "+v"(x));
+#else
+    (void)x;
+#endif
+}
+// h0, h1 /= N1 and l0, l1 /= N2: the lifting divisions of one lane's two sample pairs.  The
+// reciprocal form unless some lane of the wave holds a value so small that its residual would
+// underflow (never seen on image data; then the whole wave divides).
+template <bool FAST>
+__device__ __forceinline__ void div_n1n2(float &h0, float &h1, float &l0, float &l1)
+{
+    if constexpr (FAST) {
+        const uint32_t ka = tiny_key(h0) < tiny_key(h1) ? tiny_key(h0) : tiny_key(h1);
+        const uint32_t kb = tiny_key(l0) < tiny_key(l1) ? tiny_key(l0) : tiny_key(l1);
+        if (__builtin_amdgcn_ballot_w64((ka < kb ? ka : kb) < kTinyKey) == 0ull) {
+            h0 = div_rc(h0, PS_N1, PS_RN1); h1 = div_rc(h1, PS_N1, PS_RN1);
+            l0 = div_rc(l0, PS_N2, PS_RN2); l1 = div_rc(l1, PS_N2, PS_RN2);
+            return;
+        }
+        keep_in_branch(h0); keep_in_branch(h1); keep_in_branch(l0); keep_in_branch(l1);
+    }
+    h0 = h0 / PS_N1; h1 = h1 / PS_N1;
+    l0 = l0 / PS_N2; l1 = l1 / PS_N2;
+}
+
 // ---- horizontal analysis of one row held as (e0,o0,e1,o1) per lane ----------------------------
 // le / re: the lane owns the first / last four columns of the row (VEC kernels): the neighbour
 // sample it needs is its own mirror image (x[-1] = x[1], x[W] = x[W-2]; same for every
@@ -159,6 +212,7 @@ __device__ __forceinline__ void hfwd(float v[4], bool le, bool re)
     v[3] *= PS_N1;
 }
 // ---- horizontal synthesis of one row held as (s0,d0,s1,d1) per lane ---------------------------
+template <bool FAST>
 __device__ __forceinline__ void hinv(int v[4], bool le, bool re)
 {   // DWTGenerator.cu:295-308, lifting :81-85
     int dp = prv<int>(v[3], v[1], le);
@@ -168,13 +222,13 @@ __device__ __forceinline__ void hinv(int v[4], bool le, bool re)
     v[1] += (v[0] + v[2]) >> 1;
     v[3] += (v[2] + sn) >> 1;
 }
+template <bool FAST>
 __device__ __forceinline__ void hinv(float v[4], bool le, bool re)
 {   // DWTGenerator.cu:326-339, lifting :110-122
-    v[1] = v[1] / PS_N1;
-    v[3] = v[3] / PS_N1;
+    div_n1n2<FAST>(v[1], v[3], v[0], v[2]);
     float dp = prv<float>(v[3], v[1], le);
-    v[0] = fmaf(-(v[1] + dp), PS_A4, v[0] / PS_N2);
-    v[2] = fmaf(-(v[3] + v[1]), PS_A4, v[2] / PS_N2);
+    v[0] = fmaf(-(v[1] + dp), PS_A4, v[0]);
+    v[2] = fmaf(-(v[3] + v[1]), PS_A4, v[2]);
     float sn = nxt<float>(v[0], v[2], re);
     v[1] = fmaf(-(v[0] + v[2]), PS_A3, v[1]);
     v[3] = fmaf(-(v[2] + sn), PS_A3, v[3]);
@@ -408,56 +462,65 @@ __global__ __launch_bounds__(256) PS_DWT_OCC void dwt_fwd_kernel(DwtFwdArgs a)
 
 // ---- inverse --------------------------------------------------------------------------------
 // readSubbands* DWTGenerator.cu:477-553: de-quantisation (|v| + 0.5) * sgn(v) / Q / qs, 0 -> 0
-__device__ __forceinline__ float dequant(int32_t v, float q, float qs)
+template <bool FAST>
+__device__ __forceinline__ float dequant(int32_t v, float q, float rq, float qs, float rqs)
 {
     if (v == 0) return 0.0f;
     float m = fabsf((float)v) + 0.5f;
     float s = v < 0 ? -1.0f : 1.0f;
+    if constexpr (FAST) {
+        // the domain dequant_fast_ok has verified for this qs: 16 bit-planes, what the coder delivers
+        if ((uint32_t)(v + 65535) <= 131070u) return div_rc(div_rc(m * s, q, rq), qs, rqs);
+        keep_in_branch(m);
+    }
     return ((m * s) / q) / qs;
 }
 
-// one subband row pair-segment: s-type values for pair columns pc, pc+1 and d-type likewise
-template <typename T, bool LOSSY, bool VEC>
-__device__ __forceinline__ void load_sub4(const DwtInvArgs &a, int row_s_or_d, bool high_row,
-                                          int pc, bool inside, T v[4])
+// One subband row pair-segment as it comes from memory: d-type values (HL / HH) for pair columns pc,
+// pc+1 and s-type values (LL / LH) likewise; conversion (de-quantisation) is deferred so that the
+// loads of several row pairs can be in flight.
+struct SubRaw { uint32_t d0, d1, s0, s1; };
+
+template <typename T, bool VEC>
+__device__ __forceinline__ SubRaw load_sub_raw(const DwtInvArgs &a, int row_s_or_d, bool high_row, int pc, bool inside)
 {
     // row index already reflected by the caller.  low row: s = LL, d = HL; high row: s = LH, d = HH
     const int hW = a.W >> 1, hH = a.H >> 1;
     const int32_t *mrow = a.mallat + (size_t)(row_s_or_d + (high_row ? hH : 0)) * (size_t)a.AW;
-    const float qd = high_row ? a.q[3] : a.q[1];
-    const float qsb = high_row ? a.q[2] : a.q[0];
+    const bool from_mallat = high_row || a.first;
+    const uint32_t *srow = from_mallat ? (const uint32_t *)mrow
+                                       : (const uint32_t *)a.ll + (size_t)row_s_or_d * (size_t)a.ll_stride;
+    SubRaw r;
     if constexpr (VEC) {
         // pc is even and already clamped into [0, hW-2]: two aligned 8-byte loads per subband row
         const uint2 d = *reinterpret_cast<const uint2 *>(mrow + hW + pc);
-        if (LOSSY) { v[1] = (T)dequant((int32_t)d.x, qd, a.qs); v[3] = (T)dequant((int32_t)d.y, qd, a.qs); }
-        else { v[1] = (T)(int32_t)d.x; v[3] = (T)(int32_t)d.y; }
-        if (high_row || a.first) {
-            const uint2 sv = *reinterpret_cast<const uint2 *>(mrow + pc);
-            if (LOSSY) { v[0] = (T)dequant((int32_t)sv.x, qsb, a.qs); v[2] = (T)dequant((int32_t)sv.y, qsb, a.qs); }
-            else { v[0] = (T)(int32_t)sv.x; v[2] = (T)(int32_t)sv.y; }
-        } else {
-            const T *lrow = (const T *)a.ll + (size_t)row_s_or_d * (size_t)a.ll_stride;
-            const uint2 sv = *reinterpret_cast<const uint2 *>(lrow + pc);
-            v[0] = from_u32<T>(sv.x); v[2] = from_u32<T>(sv.y);
-        }
-        return;
+        const uint2 sv = *reinterpret_cast<const uint2 *>(srow + pc);
+        r.d0 = d.x; r.d1 = d.y; r.s0 = sv.x; r.s1 = sv.y;
+        return r;
     }
     int cs0 = pc, cs1 = pc + 1, cd0 = pc, cd1 = pc + 1;
     if (!inside) {
         cs0 = reflect_s(pc, hW); cs1 = reflect_s(pc + 1, hW);
         cd0 = reflect_d(pc, hW); cd1 = reflect_d(pc + 1, hW);
     }
-    int32_t d0 = mrow[hW + cd0], d1 = mrow[hW + cd1];
-    if (LOSSY) { v[1] = (T)dequant(d0, qd, a.qs); v[3] = (T)dequant(d1, qd, a.qs); }
-    else { v[1] = (T)d0; v[3] = (T)d1; }
+    r.d0 = (uint32_t)mrow[hW + cd0]; r.d1 = (uint32_t)mrow[hW + cd1];
+    r.s0 = srow[cs0]; r.s1 = srow[cs1];
+    return r;
+}
+
+// (s0, d0, s1, d1) of the lane's two pairs as samples: coded coefficients are int32 (de-quantised when
+// lossy), the previous level's LL is already T
+template <typename T, bool LOSSY, bool FAST>
+__device__ __forceinline__ void convert_sub(const DwtInvArgs &a, const SubRaw &r, bool high_row, T v[4])
+{
+    const float qd = high_row ? a.q[3] : a.q[1], rqd = high_row ? a.rq[3] : a.rq[1];
+    const float qsb = high_row ? a.q[2] : a.q[0], rqsb = high_row ? a.rq[2] : a.rq[0];
+    if (LOSSY) { v[1] = (T)dequant<FAST>((int32_t)r.d0, qd, rqd, a.qs, a.rqs); v[3] = (T)dequant<FAST>((int32_t)r.d1, qd, rqd, a.qs, a.rqs); }
+    else { v[1] = (T)(int32_t)r.d0; v[3] = (T)(int32_t)r.d1; }
     if (high_row || a.first) {
-        int32_t s0 = mrow[cs0], s1 = mrow[cs1];
-        if (LOSSY) { v[0] = (T)dequant(s0, qsb, a.qs); v[2] = (T)dequant(s1, qsb, a.qs); }
-        else { v[0] = (T)s0; v[2] = (T)s1; }
-    } else {
-        const T *lrow = (const T *)a.ll + (size_t)row_s_or_d * (size_t)a.ll_stride;
-        v[0] = lrow[cs0]; v[2] = lrow[cs1];
-    }
+        if (LOSSY) { v[0] = (T)dequant<FAST>((int32_t)r.s0, qsb, rqsb, a.qs, a.rqs); v[2] = (T)dequant<FAST>((int32_t)r.s1, qsb, rqsb, a.qs, a.rqs); }
+        else { v[0] = (T)(int32_t)r.s0; v[2] = (T)(int32_t)r.s1; }
+    } else { v[0] = from_u32<T>(r.s0); v[2] = from_u32<T>(r.s1); }
 }
 
 template <typename T, bool VEC>
@@ -499,7 +562,7 @@ __device__ __forceinline__ void store_row4_u8(const DwtInvArgs &a, int y, int c0
     *reinterpret_cast<uint32_t *>(a.dst_u8 + (size_t)y * (size_t)a.W + (uint32_t)c0) = w;
 }
 
-template <typename T, bool LOSSY, int BAND, bool VEC, bool U8OUT = false>
+template <typename T, bool LOSSY, int BAND, bool VEC, bool U8OUT = false, bool FAST = false>
 __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
 {
     constexpr int kInvBandRows = BAND;
@@ -517,18 +580,40 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
     const bool le = VEC && c0 == 0, re = VEC && c0 + 4 == a.W;
     const int pl = VEC ? (pc < 0 ? 0 : (pc > hW - 2 ? hW - 2 : pc)) : pc;
 
+    // The band's row pairs plus the filter's run-in: a compile-time trip count (rows past the band's
+    // end at the bottom of the image are mirrored reads whose results are not stored), so the loop
+    // unrolls fully and the raw loads of the next kInvAhead iterations are issued BEFORE this
+    // iteration's stores (one in-order memory pipe, and the compiler cannot prove dst != src).
+    constexpr int kRunIn = LOSSY ? 2 : 1;
+    constexpr int kIters = kInvBandRows / 2 + 2 * kRunIn;
+    constexpr int kInvAhead = kIters < PICSONG_DWT_INV_AHEAD ? kIters : PICSONG_DWT_INV_AHEAD;
+    const int j0 = m0 - kRunIn;
+    SubRaw rawL[kInvAhead], rawH[kInvAhead];
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int p = 0; p < kInvAhead; p++) {
+        rawL[p] = load_sub_raw<T, VEC>(a, reflect_s(j0 + p, hH), false, pl, inside);
+        rawH[p] = load_sub_raw<T, VEC>(a, reflect_d(j0 + p, hH), true, pl, inside);
+    }
+    __builtin_amdgcn_s_setprio(0);
+
     if constexpr (!LOSSY) {
         // vertical 5/3 synthesis, DWTGenerator.cu:160-181, streamed: at step j pair j-1 completes
         T Hp[4], sp[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) { Hp[k] = sp[k] = 0; }
-#pragma unroll PICSONG_DWT_UNROLL
-        for (int j = m0 - 1; j <= m1; j++) {
+#pragma unroll
+        for (int it = 0; it < kIters; it++) {
+            const int j = j0 + it;
             T Lr[4], Hr[4];
-            load_sub4<T, LOSSY, VEC>(a, reflect_s(j, hH), false, pl, inside, Lr);
-            load_sub4<T, LOSSY, VEC>(a, reflect_d(j, hH), true, pl, inside, Hr);
-            hinv(Lr, le, re);
-            hinv(Hr, le, re);
+            convert_sub<T, LOSSY, FAST>(a, rawL[it % kInvAhead], false, Lr);
+            convert_sub<T, LOSSY, FAST>(a, rawH[it % kInvAhead], true, Hr);
+            if (it + kInvAhead < kIters) {
+                rawL[it % kInvAhead] = load_sub_raw<T, VEC>(a, reflect_s(j + kInvAhead, hH), false, pl, inside);
+                rawH[it % kInvAhead] = load_sub_raw<T, VEC>(a, reflect_d(j + kInvAhead, hH), true, pl, inside);
+            }
+            hinv<FAST>(Lr, le, re);
+            hinv<FAST>(Hr, le, re);
             T ev[4], od[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -537,7 +622,7 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
                 od[k] = Hp[k] + ((sp[k] + s) >> 1);
                 sp[k] = s; Hp[k] = Hr[k];
             }
-            if (j - 1 >= m0 && wr) {
+            if (it >= 2 && j - 1 < m1 && wr) {
                 if constexpr (U8OUT) {
                     store_row4_u8<T>(a, 2 * (j - 1), c0, ev);
                     store_row4_u8<T>(a, 2 * (j - 1) + 1, c0, od);
@@ -552,18 +637,28 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
         T ddp[4], s1p[4], d1p[4], s0p[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) { ddp[k] = s1p[k] = d1p[k] = s0p[k] = (T)0; }
-#pragma unroll PICSONG_DWT_UNROLL
-        for (int j = m0 - 2; j <= m1 + 1; j++) {
+#pragma unroll
+        for (int it = 0; it < kIters; it++) {
+            const int j = j0 + it;
             T Lr[4], Hr[4];
-            load_sub4<T, LOSSY, VEC>(a, reflect_s(j, hH), false, pl, inside, Lr);
-            load_sub4<T, LOSSY, VEC>(a, reflect_d(j, hH), true, pl, inside, Hr);
-            hinv(Lr, le, re);
-            hinv(Hr, le, re);
+            convert_sub<T, LOSSY, FAST>(a, rawL[it % kInvAhead], false, Lr);
+            convert_sub<T, LOSSY, FAST>(a, rawH[it % kInvAhead], true, Hr);
+            if (it + kInvAhead < kIters) {
+                rawL[it % kInvAhead] = load_sub_raw<T, VEC>(a, reflect_s(j + kInvAhead, hH), false, pl, inside);
+                rawH[it % kInvAhead] = load_sub_raw<T, VEC>(a, reflect_d(j + kInvAhead, hH), true, pl, inside);
+            }
+            hinv<FAST>(Lr, le, re);
+            hinv<FAST>(Hr, le, re);
             T ev[4], od[4];
+            float hn[4], ln[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { hn[k] = (float)Hr[k]; ln[k] = (float)Lr[k]; }
+            div_n1n2<FAST>(hn[0], hn[1], ln[0], ln[1]);
+            div_n1n2<FAST>(hn[2], hn[3], ln[2], ln[3]);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                float dd = (float)Hr[k] / PS_N1;
-                float s1 = fmaf(-((float)ddp[k] + dd), PS_A4, (float)Lr[k] / PS_N2);
+                float dd = hn[k];
+                float s1 = fmaf(-((float)ddp[k] + dd), PS_A4, ln[k]);
                 float d1 = fmaf(-((float)s1p[k] + s1), PS_A3, (float)ddp[k]);      // d1[j-1]
                 float s0 = fmaf(-((float)d1p[k] + d1), PS_A2, (float)s1p[k]);      // s0[j-1]
                 float xo = fmaf(-((float)s0p[k] + s0), PS_A1, (float)d1p[k]);      // x[2(j-2)+1]
@@ -571,7 +666,7 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
                 od[k] = (T)xo;
                 ddp[k] = (T)dd; s1p[k] = (T)s1; d1p[k] = (T)d1; s0p[k] = (T)s0;
             }
-            if (j - 2 >= m0 && wr) {
+            if (it >= 4 && j - 2 < m1 && wr) {
                 if constexpr (U8OUT) {
                     store_row4_u8<T>(a, 2 * (j - 2), c0, ev);
                     store_row4_u8<T>(a, 2 * (j - 2) + 1, c0, od);

@@ -27,7 +27,7 @@ static const float kQSteps[10][4] = {
 };
 
 struct FwdLaunch { DwtFwdArgs a; unsigned gx, gy; bool u8; int band; bool vec; };
-struct InvLaunch { DwtInvArgs a; unsigned gx, gy; int band; bool vec; };
+struct InvLaunch { DwtInvArgs a; unsigned gx, gy; int band; bool vec; bool fast; };
 
 // The vector-only kernel instantiations need whole 4-column groups and 16-byte aligned rows
 // (PICSONG_DWT_NOVEC=1 forces the per-column kernels, used by the tests to cross-check both).
@@ -90,8 +90,38 @@ inline std::vector<FwdLaunch> plan_dwt_forward(const void *d_in, bool u8in, void
     return v;
 }
 
+// May the 9/7 synthesis of a context with this qs use the reciprocal form of its divisions
+// (div_rc, dwt_kernels.hpp)?  Checks, with the very arithmetic the kernels run, every value the
+// de-quantisation can see: m = |v| + 0.5 for |v| < 65536 (16 bit-planes) over each quantisation step
+// q of the wl levels, m / q == div_rc(m, q) and (m / q) / qs == div_rc(m / q, qs).  ~3 M divisions,
+// a few milliseconds, once per context.  PICSONG_DWT_EXACTDIV=1 forces the dividing kernels.
+inline bool dequant_fast_ok(float qs, int wl)
+{
+    if (const char *e = getenv("PICSONG_DWT_EXACTDIV")) if (atoi(e) != 0) return false;
+    if (!(qs >= 0x1p-20f && qs <= 0x1p20f)) return false;
+    const volatile float one = 1.0f;                      // the reciprocals stay IEEE divisions at -O3 too
+    const float rqs = one / qs;
+    float seen[40];
+    int nseen = 0;
+    for (int l = 0; l < wl && l < 10; l++)
+        for (int k = 0; k < 4; k++) {
+            const float q = kQSteps[l][k];
+            bool dup = false;
+            for (int i = 0; i < nseen; i++) dup = dup || seen[i] == q;
+            if (dup) continue;
+            seen[nseen++] = q;
+            const float rq = one / q;
+            for (int n = 0; n < 65536; n++) {
+                const float m = (float)n + 0.5f;
+                const float t = m / q;
+                if (div_rc(m, q, rq) != t || div_rc(t, qs, rqs) != t / qs) return false;
+            }
+        }
+    return true;
+}
+
 inline std::vector<InvLaunch> plan_dwt_inverse(const int32_t *d_in, void *d_out, int aw, int ah, int wl,
-                                               float qs)
+                                               float qs, bool fast = false)
 {
     std::vector<InvLaunch> v;
     int W = aw >> (wl - 1), H = ah >> (wl - 1);
@@ -108,7 +138,9 @@ inline std::vector<InvLaunch> plan_dwt_inverse(const int32_t *d_in, void *d_out,
         a.dst = (char *)d_out + write_off * 4;
         a.dst_u8 = nullptr; a.off = 0;
         a.qs = qs;
-        for (int k = 0; k < 4; k++) a.q[k] = kQSteps[l][k];
+        a.rqs = 1.0f / qs;
+        for (int k = 0; k < 4; k++) { a.q[k] = kQSteps[l][k]; a.rq[k] = 1.0f / a.q[k]; }
+        f.fast = fast;
         const int strips = (W + kStripUseful - 1) / kStripUseful;
         f.band = fwd_band_rows(l, strips, H);
         f.gx = (unsigned)((strips + 3) / 4);

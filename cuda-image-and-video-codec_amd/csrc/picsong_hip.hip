@@ -49,6 +49,7 @@ struct picsong_ctx {
     int device;
     int aw, ah, ncb;
     size_t P, extra;
+    bool fast_div;        // 9/7 synthesis: reciprocal form of the divisions verified for this qs
     // LUT
     picsong_lut_info li[3];
     int32_t *d_lut[3];
@@ -73,14 +74,18 @@ template <int BAND>
 static void launch_inv(const picsong_ctx *c, const InvLaunch &f, hipStream_t s)
 {
     dim3 grid(f.gx, f.gy);
+    // f.fast: the 9/7 divisions in their reciprocal form (verified for this context's qs at creation)
     if (f.vec && f.a.dst_u8) {          // finest level of the frame path: pixels out, clamp fused
-        if (c->p.lossy) dwt_inv_kernel<float, true, BAND, true, true><<<grid, 256, 0, s>>>(f.a);
+        if (c->p.lossy && f.fast) dwt_inv_kernel<float, true, BAND, true, true, true><<<grid, 256, 0, s>>>(f.a);
+        else if (c->p.lossy) dwt_inv_kernel<float, true, BAND, true, true><<<grid, 256, 0, s>>>(f.a);
         else dwt_inv_kernel<int, false, BAND, true, true><<<grid, 256, 0, s>>>(f.a);
     } else if (f.vec) {
-        if (c->p.lossy) dwt_inv_kernel<float, true, BAND, true><<<grid, 256, 0, s>>>(f.a);
+        if (c->p.lossy && f.fast) dwt_inv_kernel<float, true, BAND, true, false, true><<<grid, 256, 0, s>>>(f.a);
+        else if (c->p.lossy) dwt_inv_kernel<float, true, BAND, true><<<grid, 256, 0, s>>>(f.a);
         else dwt_inv_kernel<int, false, BAND, true><<<grid, 256, 0, s>>>(f.a);
     } else {
-        if (c->p.lossy) dwt_inv_kernel<float, true, BAND, false><<<grid, 256, 0, s>>>(f.a);
+        if (c->p.lossy && f.fast) dwt_inv_kernel<float, true, BAND, false, false, true><<<grid, 256, 0, s>>>(f.a);
+        else if (c->p.lossy) dwt_inv_kernel<float, true, BAND, false><<<grid, 256, 0, s>>>(f.a);
         else dwt_inv_kernel<int, false, BAND, false><<<grid, 256, 0, s>>>(f.a);
     }
 }
@@ -293,6 +298,7 @@ int picsong_ctx_create(const picsong_params *p, int device, picsong_ctx **out)
     c->ncb = (aw / PICSONG_CB) * (ah / PICSONG_CB);
     c->P = (size_t)aw * (size_t)ah;
     c->extra = picsong_dwt_extra(aw, ah, p->wl);
+    c->fast_div = p->lossy != 0 && dequant_fast_ok(p->qs, p->wl);
     hipError_t e = hipMalloc(&c->d_offsets, sizeof(int32_t) * (size_t)c->ncb);
     if (e == hipSuccess) e = hipMalloc(&c->d_total, sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc(&c->d_flag, sizeof(int));
@@ -434,7 +440,7 @@ static int dwt_inverse_impl(picsong_ctx *c, const int32_t *d_in, void *d_out, ui
                             hipStream_t s)
 {
     if (fused) *fused = false;
-    std::vector<InvLaunch> plan = plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs);
+    std::vector<InvLaunch> plan = plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs, c->fast_div);
     if (d_pixels && !plan.empty() && plan.back().vec && (((uintptr_t)d_pixels) & 3u) == 0) {
         plan.back().a.dst_u8 = d_pixels;
         plan.back().a.off = 1 << (c->p.bit_depth - 1);
@@ -456,7 +462,7 @@ int picsong_dwt_inverse(picsong_ctx *c, const int32_t *d_in, void *d_out, void *
 {
     if (!c || !d_in || !d_out) return fail(PICSONG_ERR_ARG, "dwt_inverse: null argument");
     hipStream_t s = (hipStream_t)stream;
-    for (const InvLaunch &f : plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs)) {
+    for (const InvLaunch &f : plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs, c->fast_div)) {
         switch (f.band) {
         case 32: launch_inv<32>(c, f, s); break;
         case 16: launch_inv<16>(c, f, s); break;

@@ -10,17 +10,45 @@
 
 using namespace picsong;
 
+// what picsong_ctx_create decides once per context (cached here per (qs, wl))
+static bool emu_fast_div(int lossy, float qs, int wl)
+{
+    static float c_qs = -1.0f;
+    static int c_wl = -1;
+    static bool c_ok = false;
+    if (!lossy) return false;
+    if (getenv("PICSONG_DWT_EXACTDIV") || qs != c_qs || wl != c_wl) { c_ok = dequant_fast_ok(qs, wl); c_qs = qs; c_wl = wl; }
+    return c_ok;
+}
+extern "C" int emu_dequant_fast_ok(float qs, int wl) { return dequant_fast_ok(qs, wl) ? 1 : 0; }
+// x / c next to the reciprocal form, for the test that sweeps them against each other
+extern "C" long emu_div_mismatches(float c, unsigned first_bits, unsigned last_bits, unsigned step)
+{
+    const volatile float one = 1.0f;
+    const float rc = one / c;
+    long bad = 0;
+    for (uint64_t u = first_bits; u <= last_bits; u += step) {
+        float x;
+        const uint32_t b = (uint32_t)u;
+        memcpy(&x, &b, 4);
+        if (div_rc(x, c, rc) != x / c) bad++;
+    }
+    return bad;
+}
+
 template <int BAND, bool VEC> static void emu_inv_v(const InvLaunch &f, int lossy)
 {
     DwtInvArgs a = f.a;
-    if (lossy) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<float, true, BAND, VEC>(a); });
+    if (lossy && f.fast) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<float, true, BAND, VEC, false, true>(a); });
+    else if (lossy) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<float, true, BAND, VEC>(a); });
     else emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<int, false, BAND, VEC>(a); });
 }
 template <int BAND> static void emu_inv(const InvLaunch &f, int lossy)
 {
     DwtInvArgs a = f.a;
     if (f.vec && a.dst_u8) {            // finest level of the frame path: pixels out, clamp fused
-        if (lossy) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<float, true, BAND, true, true>(a); });
+        if (lossy && f.fast) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<float, true, BAND, true, true, true>(a); });
+        else if (lossy) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<float, true, BAND, true, true>(a); });
         else emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<int, false, BAND, true, true>(a); });
     } else if (f.vec) emu_inv_v<BAND, true>(f, lossy);
     else emu_inv_v<BAND, false>(f, lossy);
@@ -67,7 +95,7 @@ void emu_dwt_forward(const void *in, int u8in, void *out, int aw, int ah, int wl
 
 void emu_dwt_inverse(const int32_t *in, void *out, int aw, int ah, int wl, int lossy, float qs)
 {
-    for (const InvLaunch &f : plan_dwt_inverse(in, out, aw, ah, wl, qs)) {
+    for (const InvLaunch &f : plan_dwt_inverse(in, out, aw, ah, wl, qs, emu_fast_div(lossy, qs, wl))) {
         switch (f.band) {
         case 32: emu_inv<32>(f, lossy); break;
         case 16: emu_inv<16>(f, lossy); break;
@@ -81,7 +109,7 @@ void emu_dwt_inverse(const int32_t *in, void *out, int aw, int ah, int wl, int l
 // returns 1 when that fused kernel applied
 int emu_dwt_inverse_u8(const int32_t *in, void *scratch, uint8_t *pixels, int aw, int ah, int wl, int lossy, float qs)
 {
-    std::vector<InvLaunch> plan = plan_dwt_inverse(in, scratch, aw, ah, wl, qs);
+    std::vector<InvLaunch> plan = plan_dwt_inverse(in, scratch, aw, ah, wl, qs, emu_fast_div(lossy, qs, wl));
     const bool fused = !plan.empty() && plan.back().vec && (((uintptr_t)pixels) & 3u) == 0;
     if (fused) { plan.back().a.dst_u8 = pixels; plan.back().a.off = 128; }
     for (const InvLaunch &f : plan) {

@@ -357,3 +357,50 @@ def test_bpc_deep_planes_beyond_the_register_file(oracle, E, k):
         n = sz_o[cb]
         assert np.array_equal(st_e[cb * 4096:cb * 4096 + n], st_o[cb * 4096:cb * 4096 + n]), cb
     assert np.array_equal(E.bpc_decode(st_o, sz_o, W, H, wl, lut, k=k), oracle.bpc_decode(st_o, sz_o, W, H, wl, lut, k=k))
+
+
+# ---- 9/7 synthesis: divisions in reciprocal form -------------------------------------------------
+_LIFT_DIVISORS = (1.230174104914001, 0.812893066)
+_QSTEPS = (1.965908, 1.0112865, 0.52021784, 4.1224113, 1.9968134, 0.96721643, 8.416739, 4.1833673, 2.0792568,
+           16.935543, 8.534108, 4.3004827, 33.924816, 17.166693, 8.686718, 67.87687, 34.385098, 17.41882)
+
+
+def test_reciprocal_division_equals_division(E):
+    """div_rc == `/` bit for bit: a strided sweep over every exponent the kernels send to it
+    (tools/div_check.c is the exhaustive version), and the de-quantisation domain check itself."""
+    import ctypes as C
+    L = E.lib()
+    L.emu_div_mismatches.restype = C.c_long
+    L.emu_div_mismatches.argtypes = [C.c_float, C.c_uint, C.c_uint, C.c_uint]
+    L.emu_dequant_fast_ok.argtypes = [C.c_float, C.c_int]
+    lo, hi = (127 - 96) << 23, ((127 + 100) << 23) - 1
+    for c in _LIFT_DIVISORS:
+        assert L.emu_div_mismatches(c, lo, hi, 1009) == 0
+        assert L.emu_div_mismatches(c, lo | 0x80000000, hi | 0x80000000, 4099) == 0       # negative x
+    for c in _QSTEPS:
+        assert L.emu_div_mismatches(c, (127 - 2) << 23, (127 + 17) << 23, 257) == 0
+    for qs in (1.0, 0.5, 0.25, 0.3, 0.05):
+        assert L.emu_dequant_fast_ok(qs, 6) == 1
+    assert L.emu_dequant_fast_ok(1e-9, 6) == 0                     # outside the checked range: divide
+    # below exponent -107 the residual underflows and the forms differ: what div_lift's test is for
+    assert L.emu_div_mismatches(_LIFT_DIVISORS[0], 1 << 23, (127 - 110) << 23, 1009) > 0
+
+
+@pytest.mark.parametrize("W,H,wl,qs", [(320, 192, 3, 0.5), (64, 128, 5, 0.3)])
+def test_dwt97_inverse_fast_and_dividing_kernels_agree(oracle, E, monkeypatch, W, H, wl, qs):
+    """Same coefficients through the reciprocal-form kernels and (PICSONG_DWT_EXACTDIV=1) the dividing
+    ones, values beyond 16 bit-planes included (they take the division inside the fast kernels too)."""
+    rng = np.random.default_rng(23)
+    coef = rng.integers(-300, 301, (H, W)).astype(np.int32)
+    coef[rng.random((H, W)) < 0.5] = 0
+    coef[5, 7] = 70000
+    coef[11, 3] = -131071
+    coef[H // 2 + 1, W // 2 + 2] = 65535
+    extra = oracle.dwt_extra(W, H, wl)
+    ref, ex = oracle.dwt_inverse(coef, wl, True, qs)
+    monkeypatch.delenv("PICSONG_DWT_EXACTDIV", raising=False)
+    fast = E.dwt_inverse(coef, wl, True, qs, extra=extra)
+    monkeypatch.setenv("PICSONG_DWT_EXACTDIV", "1")
+    exact = E.dwt_inverse(coef, wl, True, qs, extra=extra)
+    assert np.array_equal(exact[extra:].view(np.uint32), ref[ex:].view(np.uint32))
+    assert np.array_equal(fast[extra:].view(np.uint32), ref[ex:].view(np.uint32))
