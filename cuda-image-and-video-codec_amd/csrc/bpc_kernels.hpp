@@ -185,11 +185,33 @@ __device__ __forceinline__ PlaneLut plane_lut(const LutView &v, const LutGeo &g,
     pl.sign = lut_get(v, gi + 0) | (lut_get(v, gi + 1) << 8) | (lut_get(v, gi + 2) << 16) | (lut_get(v, gi + 3) << 24);
     return pl;
 }
-// k = 0: both codeblocks of the wave use table 0; every lane copies a 64th of it
-__device__ __forceinline__ void lut_to_lds(const int32_t *lut, int total, uint8_t *lds, uint32_t lane)
+// k = 0: every codeblock of the workgroup uses table 0; every thread copies its share of it
+__device__ __forceinline__ void lut_to_lds(const int32_t *lut, int total, uint8_t *lds)
 {
-    for (int j = (int)lane; j < total; j += 64) lds[j] = (uint8_t)((uint32_t)lut[j] & 0xFFu);
+    for (int j = (int)threadIdx.x; j < total; j += (int)blockDim.x) lds[j] = (uint8_t)((uint32_t)lut[j] & 0xFFu);
     __syncthreads();
+}
+// Workgroup shape of the k = 0 coder kernels: 4 waves = 8 codeblocks, so that the dispatcher hands a
+// CU's four SIMDs one wave each (with one-wave workgroups and room for 5 waves per SIMD it fills
+// SIMD after SIMD, and a lone launch runs on unevenly loaded SIMDs); the waves share nothing but the
+// LDS copy of the probability table.  The -k > 0 kernels keep one wave per workgroup (a table copy
+// per codeblock).
+#ifndef PICSONG_BPC_ENC_WG
+#define PICSONG_BPC_ENC_WG 4
+#endif
+#ifndef PICSONG_BPC_DEC_WG
+#define PICSONG_BPC_DEC_WG 4
+#endif
+constexpr int kBpcEncWgWaves = PICSONG_BPC_ENC_WG, kBpcDecWgWaves = PICSONG_BPC_DEC_WG;
+// stores of the wave's other lanes to addresses this lane is about to overwrite have been issued
+// (same wave, same address: the memory pipe keeps them in order)
+__device__ __forceinline__ void wave_stores_issued()
+{
+#if defined(__AMDGCN__)
+    __builtin_amdgcn_wave_barrier();
+#else
+    (void)__builtin_amdgcn_ballot_w64(true);        // emulator: lanes are coroutines, this joins them
+#endif
 }
 
 // =============================================================================================
@@ -533,11 +555,12 @@ __device__ __forceinline__ int bulk_setup(const BpcArgs &a, bool coded, int msb,
 // BULK = the -k > 0 instantiation (bulk scan after the ordinary planes, table s of the bit-plane
 // LUT files, LDS copy of that table); the k = 0 instantiation compiles to the plain coder.
 template <bool BULK>
-__global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(BpcArgs a)
+__global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(BpcArgs a)
 {
     __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
-    const int cb = a.cb_base + 2 * (int)blockIdx.x + (int)half;
+    const int wave = BULK ? (int)blockIdx.x : (int)blockIdx.x * kBpcEncWgWaves + (int)(threadIdx.x >> 6);
+    const int cb = a.cb_base + 2 * wave + (int)half;
     const bool valid = cb < a.nCB;
     const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
     const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
@@ -577,7 +600,7 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
     int cbp = 0, loff = 0;                                   // planes >= cbp take the two passes
     BulkLane bl;
     if constexpr (BULK) cbp = bulk_setup(a, coded, msb, cbx, cby, grp, t, lds_lut + half * kLutLdsMax, bl, loff);
-    else lut_to_lds(a.lut, a.g.nRef + a.g.nSig + a.g.nSign, lds_lut, lane);
+    else lut_to_lds(a.lut, a.g.nRef + a.g.nSig + a.g.nSign, lds_lut);
     const LutView lv = { lds_lut + (BULK ? half * kLutLdsMax : 0u), a.lut, a.g.nRef + a.g.nSig + a.g.nSign,
                          (a.g.nRef + a.g.nSig + a.g.nSign) * (BULK ? a.n_tables : 1), loff };
 
@@ -620,7 +643,7 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
     // planes below the 8 held in registers (a codeblock with MSB >= 8 in the wave): one more pass over
     // the rows builds them in registers that are free until the plane loop, then parks them in HBM;
     // slot j = plane kEncRegPlanes + j, layout [slot][4][lane] so that every access is a 256-byte row
-    uint32_t *const pscr = a.plane_scratch + (size_t)blockIdx.x * (size_t)kEncScratchDwordsPerWave + lane;
+    uint32_t *const pscr = a.plane_scratch + (size_t)wave * (size_t)kEncScratchDwordsPerWave + lane;
     if (np > kEncRegPlanes) {
         uint32_t Tl[kMaxPlanes - kEncRegPlanes][2], Tr[kMaxPlanes - kEncRegPlanes][2];
 #pragma unroll
@@ -771,8 +794,8 @@ __global__ __launch_bounds__(64, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(B
     const uint32_t size = (half ? c.cnt_hi : c.cnt_lo) + 1u;
     if (valid && t == 0u) { a.sizes[cb] = (int32_t)size; st[0] = msb; }
     // expansionFix :1905-1912 overwrites the whole block and must land after every codeword store
-    // of the block (they come from other lanes): drain the wave's stores first.
-    __syncthreads();
+    // of the block (they come from other lanes of this wave)
+    wave_stores_issued();
     if (valid && size == 4096u) {
         for (int i = 0; i < 64; i++) {
             int32_t v0, v1;
@@ -892,8 +915,8 @@ __device__ __forceinline__ uint64_t dec_spp_coeff(Coder &c, bool idle, uint64_t 
 }
 
 // 32 rows of the decoder's output: bit ii of plane register k is bit k of row row0 + ii's magnitude
-template <int NP>
-__device__ __forceinline__ void write_rows(const uint32_t (&PL)[kMaxPlanes], const uint32_t (&PR)[kMaxPlanes],
+template <int NP, int NA>
+__device__ __forceinline__ void write_rows(const uint32_t (&PL)[NA], const uint32_t (&PR)[NA],
                                            uint32_t sgL, uint32_t sgR, int row0, bool valid, int32_t sz,
                                            const int32_t *stage, uint32_t t, int32_t *out, int AW)
 {
@@ -920,18 +943,30 @@ __device__ __forceinline__ void write_rows(const uint32_t (&PL)[kMaxPlanes], con
     }
 }
 
-// One wave64 per workgroup; codeblocks cb_base + 2*blockIdx.x (lanes 0-31) and +1 (lanes 32-63).
+// One wave64 = codeblocks cb_base + 2*wave (lanes 0-31) and +1 (lanes 32-63).
 #ifndef PICSONG_BPC_DEC_WAVES
 #define PICSONG_BPC_DEC_WAVES 4
 #endif
-template <bool BULK>
-__global__ __launch_bounds__(64, PICSONG_BPC_DEC_WAVES) void bpc_decode_kernel(BpcArgs a)
+#ifndef PICSONG_BPC_DEC_WAVES8
+#define PICSONG_BPC_DEC_WAVES8 5
+#endif
+// Two instantiations share a launch's waves: NP = 8 keeps 8 plane registers per column half (5
+// waves / SIMD) and takes the waves whose two codeblocks have at most 8 coded planes -- nearly all --,
+// NP = 16 (4 waves / SIMD) takes the rest; the host launches both, a wave of the other class returns
+// at once.
+constexpr int kDecSmallPlanes = 8;
+template <bool BULK, int NP>
+__global__ __launch_bounds__(BULK ? 64 : 64 * kBpcDecWgWaves,
+                             (NP == kDecSmallPlanes && !BULK) ? PICSONG_BPC_DEC_WAVES8 : PICSONG_BPC_DEC_WAVES)
+void bpc_decode_kernel(BpcArgs a)
 {
+    static_assert(NP == kDecSmallPlanes || NP == kMaxPlanes, "two classes");
     __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
     __shared__ uint8_t sign_tab[256];
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
     sign_table_fill(sign_tab, lane);                        // (the LUT copy below ends with the barrier)
-    const int cb = a.cb_base + 2 * (int)blockIdx.x + (int)half;
+    const int wave = BULK ? (int)blockIdx.x : (int)blockIdx.x * kBpcDecWgWaves + (int)(threadIdx.x >> 6);
+    const int cb = a.cb_base + 2 * wave + (int)half;
     const bool valid = cb < a.nCB;
     const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
     const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
@@ -940,9 +975,9 @@ __global__ __launch_bounds__(64, PICSONG_BPC_DEC_WAVES) void bpc_decode_kernel(B
     const uint32_t prec = (uint32_t)a.g.prec;
     const uint32_t upper_mask = half ? 0xFFFFFFFFu : 0u;
 
-    uint32_t PLlo[kMaxPlanes], PLhi[kMaxPlanes], PRlo[kMaxPlanes], PRhi[kMaxPlanes];
+    uint32_t PLlo[NP], PLhi[NP], PRlo[NP], PRhi[NP];
 #pragma unroll
-    for (int k = 0; k < kMaxPlanes; k++) { PLlo[k] = PLhi[k] = PRlo[k] = PRhi[k] = 0u; }
+    for (int k = 0; k < NP; k++) { PLlo[k] = PLhi[k] = PRlo[k] = PRhi[k] = 0u; }
     M64 sgnL = { 0u, 0u }, sgnR = { 0u, 0u };
     int msb = 32;
     int32_t sz = 0;
@@ -963,13 +998,14 @@ __global__ __launch_bounds__(64, PICSONG_BPC_DEC_WAVES) void bpc_decode_kernel(B
     int cbp = 0, loff = 0;
     BulkLane bl;
     if constexpr (BULK) cbp = bulk_setup(a, coded, msb, cbx, cby, grp, t, lds_lut + half * kLutLdsMax, bl, loff);
-    else lut_to_lds(a.lut, a.g.nRef + a.g.nSig + a.g.nSign, lds_lut, lane);
+    else lut_to_lds(a.lut, a.g.nRef + a.g.nSig + a.g.nSign, lds_lut);
     const LutView lv = { lds_lut + (BULK ? half * kLutLdsMax : 0u), a.lut, a.g.nRef + a.g.nSig + a.g.nSign,
                          (a.g.nRef + a.g.nSig + a.g.nSign) * (BULK ? a.n_tables : 1), loff };
 
     int np = coded ? (msb + 1 - cbp > 0 ? msb + 1 - cbp : 0) : 0;
     { int o = __shfl_xor(np, 32); np = np > o ? np : o; }
     np = (int)__builtin_amdgcn_readfirstlane((uint32_t)np);
+    if ((NP == kDecSmallPlanes) != (np <= kDecSmallPlanes)) return;      // the other instantiation's wave
 
     for (int p = 0; p < np; p++) {
         const int bp = msb - p;
@@ -980,7 +1016,7 @@ __global__ __launch_bounds__(64, PICSONG_BPC_DEC_WAVES) void bpc_decode_kernel(B
         // make room: plane registers move up so that after the last plane index k = plane k
         if (act && p > 0) {
 #pragma unroll
-            for (int k = kMaxPlanes - 1; k > 0; k--) {
+            for (int k = NP - 1; k > 0; k--) {
                 PLlo[k] = PLlo[k - 1]; PLhi[k] = PLhi[k - 1];
                 PRlo[k] = PRlo[k - 1]; PRhi[k] = PRhi[k - 1];
             }
@@ -1075,7 +1111,7 @@ __global__ __launch_bounds__(64, PICSONG_BPC_DEC_WAVES) void bpc_decode_kernel(B
                 const uint32_t ii = (uint32_t)i & 31u, hs = (uint32_t)(bl.Bh + 1);
                 uint32_t m0 = 0u, m1 = 0u;
 #pragma unroll
-                for (int k = 0; k < kMaxPlanes; k++) {
+                for (int k = 0; k < NP; k++) {
                     uint32_t l = i < 32 ? PLlo[k] : PLhi[k], r = i < 32 ? PRlo[k] : PRhi[k];
                     m0 |= ((l >> ii) & 1u) << k;
                     m1 |= ((r >> ii) & 1u) << k;
@@ -1089,14 +1125,9 @@ __global__ __launch_bounds__(64, PICSONG_BPC_DEC_WAVES) void bpc_decode_kernel(B
         }
     } else {
         // writeCoefficients BPCEngine.cu:94-111 / copyEntireCodeblock :1915-1922.  Plane registers
-        // np.. are zero in both codeblocks of the wave: gather 8 planes unless some block has more.
-        if (np <= 8) {
-            write_rows<8>(PLlo, PRlo, sgnL.lo, sgnR.lo, 0, valid, sz, stage, t, a.coeffs_out + cbase, a.AW);
-            write_rows<8>(PLhi, PRhi, sgnL.hi, sgnR.hi, 32, valid, sz, stage, t, a.coeffs_out + cbase, a.AW);
-        } else {
-            write_rows<kMaxPlanes>(PLlo, PRlo, sgnL.lo, sgnR.lo, 0, valid, sz, stage, t, a.coeffs_out + cbase, a.AW);
-            write_rows<kMaxPlanes>(PLhi, PRhi, sgnL.hi, sgnR.hi, 32, valid, sz, stage, t, a.coeffs_out + cbase, a.AW);
-        }
+        // NP.. do not exist in this instantiation (its waves have at most NP coded planes).
+        write_rows<NP>(PLlo, PRlo, sgnL.lo, sgnR.lo, 0, valid, sz, stage, t, a.coeffs_out + cbase, a.AW);
+        write_rows<NP>(PLhi, PRhi, sgnL.hi, sgnR.hi, 32, valid, sz, stage, t, a.coeffs_out + cbase, a.AW);
     }
 }
 

@@ -506,7 +506,7 @@ static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_stag
     a.staging = d_staging; a.sizes = d_sizes;
     if (!c->d_plane_scratch) {
         HIP_TRY(hipSetDevice(c->device));
-        HIP_TRY(hipMalloc(&c->d_plane_scratch, (size_t)((c->ncb + 1) / 2) * kEncScratchDwordsPerWave * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->d_plane_scratch, (size_t)(((c->ncb + 1) / 2 + kBpcEncWgWaves - 1) / kBpcEncWgWaves * kBpcEncWgWaves) * kEncScratchDwordsPerWave * sizeof(uint32_t)));
     }
     a.plane_scratch = c->d_plane_scratch;
     // BPCEngine::deviceMemoryAllocator BPCEngine.cu:2429-2441.  Slots beyond a codeblock's length
@@ -514,7 +514,7 @@ static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_stag
     if (memset_staging) HIP_TRY(hipMemsetAsync(d_staging, 0xFF, c->P * sizeof(int32_t), s));
     // -k > 0: the BULK instantiation (bulk scan below the consecutive bit-planes, table s in LDS)
     if (a.k > 0.0f) bpc_encode_kernel<true><<<(unsigned)((cb_count + 1) / 2), 64, 0, s>>>(a);
-    else bpc_encode_kernel<false><<<(unsigned)((cb_count + 1) / 2), 64, 0, s>>>(a);
+    else bpc_encode_kernel<false><<<(unsigned)(((cb_count + 1) / 2 + kBpcEncWgWaves - 1) / kBpcEncWgWaves), 64 * kBpcEncWgWaves, 0, s>>>(a);
     HIP_TRY(hipGetLastError());
     return PICSONG_OK;
 }
@@ -534,8 +534,16 @@ static int bpc_decode_impl(picsong_ctx *c, const int32_t *d_staging, const int32
     a.coeffs_out = d_coeffs;
     a.staging = const_cast<int32_t *>(d_staging);
     a.sizes = const_cast<int32_t *>(d_sizes);
-    if (a.k > 0.0f) bpc_decode_kernel<true><<<(unsigned)((c->ncb + 1) / 2), 64, 0, s>>>(a);
-    else bpc_decode_kernel<false><<<(unsigned)((c->ncb + 1) / 2), 64, 0, s>>>(a);
+    // both plane-count classes over the same grid: each wave is taken by exactly one of them
+    const unsigned waves = (unsigned)((c->ncb + 1) / 2);
+    if (a.k > 0.0f) {
+        bpc_decode_kernel<true, kDecSmallPlanes><<<waves, 64, 0, s>>>(a);
+        bpc_decode_kernel<true, kMaxPlanes><<<waves, 64, 0, s>>>(a);
+    } else {
+        const unsigned wgs = (waves + kBpcDecWgWaves - 1) / kBpcDecWgWaves;
+        bpc_decode_kernel<false, kDecSmallPlanes><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
+        bpc_decode_kernel<false, kMaxPlanes><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
+    }
     HIP_TRY(hipGetLastError());
     return PICSONG_OK;
 }

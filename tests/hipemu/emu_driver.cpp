@@ -173,11 +173,11 @@ void emu_bpc_encode(const void *coeffs, int is_float, int aw, int ah, int wl, co
     BpcArgs a = mk(aw, ah, wl, lut, geo, staging, sizes, flag);
     a.coeffs_in = coeffs; a.is_float = is_float;
     a.k = k; a.n_tables = n_tables;
-    std::vector<uint32_t> plane_scratch((size_t)((a.nCB + 1) / 2) * kEncScratchDwordsPerWave, 0xDEADBEEFu);
+    std::vector<uint32_t> plane_scratch((size_t)(((a.nCB + 1) / 2 + kBpcEncWgWaves - 1) / kBpcEncWgWaves * kBpcEncWgWaves) * kEncScratchDwordsPerWave, 0xDEADBEEFu);
     a.plane_scratch = plane_scratch.data();
     memset(staging, 0xFF, (size_t)aw * ah * 4);
     if (k > 0.0f) emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_encode_kernel<true>(a); });
-    else emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_encode_kernel<false>(a); });
+    else emu::launch(dim3((unsigned)(((a.nCB + 1) / 2 + kBpcEncWgWaves - 1) / kBpcEncWgWaves)), dim3(64 * kBpcEncWgWaves), [&] { bpc_encode_kernel<false>(a); });
 }
 
 void emu_bpc_decode(const int32_t *staging, const int32_t *sizes, int aw, int ah, int wl, const int32_t *lut,
@@ -186,8 +186,15 @@ void emu_bpc_decode(const int32_t *staging, const int32_t *sizes, int aw, int ah
     BpcArgs a = mk(aw, ah, wl, lut, geo, const_cast<int32_t *>(staging), const_cast<int32_t *>(sizes), flag);
     a.coeffs_out = coeffs;
     a.k = k; a.n_tables = n_tables;
-    if (k > 0.0f) emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_decode_kernel<true>(a); });
-    else emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_decode_kernel<false>(a); });
+    const dim3 grid((unsigned)((a.nCB + 1) / 2));
+    if (k > 0.0f) {
+        emu::launch(grid, dim3(64), [&] { bpc_decode_kernel<true, kDecSmallPlanes>(a); });
+        emu::launch(grid, dim3(64), [&] { bpc_decode_kernel<true, kMaxPlanes>(a); });
+    } else {
+        const dim3 wgs((grid.x + kBpcDecWgWaves - 1) / kBpcDecWgWaves);
+        emu::launch(wgs, dim3(64 * kBpcDecWgWaves), [&] { bpc_decode_kernel<false, kDecSmallPlanes>(a); });
+        emu::launch(wgs, dim3(64 * kBpcDecWgWaves), [&] { bpc_decode_kernel<false, kMaxPlanes>(a); });
+    }
 }
 
 int emu_pack(const int32_t *staging, const int32_t *sizes, int ncb, const uint16_t *header, uint16_t *out)
