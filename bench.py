@@ -274,8 +274,9 @@ def main():
                 "note": "BPC is bound by vector-instruction issue, not HBM (SURVEY 8d): codeblocks/s and "
                         "valu_issue are the figures of merit, the HBM fraction is reported for completeness; "
                         "`traffic` (PMC) exceeds the algorithmic bytes because the coefficients are read twice "
-                        "(MSB search, then bit-plane transposition) and the 96-VGPR build (5 waves/SIMD, the "
-                        "faster one when frames are pipelined) spills ~50 dwords per lane to scratch"}
+                        "(MSB search, then bit-plane transposition); the 96-VGPR build (5 waves/SIMD, the "
+                        "faster one when frames are pipelined) spills 17 dwords per lane to scratch and "
+                        "parks the bit-planes below the 8 it keeps in registers in an HBM scratch"}
     roofline_dwt = {"kernel": "dwt_fwd_kernel (all levels, u8 ingest fused)", "bound": "hbm",
                     "achieved": round(dwt_b / (dwt_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(dwt_b / (dwt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
