@@ -49,6 +49,10 @@ namespace picsong {
 constexpr int kStripCols = 256;                 // columns held by one wave
 constexpr int kEdgeLanes = PICSONG_DWT_EDGE_LANES;          // recomputed, never-written lanes per side (>= 1)
 constexpr int kStripUseful = kStripCols - 8 * kEdgeLanes;   // lanes kEdgeLanes .. 63-kEdgeLanes write
+#ifndef PICSONG_DWT_INV_GROUP
+#define PICSONG_DWT_INV_GROUP 3       // 9/7 inverse kernels: unrolled iterations per trip of the counted loop (at most)
+#endif
+constexpr int inv_group(int iters, int most) { return iters % most == 0 ? most : inv_group(iters, most - 1); }
 #ifndef PICSONG_DWT_INV_AHEAD
 #define PICSONG_DWT_INV_AHEAD 6       // inverse kernels: row pairs whose loads are in flight ahead of the math
 #endif
@@ -582,11 +586,16 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
 
     // The band's row pairs plus the filter's run-in: a compile-time trip count (rows past the band's
     // end at the bottom of the image are mirrored reads whose results are not stored), so the loop
-    // unrolls fully and the raw loads of the next kInvAhead iterations are issued BEFORE this
-    // iteration's stores (one in-order memory pipe, and the compiler cannot prove dst != src).
+    // unrolls and the raw loads of the next kInvAhead iterations are issued BEFORE this iteration's
+    // stores (one in-order memory pipe, and the compiler cannot prove dst != src).  5/3: fully
+    // unrolled.  9/7: a counted loop over groups of kInvAhead unrolled iterations (kInvAhead divides the
+    // trip count, so there is no remainder loop): unrolled 12 times the 16-row kernel was 77 KB of
+    // code for a 64 KB instruction cache.
     constexpr int kRunIn = LOSSY ? 2 : 1;
     constexpr int kIters = kInvBandRows / 2 + 2 * kRunIn;
-    constexpr int kInvAhead = kIters < PICSONG_DWT_INV_AHEAD ? kIters : PICSONG_DWT_INV_AHEAD;
+    constexpr int kInvAhead = !LOSSY ? (kIters < PICSONG_DWT_INV_AHEAD ? kIters : PICSONG_DWT_INV_AHEAD)
+                              : inv_group(kIters, PICSONG_DWT_INV_GROUP);
+    static_assert(!LOSSY || kIters % kInvAhead == 0, "9/7: groups of kInvAhead iterations");
     const int j0 = m0 - kRunIn;
     SubRaw rawL[kInvAhead], rawH[kInvAhead];
     __builtin_amdgcn_s_setprio(3);
@@ -637,15 +646,18 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
         T ddp[4], s1p[4], d1p[4], s0p[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) { ddp[k] = s1p[k] = d1p[k] = s0p[k] = (T)0; }
+#pragma unroll 1
+        for (int g = 0; g < kIters / kInvAhead; g++) {
 #pragma unroll
-        for (int it = 0; it < kIters; it++) {
+        for (int r = 0; r < kInvAhead; r++) {
+            const int it = g * kInvAhead + r;
             const int j = j0 + it;
             T Lr[4], Hr[4];
-            convert_sub<T, LOSSY, FAST>(a, rawL[it % kInvAhead], false, Lr);
-            convert_sub<T, LOSSY, FAST>(a, rawH[it % kInvAhead], true, Hr);
-            if (it + kInvAhead < kIters) {
-                rawL[it % kInvAhead] = load_sub_raw<T, VEC>(a, reflect_s(j + kInvAhead, hH), false, pl, inside);
-                rawH[it % kInvAhead] = load_sub_raw<T, VEC>(a, reflect_d(j + kInvAhead, hH), true, pl, inside);
+            convert_sub<T, LOSSY, FAST>(a, rawL[r], false, Lr);
+            convert_sub<T, LOSSY, FAST>(a, rawH[r], true, Hr);
+            if (g + 1 < kIters / kInvAhead) {
+                rawL[r] = load_sub_raw<T, VEC>(a, reflect_s(j + kInvAhead, hH), false, pl, inside);
+                rawH[r] = load_sub_raw<T, VEC>(a, reflect_d(j + kInvAhead, hH), true, pl, inside);
             }
             hinv<FAST>(Lr, le, re);
             hinv<FAST>(Hr, le, re);
@@ -675,6 +687,7 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
                     store_row4<T, VEC>(a, 2 * (j - 2) + 1, c0, od);
                 }
             }
+        }
         }
     }
 }
