@@ -50,7 +50,7 @@ struct BpcArgs {
     int32_t *staging;              // int32[nCB*4096]
     int32_t *sizes;                // int32[nCB]
     int *range_flag;               // set to 1 if a codeblock has MSB > 15
-    uint32_t *plane_scratch;       // encoder: kEncScratchDwordsPerWave dwords per workgroup of the launch
+    uint32_t *plane_scratch;       // encoder: kEncScratchDwordsPerWave dwords per wave of the launch
     float k;                       // complexity-scalability factor (-k); > 0 only in BULK kernels
     int n_tables;                  // bit-plane tables laid back to back in `lut` (1 when k = 0)
 };

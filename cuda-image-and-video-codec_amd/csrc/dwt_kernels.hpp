@@ -56,9 +56,6 @@ constexpr int inv_group(int iters, int most) { return iters % most == 0 ? most :
 #ifndef PICSONG_DWT_INV_AHEAD
 #define PICSONG_DWT_INV_AHEAD 6       // inverse kernels: row pairs whose loads are in flight ahead of the math
 #endif
-#ifndef PICSONG_DWT_UNROLL
-#define PICSONG_DWT_UNROLL 4
-#endif
 // Output rows per band are a template parameter (BAND = 4, 8, 16 or 32): big levels want tall bands
 // (less vertical halo), small levels want many short waves (a level with 18 tall waves is bound by
 // one wave's serial instruction time, not by memory).  Row pairs fetched ahead = min(4, BAND/2).
