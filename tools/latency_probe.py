@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Single-frame encode / decode latency (one stream, resident buffers) on the bench frame and on a
-smooth frame whose codeblocks differ widely in bit-plane count.  PICSONG_SO selects a library variant."""
+smooth frame whose codeblocks differ widely in bit-plane count; --k=0.5 times the -k > 0 kernels.
+PICSONG_SO selects a library variant."""
 import os
 import sys
 import time
@@ -16,7 +17,12 @@ import picsong_amd as pa
 
 W, H, wl = 7680, 4320, 5
 lut = os.path.join(orc.LUT_DIR, "n1_lossless")
-c = pa.Codec(W, H, wl=wl, lossy=False, qs=1.0, lut_folder=lut)
+k = 0.0
+for a in sys.argv[1:]:
+    if a.startswith("--k="):
+        k = float(a.split("=")[1])          # complexity-scalable mode (-k): the BULK kernels
+c = pa.Codec(W, H, wl=wl, lossy=False, qs=1.0, lut_folder=lut, k=k)
+print(f"k = {k}")
 
 
 def smooth_frame():
