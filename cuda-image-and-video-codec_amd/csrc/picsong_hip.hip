@@ -280,7 +280,7 @@ int picsong_ctx_create(const picsong_params *p, int device, picsong_ctx **out)
         return fail(PICSONG_ERR_ARG, "components must be 1 (grey) or 3 with is_rgb (got %d, is_rgb %d)", p->components,
                     p->is_rgb);
     const int aw = picsong_pad_dim(p->width), ah = picsong_pad_dim(p->height);
-    if ((aw >> (p->wl - 1)) < 8 || (ah >> (p->wl - 1)) < 8 || ((aw >> (p->wl - 1)) & 1) || ((ah >> (p->wl - 1)) & 1))
+    if ((aw >> (p->wl - 1)) < 4 || (ah >> (p->wl - 1)) < 4 || ((aw >> (p->wl - 1)) & 1) || ((ah >> (p->wl - 1)) & 1))
         return fail(PICSONG_ERR_ARG, "image %dx%d too small for %d wavelet levels", aw, ah, p->wl);
     if ((size_t)aw * (size_t)ah >= ((size_t)1 << 30)) return fail(PICSONG_ERR_ARG, "frame too large");
 

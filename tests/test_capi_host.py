@@ -86,8 +86,8 @@ def test_invalid_parameters_are_rejected_without_exit():
     p = pa.make_params(512, 512, wl=3)
     p.cp = 3
     assert L.picsong_ctx_create(C.byref(p), 0, C.byref(h)) == -1
-    p = pa.make_params(64, 64, wl=5)
-    assert L.picsong_ctx_create(C.byref(p), 0, C.byref(h)) == -1        # too small for 5 levels
+    p = pa.make_params(64, 64, wl=6)
+    assert L.picsong_ctx_create(C.byref(p), 0, C.byref(h)) == -1        # too small for 6 levels (2x2 at the last)
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
