@@ -203,11 +203,11 @@ __device__ __forceinline__ void lut_to_lds(const int32_t *lut, int total, uint8_
 #define PICSONG_BPC_DEC_WG 4
 #endif
 constexpr int kBpcEncWgWaves = PICSONG_BPC_ENC_WG, kBpcDecWgWaves = PICSONG_BPC_DEC_WG;
-// stores of the wave's other lanes to addresses this lane is about to overwrite have been issued
-// (same wave, same address: the memory pipe keeps them in order)
+// stores of the wave's other lanes to addresses this lane is about to overwrite have completed
 __device__ __forceinline__ void wave_stores_issued()
 {
 #if defined(__AMDGCN__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 #else
     (void)__builtin_amdgcn_ballot_w64(true);        // emulator: lanes are coroutines, this joins them
