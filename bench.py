@@ -130,6 +130,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL's send / receive kernels share the GPU with the coder, which keeps every SIMD's wave slots
+        # full: put them on a high-priority stream so that they are dispatched as slots free up
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import picsong_amd as pa
