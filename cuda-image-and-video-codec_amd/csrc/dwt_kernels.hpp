@@ -301,10 +301,10 @@ __device__ __forceinline__ void store2(T *p, T x, T y, bool two)
 
 // writeSubbands DWTGenerator.cu:403-433 + placement :719-723.  Lrow/Hrow: vertically low / high
 // rows after horizontal analysis (s0,d0,s1,d1): s -> LL / LH, d -> HL / HH.
-template <typename T, bool LOSSY, bool VEC>
+template <typename T, bool LOSSY, bool VEC, bool NOLL = false>
 __device__ __forceinline__ void emit_pair(const DwtFwdArgs &a, int m, int pc, bool wr, bool le, bool re,
                                           T Lr[4], T Hr[4])
-{
+{   // NOLL: the LL samples (left in Lr[0], Lr[2]) stay in registers for the next level (dwt_fwd2_kernel)
     hfwd(Lr, le, re);
     hfwd(Hr, le, re);
     if (!wr || m < 0 || m >= (a.H >> 1)) return;
@@ -324,7 +324,7 @@ __device__ __forceinline__ void emit_pair(const DwtFwdArgs &a, int m, int pc, bo
         const uint32_t vo = (uint32_t)pc;
         T *rl = (T *)a.ll + (size_t)m * (size_t)a.ll_stride;
         T *r0 = mal + (size_t)m * (size_t)a.AW, *r1 = mal + (size_t)(m + hH) * (size_t)a.AW;
-        store2<T, true>(rl + vo, ll0, ll1, true);
+        if constexpr (!NOLL) store2<T, true>(rl + vo, ll0, ll1, true);
         store2<T, true>(r0 + hW + vo, hl0, hl1, true);
         store2<T, true>(r1 + vo, lh0, lh1, true);
         store2<T, true>(r1 + hW + vo, hh0, hh1, true);
@@ -457,6 +457,187 @@ __global__ __launch_bounds__(256) PS_DWT_OCC void dwt_fwd_kernel(DwtFwdArgs a)
                 }
                 emit_pair<T, LOSSY, VEC>(a, j - 1, pc, wr && j - 1 >= m0 && j <= m1, le, re, Lr, Hr);
             }
+        }
+    }
+}
+
+// ---- levels 0 and 1 in one launch -------------------------------------------------------------
+// The LL rows of level 0 never leave the registers: as the band streams down, every pair of level-0
+// row pairs feeds one step of a second sliding window (the lane's two LL samples of a row are one
+// (even, odd) pair of the level-1 row, so its horizontal lifting is the 2-wide form of hfwd over the
+// same DPP neighbours).  Saves the 4 B/sample write and read of LL1 (67 MB of an 8K frame's 256 MB)
+// and a launch.  Costs a taller run-in (level 1's run-in rows are level-0 rows that have to be
+// recomputed: 9 extra input rows per 32-row band for 5/3, 21 for 9/7) and 3 recomputed lanes per side
+// instead of 1 (the level-1 lifting reaches 2-3 lanes further).  8K: 27.4 + 13.4 -> 31.5 us (5/3),
+// 29.0 + 16.6 -> 43.1 us (9/7).
+// Iteration i does level-0 steps sA = S0 + 2i and sA + 1 (input rows 2sA+1 .. 2sA+4) and one level-1
+// step on the two LL rows they deliver; 5/3 steps emit their own pair, 9/7 steps the pair before.
+constexpr int kF2Edge = 3;
+constexpr int kF2Useful = kStripCols - 8 * kF2Edge;          // 232 columns written per wave
+#ifndef PICSONG_DWT_F2_GROUP
+#define PICSONG_DWT_F2_GROUP 0
+#endif
+// unrolled iterations per trip of the counted loop = rows fetched ahead / 4; 0 = the whole band, all its
+// rows fetched before the first store like dwt_fwd_kernel (8K 5/3, 32-row bands: 31.5 us; 3 / 5 / 6
+// iterations ahead: 42.9 / 34.4 / 37.4; 64-row bands 34.3, 16-row bands 33.9)
+constexpr int kF2GroupSet = PICSONG_DWT_F2_GROUP;
+constexpr int kF2Pairs = 8;                                  // level-1 row pairs per band (32 input rows)
+struct DwtFwd2Args { DwtFwdArgs l0, l1; };
+
+__device__ __forceinline__ void hfwd2(int v[2], bool le, bool re)
+{
+    int en = nxt<int>(v[0], v[0], re);
+    v[1] -= (v[0] + en) >> 1;
+    int dp = prv<int>(v[1], v[1], le);
+    v[0] += (dp + v[1] + 2) >> 2;
+}
+__device__ __forceinline__ void hfwd2(float v[2], bool le, bool re)
+{
+    float en = nxt<float>(v[0], v[0], re);
+    v[1] = fmaf(v[0] + en, PS_A1, v[1]);
+    float dp = prv<float>(v[1], v[1], le);
+    v[0] = fmaf(v[1] + dp, PS_A2, v[0]);
+    float sn = nxt<float>(v[0], v[0], re);
+    v[1] = fmaf(v[0] + sn, PS_A3, v[1]);
+    dp = prv<float>(v[1], v[1], le);
+    v[0] = fmaf(v[1] + dp, PS_A4, v[0]) * PS_N2;
+    v[1] *= PS_N1;
+}
+
+// One vertical analysis step over N columns: consumes rows xo = x[2j+1], xn = x[2j+2] (xe = x[2j] is
+// state).  5/3 (st[0] = d[j-1]) delivers pair j, 9/7 (st = d1[j-1], s1[j-1], d2[j-2]) pair j-1.
+template <typename T, bool LOSSY, int N>
+__device__ __forceinline__ void vstep(T (&xe)[N], T (&st)[3][N], const T (&xo)[N], const T (&xn)[N], T (&L)[N], T (&H)[N])
+{
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        if constexpr (LOSSY) {
+            float d1 = fmaf((float)xe[k] + (float)xn[k], PS_A1, (float)xo[k]);
+            float s1 = fmaf((float)st[0][k] + d1, PS_A2, (float)xe[k]);
+            float d2 = fmaf((float)st[1][k] + s1, PS_A3, (float)st[0][k]);
+            float s2 = fmaf((float)st[2][k] + d2, PS_A4, (float)st[1][k]);
+            L[k] = (T)(s2 * PS_N2);
+            H[k] = (T)(d2 * PS_N1);
+            st[0][k] = (T)d1; st[1][k] = (T)s1; st[2][k] = (T)d2;
+        } else {
+            T d = xo[k] - ((xe[k] + xn[k]) >> 1);
+            L[k] = xe[k] + ((st[0][k] + d + 2) >> 2);
+            H[k] = d;
+            st[0][k] = d;
+        }
+        xe[k] = xn[k];
+    }
+}
+
+// `row` = an LL row of the lane (2 samples) with index N + over in a band of N rows: for over >= 0 it
+// is replaced by row N - 2 - over, which was delivered 2 * (over + 1) rows ago (hist[0] = the row
+// before this one); then the history moves on.  `over` is wave-uniform.
+template <typename T, int NH>
+__device__ __forceinline__ void ll_row_or_mirror(T (&row)[2], T (&hist)[NH][2], int over)
+{
+    if (over >= 0) {
+#pragma unroll
+        for (int d = 0; d < NH / 2; d++)
+            if (over == d) { row[0] = hist[2 * d + 1][0]; row[1] = hist[2 * d + 1][1]; }
+    }
+#pragma unroll
+    for (int k = NH - 1; k > 0; k--) { hist[k][0] = hist[k - 1][0]; hist[k][1] = hist[k - 1][1]; }
+    hist[0][0] = row[0]; hist[0][1] = row[1];
+}
+
+// level-1 subband samples of one lane (one pair per row pair): 4-byte stores, a 256-byte row per wave
+template <typename T, bool LOSSY>
+__device__ __forceinline__ void emit_pair1(const DwtFwdArgs &a, int n, int pc, bool wr, bool le, bool re,
+                                           T (&Lr)[2], T (&Hr)[2])
+{
+    hfwd2(Lr, le, re);
+    hfwd2(Hr, le, re);
+    if (!wr || n < 0 || n >= (a.H >> 1)) return;
+    T ll = Lr[0], hl = Lr[1], lh = Hr[0], hh = Hr[1];
+    if (LOSSY) {
+        if (a.last) ll = (T)(((float)ll * a.q[0]) * a.qs);
+        hl = (T)(((float)hl * a.q[1]) * a.qs);
+        lh = (T)(((float)lh * a.q[2]) * a.qs);
+        hh = (T)(((float)hh * a.q[3]) * a.qs);
+    }
+    const int hW = a.W >> 1, hH = a.H >> 1;
+    T *mal = (T *)a.mallat;
+    const uint32_t vo = (uint32_t)pc;
+    ((T *)a.ll + (size_t)n * (size_t)a.ll_stride)[vo] = ll;
+    (mal + (size_t)n * (size_t)a.AW + hW)[vo] = hl;
+    (mal + (size_t)(n + hH) * (size_t)a.AW)[vo] = lh;
+    (mal + (size_t)(n + hH) * (size_t)a.AW + hW)[vo] = hh;
+}
+
+// grid.x = ceil(strips / 4) with strips of kF2Useful columns, grid.y = bands of NB level-1 row pairs
+template <typename T, bool LOSSY, bool U8IN, int NB>
+__global__ __launch_bounds__(256) void dwt_fwd2_kernel(DwtFwd2Args a2)
+{
+    const DwtFwdArgs &a = a2.l0, &a1 = a2.l1;
+    constexpr int kIters0 = NB + (LOSSY ? 5 : 2);
+    constexpr int kF2Group = kF2GroupSet > 0 && kF2GroupSet < kIters0 ? kF2GroupSet : kIters0;
+    constexpr int kIters = (kIters0 + kF2Group - 1) / kF2Group * kF2Group;   // padded: the extra ones store nothing
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int strip = blockIdx.x * 4 + wave;
+    if (strip * kF2Useful >= a.W) return;
+    const int c0 = strip * kF2Useful - 4 * kF2Edge + 4 * lane;
+    const int n0 = blockIdx.y * NB;
+    int n1 = n0 + NB;
+    if (n1 > (a1.H >> 1)) n1 = a1.H >> 1;
+    const bool wr = lane >= kF2Edge && lane <= 63 - kF2Edge && c0 >= 0 && c0 < a.W;
+    const bool le = c0 == 0, re = c0 + 4 == a.W;
+    const int cl = c0 < 0 ? 0 : (c0 > a.W - 4 ? a.W - 4 : c0);
+    const int pc = cl >> 1, pc1 = cl >> 2;
+    const int S0 = 2 * n0 - (LOSSY ? 6 : 3);                 // first level-0 step
+
+    constexpr int kHist = LOSSY ? 6 : 2;                     // LL rows kept for level 1's bottom mirror
+    T xe[4], st0[3][4], xe1[2], st1[3][2], hist[kHist][2];
+#pragma unroll
+    for (int k = 0; k < kHist; k++) { hist[k][0] = hist[k][1] = (T)0; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { st0[0][k] = st0[1][k] = st0[2][k] = (T)0; }
+#pragma unroll
+    for (int k = 0; k < 2; k++) { xe1[k] = st1[0][k] = st1[1][k] = st1[2][k] = (T)0; }
+    RawRow<U8IN> raw[kF2Group][4];
+    __builtin_amdgcn_s_setprio(3);
+    const RawRow<U8IN> r0 = load_raw<T, U8IN, true>(a, 2 * S0, cl);
+#pragma unroll
+    for (int p = 0; p < kF2Group; p++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) raw[p][q] = load_raw<T, U8IN, true>(a, 2 * S0 + 1 + 4 * p + q, cl);
+    __builtin_amdgcn_s_setprio(0);
+    unpack_row<T, U8IN>(r0, xe);
+
+#pragma unroll 1
+    for (int g = 0; g < kIters / kF2Group; g++) {
+#pragma unroll
+        for (int r = 0; r < kF2Group; r++) {
+            const int i = g * kF2Group + r;
+            T x[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) unpack_row<T, U8IN>(raw[r][q], x[q]);
+            if (g + 1 < kIters / kF2Group) {
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    raw[r][q] = load_raw<T, U8IN, true>(a, 2 * S0 + 1 + 4 * (i + kF2Group) + q, cl);
+            }
+            const int mA = S0 + 2 * i - (LOSSY ? 1 : 0);     // the pair level-0 step sA delivers
+            T LA[4], HA[4], LB[4], HB[4];
+            vstep<T, LOSSY, 4>(xe, st0, x[0], x[1], LA, HA);
+            emit_pair<T, LOSSY, true, true>(a, mA, pc, wr && mA >= 2 * n0 && mA < 2 * n1, le, re, LA, HA);
+            vstep<T, LOSSY, 4>(xe, st0, x[2], x[3], LB, HB);
+            emit_pair<T, LOSSY, true, true>(a, mA + 1, pc, wr && mA + 1 >= 2 * n0 && mA + 1 < 2 * n1, le, re, LB, HB);
+            // level 1: LL rows mA (odd row of its pair) and mA + 1 (the even row after it).  Past the
+            // bottom of the image they are level 1's OWN mirror, LL[N + k] = LL[N - 2 - k]: mirrored input
+            // rows do not give that (the input's mirror centre H - 1 is an odd row, so the even-row
+            // subsequence comes out half-sample symmetric) -- taken from the rows kept in `hist`.
+            T la[2] = { LA[0], LA[2] }, lb[2] = { LB[0], LB[2] };
+            ll_row_or_mirror<T, kHist>(la, hist, mA - a1.H);
+            ll_row_or_mirror<T, kHist>(lb, hist, mA + 1 - a1.H);
+            T L1[2], H1[2];
+            vstep<T, LOSSY, 2>(xe1, st1, la, lb, L1, H1);
+            const int n = LOSSY ? n0 - 5 + i : n0 - 2 + i;   // the pair that level-1 step delivers
+            emit_pair1<T, LOSSY>(a1, n, pc1, wr && n >= n0 && n < n1, le, re, L1, H1);
         }
     }
 }

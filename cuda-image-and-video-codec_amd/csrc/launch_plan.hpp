@@ -120,6 +120,28 @@ inline bool dequant_fast_ok(float qs, int wl)
     return true;
 }
 
+// Levels 0 and 1 of a forward plan as ONE launch of dwt_fwd2_kernel (dwt_kernels.hpp): the frame path
+// (u8 input: a band's 41-53 rows fit the registers as one dword each), both levels on the vector path,
+// enough rows for the mirrored run-in.  `wanted`: the context's choice (not when it is told that other
+// frames share the GPU, picsong_ctx_set_pipelined); PICSONG_DWT_NOFUSE01=1 / PICSONG_DWT_FUSE01=1 force
+// two launches / the fused one (the tests cross-check both).
+struct Fwd2Launch { DwtFwd2Args a; unsigned gx, gy; };
+inline bool plan_dwt_fwd2(const std::vector<FwdLaunch> &plan, Fwd2Launch &f, bool wanted = true)
+{
+    if (const char *e = getenv("PICSONG_DWT_NOFUSE01")) if (atoi(e) != 0) return false;
+    if (const char *e = getenv("PICSONG_DWT_FUSE01")) wanted = wanted || atoi(e) != 0;
+    if (!wanted) return false;
+    if (plan.size() < 2 || !plan[0].vec || !plan[1].vec || !plan[0].u8) return false;
+    const DwtFwdArgs &l0 = plan[0].a;
+    if (l0.H < 64 || (l0.H & 3) || l0.W < 8 || (l0.W & 7)) return false;
+    f.a.l0 = l0; f.a.l1 = plan[1].a;
+    const int strips = (l0.W + kF2Useful - 1) / kF2Useful;
+    f.gx = (unsigned)((strips + 3) / 4);
+    const int pairs1 = l0.H >> 2;                                   // level-1 row pairs
+    f.gy = (unsigned)((pairs1 + kF2Pairs - 1) / kF2Pairs);
+    return true;
+}
+
 inline std::vector<InvLaunch> plan_dwt_inverse(const int32_t *d_in, void *d_out, int aw, int ah, int wl,
                                                float qs, bool fast = false)
 {

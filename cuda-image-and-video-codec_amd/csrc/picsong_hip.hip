@@ -50,6 +50,7 @@ struct picsong_ctx {
     int aw, ah, ncb;
     size_t P, extra;
     bool fast_div;        // 9/7 synthesis: reciprocal form of the divisions verified for this qs
+    bool pipelined;       // picsong_ctx_set_pipelined: other frames share the GPU (throughput over latency)
     // LUT
     picsong_lut_info li[3];
     int32_t *d_lut[3];
@@ -109,6 +110,14 @@ static void launch_fwd(const picsong_ctx *c, const FwdLaunch &f, hipStream_t s)
     if (f.vec) launch_fwd_v<BAND, true>(c->p.lossy != 0, f, grid, s);
     else launch_fwd_v<BAND, false>(c->p.lossy != 0, f, grid, s);
 }
+
+static void launch_fwd2(bool lossy, const Fwd2Launch &f, hipStream_t s)
+{
+    dim3 grid(f.gx, f.gy);
+    if (lossy) dwt_fwd2_kernel<float, true, true, kF2Pairs><<<grid, 256, 0, s>>>(f.a);
+    else dwt_fwd2_kernel<int, false, true, kF2Pairs><<<grid, 256, 0, s>>>(f.a);
+}
+
 
 extern "C" {
 
@@ -368,6 +377,13 @@ int picsong_ctx_set_lut(picsong_ctx *c, const picsong_lut_info *info, const int3
     return picsong_ctx_set_lut_component(c, 0, info, host_table);
 }
 
+int picsong_ctx_set_pipelined(picsong_ctx *c, int on)
+{
+    if (!c) return fail(PICSONG_ERR_ARG, "set_pipelined: null context");
+    c->pipelined = on != 0;
+    return PICSONG_OK;
+}
+
 int picsong_ctx_padded_dims(const picsong_ctx *c, int *aw, int *ah, int *ncb)
 {
     if (!c) return fail(PICSONG_ERR_ARG, "null ctx");
@@ -410,7 +426,15 @@ int picsong_level_shift_inv(picsong_ctx *c, void *d_data, void *stream)
 // ---------------------------------------------------------------------------------------------
 static int dwt_forward_impl(picsong_ctx *c, const void *d_in, bool u8in, void *d_out, hipStream_t s)
 {
-    for (const FwdLaunch &f : plan_dwt_forward(d_in, u8in, d_out, c->aw, c->ah, c->p.wl, c->p.qs)) {
+    const std::vector<FwdLaunch> plan = plan_dwt_forward(d_in, u8in, d_out, c->aw, c->ah, c->p.wl, c->p.qs);
+    Fwd2Launch f2;
+    const bool fused01 = plan_dwt_fwd2(plan, f2, !c->pipelined);
+    if (fused01) {                       // levels 0 and 1 in one launch, LL1 stays in registers
+        launch_fwd2(c->p.lossy != 0, f2, s);
+        HIP_TRY(hipGetLastError());
+    }
+    for (size_t l = fused01 ? 2 : 0; l < plan.size(); l++) {
+        const FwdLaunch &f = plan[l];
         switch (f.band) {
         case 32: launch_fwd<32>(c, f, s); break;
         case 16: launch_fwd<16>(c, f, s); break;

@@ -289,6 +289,7 @@ int run_encode(Options o)
     std::vector<Worker> w((size_t)nstreams);
     for (auto &k : w) {
         CK(picsong_ctx_create(&params, o.device, &k.ctx));
+        if (nstreams > 1) CK(picsong_ctx_set_pipelined(k.ctx, 1));     // the video engine keeps frames in flight
         load_lut(k.ctx, o, o.wl, 1, o.k);
         HIPCK(hipStreamCreate(&k.stream));
         HIPCK(hipHostMalloc(&k.h_in, P));

@@ -33,6 +33,7 @@ EXPORTS = [
     "picsong_max_stream_shorts", "picsong_header_pack", "picsong_header_unpack", "picsong_lut_load",
     "picsong_lut_load_k",
     "picsong_ctx_create", "picsong_ctx_destroy", "picsong_ctx_set_lut", "picsong_ctx_padded_dims",
+    "picsong_ctx_set_pipelined",
     "picsong_level_shift_fwd", "picsong_level_shift_inv", "picsong_dwt_forward", "picsong_dwt_inverse",
     "picsong_dwt_forward_u8", "picsong_bpc_encode", "picsong_bpc_decode", "picsong_bitstream_pack",
     "picsong_bitstream_unpack", "picsong_last_total", "picsong_encode_frame", "picsong_decode_frame",
@@ -74,6 +75,7 @@ def load():
     L.picsong_ctx_destroy.restype = None
     L.picsong_ctx_set_lut.argtypes = [vp, C.POINTER(LutInfo), vp]
     L.picsong_ctx_padded_dims.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    L.picsong_ctx_set_pipelined.argtypes = [vp, i]
     L.picsong_level_shift_fwd.argtypes = [vp, vp, vp, vp]
     L.picsong_level_shift_inv.argtypes = [vp, vp, vp]
     L.picsong_dwt_forward.argtypes = [vp, vp, vp, vp]
@@ -153,7 +155,7 @@ class Codec:
     objects + the LUT upload of Engine::initLUT).  All tensor arguments are torch CUDA tensors."""
 
     def __init__(self, width, height, wl=5, lossy=False, qs=1.0, lut_folder=None, lut_fill=0,
-                 device=0, frames=0, rgb=False, k=0.0):
+                 device=0, frames=0, rgb=False, k=0.0, pipelined=False):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("no GPU visible: the picsong HIP path has no CPU fallback")
@@ -165,6 +167,8 @@ class Codec:
         h = C.c_void_p()
         _check(self.L.picsong_ctx_create(C.byref(self.params), device, C.byref(h)))
         self.h = h
+        if pipelined:                 # frames of other contexts share the GPU: throughput over latency
+            _check(self.L.picsong_ctx_set_pipelined(self.h, 1))
         aw, ah, ncb = C.c_int(), C.c_int(), C.c_int()
         _check(self.L.picsong_ctx_padded_dims(self.h, C.byref(aw), C.byref(ah), C.byref(ncb)))
         self.aw, self.ah, self.ncb = aw.value, ah.value, ncb.value

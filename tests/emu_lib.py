@@ -63,8 +63,8 @@ def dwt_forward(x, wl, lossy, qs=1.0, extra=0):
     AH, AW = x.shape
     x = aligned_copy(np.ascontiguousarray(x))
     out = aligned_zeros(AW * AH + extra, np.float32 if lossy else np.int32)
-    lib().emu_dwt_forward(_p(x), int(x.dtype == np.uint8), _p(out), AW, AH, wl, int(lossy),
-                          C.c_float(qs))
+    dwt_forward.fused01 = bool(lib().emu_dwt_forward(_p(x), int(x.dtype == np.uint8), _p(out), AW, AH, wl,
+                                                     int(lossy), C.c_float(qs)))
     return out
 
 

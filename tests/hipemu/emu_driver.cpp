@@ -70,6 +70,14 @@ template <int BAND> static void emu_fwd(const FwdLaunch &f, int lossy)
     if (f.vec) emu_fwd_v<BAND, true>(f, lossy); else emu_fwd_v<BAND, false>(f, lossy);
 }
 
+static void emu_fwd2(const Fwd2Launch &f, int lossy)
+{
+    DwtFwd2Args a = f.a;
+    const dim3 grid(f.gx, f.gy);
+    if (lossy) emu::launch(grid, dim3(256), [&] { dwt_fwd2_kernel<float, true, true, kF2Pairs>(a); });
+    else emu::launch(grid, dim3(256), [&] { dwt_fwd2_kernel<int, false, true, kF2Pairs>(a); });
+}
+
 extern "C" {
 
 // how many levels of the plans take the vector-only kernel instantiations (tests assert on it)
@@ -81,9 +89,17 @@ int emu_dwt_vec_levels(const void *in, void *out, int aw, int ah, int wl)
     return n;
 }
 
-void emu_dwt_forward(const void *in, int u8in, void *out, int aw, int ah, int wl, int lossy, float qs)
+// mirrors dwt_forward_impl (picsong_hip.hip); returns 1 when levels 0 and 1 went through the fused kernel
+int emu_dwt_forward(const void *in, int u8in, void *out, int aw, int ah, int wl, int lossy, float qs)
 {
-    for (const FwdLaunch &f : plan_dwt_forward(in, u8in != 0, out, aw, ah, wl, qs)) {
+    const std::vector<FwdLaunch> plan = plan_dwt_forward(in, u8in != 0, out, aw, ah, wl, qs);
+    Fwd2Launch f2;
+    const bool fused01 = plan_dwt_fwd2(plan, f2);
+    if (fused01) {
+        emu_fwd2(f2, lossy);
+    }
+    for (size_t l = fused01 ? 2 : 0; l < plan.size(); l++) {
+        const FwdLaunch &f = plan[l];
         switch (f.band) {
         case 32: emu_fwd<32>(f, lossy); break;
         case 16: emu_fwd<16>(f, lossy); break;
@@ -91,6 +107,7 @@ void emu_dwt_forward(const void *in, int u8in, void *out, int aw, int ah, int wl
         default: emu_fwd<4>(f, lossy); break;
         }
     }
+    return fused01 ? 1 : 0;
 }
 
 void emu_dwt_inverse(const int32_t *in, void *out, int aw, int ah, int wl, int lossy, float qs)

@@ -352,3 +352,18 @@ def test_deep_planes_beyond_the_register_file(oracle, pa, torch, k):
     back = c.bpc_decode(_dev(torch, st_ref), _dev(torch, sz_ref)).cpu().numpy().reshape(H, W)
     assert np.array_equal(back, coef)
     c.close()
+
+
+def test_pipelined_hint_changes_launches_not_results(oracle, pa, torch):
+    """picsong_ctx_set_pipelined: the frame path runs DWT levels 0 and 1 as two launches instead of the
+    fused kernel; the codestream is the same, and both equal the oracle's."""
+    for (W, H, wl, lossy, qs) in ((1920, 1080, 5, False, 1.0), (1024, 768, 4, True, 0.5)):
+        img = oracle.gen_frame(W, H, 9)
+        ref = oracle.encode_frame(img, wl, lossy, qs, oracle.lut_for(lossy, wl), 0, 0)
+        frame = _dev(torch, oracle.pad_frame(img))
+        got = []
+        for hint in (False, True):
+            c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=_lutdir(oracle, lossy), pipelined=hint)
+            got.append(c.encode_frame(frame, 0).cpu().numpy().view(np.uint16))
+            c.close()
+        assert np.array_equal(got[0], ref) and np.array_equal(got[1], ref)

@@ -404,3 +404,27 @@ def test_dwt97_inverse_fast_and_dividing_kernels_agree(oracle, E, monkeypatch, W
     exact = E.dwt_inverse(coef, wl, True, qs, extra=extra)
     assert np.array_equal(exact[extra:].view(np.uint32), ref[ex:].view(np.uint32))
     assert np.array_equal(fast[extra:].view(np.uint32), ref[ex:].view(np.uint32))
+
+
+# ---- levels 0 + 1 of the forward transform in one launch (dwt_fwd2_kernel) ---------------------------
+@pytest.mark.parametrize("W,H,wl,lossy,qs", [(320, 192, 3, False, 1.0), (64, 64, 5, False, 1.0), (256, 64, 2, False, 1.0),
+                                             (1024, 320, 4, False, 1.0), (768, 128, 2, True, 0.5),
+                                             (64, 128, 5, True, 0.3), (512, 256, 6, True, 1.0)])
+def test_dwt_fused_levels_0_and_1(oracle, E, monkeypatch, W, H, wl, lossy, qs):
+    """The frame path's first two levels as one launch: LL1 stays in registers, level 1's own mirror at
+    the bottom of the image comes from the kept rows.  Same words as the oracle and as two launches."""
+    monkeypatch.delenv("PICSONG_DWT_NOVEC", raising=False)
+    monkeypatch.delenv("PICSONG_DWT_NOFUSE01", raising=False)
+    img = oracle.gen_frame(W, H, 7)
+    x = oracle.level_shift_fwd(img, lossy)
+    extra = oracle.dwt_extra(W, H, wl)
+    ref = oracle.dwt_forward(x, wl, qs) if lossy else oracle.dwt_forward(x, wl)
+    got = E.dwt_forward(img, wl, lossy, qs, extra=extra)
+    assert E.dwt_forward.fused01
+    assert np.array_equal(got[:W * H].view(np.uint32), ref[:W * H].view(np.uint32))
+    E.dwt_forward(x, wl, lossy, qs, extra=extra)
+    assert not E.dwt_forward.fused01                      # 32-bit input: the two-launch path
+    monkeypatch.setenv("PICSONG_DWT_NOFUSE01", "1")
+    two = E.dwt_forward(img, wl, lossy, qs, extra=extra)
+    assert not E.dwt_forward.fused01
+    assert np.array_equal(two[:W * H].view(np.uint32), ref[:W * H].view(np.uint32))
