@@ -66,8 +66,10 @@ def pmc_traffic(workload):
         b = float(r["MeanValue"]) * 1024.0 * mult
         if "bpc_encode_kernel" in r["Kernel_Name"]:
             bpc += b
-        elif "dwt_fwd_kernel" in r["Kernel_Name"] and frames:
-            dwt += b * int(r["Dispatches"]) / frames       # all levels of one frame
+        elif "dwt_fwd" in r["Kernel_Name"] and frames:
+            # all levels of one frame; the counter passes run --streams 1, i.e. the context that is not
+            # set pipelined: dwt_fwd2_kernel (levels 0 + 1) + dwt_fwd_kernel (the rest)
+            dwt += b * int(r["Dispatches"]) / frames
     return (int(bpc) if bpc else None), (int(dwt) if dwt else None)
 
 
