@@ -474,6 +474,9 @@ __global__ __launch_bounds__(256) PS_DWT_OCC void dwt_fwd_kernel(DwtFwdArgs a)
 // step on the two LL rows they deliver; 5/3 steps emit their own pair, 9/7 steps the pair before.
 constexpr int kF2Edge = 3;
 constexpr int kF2Useful = kStripCols - 8 * kF2Edge;          // 232 columns written per wave
+#ifndef PICSONG_DWT_F2_WAVES
+#define PICSONG_DWT_F2_WAVES 5      // 96 VGPRs: the 9/7 instantiation needs 98 without the cap (43.3 -> 41.3 us)
+#endif
 #ifndef PICSONG_DWT_F2_GROUP
 #define PICSONG_DWT_F2_GROUP 0
 #endif
@@ -571,7 +574,7 @@ __device__ __forceinline__ void emit_pair1(const DwtFwdArgs &a, int n, int pc, b
 
 // grid.x = ceil(strips / 4) with strips of kF2Useful columns, grid.y = bands of NB level-1 row pairs
 template <typename T, bool LOSSY, bool U8IN, int NB>
-__global__ __launch_bounds__(256) void dwt_fwd2_kernel(DwtFwd2Args a2)
+__global__ __launch_bounds__(256, PICSONG_DWT_F2_WAVES) void dwt_fwd2_kernel(DwtFwd2Args a2)
 {
     const DwtFwdArgs &a = a2.l0, &a1 = a2.l1;
     constexpr int kIters0 = NB + (LOSSY ? 5 : 2);
