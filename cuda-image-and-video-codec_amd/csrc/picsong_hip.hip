@@ -584,6 +584,7 @@ int picsong_range_flag(picsong_ctx *c, void *stream, int *h_flag)
     if (!c || !h_flag) return fail(PICSONG_ERR_ARG, "range_flag: null argument");
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(&c->h_pinned[1], c->d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemsetAsync(c->d_flag, 0, sizeof(int), s));      // read and clear: the next query covers later calls only
     HIP_TRY(hipStreamSynchronize(s));
     *h_flag = c->h_pinned[1];
     return PICSONG_OK;

@@ -198,8 +198,9 @@ int picsong_pad_frame_host(const uint8_t *in, int w, int h, uint8_t *out, int aw
 int picsong_profile_begin(picsong_ctx *ctx, int capacity);
 int picsong_profile_read(picsong_ctx *ctx, int *n_frames, float *ms, int ms_capacity_frames);
 
-/* ---- diagnostics: nonzero if any codeblock of the last bpc call on ctx had MSB > 15 (outside
- *      the LUT's 15 bit-planes), or if picsong_bitstream_unpack / picsong_decode_frame
+/* ---- diagnostics: nonzero if, since the previous query (reading clears it), any codeblock of a
+ *      bpc call on ctx had MSB > 15 (outside the LUT's 15 bit-planes), or if
+ *      picsong_bitstream_unpack / picsong_decode_frame
  *      met a codeblock length outside 1..4096 (damaged stream: the length is clamped, so no access
  *      leaves the staging or 9 + 2n + 4095n + 1 shorts of the stream buffer); synchronises `stream`. ---- */
 int picsong_range_flag(picsong_ctx *ctx, void *stream, int *h_flag);

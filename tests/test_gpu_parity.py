@@ -367,3 +367,31 @@ def test_pipelined_hint_changes_launches_not_results(oracle, pa, torch):
             got.append(c.encode_frame(frame, 0).cpu().numpy().view(np.uint16))
             c.close()
         assert np.array_equal(got[0], ref) and np.array_equal(got[1], ref)
+
+
+def test_damaged_streams_decode_without_leaving_their_buffers(oracle, pa, torch):
+    """Garbage in: every length is clamped into 1..4096 and every MSB into 0..15 (range flag set), the
+    decoder's loops are bounded by 16 planes x 64 rows, codeword slots by 4094 -- so a damaged stream
+    decodes to SOMETHING and returns; it must not fault or hang.  Payload-only damage (table intact)
+    keeps the flag clear."""
+    W, H, wl = 256, 192, 2
+    c = pa.Codec(W, H, wl=wl, lut_folder=_lutdir(oracle, False))
+    rng = np.random.default_rng(12)
+    n = c.max_stream_shorts()
+    junk = torch.from_numpy(rng.integers(-32768, 32768, n, dtype=np.int16)).cuda()
+    out = c.decode_frame(junk)
+    torch.cuda.synchronize()
+    assert out.shape == (c.ah, c.aw) and c.range_flag() == 1
+    img = oracle.gen_frame(W, H, 4)
+    good = c.encode_frame(_dev(torch, oracle.pad_frame(img)), 0).cpu().numpy().copy()
+    bad = np.zeros(n, np.int16)
+    bad[:good.size] = good
+    first_payload = 9 + 2 * c.ncb
+    idx = rng.integers(first_payload, good.size, 200)
+    bad[idx] = rng.integers(-32768, 32768, idx.size, dtype=np.int16)
+    out = c.decode_frame(torch.from_numpy(bad).cuda())
+    torch.cuda.synchronize()
+    assert c.range_flag() == 0 and out.shape == (c.ah, c.aw)
+    # and the context is still good for a clean stream
+    assert np.array_equal(c.decode_frame(torch.from_numpy(good).cuda()).cpu().numpy()[:H, :W], img)
+    c.close()
