@@ -9,7 +9,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python3 bench.py > $out/bench.json 2> $out/bench.err
 echo "bench done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_default -- python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline > $out/bench_prof_default.json 2> $out/prof_default.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_default -- python3 bench.py --no-cpu-baseline > $out/bench_prof_default.json 2> $out/prof_default.err
 echo "prof default done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_single -- python3 bench.py --steps 30 --warmup 3 --streams 1 --no-cpu-baseline > $out/bench_prof_single.json 2> $out/prof_single.err
 echo "prof single done"
