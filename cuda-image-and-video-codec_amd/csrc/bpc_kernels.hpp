@@ -306,6 +306,17 @@ __device__ __forceinline__ uint32_t wave_or32(uint32_t v)
     return __builtin_amdgcn_readfirstlane(v);
 }
 
+// A lane mask (all ones / zero) the optimiser must keep as a register: it otherwise turns every
+// `mask & x` back into a select on the condition the mask came from (a move and a select where one
+// v_and does), at the three or four slot reservations of every scanned coefficient.
+__device__ __forceinline__ uint32_t opaque_mask(uint32_t m)
+{
+#if defined(__AMDGCN__)
+    asm volatile("" : "+v"(m));
+#endif
+    return m;
+}
+
 // Slot reservation: m = ballot of the lanes that need a codeword.  The rank of a lane among the
 // requesting lanes of ITS codeblock is v_mbcnt over the two ballot words; v_mbcnt_lo counts all of the
 // lower word for lanes 32-63, so those start at (their counter - popcount(lower word)).  The counters
@@ -684,7 +695,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     }
 
     Coder c = { 0u, 0u, 0u, 0u, 0u, 0u, ~0ull };
-    const uint32_t upper_mask = half ? 0xFFFFFFFFu : 0u;
+    const uint32_t upper_mask = opaque_mask(half ? 0xFFFFFFFFu : 0u);
     U64 AL = { 0u, 0u }, AR = { 0u, 0u };                 // significant before the current plane
     const U64 sgPL = u_prev(sgR, t), sgNL = u_next(sgL, t);     // neighbour sign columns
 
@@ -973,7 +984,7 @@ void bpc_decode_kernel(BpcArgs a)
     const int32_t *stage = a.staging + (size_t)(valid ? cb : a.cb_base) * 4096u;
     const int32_t *cw = stage + 1;                          // codeword array: slot k lives at stage[1 + k]
     const uint32_t prec = (uint32_t)a.g.prec;
-    const uint32_t upper_mask = half ? 0xFFFFFFFFu : 0u;
+    const uint32_t upper_mask = opaque_mask(half ? 0xFFFFFFFFu : 0u);
 
     uint32_t PLlo[NP], PLhi[NP], PRlo[NP], PRhi[NP];
 #pragma unroll
