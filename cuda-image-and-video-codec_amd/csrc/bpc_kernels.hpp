@@ -317,6 +317,18 @@ __device__ __forceinline__ uint32_t opaque_mask(uint32_t m)
     return m;
 }
 
+// ballot(v == 0)
+__device__ __forceinline__ uint64_t zero_mask(uint32_t v)
+{
+#if defined(__AMDGCN__)
+    uint64_t m;
+    asm("v_cmp_eq_u32_e64 %0, 0, %1" : "=s"(m) : "v"(v));
+    return m;
+#else
+    return __builtin_amdgcn_ballot_w64(v == 0u);
+#endif
+}
+
 // Slot reservation: m = ballot of the lanes that need a codeword.  The rank of a lane among the
 // requesting lanes of ITS codeblock is v_mbcnt over the two ballot words; v_mbcnt_lo counts all of the
 // lower word for lanes 32-63, so those start at (their counter - popcount(lower word)).  The counters
@@ -349,15 +361,16 @@ __device__ __forceinline__ void enc_site_on(Coder &c, bool on, uint64_t onm, uin
     // which lanes have an exhausted interval is known from the end of the previous call site: the
     // one compare per site (below) serves the codeword store of this site and the need-ballot of the next
     const uint64_t m = c.emptym & onm;
-    if (m != 0ull) reserve_enc(c, on && c.S == 0u, m, upper_mask);
+    if (m != 0ull) reserve_enc(c, __builtin_amdgcn_inverse_ballot_w64(m), m, upper_mask);   // m IS the lanes that need one
     if (on) {
         const uint32_t a = (mul_u24(c.S, p) >> prec) + sym;
         c.S = sym != 0u ? c.S - a : a;          // v_sub + v_cndmask (a 24-bit mad form costs two shifts more)
         c.L = __umul24(sym, a) + c.L;
     }
-    const bool z = c.S == 0u;
-    c.emptym = __builtin_amdgcn_ballot_w64(z);
-    if (on && z) st[c.slot] = (int32_t)c.L;               // st = the codeblock's codeword array (staging + 1)
+    // The exhausted-interval mask as the compare's own 64-bit result, hidden from the optimiser: told
+    // that S == 0 inside the store's region it re-materialises S there (a move per call site).
+    c.emptym = zero_mask(c.S);
+    if (__builtin_amdgcn_inverse_ballot_w64(c.emptym & onm)) st[c.slot] = (int32_t)c.L;   // st = staging + 1
 }
 __device__ __forceinline__ void enc_site(Coder &c, uint32_t inact, uint32_t sym, uint32_t p, uint32_t prec,
                                          uint32_t upper_mask, int32_t *st)

@@ -88,6 +88,10 @@ static inline unsigned long long __builtin_amdgcn_ballot_w64(bool p)
 {
     return emu::collective(emu::OP_BALLOT, p ? 1 : 0, 0, 0);
 }
+static inline bool __builtin_amdgcn_inverse_ballot_w64(unsigned long long m)
+{
+    return ((m >> (threadIdx.x & 63u)) & 1ull) != 0ull;
+}
 static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned m, unsigned base)
 {
     unsigned lane = threadIdx.x & 63u;
