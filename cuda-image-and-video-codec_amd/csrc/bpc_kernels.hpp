@@ -27,12 +27,14 @@
 namespace picsong {
 
 constexpr int kMaxPlanes = 16;     // bit-planes a codeblock may have: supports MSB <= 15
-// The encoder keeps the 8 topmost planes of its two columns in registers (32 VGPRs); the planes below
-// them -- only codeblocks with MSB >= 8 have any -- wait in a scratch array in HBM (8 KB per wave,
-// written once after the transposition, one plane read back per plane step).  With all 16 in
-// registers the kernel needed 128 VGPRs (4 waves/SIMD) or spilled ~50 dwords per lane at 96.
-constexpr int kEncRegPlanes = 8;
-constexpr int kEncScratchDwordsPerWave = (kMaxPlanes - kEncRegPlanes) * 4 * 64;
+// The encoder holds ONE bit-plane of its two columns in registers (4 VGPRs): the one being coded.  All
+// planes are built in a single pass over the coefficients (8 at a time, in registers that are free
+// before the plane loop), parked in a scratch array in HBM -- [plane][4][lane] dwords, 16 KB per wave,
+// every access a 256-byte row -- and read back one plane per plane step, a plane ahead.  With 8 planes
+// resident (round 1) the kernel needed 96 VGPRs and still spilled 17; now 8 waves fit a SIMD.
+constexpr int kEncPassPlanes = 8;                       // planes built per pass over the coefficients
+constexpr int kEncPlaneDwords = 4 * 64;                 // one plane of a wave: L.lo, L.hi, R.lo, R.hi x 64 lanes
+constexpr int kEncScratchDwordsPerWave = kMaxPlanes * kEncPlaneDwords;
 
 struct LutGeo {
     int nBp, nSub, cRef, cSign, cSig, prec;
@@ -295,8 +297,19 @@ __device__ __forceinline__ ColHalf make_col(uint32_t x1, uint32_t x2, uint32_t x
     return r;
 }
 
+// OR over the 64 lanes, wave-uniform result.  DPP row shifts + row broadcasts (6 VALU, no LDS crossbar:
+// the ds_bpermute butterfly this replaces cost six LDS round trips at every half-pass of every plane).
 __device__ __forceinline__ uint32_t wave_or32(uint32_t v)
 {
+#if defined(__AMDGCN__)
+    v |= __builtin_amdgcn_update_dpp(0u, v, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+    v |= __builtin_amdgcn_update_dpp(0u, v, 0x112 /*row_shr:2*/, 0xf, 0xf, true);
+    v |= __builtin_amdgcn_update_dpp(0u, v, 0x114 /*row_shr:4*/, 0xf, 0xf, true);
+    v |= __builtin_amdgcn_update_dpp(0u, v, 0x118 /*row_shr:8*/, 0xf, 0xf, true);       // lane 15 of a row: the row's OR
+    v |= __builtin_amdgcn_update_dpp(0u, v, 0x142 /*row_bcast:15*/, 0xa, 0xf, false);   // rows 1, 3 take rows 0, 2
+    v |= __builtin_amdgcn_update_dpp(0u, v, 0x143 /*row_bcast:31*/, 0xc, 0xf, false);   // rows 2, 3 take lane 31
+    return __builtin_amdgcn_readlane(v, 63);
+#else
     v |= __shfl_xor(v, 32);
     v |= __shfl_xor(v, 16);
     v |= __shfl_xor(v, 8);
@@ -304,6 +317,23 @@ __device__ __forceinline__ uint32_t wave_or32(uint32_t v)
     v |= __shfl_xor(v, 2);
     v |= __shfl_xor(v, 1);
     return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+// OR over the 32 lanes of each half, every lane receiving its half's value
+__device__ __forceinline__ uint32_t half_or_dpp(uint32_t v, uint32_t upper_mask)
+{
+#if defined(__AMDGCN__)
+    v |= __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true);
+    v |= __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, true);
+    v |= __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, true);
+    v |= __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, true);
+    v |= __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);                    // lanes 31 / 63: the halves' ORs
+    const uint32_t lo = __builtin_amdgcn_readlane(v, 31), hi = __builtin_amdgcn_readlane(v, 63);
+    return lo ^ (upper_mask & (lo ^ hi));
+#else
+    (void)upper_mask;
+    return half_or(v);
+#endif
 }
 
 // A lane mask (all ones / zero) the optimiser must keep as a register: it otherwise turns every
@@ -348,35 +378,67 @@ __device__ __forceinline__ void reserve_enc(Coder &c, bool need, uint64_t m, uin
     c.cnt_hi = __builtin_amdgcn_readfirstlane(b > 4095u ? 4095u : b);
 }
 
-// arithmeticEncoder BPCEngine.cu:371-399, one call site; `inact` = 1 for lanes that sit this call
-// site out.  VALU instructions are what this kernel is bound by (SALU issues beside them), so: the
-// need-ballot is two compares whose masks are ANDed by SALU (the inact compare is the one the exec
-// region below needs anyway), the state update runs inside an exec-masked region (no selects for
-// idle lanes):  a = ((S*p) >> prec) + sym;  S' = sym ? S - a : a;  L' = L + sym*a.
-// onm = ballot(on): the callers have it already (they skip the site when it is 0); handing it over
-// keeps `on` a lane mask in SGPRs instead of a 0/1 VGPR that has to be compared again.
-__device__ __forceinline__ void enc_site_on(Coder &c, bool on, uint64_t onm, uint32_t sym, uint32_t p, uint32_t prec,
-                                            uint32_t upper_mask, int32_t *st)
+// ---- encoder call site (arithmeticEncoder BPCEngine.cu:371-399) ------------------------------------
+// Per-lane state of the encoder: interval (L, S) and the BYTE offset `off`, from the wave's staging
+// base, of the codeword slot the lane has reserved.  Wave state: the two codeblocks' codeword counters
+// (SGPRs), the ballot of exhausted intervals, and constants of the wave.
+struct EncCoder {
+    uint32_t L, S, off;
+    uint32_t cnt_lo, cnt_hi;
+    uint64_t emptym;            // ballot(S == 0) as of the end of the previous call site
+    uint32_t halfoff4;          // byte offset of slot 0 of the lane's codeblock: half * 16384 + 4
+    uint32_t pone;              // 1 << prec: the "probability" that leaves an idle lane's interval alone
+    char *stw;                  // staging of the wave's first codeblock (wave-uniform)
+};
+
+// Slot reservation for the lanes in m (!= 0): as reserve_enc, plus the store of the codeword the lane
+// has just finished.  The reference stores L the moment the interval is exhausted (:395-397) and again
+// at the flush (:1719); a lane writes a slot only with the value it holds when it leaves the slot, so the
+// store can wait until the lane moves on -- here, where an exec-masked region exists anyway -- and the
+// call site loses a compare-and-branch region of its own.  A lane's first reservation stores the L = 0
+// it starts with to word 0 of its codeblock's staging (off starts there), which the kernel's epilogue
+// overwrites with the MSB after the wave's stores have drained.
+__device__ __forceinline__ void enc_reserve(EncCoder &c, uint64_t m, uint32_t upper_mask)
 {
-    // which lanes have an exhausted interval is known from the end of the previous call site: the
-    // one compare per site (below) serves the codeword store of this site and the need-ballot of the next
-    const uint64_t m = c.emptym & onm;
-    if (m != 0ull) reserve_enc(c, __builtin_amdgcn_inverse_ballot_w64(m), m, upper_mask);   // m IS the lanes that need one
-    if (on) {
-        const uint32_t a = (mul_u24(c.S, p) >> prec) + sym;
-        c.S = sym != 0u ? c.S - a : a;          // v_sub + v_cndmask (a 24-bit mad form costs two shifts more)
-        c.L = __umul24(sym, a) + c.L;
+    const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
+    const uint32_t nlo = (uint32_t)__builtin_popcount(mlo), nhi = (uint32_t)__builtin_popcount(mhi);
+    const uint32_t base = c.cnt_lo + (upper_mask & (c.cnt_hi - nlo - c.cnt_lo));
+    if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+        *reinterpret_cast<int32_t *>(c.stw + c.off) = (int32_t)c.L;
+        uint32_t s = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, base));
+        s = s > 4094u ? 4094u : s;
+        c.off = (s << 2) + c.halfoff4;
+        c.L = 0u; c.S = 0xFFFFu;
     }
-    // The exhausted-interval mask as the compare's own 64-bit result, hidden from the optimiser: told
-    // that S == 0 inside the store's region it re-materialises S there (a move per call site).
-    c.emptym = zero_mask(c.S);
-    if (__builtin_amdgcn_inverse_ballot_w64(c.emptym & onm)) st[c.slot] = (int32_t)c.L;   // st = staging + 1
+    const uint32_t a = c.cnt_lo + nlo, b = c.cnt_hi + nhi;
+    c.cnt_lo = __builtin_amdgcn_readfirstlane(a > 4095u ? 4095u : a);
+    c.cnt_hi = __builtin_amdgcn_readfirstlane(b > 4095u ? 4095u : b);
 }
-__device__ __forceinline__ void enc_site(Coder &c, uint32_t inact, uint32_t sym, uint32_t p, uint32_t prec,
-                                         uint32_t upper_mask, int32_t *st)
+
+// One call site.  onm = ballot of the lanes that code a symbol here, onem = those of them whose symbol
+// is 1 (both wave-uniform SGPR pairs the callers have anyway).  The interval update runs in EVERY lane:
+// an idle lane multiplies by pone = 1 << prec, (S * pone) >> prec == S, so no exec-masked region and no
+// branch surrounds it; a lane coding a 1 takes  S' = S - a0 - 1, L' = L + a0 + 1  (a = a0 + sym), a lane
+// coding a 0 takes S' = a0.  One dependent round trip VALU -> SGPR -> branch per site (the reservation).
+__device__ __forceinline__ void enc_site2(EncCoder &c, uint64_t onm, uint64_t onem, uint32_t p, uint32_t prec,
+                                          uint32_t upper_mask)
 {
-    const bool on = inact == 0u;
-    enc_site_on(c, on, __builtin_amdgcn_ballot_w64(on), sym, p, prec, upper_mask, st);
+    const uint64_t m = c.emptym & onm;
+    if (m != 0ull) enc_reserve(c, m, upper_mask);
+    const uint32_t pe = __builtin_amdgcn_inverse_ballot_w64(onm) ? p : c.pone;
+    const uint32_t a0 = mul_u24(c.S, pe) >> prec;
+    const bool one = __builtin_amdgcn_inverse_ballot_w64(onem);
+    c.S = one ? c.S + ~a0 : a0;                  // v_xad_u32 + v_cndmask
+    c.L = one ? c.L + a0 + 1u : c.L;             // v_add3_u32 + v_cndmask
+    // the exhausted-interval mask as the compare's own 64-bit result, opaque to the optimiser
+    c.emptym = zero_mask(c.S);
+}
+// generic form (bulk scan): `inact` = 1 for lanes that sit the site out
+__device__ __forceinline__ void enc_site(EncCoder &c, uint32_t inact, uint32_t sym, uint32_t p, uint32_t prec,
+                                         uint32_t upper_mask, int32_t *)
+{
+    const uint64_t onm = __builtin_amdgcn_ballot_w64(inact == 0u);
+    enc_site2(c, onm, onm & __builtin_amdgcn_ballot_w64(sym != 0u), p, prec, upper_mask);
 }
 
 // Context masks are kept pre-rotated (n1 by 1, n2 and n3 by 2 bits; sign bits c1 by 3, c2 by 4) so
@@ -384,12 +446,15 @@ __device__ __forceinline__ void enc_site(Coder &c, uint32_t inact, uint32_t sym,
 __device__ __forceinline__ uint32_t rotr32(uint32_t v, uint32_t sh) { return __builtin_amdgcn_alignbit(v, v, sh); }
 __device__ __forceinline__ uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
 
-// A: significant-before mask of the column's 32 rows (all ones for an idle half): a set bit = skip.
-__device__ __forceinline__ void enc_spp_coeff(Coder &c, uint32_t ii, uint32_t A, uint32_t B, const ColHalf &cp,
-                                              const PlaneLut &pl, uint32_t prec,                                               uint32_t upper_mask, int32_t *st)
+// One coefficient of the significance propagation pass.  rowbit = 1 << ii.  A: significant-before mask
+// of the column's 32 rows (all ones for an idle half: never on); N: becomes significant in this plane
+// (0 for an idle half).
+__device__ __forceinline__ void enc_spp_coeff(EncCoder &c, uint32_t ii, uint32_t rowbit, uint32_t A, uint32_t N,
+                                              const ColHalf &cp, const PlaneLut &pl, uint32_t prec, uint32_t upper_mask)
 {
-    const bool on = ((A >> ii) & 1u) == 0u;
-    const uint32_t sym = (B >> ii) & 1u;
+    const uint64_t onm = __builtin_amdgcn_ballot_w64((A & rowbit) == 0u);
+    if (onm == 0ull) return;                                // no lane has this column's coefficient to code
+    const uint64_t onem = __builtin_amdgcn_ballot_w64((N & rowbit) != 0u);       // N is a subset of ~A
     // byte selector of v_perm: bits 0..2 = context 0..7, other selector bytes = 0x0C (constant 0)
     uint32_t sel = (rotr32(cp.n0, ii) & 1u) | 0x0C0C0C00u;
     sel = bfi32(2u, rotr32(cp.n1, ii), sel);
@@ -397,15 +462,12 @@ __device__ __forceinline__ void enc_spp_coeff(Coder &c, uint32_t ii, uint32_t A,
     const uint32_t p07 = __builtin_amdgcn_perm(pl.sig1, pl.sig0, sel);
     // context 8 (n3 set => n0 = n1 = n2 = 0): a second byte select takes p8 (byte 4) instead of p07
     const uint32_t p = __builtin_amdgcn_perm(pl.sig8, p07, (rotr32(cp.n3, ii) & 4u) | 0x0C0C0C00u);
-    const uint64_t onm = __builtin_amdgcn_ballot_w64(on);
-    enc_site_on(c, on, onm, sym, p, prec, upper_mask, st);
-    const bool one = sym != 0u, on2 = on && one;            // one compare; the masks are ANDed by SALU
-    const uint64_t on2m = onm & __builtin_amdgcn_ballot_w64(one);
-    if (on2m != 0ull) {
+    enc_site2(c, onm, onem, p, prec, upper_mask);
+    if (onem != 0ull) {
         // bit offset of the sign probability inside pl.sign = 8 * (c >> 1)
         const uint32_t off = (rotr32(cp.c2, ii) & 16u) | (rotr32(cp.c1, ii) & 8u);
         const uint32_t p2 = (pl.sign >> off) & 0xFFu;
-        enc_site_on(c, on2, on2m, (cp.s2 >> ii) & 1u, p2, prec, upper_mask, st);
+        enc_site2(c, onem, onem & __builtin_amdgcn_ballot_w64((cp.s2 & rowbit) != 0u), p2, prec, upper_mask);
     }
 }
 
@@ -475,8 +537,8 @@ __device__ __forceinline__ int bulk_sc(uint32_t pw, uint32_t q)
 // All remaining planes of ONE coefficient (encodeBulkProcessing :1285-1314 / decodeBulkProcessing
 // :1454-1500).  u: the coefficient's unprocessed word; low: its low magnitude bits (encoder).
 // Returns the processed word.
-template <bool DEC>
-__device__ __forceinline__ uint32_t bulk_coeff(Coder &c, uint32_t u, uint32_t low, uint32_t ctx, uint32_t up,
+template <bool DEC, class CT>
+__device__ __forceinline__ uint32_t bulk_coeff(CT &c, uint32_t u, uint32_t low, uint32_t ctx, uint32_t up,
                                                uint32_t lf, uint32_t rt, uint32_t dn, const BulkLane &b, int Bmax,
                                                uint32_t prec, uint32_t upper_mask,
                                                int32_t *st)
@@ -490,7 +552,7 @@ __device__ __forceinline__ uint32_t bulk_coeff(Coder &c, uint32_t u, uint32_t lo
         const uint32_t iA = (on & sig) ^ 1u;
         if (__builtin_amdgcn_ballot_w64(iA == 0u) != 0ull) {
             const uint32_t p = bulk_lut(b, b.ref0 + (uint32_t)q * b.cRef);
-            if (DEC) low |= dec_site(c, iA, p, prec, upper_mask, st) << q;
+            if constexpr (DEC) low |= dec_site(c, iA, p, prec, upper_mask, st) << q;
             else enc_site(c, iA, bit, p, prec, upper_mask, st);
         }
         // significance call site: the others
@@ -498,7 +560,7 @@ __device__ __forceinline__ uint32_t bulk_coeff(Coder &c, uint32_t u, uint32_t lo
         uint32_t ns = 0u;
         if (__builtin_amdgcn_ballot_w64(iB == 0u) != 0ull) {
             const uint32_t p = bulk_lut(b, b.sig0 + (uint32_t)q * b.cSig + ctx);
-            if (DEC) { ns = dec_site(c, iB, p, prec, upper_mask, st); low |= ns << q; }
+            if constexpr (DEC) { ns = dec_site(c, iB, p, prec, upper_mask, st); low |= ns << q; }
             else { enc_site(c, iB, bit, p, prec, upper_mask, st); ns = (iB ^ 1u) & bit; }
         }
         // sign call site: coefficients that just became significant
@@ -506,7 +568,7 @@ __device__ __forceinline__ uint32_t bulk_coeff(Coder &c, uint32_t u, uint32_t lo
             const uint32_t sc = sign_ctx(bulk_sc(lf, (uint32_t)q) + bulk_sc(rt, (uint32_t)q),
                                          bulk_sc(up, (uint32_t)q) + bulk_sc(dn, (uint32_t)q));
             const uint32_t p = bulk_lut(b, b.sign0 + (uint32_t)q * b.cSign + (sc >> 1));
-            if (DEC) {
+            if constexpr (DEC) {
                 const uint32_t s2 = dec_site(c, ns ^ 1u, p, prec, upper_mask, st);
                 if (ns) neg = s2 ^ (sc & 1u);                  // :1488-1490
             } else {
@@ -520,8 +582,8 @@ __device__ __forceinline__ uint32_t bulk_coeff(Coder &c, uint32_t u, uint32_t lo
 
 // One row of the bulk scan for the lane's two columns.  uL/uR: unprocessed words of the row,
 // dL/dR: of the row below, pUL/pUR: processed words of the row above (updated to this row's).
-template <bool DEC>
-__device__ __forceinline__ void bulk_row(Coder &c, uint32_t t, uint32_t uL, uint32_t uR, uint32_t lowL, uint32_t lowR,
+template <bool DEC, class CT>
+__device__ __forceinline__ void bulk_row(CT &c, uint32_t t, uint32_t uL, uint32_t uR, uint32_t lowL, uint32_t lowR,
                                          uint32_t dL, uint32_t dR, uint32_t &pUL, uint32_t &pUR, const BulkLane &b,
                                          int Bmax, uint32_t prec, uint32_t upper_mask,
                                          int32_t *st)
@@ -533,12 +595,12 @@ __device__ __forceinline__ void bulk_row(Coder &c, uint32_t t, uint32_t uL, uint
     // left coefficients of all lanes (encodeLeftCoefficients :1320-1381)
     const uint32_t ctxL = bulk_cc(P_ur, sh) + bulk_cc(pUL, sh) + bulk_cc(pUR, sh) + bulk_cc(P_r, sh) +
                           bulk_cc(uR, sh) + bulk_cc(P_dr, sh) + bulk_cc(dL, sh) + bulk_cc(dR, sh);
-    const uint32_t nL = bulk_coeff<DEC>(c, uL, lowL, ctxL, pUL, P_r, uR, dL, b, Bmax, prec, upper_mask, st);
+    const uint32_t nL = bulk_coeff<DEC, CT>(c, uL, lowL, ctxL, pUL, P_r, uR, dL, b, Bmax, prec, upper_mask, st);
     // right coefficients (encodeRightCoefficients :1387-1448): the left ones of this row are done
     const uint32_t N_l = from_next32(nL, t);
     const uint32_t ctxR = bulk_cc(pUL, sh) + bulk_cc(pUR, sh) + bulk_cc(N_ul, sh) + bulk_cc(nL, sh) +
                           bulk_cc(N_l, sh) + bulk_cc(dL, sh) + bulk_cc(dR, sh) + bulk_cc(N_dl, sh);
-    const uint32_t nR = bulk_coeff<DEC>(c, uR, lowR, ctxR, pUR, nL, N_l, dR, b, Bmax, prec, upper_mask, st);
+    const uint32_t nR = bulk_coeff<DEC, CT>(c, uR, lowR, ctxR, pUR, nL, N_l, dR, b, Bmax, prec, upper_mask, st);
     pUL = nL; pUR = nR;
 }
 
@@ -615,7 +677,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     }
     ormag = half_or(ormag);
     int msb = ormag ? 31 - __builtin_clz(ormag) : 32;
-    if (valid && msb != 32 && msb > kMaxPlanes - 1) { *a.range_flag = 1; msb = kMaxPlanes - 1; }
+    if (valid && msb != 32 && msb > kMaxPlanes - 1) { atomicOr(a.range_flag, 1); msb = kMaxPlanes - 1; }
     const bool coded = valid && msb != 32;
 
     int level, sb;
@@ -1007,7 +1069,7 @@ void bpc_decode_kernel(BpcArgs a)
     int32_t sz = 0;
     if (valid) { msb = stage[0]; sz = a.sizes[cb]; }
     if (valid && sz != 4096 && msb != 32 && (msb < 0 || msb > kMaxPlanes - 1)) {
-        *a.range_flag = 1;
+        atomicOr(a.range_flag, 1);
         msb = kMaxPlanes - 1;
     }
     const bool coded = valid && msb != 32 && sz != 4096;

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void read_sizes_kernel(const uint16_t *stream,
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         int v = stream[10 + 2 * i];
-        if (v < 1 || v > 4096) { *flag = 1; v = v < 1 ? 1 : 4096; }
+        if (v < 1 || v > 4096) { atomicOr(flag, 1); v = v < 1 ? 1 : 4096; }
         sizes[i] = v;
     }
 }

@@ -55,6 +55,7 @@ struct picsong_ctx {
     picsong_lut_info li[3];
     int32_t *d_lut[3];
     bool has_lut[3];
+    bool lut_borrowed[3]; // d_lut[k] is the caller's device table (picsong_ctx_set_lut_device): not freed here
     // small scratch
     int32_t *d_offsets;   // nCB
     uint32_t *d_plane_scratch;   // encoder: planes below the 8 held in registers, 8 KB per wave (lazy)
@@ -145,6 +146,10 @@ size_t picsong_max_stream_shorts(int aw, int ah)
 int picsong_header_pack(const picsong_params *p, uint16_t o[PICSONG_HDR_SHORTS])
 {
     if (!p || !o) return fail(PICSONG_ERR_ARG, "header_pack: null argument");
+    if (p->width <= 0 || p->height <= 0 || p->height > 65535 || p->components <= 0 || p->frames < 0 ||
+        p->frames >= (1 << 17) ||
+        (uint64_t)p->width * (uint64_t)p->height * (uint64_t)p->components >= ((uint64_t)1 << 32))
+        return fail(PICSONG_ERR_ARG, "header_pack: a field exceeds its width (height 16 bits, frames 17, samples 32)");
     const uint32_t n = (uint32_t)p->width * (uint32_t)p->height * (uint32_t)p->components;
     const int qs4 = (int)(p->qs * 10000), k3 = (int)(p->k * 1000);
     o[0] = (uint16_t)(n & 0xFFFFu);
@@ -288,7 +293,16 @@ int picsong_ctx_create(const picsong_params *p, int device, picsong_ctx **out)
     if (!((p->components == 1 && !p->is_rgb) || (p->components == 3 && p->is_rgb)))
         return fail(PICSONG_ERR_ARG, "components must be 1 (grey) or 3 with is_rgb (got %d, is_rgb %d)", p->components,
                     p->is_rgb);
+    // header field widths (BitStreamBuilder.cpp:54-93): height 16 bits, frames 17 bits, samples 32 bits
+    if (p->height > 65535) return fail(PICSONG_ERR_ARG, "ySize %d exceeds the header's 16 bits", p->height);
+    if (p->frames < 0 || p->frames >= (1 << 17)) return fail(PICSONG_ERR_ARG, "frames %d outside the header's 17 bits", p->frames);
+    if ((uint64_t)p->width * (uint64_t)p->height * (uint64_t)p->components >= ((uint64_t)1 << 32))
+        return fail(PICSONG_ERR_ARG, "xSize * ySize * components exceeds the header's 32 bits");
     const int aw = picsong_pad_dim(p->width), ah = picsong_pad_dim(p->height);
+    // the mirror padding of IOManager::loadFrameCAdaptedSizes is only defined while the added columns / rows
+    // do not outnumber the frame's own (picsong_pad_frame_host)
+    if (aw - p->width > p->width || ah - p->height > p->height)
+        return fail(PICSONG_ERR_ARG, "frame %dx%d is too small to be mirror-padded to %dx%d", p->width, p->height, aw, ah);
     if ((aw >> (p->wl - 1)) < 4 || (ah >> (p->wl - 1)) < 4 || ((aw >> (p->wl - 1)) & 1) || ((ah >> (p->wl - 1)) & 1))
         return fail(PICSONG_ERR_ARG, "image %dx%d too small for %d wavelet levels", aw, ah, p->wl);
     if ((size_t)aw * (size_t)ah >= ((size_t)1 << 30)) return fail(PICSONG_ERR_ARG, "frame too large");
@@ -327,7 +341,7 @@ void picsong_ctx_destroy(picsong_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (int k = 0; k < 3; k++)
-        if (c->d_lut[k]) (void)hipFree(c->d_lut[k]);
+        if (c->d_lut[k] && !c->lut_borrowed[k]) (void)hipFree(c->d_lut[k]);
     if (c->d_offsets) (void)hipFree(c->d_offsets);
     if (c->d_plane_scratch) (void)hipFree(c->d_plane_scratch);
     if (c->d_total) (void)hipFree(c->d_total);
@@ -363,11 +377,38 @@ int picsong_ctx_set_lut_component(picsong_ctx *c, int comp, const picsong_lut_in
         if (host_table[i] < 0 || host_table[i] > 255)
             return fail(PICSONG_ERR_ARG, "LUT entry %zu = %d outside 0..255", i, host_table[i]);
     HIP_TRY(hipSetDevice(c->device));
-    if (c->d_lut[comp]) { (void)hipFree(c->d_lut[comp]); c->d_lut[comp] = nullptr; }
+    if (c->d_lut[comp] && !c->lut_borrowed[comp]) (void)hipFree(c->d_lut[comp]);
+    c->d_lut[comp] = nullptr;
+    c->lut_borrowed[comp] = false;
     HIP_TRY(hipMalloc(&c->d_lut[comp], total * sizeof(int32_t)));
     HIP_TRY(hipMemcpy(c->d_lut[comp], host_table, total * sizeof(int32_t), hipMemcpyHostToDevice));
     c->li[comp] = *info;
     c->li[comp].n_tables = n_tables;
+    c->has_lut[comp] = true;
+    return PICSONG_OK;
+}
+
+int picsong_ctx_set_lut_device(picsong_ctx *c, int comp, const picsong_lut_info *info, const int32_t *d_table)
+{
+    if (!c || !info || !d_table) return fail(PICSONG_ERR_ARG, "set_lut_device: null argument");
+    if (comp < 0 || comp > 2) return fail(PICSONG_ERR_ARG, "set_lut_device: component %d outside 0..2", comp);
+    if (info->ctx_sig != 9 || info->ctx_sign != 4 || info->ctx_ref != 1)
+        return fail(PICSONG_ERR_ARG, "LUT contexts must be 9/4/1 (sig/sign/ref), got %d/%d/%d", info->ctx_sig,
+                    info->ctx_sign, info->ctx_ref);
+    if (info->precision < 1 || info->precision > 8) return fail(PICSONG_ERR_ARG, "LUT precision %d", info->precision);
+    picsong_lut_info li = *info;
+    // section sizes follow from the geometry (IO/IOManager.ipp:431-433) when the caller left them 0
+    const int wl = c->p.wl;
+    if (li.n_ref <= 0) li.n_ref = li.n_subbands * li.n_bitplanes * li.ctx_ref * wl + li.n_bitplanes * li.ctx_ref;
+    if (li.n_sig <= 0) li.n_sig = li.n_subbands * li.n_bitplanes * li.ctx_sig * wl + li.n_bitplanes * li.ctx_sig;
+    if (li.n_sign <= 0) li.n_sign = li.n_subbands * li.n_bitplanes * li.ctx_sign * wl + li.n_bitplanes * li.ctx_sign;
+    if ((size_t)li.n_ref + li.n_sig + li.n_sign > (size_t)kLutLdsMax)
+        return fail(PICSONG_ERR_ARG, "LUT table exceeds the %d entries the coder kernels hold in LDS", kLutLdsMax);
+    if (li.n_tables <= 0) li.n_tables = 1;
+    if (c->d_lut[comp] && !c->lut_borrowed[comp]) (void)hipFree(c->d_lut[comp]);
+    c->d_lut[comp] = const_cast<int32_t *>(d_table);
+    c->lut_borrowed[comp] = true;
+    c->li[comp] = li;
     c->has_lut[comp] = true;
     return PICSONG_OK;
 }
@@ -577,6 +618,20 @@ int picsong_bpc_decode(picsong_ctx *c, const int32_t *d_staging, const int32_t *
 {
     if (!c || !d_coeffs || !d_staging || !d_sizes) return fail(PICSONG_ERR_ARG, "bpc_decode: null argument");
     return bpc_decode_impl(c, d_staging, d_sizes, d_coeffs, (hipStream_t)stream);
+}
+
+int picsong_bpc_encode_component(picsong_ctx *c, int comp, const void *d_coeffs, int32_t *d_staging, int32_t *d_sizes,
+                                 void *stream)
+{
+    if (!c || !d_coeffs || !d_staging || !d_sizes) return fail(PICSONG_ERR_ARG, "bpc_encode: null argument");
+    return bpc_encode_impl(c, d_coeffs, d_staging, d_sizes, true, (hipStream_t)stream, 0, -1, comp);
+}
+
+int picsong_bpc_decode_component(picsong_ctx *c, int comp, const int32_t *d_staging, const int32_t *d_sizes,
+                                 int32_t *d_coeffs, void *stream)
+{
+    if (!c || !d_coeffs || !d_staging || !d_sizes) return fail(PICSONG_ERR_ARG, "bpc_decode: null argument");
+    return bpc_decode_impl(c, d_staging, d_sizes, d_coeffs, (hipStream_t)stream, comp);
 }
 
 int picsong_range_flag(picsong_ctx *c, void *stream, int *h_flag)
@@ -804,6 +859,11 @@ int picsong_decode_plane(picsong_ctx *c, const uint16_t *d_stream, int comp, voi
 int picsong_pad_frame_host(const uint8_t *in, int w, int h, uint8_t *out, int aw, int ah)
 {
     if (!in || !out || w <= 0 || h <= 0 || aw < w || ah < h) return fail(PICSONG_ERR_ARG, "pad_frame: bad argument");
+    // column w + j mirrors column w - 1 - j, row h + r mirrors row h - 1 - r: with more added columns
+    // (rows) than columns (rows) the reference's loop indexes before its vector's begin
+    // (IO/IOManager.ipp:101-108, undefined behaviour on row 0) -- refused here
+    if (aw - w > w || ah - h > h)
+        return fail(PICSONG_ERR_ARG, "pad_frame: %dx%d -> %dx%d adds more columns/rows than the frame has", w, h, aw, ah);
     for (int y = 0; y < h; y++) {
         memcpy(out + (size_t)y * aw, in + (size_t)y * w, (size_t)w);
         for (int j = 0; j < aw - w; j++) out[(size_t)y * aw + w + j] = in[(size_t)y * w + (w - 1 - j)];

@@ -40,6 +40,7 @@ EXPORTS = [
     "picsong_pad_frame_host", "picsong_range_flag", "picsong_profile_begin", "picsong_profile_read",
     "picsong_encode_frame_stripe", "picsong_ctx_set_lut_component", "picsong_rgb_forward", "picsong_rgb_inverse",
     "picsong_encode_plane", "picsong_decode_plane",
+    "picsong_ctx_set_lut_device", "picsong_bpc_encode_component", "picsong_bpc_decode_component",
 ]
 
 _lib = None

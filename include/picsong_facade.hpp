@@ -4,10 +4,12 @@
 //     BPCCuda<T>::Code / Decode                               (reference BPC/BPCEngine.hpp:15-17)
 // (the way Engines/CodingEngine.cu:634-674 and Engines/DecodingEngine.cu:770-794 are) can link
 // libpicsong_hip.so instead of the CUDA translation units.  Same class names, constructor
-// arguments and call sequence; the scratch arguments of Code / Decode that the MI355X kernels do
-// not need (prefix arrays, CUB temp storage, binary-search LUT) are gone, and the LUT is handed over
-// once (setLUT) instead of as seven geometry integers per call.  Error behaviour is the
-// reference's: print the message and exit (SupportFunctions/AuxiliarFunctions.cpp:39-56).
+// arguments and member signatures: BPCCuda<T>::Code / Decode take the reference's full argument lists
+// (cudaStream_t spelled hipStream_t), so a call site such as Engines/CodingEngine.cu:661-662 or
+// Engines/DecodingEngine.cu:774-775 compiles unchanged; the scratch arguments the MI355X kernels do not
+// need (prefix array, CUB temp storage, binary-search LUT) are accepted and ignored.  Short overloads
+// (LUT handed over once with setLUT) are kept for new code.  Error behaviour is the reference's: print
+// the message and exit (SupportFunctions/AuxiliarFunctions.cpp:39-56).
 //
 // `ImageT` is anything with getWidth() / getHeight() / getBitDepth() / getComponents() -- the
 // reference's Image class (Image/Image.hpp) qualifies unchanged.
@@ -17,6 +19,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 
@@ -82,12 +85,22 @@ template <class T> class BPCCuda {
     picsong_ctx *ctx_ = nullptr;
     T *data_;
     picsong_params p_;
+    int lut_files_;
+
+    picsong_lut_info geometry(int nBp, int nSub, int cRef, int cSign, int cSig, int prec) const
+    {
+        picsong_lut_info li{};
+        li.n_bitplanes = nBp; li.n_subbands = nSub; li.ctx_ref = cRef; li.ctx_sign = cSign; li.ctx_sig = cSig;
+        li.precision = prec; li.n_files = 3; li.n_bp_files = lut_files_;
+        li.n_tables = p_.k > 0.0f ? lut_files_ : 1;         // Engine::initLUT, Engines/Engine.cu:12-56
+        return li;                                            // section sizes: derived by the library
+    }
 
 public:
     template <class ImageT>
     BPCCuda(ImageT *img, T *data, int wl, int cbW, int cbH, int cp, bool lossy, float qs, float k,
-            int /*amountOfLUTFiles*/, int device = 0)
-        : data_(data)
+            int amountOfLUTFiles, int device = 0)
+        : data_(data), lut_files_(amountOfLUTFiles)
     {
         p_ = picsong_facade::params_of(img, lossy, wl, cbW, cbH, qs, cp, k);
         picsong_facade::check(picsong_ctx_create(&p_, device, &ctx_));
@@ -96,17 +109,83 @@ public:
     BPCCuda(const BPCCuda &) = delete;
     BPCCuda &operator=(const BPCCuda &) = delete;
 
-    // Engine::initLUT's table (Engines/Engine.cu:101-141), once per object; component 0..2
+    // ---- the reference's member functions, argument for argument (BPC/BPCEngine.hpp:16-17) ----------
+    // LUTInformation: the DEVICE table of the component being coded (the engines pass _LUTInformation[i]);
+    // DCodeStreamValues: int staging; DSizeArray: per-codeblock lengths; HExtraInformation: receives the 9
+    // header shorts when iter == 0; HTotalBSSize[0]: stream length in shorts; measurementsBPC[0]: seconds
+    // spent in the coder kernel, accumulated (BPCEngine.cu:2318-2422).  DPrefixedArray, DTempStoragePArray,
+    // DLUTBSTable and HLUTBSTableSteps belong to the reference's scan / search and are not used.
+    void Code(int LUTNumberOfBitplanes, int LUTNumberOfSubbands, int LUTContextRefinement, int LUTContextSign,
+              int LUTContextSignificance, int LUTMultPrecision, int *LUTInformation, int *DCodeStreamValues,
+              int * /*DPrefixedArray*/, int * /*DTempStoragePArray*/, int *DSizeArray,
+              unsigned short *HExtraInformation, unsigned short *DBitStreamValues, int *HTotalBSSize,
+              int * /*DLUTBSTable*/, int /*HLUTBSTableSteps*/, int iter, hipStream_t mainStream, int numberOfFrames,
+              double *measurementsBPC)
+    {
+        const picsong_lut_info li = geometry(LUTNumberOfBitplanes, LUTNumberOfSubbands, LUTContextRefinement,
+                                             LUTContextSign, LUTContextSignificance, LUTMultPrecision);
+        picsong_facade::check(picsong_ctx_set_lut_device(ctx_, 0, &li, LUTInformation));
+        const auto t0 = std::chrono::steady_clock::now();
+        picsong_facade::check(picsong_bpc_encode(ctx_, data_, DCodeStreamValues, DSizeArray, mainStream));
+        (void)hipStreamSynchronize(mainStream);
+        if (measurementsBPC)
+            measurementsBPC[0] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        uint16_t hdr[PICSONG_HDR_SHORTS];
+        if (iter == 0) {
+            picsong_params p = p_;
+            p.frames = numberOfFrames;
+            picsong_facade::check(picsong_header_pack(&p, hdr));
+            if (HExtraInformation)
+                for (int i = 0; i < PICSONG_HDR_SHORTS; i++) HExtraInformation[i] = hdr[i];
+        }
+        picsong_facade::check(picsong_bitstream_pack(ctx_, DCodeStreamValues, DSizeArray, iter == 0 ? hdr : nullptr,
+                                                     DBitStreamValues, HTotalBSSize, mainStream));
+    }
+    // `data` of the constructor is the HOST copy of the bit-stream (retrieveSizeArray walks it,
+    // BitStreamBuilder.cpp:119-129): HSizeArray, when given, is filled from it the same way; the device
+    // copy DBitStreamValues is what the kernels read.  HBasicInformation[1] / [4] (coding passes, wavelet
+    // levels) must agree with the constructor's, as they do in DecodingEngine.cu:774.
+    void Decode(int /*size*/, int LUTNumberOfBitplanes_, int LUTNumberOfSubbands_, int LUTContextRefinement_,
+                int LUTContextSign_, int LUTContextSignificance_, int LUTMultPrecision_, int *LUTInformation_,
+                int * /*DPrefixedArray*/, int *DSizeArray, int *HBasicInformation, int * /*DTempStoragePArray*/,
+                unsigned short *DBitStreamValues, int *DCodeStreamValues, int *HSizeArray, int *HTotalBSSize,
+                int *DWaveletCoefficients, hipStream_t mainStream, int /*HLUTBSTableSteps*/, int * /*DLUTBSTable*/,
+                double *measurementsBPC)
+    {
+        if (HBasicInformation && (HBasicInformation[1] != p_.cp || HBasicInformation[4] != p_.wl)) {
+            std::puts("BPCCuda::Decode: HBasicInformation disagrees with the constructor's coding passes / wavelet levels");
+            std::exit(EXIT_FAILURE);
+        }
+        const picsong_lut_info li = geometry(LUTNumberOfBitplanes_, LUTNumberOfSubbands_, LUTContextRefinement_,
+                                             LUTContextSign_, LUTContextSignificance_, LUTMultPrecision_);
+        picsong_facade::check(picsong_ctx_set_lut_device(ctx_, 0, &li, LUTInformation_));
+        int aw = 0, ah = 0, ncb = 0;
+        picsong_facade::check(picsong_ctx_padded_dims(ctx_, &aw, &ah, &ncb));
+        const unsigned short *host = reinterpret_cast<const unsigned short *>(data_);
+        if (HSizeArray && host) {
+            long sum = 0;
+            for (int i = 0; i < ncb; i++) { HSizeArray[i] = host[PICSONG_HDR_SHORTS + 1 + 2 * i]; sum += HSizeArray[i] - 1; }
+            if (HTotalBSSize) HTotalBSSize[0] = (int)(PICSONG_HDR_SHORTS + 2 * (long)ncb + sum + 1);
+        }
+        picsong_facade::check(picsong_bitstream_unpack(ctx_, DBitStreamValues, DCodeStreamValues, DSizeArray, mainStream));
+        const auto t0 = std::chrono::steady_clock::now();
+        picsong_facade::check(picsong_bpc_decode(ctx_, DCodeStreamValues, DSizeArray, DWaveletCoefficients, mainStream));
+        (void)hipStreamSynchronize(mainStream);
+        if (measurementsBPC)
+            measurementsBPC[0] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+
+    // ---- short forms for new code: the table is handed over once per object ---------------------------
+    // Engine::initLUT's table (Engines/Engine.cu:101-141) from the host; component slot 0..2
     void setLUT(const picsong_lut_info &info, const int32_t *hostTable, int component = 0)
     {
         picsong_facade::check(picsong_ctx_set_lut_component(ctx_, component, &info, hostTable));
     }
-    // == BPCCuda<T>::Code: staging fill + coder kernel + createBitStream.  hTotal[0] = shorts written.
+    // staging fill + coder kernel + createBitStream with component's table.  hTotal[0] = shorts written.
     void Code(int *dStaging, int *dSizes, unsigned short *dBitstream, int *hTotal, int iter, hipStream_t s,
               int numberOfFrames, int component = 0)
     {
-        (void)component;
-        picsong_facade::check(picsong_bpc_encode(ctx_, data_, dStaging, dSizes, s));
+        picsong_facade::check(picsong_bpc_encode_component(ctx_, component, data_, dStaging, dSizes, s));
         uint16_t hdr[PICSONG_HDR_SHORTS];
         picsong_params p = p_;
         p.frames = numberOfFrames;
@@ -114,12 +193,11 @@ public:
         picsong_facade::check(picsong_bitstream_pack(ctx_, dStaging, dSizes, iter == 0 ? hdr : nullptr, dBitstream,
                                                      hTotal, s));
     }
-    // == BPCCuda<unsigned short>::Decode: createCodeStream + decoder kernel; `data` of the
-    // constructor is the device bit-stream
-    void Decode(int *dStaging, int *dSizes, int *dCoeffs, hipStream_t s)
+    // createCodeStream + decoder kernel; `data` of the constructor is the DEVICE bit-stream here
+    void Decode(int *dStaging, int *dSizes, int *dCoeffs, hipStream_t s, int component = 0)
     {
         picsong_facade::check(picsong_bitstream_unpack(ctx_, (const uint16_t *)data_, dStaging, dSizes, s));
-        picsong_facade::check(picsong_bpc_decode(ctx_, dStaging, dSizes, dCoeffs, s));
+        picsong_facade::check(picsong_bpc_decode_component(ctx_, component, dStaging, dSizes, dCoeffs, s));
         (void)hipStreamSynchronize(s);
     }
 };

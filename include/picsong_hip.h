@@ -45,7 +45,7 @@ typedef struct picsong_params {
     int cp;                 /* -cp, only 2 is implemented */
     int lossy;              /* -type: 0 = 5/3 reversible, 1 = 9/7 + quantisation */
     float qs;               /* -qs */
-    float k;                /* -k, only 0 is implemented */
+    float k;                /* -k: 0 = two coding passes on every plane; > 0 = complexity-scalable bulk mode */
     int cb_width, cb_height;/* -cbWidth / -cbHeight: header-only */
     int bit_depth;          /* -bps (8) */
     int frames;             /* -frames (header only) */
@@ -111,6 +111,14 @@ int  picsong_ctx_set_pipelined(picsong_ctx *ctx, int on);
 int  picsong_ctx_set_lut_component(picsong_ctx *ctx, int component, const picsong_lut_info *info,
                                    const int32_t *host_table);
 
+/* The reference hands BPCCuda<T>::Code / Decode the DEVICE copy of the table with its geometry on every call
+ * (`int* LUTInformation` + six integers, BPC/BPCEngine.hpp:16-17; Engine::initLUT made that copy,
+ * Engines/Engine.cu:111-136).  This adopts such a caller-owned device table for component slot c without
+ * copying it: it must stay valid while the context uses it.  info->n_ref / n_sig / n_sign == 0 are derived
+ * from the geometry and the context's wl (IO/IOManager.ipp:431-433). */
+int  picsong_ctx_set_lut_device(picsong_ctx *ctx, int component, const picsong_lut_info *info,
+                                const int32_t *d_table);
+
 /* ---- level shift: offsetImage<T> Engines/CodingEngine.cu:581-588 and
  *      removeOffsetAndApplyMaxMin(/Lossy) Engines/DecodingEngine.cu:706-729.
  *      T = int32 (lossless ctx) or float (lossy ctx); n = AW*AH. ---- */
@@ -136,6 +144,13 @@ int picsong_bpc_encode(picsong_ctx *ctx, const void *d_coeffs, int32_t *d_stagin
                        int32_t *d_sizes, void *stream);
 int picsong_bpc_decode(picsong_ctx *ctx, const int32_t *d_staging, const int32_t *d_sizes,
                        int32_t *d_coeffs, void *stream);
+
+/* the same with the table of component slot 0..2 (RGB: the reference passes _LUTInformation[i],
+ * Engines/CodingEngine.cu:617, Engines/DecodingEngine.cu:799-823) */
+int picsong_bpc_encode_component(picsong_ctx *ctx, int component, const void *d_coeffs, int32_t *d_staging,
+                                 int32_t *d_sizes, void *stream);
+int picsong_bpc_decode_component(picsong_ctx *ctx, int component, const int32_t *d_staging,
+                                 const int32_t *d_sizes, int32_t *d_coeffs, void *stream);
 
 /* ---- BitStreamBuilder: createBitStream BitStreamBuilder.cpp:100-114 (CUB InclusiveSum +
  *      index LUT + buildBitStreamLUTBS BitStreamBuilder.cu:106-137,290-323) and createCodeStream
@@ -186,7 +201,8 @@ int picsong_decode_plane(picsong_ctx *ctx, const uint16_t *d_stream, int compone
  *      Asynchronous; length via picsong_last_total(). ---- */
 int picsong_encode_frame_stripe(picsong_ctx *ctx, const uint8_t *d_frame, int cb_begin, int cb_count,
                                 uint16_t *d_stream, void *stream);
-/* host helper: IOManager::loadFrameCAdaptedSizes' mirror padding (IO/IOManager.ipp:72-112) */
+/* host helper: IOManager::loadFrameCAdaptedSizes' mirror padding (IO/IOManager.ipp:72-112).
+ * PICSONG_ERR_ARG when aw - w > w or ah - h > h: the reference's loop is undefined there. */
 int picsong_pad_frame_host(const uint8_t *in, int w, int h, uint8_t *out, int aw, int ah);
 
 /* ---- measurement: per-stage durations of picsong_encode_frame, taken with HIP events recorded

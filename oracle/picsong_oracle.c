@@ -46,8 +46,13 @@ int po_pad_dim(int v) { return ((v + PO_CB - 1) / PO_CB) * PO_CB; }
 /* IO/IOManager.ipp:72-112 -- pad right then bottom by edge-inclusive mirror:
  * col W+j = col W-1-j (per row, :99-106); row H+r = row H-1-r of the already widened image
  * (:107-110). */
-void po_pad_frame(const uint8_t *in, int W, int H, uint8_t *out, int AW, int AH)
+/* Mirror padding of IOManager::loadFrameCAdaptedSizes (IO/IOManager.ipp:72-112).  The reference's
+ * insert loop reads memblock[W - 1 - j] of the row for added column j and row H - 1 - r for added row
+ * r: with more added columns than columns (2W < AW) or more added rows than rows (2H < AH) it indexes
+ * before the vector's begin (undefined behaviour on row 0) -- such frames are refused, -1. */
+int po_pad_frame(const uint8_t *in, int W, int H, uint8_t *out, int AW, int AH)
 {
+    if (W <= 0 || H <= 0 || AW < W || AH < H || AW - W > W || AH - H > H) return -1;
     for (int y = 0; y < H; y++) {
         memcpy(out + (size_t)y * AW, in + (size_t)y * W, (size_t)W);
         for (int j = 0; j < AW - W; j++)
@@ -55,6 +60,7 @@ void po_pad_frame(const uint8_t *in, int W, int H, uint8_t *out, int AW, int AH)
     }
     for (int r = 0; r < AH - H; r++)
         memcpy(out + (size_t)(H + r) * AW, out + (size_t)(H - 1 - r) * AW, (size_t)AW);
+    return 0;
 }
 
 void po_crop_frame_u8(const uint8_t *in, int AW, int AH, uint8_t *out, int W, int H)
@@ -1207,7 +1213,7 @@ size_t po_encode_frame_k(const uint8_t *frame, int W, int H, int wl, int lossy, 
     uint8_t *pad = (uint8_t *)malloc(P);
     int32_t *staging = (int32_t *)malloc(P * sizeof(int32_t));
     int32_t *sizes = (int32_t *)malloc((size_t)n_cb * sizeof(int32_t));
-    po_pad_frame(frame, W, H, pad, AW, AH);
+    if (po_pad_frame(frame, W, H, pad, AW, AH) != 0) { free(pad); free(staging); free(sizes); return 0; }
     if (!lossy) {
         int32_t *a = (int32_t *)malloc(P * sizeof(int32_t));
         int32_t *b = (int32_t *)malloc((P + extra) * sizeof(int32_t));

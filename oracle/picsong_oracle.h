@@ -70,7 +70,7 @@ int  po_max_threads(void);
 
 /* ---- geometry / ingest (IO/IOManager.ipp:72-112, SupportFunctions/AuxiliarFunctions.cpp:22-26) */
 int  po_pad_dim(int v);
-void po_pad_frame(const uint8_t *in, int W, int H, uint8_t *out, int AW, int AH);
+int po_pad_frame(const uint8_t *in, int W, int H, uint8_t *out, int AW, int AH);   /* -1: 2W < AW or 2H < AH */
 void po_crop_frame_u8(const uint8_t *in, int AW, int AH, uint8_t *out, int W, int H);
 /* integer-only synthetic frame generator, SURVEY.md 8(d) */
 void po_gen_frame(uint8_t *out, int W, int H, uint32_t frame, uint32_t seed);

@@ -1,7 +1,8 @@
 // TEST PROGRAM: drives one frame through the reference-shaped facade classes of
-// include/picsong_facade.hpp (DWT<T,Y>, BPCCuda<T>) exactly as Engines/CodingEngine.cu:634-674 and
-// Engines/DecodingEngine.cu:770-794 call them, and checks the codestream against
-// picsong_encode_frame and the reconstruction against the input.
+// include/picsong_facade.hpp (DWT<T,Y>, BPCCuda<T>) with call sites in the shape of
+// Engines/CodingEngine.cu:661-662 and Engines/DecodingEngine.cu:773-779 (the reference's full argument
+// lists, its member names), and checks the codestream against picsong_encode_frame and the
+// reconstruction against the input.
 //   usage: facade_demo W H wl lossy qs LUTFolder
 #include <cmath>
 #include <cstdint>
@@ -58,14 +59,52 @@ static int run(int W, int H, int wl, bool lossy, float qs, const char *lutdir)
     HIPCK(hipMalloc(&d_bits_ref, max_shorts * 2));
     HIPCK(hipMemcpy(d_u8, padded.data(), P, hipMemcpyHostToDevice));
 
-    // ---- encode, the reference's call sequence (CodingEngine.cu:651-667)
+    // the members CodingEngine / DecodingEngine hold (Engines/Engine.cuh:60-160), under their names
+    DemoImage *_frameStructure = &img;
+    const int _waveletLevels = wl, _DWTCBWidth = 64, _DWTCBHeight = 18, _codingPasses = 2, _LUTAmountOfBitplaneFiles = 1;
+    const bool _waveletType = lossy;
+    const float _quantizationSize = qs, _k = 0.0f;
+    const int _LUTNumberOfBitplanes = info.n_bitplanes, _LUTNumberOfSubbands = info.n_subbands,
+              _LUTContextRefinement = info.ctx_ref, _LUTContextSign = info.ctx_sign,
+              _LUTContextSignificance = info.ctx_sig, _LUTMultPrecision = info.precision, _HLUTBSTableSteps = 0,
+              _numberOfFrames = 0;
+    int *_LUTInformation[3] = { nullptr, nullptr, nullptr };      // Engine::initLUT: device copies of the tables
+    HIPCK(hipMalloc(&_LUTInformation[0], table.size() * sizeof(int)));
+    HIPCK(hipMemcpy(_LUTInformation[0], table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice));
+    T *_DWaveletCoefficients = d_coef;
+    int *_DCodeStreamValues = d_staging, *_DSizeArray = d_sizes, *_DPrefixedArray = nullptr, *_DTempStoragePArray = nullptr,
+        *_DLUTBSTable = nullptr;
+    unsigned short _HExtraInformation[9], *_DBitStreamValues = d_bits;
+    int _HTotalBSSize[1] = { 0 };
+    double _measurementsBPC[1] = { 0.0 };
+    const hipStream_t cudaStreamDefault = s;
+
+    // ---- encode: the two statements of CodingEngine.cu:661-662, argument for argument
     int total = 0;
     {
-        DWT<T, Y> dwt(&img, lossy, wl, 64, 18, qs);
-        dwt.DWTEncodeChar(d_u8, d_coef, s);
+        DWT<T, Y> *DWTGen = new DWT<T, Y>(_frameStructure, _waveletType, _waveletLevels, _DWTCBWidth, _DWTCBHeight, _quantizationSize);
+        DWTGen->DWTEncodeChar(d_u8, _DWaveletCoefficients, cudaStreamDefault);
+        BPCCuda<T>* BPC = new BPCCuda<T>(_frameStructure, _DWaveletCoefficients, _waveletLevels, _DWTCBWidth, _DWTCBHeight, _codingPasses, _waveletType, _quantizationSize, _k, _LUTAmountOfBitplaneFiles);
+        BPC->Code(_LUTNumberOfBitplanes, _LUTNumberOfSubbands, _LUTContextRefinement, _LUTContextSign, _LUTContextSignificance, _LUTMultPrecision, _LUTInformation[0], _DCodeStreamValues, _DPrefixedArray, _DTempStoragePArray, _DSizeArray, _HExtraInformation, _DBitStreamValues, _HTotalBSSize, _DLUTBSTable, _HLUTBSTableSteps, 0, cudaStreamDefault, _numberOfFrames, &_measurementsBPC[0]);
+        total = _HTotalBSSize[0];
+        delete BPC;
+        delete DWTGen;
+        // the short form gives the same stream
+        int total2 = 0;
         BPCCuda<T> bpc(&img, d_coef, wl, 64, 18, 2, lossy, qs, 0.0f, 1);
         bpc.setLUT(info, table.data());
-        bpc.Code(d_staging, d_sizes, d_bits, &total, 0, s, 0);
+        bpc.Code(d_staging, d_sizes, d_bits_ref, &total2, 0, s, 0);
+        std::vector<unsigned short> a(total), b(total2);
+        HIPCK(hipMemcpy(a.data(), d_bits, (size_t)total * 2, hipMemcpyDeviceToHost));
+        HIPCK(hipMemcpy(b.data(), d_bits_ref, (size_t)total2 * 2, hipMemcpyDeviceToHost));
+        if (total != total2 || std::memcmp(a.data(), b.data(), (size_t)total * 2) != 0) {
+            std::printf("FACADE MISMATCH: the reference-signature Code and the short Code differ (%d / %d shorts)\n", total, total2);
+            return 1;
+        }
+        uint16_t hdr[9];
+        picsong_params hp = picsong_facade::params_of(&img, lossy, wl, 64, 18, qs);
+        picsong_facade::check(picsong_header_pack(&hp, hdr));
+        if (std::memcmp(hdr, _HExtraInformation, sizeof hdr) != 0) { std::printf("FACADE MISMATCH: HExtraInformation\n"); return 1; }
     }
     // ---- the same frame through the fused entry point
     int total_ref = 0;
@@ -86,13 +125,21 @@ static int run(int W, int H, int wl, bool lossy, float qs, const char *lutdir)
         return 1;
     }
 
-    // ---- decode, the reference's call sequence (DecodingEngine.cu:774-784)
+    // ---- decode: the statements of DecodingEngine.cu:773-779, argument for argument
     {
-        BPCCuda<unsigned short> bpc(&img, d_bits, wl, 64, 18, 2, lossy, qs, 0.0f, 1);
-        bpc.setLUT(info, table.data());
-        bpc.Decode(d_staging, d_sizes, d_coef_i, s);
-        DWT<T, Y> dwt(&img, lossy, wl, 64, 18, qs);
-        dwt.DWTDecode(d_coef_i, d_img, s);
+        std::vector<unsigned short> hostStream = a;                      // readCompressedImage's host copy
+        unsigned short *_HBitStreamValues = hostStream.data();
+        std::vector<int> hSizes((size_t)ncb);
+        int *_HSizeArray = hSizes.data(), *_DWaveletCoefficientsI = d_coef_i;
+        int _HBasicInformation[8] = { 0, _codingPasses, 0, 0, _waveletLevels, 0, 0, 0 };   // getExtraInformation
+        T *_DImagePixels = d_img;
+        BPCCuda<unsigned short>* BPC = new BPCCuda<unsigned short>(_frameStructure, _HBitStreamValues, _waveletLevels, _DWTCBWidth, _DWTCBHeight, _codingPasses, _waveletType, _quantizationSize, _k, _LUTAmountOfBitplaneFiles);
+        BPC->Decode(aw * ah, _LUTNumberOfBitplanes, _LUTNumberOfSubbands, _LUTContextRefinement, _LUTContextSign, _LUTContextSignificance, _LUTMultPrecision, _LUTInformation[0], _DPrefixedArray, _DSizeArray, _HBasicInformation, _DTempStoragePArray, _DBitStreamValues, _DCodeStreamValues, _HSizeArray, _HTotalBSSize, _DWaveletCoefficientsI, cudaStreamDefault, _HLUTBSTableSteps, _DLUTBSTable, &_measurementsBPC[0]);
+        DWT<T, Y>* DWTGen = new DWT<T, Y>(_frameStructure, _waveletType, _waveletLevels, _DWTCBWidth, _DWTCBHeight, _quantizationSize);
+        DWTGen->DWTDecode(_DWaveletCoefficientsI, _DImagePixels, cudaStreamDefault);
+        delete BPC;
+        delete DWTGen;
+        if (_HTotalBSSize[0] != total) { std::printf("FACADE MISMATCH: Decode's HTotalBSSize %d != %d\n", _HTotalBSSize[0], total); return 1; }
     }
     std::vector<T> rec(P);
     HIPCK(hipMemcpy(rec.data(), d_img + extra, P * sizeof(T), hipMemcpyDeviceToHost));

@@ -148,6 +148,13 @@ static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v)
 static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 static inline int emu_sext24(int v) { return (int)((((unsigned)v & 0xFFFFFFu) ^ 0x800000u)) - 0x800000; }
 static inline int __mul24(int a, int b) { return (int)(unsigned)((long long)emu_sext24(a) * (long long)emu_sext24(b)); }
+// the emulator runs one lane at a time: atomics are plain read-modify-writes
+static inline int atomicOr(int *p, int v) { int o = *p; *p = o | v; return o; }
+static inline unsigned atomicOr(unsigned *p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+static inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned *p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline int atomicMax(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
+static inline void __threadfence() {}
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __syncthreads() { emu::barrier(); }

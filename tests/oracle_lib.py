@@ -54,6 +54,7 @@ def lib():
     L.po_pad_dim.restype = i32
     L.po_pad_dim.argtypes = [i32]
     L.po_pad_frame.argtypes = [vp, i32, i32, vp, i32, i32]
+    L.po_pad_frame.restype = i32
     L.po_gen_frame.argtypes = [vp, i32, i32, C.c_uint32, C.c_uint32]
     L.po_level_shift_fwd_i32.argtypes = [vp, vp, sz, i32]
     L.po_level_shift_fwd_f32.argtypes = [vp, vp, sz, i32]
@@ -115,6 +116,23 @@ def max_threads():
     return lib().po_max_threads()
 
 
+def host_cores():
+    """CPU cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def usable_threads():
+    """Threads worth giving the oracle's OpenMP loops on this box."""
+    return max(1, min(max_threads(), host_cores()))
+
+
 class Lut:
     """Loaded LUT (keeps the C struct alive; .table is a numpy copy)."""
 
@@ -171,7 +189,8 @@ def pad_frame(img):
     AW, AH = pad_dim(W), pad_dim(H)
     out = np.empty((AH, AW), np.uint8)
     img = np.ascontiguousarray(img)
-    lib().po_pad_frame(_p(img), W, H, _p(out), AW, AH)
+    if lib().po_pad_frame(_p(img), W, H, _p(out), AW, AH) != 0:
+        raise ValueError(f"pad_frame: {W}x{H} needs more added columns/rows than it has (2W < AW or 2H < AH)")
     return out
 
 

@@ -77,6 +77,56 @@ def test_pad_frame_host_matches_oracle(oracle):
     assert rc == 0 and np.array_equal(out, oracle.pad_frame(img))
 
 
+@pytest.mark.parametrize("w,h", [(10, 10), (100, 20), (31, 64), (64, 31)])
+def test_pad_frame_refuses_frames_smaller_than_their_padding(oracle, w, h):
+    """Column w + j mirrors column w - 1 - j: with 2w < AW (or 2h < AH) the reference's loop
+    (IO/IOManager.ipp:101-108) indexes before its vector -- refused by the library, the oracle and
+    picsong_ctx_create alike instead of reading out of bounds."""
+    L = pa.load()
+    aw, ah = pa.pad_dim(w), pa.pad_dim(h)
+    # guard pages' worth of poison around the input: an under-read would not go unnoticed under ASan,
+    # and here the call must not touch anything at all
+    img = np.full(w * h, 7, np.uint8)
+    out = np.full((ah, aw), 0xAB, np.uint8)
+    rc = L.picsong_pad_frame_host(img.ctypes.data_as(C.c_void_p), w, h, out.ctypes.data_as(C.c_void_p), aw, ah)
+    assert rc == -1 and b"pad_frame" in L.picsong_last_error()
+    assert (out == 0xAB).all()
+    with pytest.raises(ValueError):
+        oracle.pad_frame(img.reshape(h, w))
+    hnd = C.c_void_p()
+    p = pa.make_params(w, h, wl=1)
+    assert L.picsong_ctx_create(C.byref(p), 0, C.byref(hnd)) == -1
+    assert b"mirror-padded" in L.picsong_last_error()
+
+
+@pytest.mark.parametrize("w,h", [(32, 32), (33, 40), (64, 32), (127, 65)])
+def test_pad_frame_smallest_accepted_frames_match_oracle(oracle, w, h):
+    L = pa.load()
+    aw, ah = pa.pad_dim(w), pa.pad_dim(h)
+    img = oracle.gen_frame(w, h)
+    out = np.empty((ah, aw), np.uint8)
+    assert L.picsong_pad_frame_host(img.ctypes.data_as(C.c_void_p), w, h, out.ctypes.data_as(C.c_void_p), aw, ah) == 0
+    assert np.array_equal(out, oracle.pad_frame(img))
+    assert np.array_equal(out[:h, w:], img[:, ::-1][:, :aw - w])          # edge-inclusive mirror
+    assert np.array_equal(out[h:], out[:h][::-1][:ah - h])
+
+
+def test_header_field_widths_are_enforced():
+    """height is 16 bits, frames 17 bits, samples 32 bits in the 9-short header
+    (BitStreamBuilder.cpp:54-93): a value that would spill into its neighbour is refused."""
+    L = pa.load()
+    hnd = C.c_void_p()
+    out = (C.c_uint16 * 9)()
+    for kw in (dict(width=64, height=70000), dict(width=64, height=64, frames=1 << 17), dict(width=70000, height=65535)):
+        p = pa.make_params(kw["width"], kw["height"], wl=1, frames=kw.get("frames", 0))
+        assert L.picsong_ctx_create(C.byref(p), 0, C.byref(hnd)) == -1, kw
+        assert L.picsong_header_pack(C.byref(p), out) == -1, kw
+    p = pa.make_params(64, 65535, wl=1, frames=(1 << 17) - 1)
+    assert L.picsong_header_pack(C.byref(p), out) == 0
+    q = pa.header_unpack(np.frombuffer(out, np.uint16))
+    assert (q.width, q.height, q.frames) == (64, 65535, (1 << 17) - 1)
+
+
 def test_invalid_parameters_are_rejected_without_exit():
     L = pa.load()
     h = C.c_void_p()

@@ -85,6 +85,40 @@ def test_video_files_roundtrip(oracle, tmp_path):
 
 
 @pytest.mark.gpu
+def test_4k_video_file_equals_oracle_frame_by_frame(oracle, tmp_path):
+    """BASELINE configs[3] on one GPU through the CLI: a 4K (3840x2160) greyscale video, -type 0, wl 5,
+    -numberOfStreams 3; every frame's codestream equals the oracle's (header on frame 0 only,
+    BitStreamBuilder.cu:277-278), _SIZE lists the lengths in frame order, decode returns the frames
+    (CodingEngine::runVideo Engines/CodingEngine.cu:819-872, writeCodedFrame IO/IOManager.ipp:176-190)."""
+    W, H, wl, F = 3840, 2160, 5, 18
+    oracle.set_threads(oracle.usable_threads())
+    try:
+        lutdir = os.path.join(oracle.LUT_DIR, "n1_lossless")
+        raw, enc, dec = tmp_path / "v4k.raw", tmp_path / "v4k.enc", tmp_path / "v4k.dec"
+        with open(raw, "wb") as f:
+            for i in range(F):
+                f.write(oracle.gen_frame(W, H, i).tobytes())
+        r = _run("-cd", 0, "-i", raw, "-o", enc, "-xSize", W, "-ySize", H, "-wl", wl, "-type", 0,
+                 "-video", 1, "-frames", F, "-numberOfStreams", 3, "-LUTFolder", lutdir)
+        assert r.returncode == 0, r.stdout + r.stderr
+        lut = oracle.lut_for(False, wl)
+        got = np.fromfile(enc, np.uint16)
+        sizes = [int(x) for x in open(str(enc) + "_SIZE").read().split(",")]
+        assert len(sizes) == F and sum(sizes) == got.size
+        pos = 0
+        for i in range(F):
+            ref = oracle.encode_frame(oracle.gen_frame(W, H, i), wl, False, 1.0, lut, 0 if i == 0 else 1, F)
+            assert sizes[i] == ref.size, f"frame {i}: _SIZE {sizes[i]} != oracle {ref.size}"
+            assert np.array_equal(got[pos:pos + sizes[i]], ref), f"frame {i} differs from the oracle"
+            pos += sizes[i]
+        r = _run("-cd", 1, "-i", enc, "-o", dec, "-video", 1, "-LUTFolder", lutdir)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert np.array_equal(np.fromfile(dec, np.uint8), np.fromfile(raw, np.uint8))
+    finally:
+        oracle.set_threads(1)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("lossy,video", [(False, False), (True, True)])
 def test_rgb_files_roundtrip_and_oracle_parity(oracle, tmp_path, lossy, video):
     """-isRGB 1 -components 3: planar R,G,B planes; every component stream equals the oracle's

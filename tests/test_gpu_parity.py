@@ -162,9 +162,45 @@ def test_missing_lut_is_an_error(pa, torch):
     c.close()
 
 
-# ---- full BASELINE sizes: size-independent properties (the oracle would take minutes) ----------
+# ---- full BASELINE sizes: the whole codestream against the oracle (OpenMP over codeblocks and DWT
+# rows on all of the box's cores: well under a second per 8K frame), then size-independent properties
 def _gen_device(torch, oracle, W, H, f=0):
     return _dev(torch, oracle.pad_frame(oracle.gen_frame(W, H, f)))
+
+
+@pytest.mark.parametrize("W,H,wl,lossy,qs", [
+    (3840, 2160, 5, False, 1.0),      # BASELINE configs[1]: 4K, -type 0, wl 5
+    (7680, 4320, 5, False, 1.0),      # the metric's workload: 8K, -type 0, wl 5
+    (7680, 4320, 6, True, 0.5),       # BASELINE configs[2]: 8K, -type 1, qs 0.5, wl 6
+])
+def test_full_size_codestream_equals_oracle(oracle, pa, torch, W, H, wl, lossy, qs):
+    """Every BASELINE single-frame configuration at its full size: header, per-codeblock (MSB, length)
+    table, payload and the trailing short of the HIP codestream equal the oracle's, and the HIP decode of
+    it equals the oracle's decode (CodingEngine::runImage Engines/CodingEngine.cu:634-674,713-751;
+    DecodingEngine::runImage Engines/DecodingEngine.cu:770-794)."""
+    oracle.set_threads(oracle.usable_threads())
+    try:
+        img = oracle.gen_frame(W, H, 0)
+        lut = oracle.lut_for(lossy, wl)
+        ref = oracle.encode_frame(img, wl, lossy, qs, lut)
+        c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=_lutdir(oracle, lossy))
+        frame = _dev(torch, oracle.pad_frame(img))
+        s = c.encode_frame(frame, 0)
+        got = s.cpu().numpy().view(np.uint16)
+        ncb = c.ncb
+        assert got.size == ref.size
+        assert np.array_equal(got[:9], ref[:9])                                            # header
+        assert np.array_equal(got[9:9 + 2 * ncb:2], ref[9:9 + 2 * ncb:2])                  # MSB per codeblock
+        assert np.array_equal(got[10:10 + 2 * ncb:2], ref[10:10 + 2 * ncb:2])              # sizeArray
+        assert np.array_equal(got, ref)                                                    # everything
+        dec = c.decode_frame(s).cpu().numpy()
+        ref_dec = oracle.decode_frame(ref, W, H, wl, lossy, qs, lut)
+        assert np.array_equal(dec[:H, :W], ref_dec[:H, :W])
+        if not lossy:
+            assert np.array_equal(dec[:H, :W], img)
+        c.close()
+    finally:
+        oracle.set_threads(1)
 
 
 @pytest.mark.parametrize("W,H,wl", [(3840, 2160, 5), (7680, 4320, 5)])

@@ -1,0 +1,213 @@
+// valu_probe.hip -- measures what one MI355X SIMD actually issues, for the instruction mix of the BPC
+// coder (bpc_kernels.hpp): independent and dependent chains of v_and_b32 / v_alignbit_b32 /
+// v_mul_u32_u24 / v_perm_b32 / v_mbcnt / DPP moves, and the coder's call-site round trips
+// (VALU compare -> SGPR mask -> SALU -> exec-masked VALU, with and without a branch), at 1..8 resident
+// waves per SIMD.  Prints, per pattern and occupancy, cycles per wave-instruction as one wave sees them
+// (s_memtime) and wave-instructions per cycle per SIMD for the whole chip (HIP events + measured clock).
+// bench.py takes its VALU issue peak from this table (tools/valu_probe.json) and from the guide.
+//
+// build: hipcc -O3 --offload-arch=gfx950 -o valu_probe valu_probe.hip ; run: ./valu_probe [json path]
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+enum Kind {
+    AND_INDEP, AND_DEP, ALIGNBIT_INDEP, ALIGNBIT_DEP, MUL24_INDEP, MUL24_DEP, PERM_INDEP, PERM_DEP,
+    MBCNT_DEP, DPP_INDEP, DPP_DEP, CNDMASK_DEP, BFE_INDEP,
+    CMP_SALU_CND,        // v_cmp -> s_and -> v_cndmask, dependent (the ballot / mask round trip)
+    CMP_SAVEEXEC,        // v_cmp -> s_and_saveexec -> v_add -> s_or exec (an exec-masked region)
+    CMP_BRANCH_NT,       // v_cmp -> s_and -> s_cmp -> s_cbranch (not taken) -> v_add
+    CMP_BRANCH_T,        // the same, taken (forward over 2 instructions)
+    SALU_DEP,            // s_add chain
+    SITE_LIKE,           // one call site of the coder, as compiled today (instruction classes and order)
+    NKINDS
+};
+static const char *kKindName[NKINDS] = {
+    "v_and_b32 x8 independent", "v_and_b32 dependent", "v_alignbit_b32 x8 independent", "v_alignbit_b32 dependent",
+    "v_mul_u32_u24 x8 independent", "v_mul_u32_u24 dependent", "v_perm_b32 x8 independent", "v_perm_b32 dependent",
+    "v_mbcnt_lo+hi dependent", "v_mov_b32 dpp wave_shr:1 x8 independent", "v_mov_b32 dpp wave_shr:1 dependent",
+    "v_cndmask_b32 dependent", "v_bfe_u32 x8 independent",
+    "v_cmp -> s_and_b64 -> v_cndmask (3 inst round trip)", "v_cmp -> s_and_saveexec -> v_add -> s_or exec (4 inst)",
+    "v_cmp -> s_and -> s_cmp -> s_cbranch not taken -> v_add (5 inst)", "v_cmp -> s_and -> s_cmp -> s_cbranch taken -> v_add (5 inst)",
+    "s_add_u32 dependent", "coder call site mix (24 inst: 15 VALU, 9 SALU)" };
+// instructions per unrolled block (what "per instruction" divides by)
+static const int kBlockInsts[NKINDS] = { 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 64, 32, 32, 24, 32, 40, 40, 32, 24 };
+static const int kBlockValu[NKINDS] = { 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 16, 16, 16, 16, 0, 15 };
+
+#define R4(x) x x x x
+#define R8(x) R4(x) R4(x)
+#define R16(x) R8(x) R8(x)
+#define R32(x) R16(x) R16(x)
+
+template <int KIND>
+__global__ __launch_bounds__(256) void probe_kernel(uint32_t *out, uint64_t *cyc, int iters, uint32_t seed)
+{
+    uint32_t a0 = threadIdx.x * 2654435761u + seed, a1 = a0 ^ 0x9E3779B9u, a2 = a0 + 77u, a3 = a1 + 5u;
+    uint32_t a4 = a0 * 3u, a5 = a1 * 5u, a6 = a2 * 7u, a7 = a3 * 11u, k = seed | 0x01010101u;
+    uint64_t sm = 0;            // scalar mask scratch
+    uint32_t sc = seed;
+    __builtin_amdgcn_s_barrier();
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; it++) {
+        if constexpr (KIND == AND_INDEP) {
+            asm volatile(R4("v_and_b32 %0, %0, %8\n v_and_b32 %1, %1, %8\n v_and_b32 %2, %2, %8\n v_and_b32 %3, %3, %8\n"
+                            "v_and_b32 %4, %4, %8\n v_and_b32 %5, %5, %8\n v_and_b32 %6, %6, %8\n v_and_b32 %7, %7, %8\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));
+        } else if constexpr (KIND == AND_DEP) {
+            asm volatile(R32("v_and_b32 %0, %0, %1\n") : "+v"(a0) : "v"(k));
+        } else if constexpr (KIND == ALIGNBIT_INDEP) {
+            asm volatile(R4("v_alignbit_b32 %0, %0, %0, 3\n v_alignbit_b32 %1, %1, %1, 3\n v_alignbit_b32 %2, %2, %2, 3\n v_alignbit_b32 %3, %3, %3, 3\n"
+                            "v_alignbit_b32 %4, %4, %4, 3\n v_alignbit_b32 %5, %5, %5, 3\n v_alignbit_b32 %6, %6, %6, 3\n v_alignbit_b32 %7, %7, %7, 3\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if constexpr (KIND == ALIGNBIT_DEP) {
+            asm volatile(R32("v_alignbit_b32 %0, %0, %0, 3\n") : "+v"(a0));
+        } else if constexpr (KIND == MUL24_INDEP) {
+            asm volatile(R4("v_mul_u32_u24 %0, %0, %8\n v_mul_u32_u24 %1, %1, %8\n v_mul_u32_u24 %2, %2, %8\n v_mul_u32_u24 %3, %3, %8\n"
+                            "v_mul_u32_u24 %4, %4, %8\n v_mul_u32_u24 %5, %5, %8\n v_mul_u32_u24 %6, %6, %8\n v_mul_u32_u24 %7, %7, %8\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));
+        } else if constexpr (KIND == MUL24_DEP) {
+            asm volatile(R32("v_mul_u32_u24 %0, %0, %1\n") : "+v"(a0) : "v"(k));
+        } else if constexpr (KIND == PERM_INDEP) {
+            asm volatile(R4("v_perm_b32 %0, %0, %8, %8\n v_perm_b32 %1, %1, %8, %8\n v_perm_b32 %2, %2, %8, %8\n v_perm_b32 %3, %3, %8, %8\n"
+                            "v_perm_b32 %4, %4, %8, %8\n v_perm_b32 %5, %5, %8, %8\n v_perm_b32 %6, %6, %8, %8\n v_perm_b32 %7, %7, %8, %8\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));
+        } else if constexpr (KIND == PERM_DEP) {
+            asm volatile(R32("v_perm_b32 %0, %0, %1, %1\n") : "+v"(a0) : "v"(k));
+        } else if constexpr (KIND == MBCNT_DEP) {
+            asm volatile(R16("v_mbcnt_lo_u32_b32 %0, %1, %0\n v_mbcnt_hi_u32_b32 %0, %1, %0\n") : "+v"(a0) : "s"(sc));
+        } else if constexpr (KIND == DPP_INDEP) {
+            asm volatile(R4("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %1, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                            "v_mov_b32_dpp %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                            "v_mov_b32_dpp %4, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+                            "v_mov_b32_dpp %6, %6 wave_shr:1 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %7, %7 wave_shr:1 row_mask:0xf bank_mask:0xf\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if constexpr (KIND == DPP_DEP) {
+            asm volatile(R32("s_nop 1\n v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf\n") : "+v"(a0));
+        } else if constexpr (KIND == CNDMASK_DEP) {
+            asm volatile(R32("v_cndmask_b32 %0, %0, %1, vcc\n") : "+v"(a0) : "v"(k) : "vcc");
+        } else if constexpr (KIND == BFE_INDEP) {
+            asm volatile(R4("v_bfe_u32 %0, %0, %8, 9\n v_bfe_u32 %1, %1, %8, 9\n v_bfe_u32 %2, %2, %8, 9\n v_bfe_u32 %3, %3, %8, 9\n"
+                            "v_bfe_u32 %4, %4, %8, 9\n v_bfe_u32 %5, %5, %8, 9\n v_bfe_u32 %6, %6, %8, 9\n v_bfe_u32 %7, %7, %8, 9\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));
+        } else if constexpr (KIND == CMP_SALU_CND) {
+            asm volatile(R8("v_cmp_ne_u32_e64 %1, %0, %2\n s_and_b64 %1, %1, exec\n v_cndmask_b32_e64 %0, %0, %2, %1\n")
+                         : "+v"(a0), "+s"(sm) : "v"(k) : "scc");
+        } else if constexpr (KIND == CMP_SAVEEXEC) {
+            asm volatile(R8("v_cmp_ne_u32_e64 vcc, %0, %2\n s_and_saveexec_b64 %1, vcc\n v_add_u32 %0, %0, %2\n s_or_b64 exec, exec, %1\n")
+                         : "+v"(a0), "+s"(sm) : "v"(k) : "vcc", "scc");
+        } else if constexpr (KIND == CMP_BRANCH_NT) {
+            // a0 != k always (k has bit 0 set per byte, a0 changes): mask nonzero -> scc1 branch on "== 0" not taken
+            asm volatile(R8("v_cmp_ne_u32_e64 %1, %0, %2\n s_and_b64 %1, %1, exec\n s_cmp_eq_u64 %1, 0\n s_cbranch_scc1 1\n v_add_u32 %0, %0, %2\n")
+                         : "+v"(a0), "+s"(sm) : "v"(k) : "scc");
+        } else if constexpr (KIND == CMP_BRANCH_T) {
+            asm volatile(R8("v_cmp_ne_u32_e64 %1, %0, %2\n s_and_b64 %1, %1, exec\n s_cmp_lg_u64 %1, 0\n s_cbranch_scc1 1\n v_add_u32 %0, %0, %2\n")
+                         : "+v"(a0), "+s"(sm) : "v"(k) : "scc");
+        } else if constexpr (KIND == SALU_DEP) {
+            asm volatile(R32("s_add_u32 %0, %0, 3\n") : "+s"(sc) : : "scc");
+        } else if constexpr (KIND == SITE_LIKE) {
+            // the significance call site of bpc_encode_kernel as compiled in round 1 (see the disassembly):
+            // on-compare, need-mask, reservation under exec, update under exec, exhausted-compare, store region
+            asm volatile(
+                "v_and_b32 %2, %4, %0\n v_cmp_ne_u32_e64 vcc, 0, %2\n s_and_b64 %3, vcc, exec\n s_cmp_eq_u64 %3, 0\n s_cbranch_scc1 1\n s_nop 0\n"
+                "s_and_saveexec_b64 %3, vcc\n v_alignbit_b32 %2, %0, %0, 5\n v_and_b32 %2, 1, %2\n v_alignbit_b32 %1, %1, %1, 7\n"
+                "v_and_or_b32 %2, %1, 2, %2\n v_perm_b32 %2, %0, %1, %2\n v_mul_u32_u24 %2, %0, %2\n v_lshrrev_b32 %2, 7, %2\n"
+                "v_add_u32 %2, %2, %4\n v_sub_u32 %1, %0, %2\n v_cndmask_b32 %0, %1, %2, vcc\n v_mad_u32_u24 %1, %2, %4, %1\n"
+                "s_or_b64 exec, exec, %3\n v_cmp_ne_u32_e64 %3, 0, %0\n s_and_b64 %3, %3, vcc\n s_and_saveexec_b64 %3, %3\n v_add_u32 %1, %1, %4\n s_or_b64 exec, exec, %3\n"
+                : "+v"(a0), "+v"(a1), "+v"(a2), "+s"(sm) : "v"(k) : "vcc", "scc");
+        }
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ (uint32_t)sm ^ sc;
+    if ((threadIdx.x & 63u) == 0u) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+__global__ void clock_kernel(uint64_t *out)
+{
+    const uint64_t c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t r1 = r0;
+    while (r1 - r0 < 200000ull) r1 = __builtin_amdgcn_s_memrealtime();     // 2 ms of the 100 MHz counter
+    const uint64_t c1 = __builtin_amdgcn_s_memtime();
+    out[0] = c1 - c0; out[1] = r1 - r0;
+}
+
+template <int KIND>
+static void run_kind(int ncu, double mhz, uint32_t *d_out, uint64_t *d_cyc, std::string &json)
+{
+    const int iters = 4000;
+    char buf[512];
+    printf("%-66s", kKindName[KIND]);
+    fflush(stdout);
+    json += std::string("  {\"pattern\": \"") + kKindName[KIND] + "\", \"rows\": [";
+    for (int w = 1; w <= 8; w++) {
+        const int blocks = ncu * w;                    // 256-thread workgroups: one wave per SIMD each
+        std::vector<uint64_t> h((size_t)blocks * 4);
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        probe_kernel<KIND><<<blocks, 256>>>(d_out, d_cyc, 100, 12345u);        // warm-up
+        CK(hipEventRecord(e0));
+        probe_kernel<KIND><<<blocks, 256>>>(d_out, d_cyc, iters, 12345u);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        CK(hipMemcpy(h.data(), d_cyc, h.size() * 8, hipMemcpyDeviceToHost));
+        double mean = 0;
+        for (uint64_t v : h) mean += (double)v;
+        mean /= (double)h.size();
+        const double per_wave = mean / ((double)iters * kBlockInsts[KIND]);
+        const double chip = (double)blocks * 4.0 * iters * kBlockInsts[KIND] / (ms * 1e-3 * mhz * 1e6) / (ncu * 4.0);
+        printf(" %5.2f/%4.2f", per_wave, chip);
+        fflush(stdout);
+        snprintf(buf, sizeof buf, "%s{\"waves_per_simd\": %d, \"cycles_per_inst_one_wave\": %.3f, \"insts_per_cycle_per_simd\": %.4f, \"valu_per_cycle_per_simd\": %.4f}",
+                 w == 1 ? "" : ", ", w, per_wave, chip, chip * kBlockValu[KIND] / kBlockInsts[KIND]);
+        json += buf;
+        CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+    }
+    printf("\n");
+    json += "]}";
+}
+
+template <int K>
+static void run_all(int ncu, double mhz, uint32_t *d_out, uint64_t *d_cyc, std::string &json)
+{
+    if constexpr (K < NKINDS) {
+        if (K) json += ",\n";
+        run_kind<K>(ncu, mhz, d_out, d_cyc, json);
+        run_all<K + 1>(ncu, mhz, d_out, d_cyc, json);
+    }
+}
+
+int main(int argc, char **argv)
+{
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int ncu = prop.multiProcessorCount;
+    uint32_t *d_out; uint64_t *d_cyc, *d_clk;
+    CK(hipMalloc(&d_out, (size_t)ncu * 8 * 256 * 4));
+    CK(hipMalloc(&d_cyc, (size_t)ncu * 8 * 4 * 8));
+    CK(hipMalloc(&d_clk, 16));
+    uint64_t clk[2];
+    clock_kernel<<<1, 64>>>(d_clk);
+    CK(hipMemcpy(clk, d_clk, 16, hipMemcpyDeviceToHost));
+    clock_kernel<<<1, 64>>>(d_clk);
+    CK(hipMemcpy(clk, d_clk, 16, hipMemcpyDeviceToHost));
+    const double mhz = (double)clk[0] / (double)clk[1] * 100.0;
+    printf("%s: %d CUs, s_memtime runs at %.0f MHz (vs the 100 MHz s_memrealtime), clockRate %d kHz\n", prop.name, ncu, mhz,
+           prop.clockRate);
+    printf("columns: waves per SIMD 1..8; each cell = cycles per instruction as one wave sees them / instructions per cycle per SIMD (chip-wide)\n");
+    std::string json = "{\"device\": \"" + std::string(prop.name) + "\", \"cus\": " + std::to_string(ncu) +
+                       ", \"shader_mhz\": " + std::to_string(mhz) + ", \"patterns\": [\n";
+    run_all<0>(ncu, mhz, d_out, d_cyc, json);
+    json += "\n]}\n";
+    if (argc > 1) {
+        FILE *f = fopen(argv[1], "w");
+        if (f) { fputs(json.c_str(), f); fclose(f); }
+    }
+    return 0;
+}
