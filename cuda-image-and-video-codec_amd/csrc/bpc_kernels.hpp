@@ -631,13 +631,30 @@ __device__ __forceinline__ int bulk_setup(const BpcArgs &a, bool coded, int msb,
     return cbp;
 }
 
-// Waves per SIMD the register allocator must leave room for.  Measured on MI355X, 8K frames, frames
-// in flight on 2 / 3 streams: 4 waves (128 VGPRs, 14 spilled) 87 / 83 Gpixel/s and the shortest single
-// launch (0.45 ms); 5 waves (96 VGPRs) 87 / 91 Gpixel/s, single launch 0.52 ms; 6 and 8 waves lose to
-// spill traffic (84 / 83 at best).  The pipelined throughput is the figure of merit: 5.
+// Waves per SIMD the register allocator must leave room for (512 VGPRs per SIMD lane: 8 waves = 64,
+// 7 = 72, 6 = 80, 5 = 96).  Round 1 (8 planes resident): 5.  With one plane resident the kernel fits 64.
 #ifndef PICSONG_BPC_ENC_WAVES
-#define PICSONG_BPC_ENC_WAVES 5
+#define PICSONG_BPC_ENC_WAVES 8
 #endif
+
+// one row (two coefficients of the lane) of the coefficient array as magnitudes and sign bits
+// (byte offset `off` from the array's base: AW * AH * 4 < 2^32, so a row is one uniform base + a 32-bit
+// lane offset, and stepping a row down is one add -- no 64-bit address per row to keep or spill)
+__device__ __forceinline__ void load_row(const BpcArgs &a, uint32_t off, uint32_t &m0, uint32_t &m1, uint32_t &n0, uint32_t &n1)
+{
+    int32_t v0, v1;
+    const char *const p = reinterpret_cast<const char *>(a.coeffs_in) + (size_t)off;
+    if (a.is_float) {
+        float2 f = *reinterpret_cast<const float2 *>(p);
+        v0 = (int32_t)f.x; v1 = (int32_t)f.y;               // BPCEngine.cu:49: truncation toward zero
+    } else {
+        int2 q = *reinterpret_cast<const int2 *>(p);
+        v0 = q.x; v1 = q.y;
+    }
+    m0 = (uint32_t)(v0 < 0 ? -v0 : v0); m1 = (uint32_t)(v1 < 0 ? -v1 : v1);
+    n0 = (uint32_t)v0 >> 31; n1 = (uint32_t)v1 >> 31;
+}
+
 // BULK = the -k > 0 instantiation (bulk scan after the ordinary planes, table s of the bit-plane
 // LUT files, LDS copy of that table); the k = 0 instantiation compiles to the plain coder.
 template <bool BULK>
@@ -645,40 +662,75 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
 {
     __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
-    const int wave = BULK ? (int)blockIdx.x : (int)blockIdx.x * kBpcEncWgWaves + (int)(threadIdx.x >> 6);
+    const int wave = BULK ? (int)blockIdx.x
+                          : (int)blockIdx.x * kBpcEncWgWaves + (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cb = a.cb_base + 2 * wave + (int)half;
     const bool valid = cb < a.nCB;
     const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
     const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
-    int32_t *st = a.staging + (size_t)(valid ? cb : a.cb_base) * 4096u;
-    int32_t *cw = st + 1;                                   // codeword array: slot k lives at st[1 + k]
+    const uint32_t cbyte = (uint32_t)cbase * 4u, rstride = (uint32_t)a.AW * 4u;  // byte offset of row 0 / of a row step
+    int32_t *const stw = a.staging + (size_t)(a.cb_base + 2 * wave) * 4096u;     // wave-uniform: the pair's first codeblock
+    int32_t *const st = stw + (size_t)half * 4096u;                             // (an invalid upper half never touches it)
     const uint32_t prec = (uint32_t)a.g.prec;
+    const uint32_t upper_mask = opaque_mask(half ? 0xFFFFFFFFu : 0u);
+    uint32_t *const pscr = a.plane_scratch + (size_t)wave * (size_t)kEncScratchDwordsPerWave + lane;
 
-    uint32_t PLlo[kEncRegPlanes], PLhi[kEncRegPlanes], PRlo[kEncRegPlanes], PRhi[kEncRegPlanes];
-#pragma unroll
-    for (int k = 0; k < kEncRegPlanes; k++) { PLlo[k] = PLhi[k] = PRlo[k] = PRhi[k] = 0u; }
+    // ---- ONE pass over the coefficients: findMSB (BPCEngine.cu:176-192) and the transposition, plane k
+    // of row i -> bit i of the plane's row mask; planes 0..7 of every block are built (a block's planes
+    // above its MSB are zero) and parked in the scratch.  A second pass builds planes 8..15 only for a wave
+    // that has a codeblock with MSB >= 8.
     U64 sgL = { 0u, 0u }, sgR = { 0u, 0u };
-
-    // ---- findMSB (BPCEngine.cu:176-192)
     uint32_t ormag = 0u;
-    if (valid) {
-        for (int i = 0; i < 64; i++) {
-            int32_t v0, v1;
-            size_t idx = cbase + (size_t)i * (size_t)a.AW;
-            if (a.is_float) {
-                float2 f = *reinterpret_cast<const float2 *>((const float *)a.coeffs_in + idx);
-                v0 = (int32_t)f.x; v1 = (int32_t)f.y;
-            } else {
-                int2 q = *reinterpret_cast<const int2 *>((const int32_t *)a.coeffs_in + idx);
-                v0 = q.x; v1 = q.y;
+    int msb = 32, msbmax = -1;
+    bool coded = false;
+#pragma unroll 1
+    for (int pass = 0; pass < kMaxPlanes / kEncPassPlanes; pass++) {
+        uint32_t T[kEncPassPlanes][4];
+#pragma unroll
+        for (int k = 0; k < kEncPassPlanes; k++) { T[k][0] = T[k][1] = T[k][2] = T[k][3] = 0u; }
+        if (valid) {
+            const uint32_t dn = (uint32_t)(pass * kEncPassPlanes);
+            uint32_t roff = cbyte;
+#pragma unroll
+            for (int hw = 0; hw < 2; hw++) {
+#pragma unroll 8
+                for (int ii = 0; ii < 32; ii++) {
+                    uint32_t m0, m1, n0, n1;
+                    load_row(a, roff, m0, m1, n0, n1);
+                    roff += rstride;
+                    if (pass == 0) {
+                        ormag |= m0 | m1;
+                        if (hw == 0) { sgL.lo |= n0 << ii; sgR.lo |= n1 << ii; }
+                        else         { sgL.hi |= n0 << ii; sgR.hi |= n1 << ii; }
+                    }
+                    m0 >>= dn; m1 >>= dn;
+#pragma unroll
+                    for (int k = 0; k < kEncPassPlanes; k++) {
+                        T[k][hw] |= ((m0 >> k) & 1u) << ii;
+                        T[k][2 + hw] |= ((m1 >> k) & 1u) << ii;
+                    }
+                }
             }
-            ormag |= (uint32_t)(v0 < 0 ? -v0 : v0) | (uint32_t)(v1 < 0 ? -v1 : v1);
         }
+        if (pass == 0) {
+            ormag = half_or_dpp(ormag, upper_mask);
+            msb = ormag ? 31 - __builtin_clz(ormag) : 32;
+            if (valid && msb != 32 && msb > kMaxPlanes - 1) { atomicOr(a.range_flag, 1); msb = kMaxPlanes - 1; }
+            coded = valid && msb != 32;
+            int mm = coded ? msb : -1;
+            { int o = __shfl_xor(mm, 32); mm = mm > o ? mm : o; }
+            msbmax = (int)__builtin_amdgcn_readfirstlane((uint32_t)mm);
+        }
+#pragma unroll
+        for (int k = 0; k < kEncPassPlanes; k++) {
+            const int pk = pass * kEncPassPlanes + k;
+            if (pk <= msbmax) {
+                pscr[(pk * 4 + 0) * 64] = T[k][0]; pscr[(pk * 4 + 1) * 64] = T[k][1];
+                pscr[(pk * 4 + 2) * 64] = T[k][2]; pscr[(pk * 4 + 3) * 64] = T[k][3];
+            }
+        }
+        if (msbmax < (pass + 1) * kEncPassPlanes) break;
     }
-    ormag = half_or(ormag);
-    int msb = ormag ? 31 - __builtin_clz(ormag) : 32;
-    if (valid && msb != 32 && msb > kMaxPlanes - 1) { atomicOr(a.range_flag, 1); msb = kMaxPlanes - 1; }
-    const bool coded = valid && msb != 32;
 
     int level, sb;
     find_subband(cbx * 64 + 2 * (int)t, cby * 64, a.AW, a.AH, a.wl, level, sb);
@@ -694,85 +746,24 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     { int o = __shfl_xor(np, 32); np = np > o ? np : o; }
     np = (int)__builtin_amdgcn_readfirstlane((uint32_t)np);      // wave-uniform: keep it scalar
 
-    // ---- transpose: plane (msb - k) of row i -> bit i of P[k]; only the planes some block needs
-    if (coded) {
-        const uint32_t up = (uint32_t)(kMaxPlanes - 1 - msb);
-#pragma unroll
-        for (int hw = 0; hw < 2; hw++) {
-            for (int ii = 0; ii < 32; ii++) {
-                int32_t v0, v1;
-                size_t idx = cbase + (size_t)(hw * 32 + ii) * (size_t)a.AW;
-                if (a.is_float) {
-                    float2 f = *reinterpret_cast<const float2 *>((const float *)a.coeffs_in + idx);
-                    v0 = (int32_t)f.x; v1 = (int32_t)f.y;
-                } else {
-                    int2 q = *reinterpret_cast<const int2 *>((const int32_t *)a.coeffs_in + idx);
-                    v0 = q.x; v1 = q.y;
-                }
-                uint32_t m0 = ((uint32_t)(v0 < 0 ? -v0 : v0) << up) & 0xFFFFu;
-                uint32_t m1 = ((uint32_t)(v1 < 0 ? -v1 : v1) << up) & 0xFFFFu;
-                uint32_t n0 = v0 < 0, n1 = v1 < 0;
-                if (hw == 0) { sgL.lo |= n0 << ii; sgR.lo |= n1 << ii; }
-                else         { sgL.hi |= n0 << ii; sgR.hi |= n1 << ii; }
-#pragma unroll
-                for (int k = 0; k < kEncRegPlanes; k++) {
-                    if (k < np) {
-                        uint32_t b0 = (m0 >> (kMaxPlanes - 1 - k)) & 1u;
-                        uint32_t b1 = (m1 >> (kMaxPlanes - 1 - k)) & 1u;
-                        if (hw == 0) { PLlo[k] |= b0 << ii; PRlo[k] |= b1 << ii; }
-                        else         { PLhi[k] |= b0 << ii; PRhi[k] |= b1 << ii; }
-                    }
-                }
-            }
+    // the plane a lane codes at step p is plane msb - p of ITS codeblock
+    auto load_plane = [&](int p, U64 &bL, U64 &bR) {
+        const int bp = msb - p;
+        bL = U64{ 0u, 0u }; bR = U64{ 0u, 0u };
+        if (coded && bp >= 0) {
+            const uint32_t *q = pscr + (size_t)bp * kEncPlaneDwords;
+            bL.lo = q[0]; bL.hi = q[64]; bR.lo = q[128]; bR.hi = q[192];
         }
-    }
-    // planes below the 8 held in registers (a codeblock with MSB >= 8 in the wave): one more pass over
-    // the rows builds them in registers that are free until the plane loop, then parks them in HBM;
-    // slot j = plane kEncRegPlanes + j, layout [slot][4][lane] so that every access is a 256-byte row
-    uint32_t *const pscr = a.plane_scratch + (size_t)wave * (size_t)kEncScratchDwordsPerWave + lane;
-    if (np > kEncRegPlanes) {
-        uint32_t Tl[kMaxPlanes - kEncRegPlanes][2], Tr[kMaxPlanes - kEncRegPlanes][2];
-#pragma unroll
-        for (int j = 0; j < kMaxPlanes - kEncRegPlanes; j++) { Tl[j][0] = Tl[j][1] = Tr[j][0] = Tr[j][1] = 0u; }
-        if (coded) {
-            const uint32_t up = (uint32_t)(kMaxPlanes - 1 - msb);
-#pragma unroll
-            for (int hw = 0; hw < 2; hw++) {
-                for (int ii = 0; ii < 32; ii++) {
-                    int32_t v0, v1;
-                    size_t idx = cbase + (size_t)(hw * 32 + ii) * (size_t)a.AW;
-                    if (a.is_float) {
-                        float2 f = *reinterpret_cast<const float2 *>((const float *)a.coeffs_in + idx);
-                        v0 = (int32_t)f.x; v1 = (int32_t)f.y;
-                    } else {
-                        int2 q = *reinterpret_cast<const int2 *>((const int32_t *)a.coeffs_in + idx);
-                        v0 = q.x; v1 = q.y;
-                    }
-                    const uint32_t m0 = ((uint32_t)(v0 < 0 ? -v0 : v0) << up) & 0xFFFFu;
-                    const uint32_t m1 = ((uint32_t)(v1 < 0 ? -v1 : v1) << up) & 0xFFFFu;
-#pragma unroll
-                    for (int j = 0; j < kMaxPlanes - kEncRegPlanes; j++) {
-                        if (kEncRegPlanes + j < np) {
-                            Tl[j][hw] |= ((m0 >> (kMaxPlanes - 1 - kEncRegPlanes - j)) & 1u) << ii;
-                            Tr[j][hw] |= ((m1 >> (kMaxPlanes - 1 - kEncRegPlanes - j)) & 1u) << ii;
-                        }
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < kMaxPlanes - kEncRegPlanes; j++) {
-            if (kEncRegPlanes + j < np) {
-                pscr[(j * 4 + 0) * 64] = Tl[j][0]; pscr[(j * 4 + 1) * 64] = Tl[j][1];
-                pscr[(j * 4 + 2) * 64] = Tr[j][0]; pscr[(j * 4 + 3) * 64] = Tr[j][1];
-            }
-        }
-    }
+    };
 
-    Coder c = { 0u, 0u, 0u, 0u, 0u, 0u, ~0ull };
-    const uint32_t upper_mask = opaque_mask(half ? 0xFFFFFFFFu : 0u);
+    EncCoder c;
+    c.L = 0u; c.S = 0u; c.off = half * 16384u;                // a first reservation "stores" L = 0 to word 0 (see enc_reserve)
+    c.cnt_lo = 0u; c.cnt_hi = 0u; c.emptym = ~0ull;
+    c.halfoff4 = half * 16384u + 4u; c.pone = 1u << prec;
+    c.stw = reinterpret_cast<char *>(stw);
     U64 AL = { 0u, 0u }, AR = { 0u, 0u };                 // significant before the current plane
-    const U64 sgPL = u_prev(sgR, t), sgNL = u_next(sgL, t);     // neighbour sign columns
+    U64 BLn, BRn;
+    load_plane(0, BLn, BRn);
 
     for (int p = 0; p < np; p++) {
         const int bp = msb - p;
@@ -781,61 +772,56 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
         PlaneLut pl = { 0u, 0u, 0u, 0u, 0u };
         if (act) pl = plane_lut(lv, a.g, grp, bp);
 
-        const U64 BL = { PLlo[0], PLhi[0] }, BR = { PRlo[0], PRhi[0] };
-        const U64 NL = u_andn(BL, AL), NR = u_andn(BR, AR);          // become significant in this plane
-        const U64 AL2 = u_or(AL, NL), AR2 = u_or(AR, NR);            // state after this plane's SPP
-        const U64 APL = u_prev(AR, t), APL2 = u_prev(AR2, t);        // lane-1's right column
-        const U64 ANL = u_next(AL, t), ANL2 = u_next(AL2, t);        // lane+1's left column
+        const U64 BL = BLn, BR = BRn;
+        const U64 AL2 = u_or(AL, BL), AR2 = u_or(AR, BR);            // state after this plane's SPP
+        {
+            const U64 sgPL = u_prev(sgR, t), sgNL = u_next(sgL, t);  // neighbour sign columns
+            const U64 APL = u_prev(AR, t), APL2 = u_prev(AR2, t);    // lane-1's right column
+            const U64 ANL = u_next(AL, t), ANL2 = u_next(AL2, t);    // lane+1's left column
 
-        // ---- significance propagation pass, 32 rows at a time; only rows where some lane of the
-        // wave still has an insignificant coefficient
+            // ---- significance propagation pass, 32 rows at a time; only rows where some lane of the
+            // wave still has an insignificant coefficient
 #pragma unroll
-        for (int hw = 0; hw < 2; hw++) {
-            const ColHalf cpL = make_col(up_of(APL2, hw), up_of(AL2, hw), up_of(AR2, hw), w_of(APL, hw), w_of(AR, hw),
-                                         dn_of(APL, hw), dn_of(AL, hw), dn_of(AR, hw),
-                                         up_of(AL2, hw), up_of(sgL, hw), dn_of(AL, hw), dn_of(sgL, hw),
-                                         w_of(APL, hw), w_of(sgPL, hw), w_of(AR, hw), w_of(sgR, hw), w_of(sgL, hw));
-            const ColHalf cpR = make_col(up_of(AL2, hw), up_of(AR2, hw), up_of(ANL2, hw), w_of(AL2, hw), w_of(ANL2, hw),
-                                         dn_of(AL, hw), dn_of(AR, hw), dn_of(ANL, hw),
-                                         up_of(AR2, hw), up_of(sgR, hw), dn_of(AR, hw), dn_of(sgR, hw),
-                                         w_of(AL2, hw), w_of(sgL, hw), w_of(ANL2, hw), w_of(sgNL, hw), w_of(sgR, hw));
-            const uint32_t al = act ? w_of(AL, hw) : 0xFFFFFFFFu, ar = act ? w_of(AR, hw) : 0xFFFFFFFFu;
-            const uint32_t bl = w_of(BL, hw), br = w_of(BR, hw);
-            uint32_t rows = wave_or32(~(al & ar));
-            while (rows) {
-                const uint32_t ii = (uint32_t)__builtin_ctz(rows);
-                rows &= rows - 1u;
-                enc_spp_coeff(c, ii, al, bl, cpL, pl, prec, upper_mask, cw);
-                enc_spp_coeff(c, ii, ar, br, cpR, pl, prec, upper_mask, cw);
+            for (int hw = 0; hw < 2; hw++) {
+                const ColHalf cpL = make_col(up_of(APL2, hw), up_of(AL2, hw), up_of(AR2, hw), w_of(APL, hw), w_of(AR, hw),
+                                             dn_of(APL, hw), dn_of(AL, hw), dn_of(AR, hw),
+                                             up_of(AL2, hw), up_of(sgL, hw), dn_of(AL, hw), dn_of(sgL, hw),
+                                             w_of(APL, hw), w_of(sgPL, hw), w_of(AR, hw), w_of(sgR, hw), w_of(sgL, hw));
+                const ColHalf cpR = make_col(up_of(AL2, hw), up_of(AR2, hw), up_of(ANL2, hw), w_of(AL2, hw), w_of(ANL2, hw),
+                                             dn_of(AL, hw), dn_of(AR, hw), dn_of(ANL, hw),
+                                             up_of(AR2, hw), up_of(sgR, hw), dn_of(AR, hw), dn_of(sgR, hw),
+                                             w_of(AL2, hw), w_of(sgL, hw), w_of(ANL2, hw), w_of(sgNL, hw), w_of(sgR, hw));
+                const uint32_t al = act ? w_of(AL, hw) : 0xFFFFFFFFu, ar = act ? w_of(AR, hw) : 0xFFFFFFFFu;
+                const uint32_t nl = w_of(BL, hw) & ~al, nr = w_of(BR, hw) & ~ar;      // become significant in this plane
+                uint32_t rows = wave_or32(~(al & ar));
+                while (rows) {
+                    const uint32_t ii = (uint32_t)__builtin_ctz(rows);
+                    const uint32_t rowbit = 1u << ii;
+                    rows &= rows - 1u;
+                    enc_spp_coeff(c, ii, rowbit, al, nl, cpL, pl, prec, upper_mask);
+                    enc_spp_coeff(c, ii, rowbit, ar, nr, cpR, pl, prec, upper_mask);
+                }
             }
         }
+        // the next plane is on its way from the scratch while the refinement pass runs
+        if (p + 1 < np) load_plane(p + 1, BLn, BRn);
         // ---- magnitude refinement pass: coefficients significant before this plane
 #pragma unroll
         for (int hw = 0; hw < 2; hw++) {
-            const uint32_t ml = act ? (hw ? AL.hi : AL.lo) : 0u, mr = act ? (hw ? AR.hi : AR.lo) : 0u;
-            const uint32_t bl = hw ? BL.hi : BL.lo, br = hw ? BR.hi : BR.lo;
+            const uint32_t ml = act ? w_of(AL, hw) : 0u, mr = act ? w_of(AR, hw) : 0u;
+            const uint32_t bl = w_of(BL, hw) & ml, br = w_of(BR, hw) & mr;
             uint32_t rows = wave_or32(ml | mr);
             while (rows) {
                 const uint32_t ii = (uint32_t)__builtin_ctz(rows);
+                const uint32_t rowbit = 1u << ii;
                 rows &= rows - 1u;
-                const bool oL = ((ml >> ii) & 1u) != 0u, oR = ((mr >> ii) & 1u) != 0u;
-                const uint64_t mL = __builtin_amdgcn_ballot_w64(oL), mR = __builtin_amdgcn_ballot_w64(oR);
-                if (mL != 0ull) enc_site_on(c, oL, mL, (bl >> ii) & 1u, pl.ref, prec, upper_mask, cw);
-                if (mR != 0ull) enc_site_on(c, oR, mR, (br >> ii) & 1u, pl.ref, prec, upper_mask, cw);
+                const uint64_t mL = __builtin_amdgcn_ballot_w64((ml & rowbit) != 0u);
+                if (mL != 0ull) enc_site2(c, mL, __builtin_amdgcn_ballot_w64((bl & rowbit) != 0u), pl.ref, prec, upper_mask);
+                const uint64_t mR = __builtin_amdgcn_ballot_w64((mr & rowbit) != 0u);
+                if (mR != 0ull) enc_site2(c, mR, __builtin_amdgcn_ballot_w64((br & rowbit) != 0u), pl.ref, prec, upper_mask);
             }
         }
         AL = AL2; AR = AR2;
-#pragma unroll
-        for (int k = 0; k < kEncRegPlanes - 1; k++) {
-            PLlo[k] = PLlo[k + 1]; PLhi[k] = PLhi[k + 1];
-            PRlo[k] = PRlo[k + 1]; PRhi[k] = PRhi[k + 1];
-        }
-        // the plane that moves into the last register: slot p of the scratch (plane p + kEncRegPlanes)
-        PLlo[kEncRegPlanes - 1] = PLhi[kEncRegPlanes - 1] = PRlo[kEncRegPlanes - 1] = PRhi[kEncRegPlanes - 1] = 0u;
-        if (p + kEncRegPlanes < np) {
-            PLlo[kEncRegPlanes - 1] = pscr[(p * 4 + 0) * 64]; PLhi[kEncRegPlanes - 1] = pscr[(p * 4 + 1) * 64];
-            PRlo[kEncRegPlanes - 1] = pscr[(p * 4 + 2) * 64]; PRhi[kEncRegPlanes - 1] = pscr[(p * 4 + 3) * 64];
-        }
     }
 
     // ---- bulk scan of the planes below cbp (encodeBulkMode :1640-1648): the rows are read again
@@ -849,17 +835,10 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
             const uint32_t magmask = coded ? ((2u << msb) - 1u) : 0u;
             const uint32_t sbsh = (uint32_t)(bl.Bh + 2);            // word >> (Bh+2) = magnitude >> (Bh+1)
             auto row_words = [&](int i, uint32_t &w0, uint32_t &w1) {
-                int32_t v0, v1;
-                size_t idx = cbase + (size_t)i * (size_t)a.AW;
-                if (a.is_float) {
-                    float2 f = *reinterpret_cast<const float2 *>((const float *)a.coeffs_in + idx);
-                    v0 = (int32_t)f.x; v1 = (int32_t)f.y;
-                } else {
-                    int2 q = *reinterpret_cast<const int2 *>((const int32_t *)a.coeffs_in + idx);
-                    v0 = q.x; v1 = q.y;
-                }
-                w0 = ((((uint32_t)(v0 < 0 ? -v0 : v0)) & magmask) << 1) | (uint32_t)(v0 < 0);
-                w1 = ((((uint32_t)(v1 < 0 ? -v1 : v1)) & magmask) << 1) | (uint32_t)(v1 < 0);
+                uint32_t m0, m1, n0, n1;
+                load_row(a, cbyte + (uint32_t)i * rstride, m0, m1, n0, n1);
+                w0 = ((m0 & magmask) << 1) | n0;
+                w1 = ((m1 & magmask) << 1) | n1;
             };
             // unprocessed word: sign | significant-before-the-scan << 1
             auto unp = [&](uint32_t w) -> uint32_t { return (w & 1u) | ((w >> sbsh) != 0u ? 2u : 0u); };
@@ -869,34 +848,28 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
                 if (i < 63) row_words(i + 1, n0, n1); else { n0 = 0u; n1 = 0u; }
                 bulk_row<false>(c, t, unp(c0), unp(c1), (c0 >> 1) & lowmask, (c1 >> 1) & lowmask,
                                 i < 63 ? unp(n0) : 0u, i < 63 ? unp(n1) : 0u, pUL, pUR, bl, Bmax, prec,
-                                upper_mask, cw);
+                                upper_mask, (int32_t *)nullptr);
                 c0 = n0; c1 = n1;
             }
         }
     }
 
     // flush (Encode BPCEngine.cu:1719) + sizeArray (:2010) + MSB slot (:1998)
-    if (coded) st[1u + c.slot] = (int32_t)c.L;
+    if (coded) *reinterpret_cast<int32_t *>(c.stw + c.off) = (int32_t)c.L;
     const uint32_t size = (half ? c.cnt_hi : c.cnt_lo) + 1u;
-    if (valid && t == 0u) { a.sizes[cb] = (int32_t)size; st[0] = msb; }
-    // expansionFix :1905-1912 overwrites the whole block and must land after every codeword store
-    // of the block (they come from other lanes of this wave)
+    if (valid && t == 0u) a.sizes[cb] = (int32_t)size;
+    // word 0 (the MSB) and expansionFix :1905-1912 (which overwrites the whole block) must land after every
+    // codeword store of the block, the lanes' first-reservation stores to word 0 included
     wave_stores_issued();
     if (valid && size == 4096u) {
         for (int i = 0; i < 64; i++) {
-            int32_t v0, v1;
-            size_t idx = cbase + (size_t)i * (size_t)a.AW;
-            if (a.is_float) {
-                float2 f = *reinterpret_cast<const float2 *>((const float *)a.coeffs_in + idx);
-                v0 = (int32_t)f.x; v1 = (int32_t)f.y;
-            } else {
-                int2 q = *reinterpret_cast<const int2 *>((const int32_t *)a.coeffs_in + idx);
-                v0 = q.x; v1 = q.y;
-            }
-            uint32_t w0 = (((uint32_t)(v0 < 0 ? -v0 : v0) << 1) + (uint32_t)(v0 < 0)) & 0xFFFFu;
-            uint32_t w1 = (((uint32_t)(v1 < 0 ? -v1 : v1) << 1) + (uint32_t)(v1 < 0)) & 0xFFFFu;
+            uint32_t m0, m1, n0, n1;
+            load_row(a, cbyte + (uint32_t)i * rstride, m0, m1, n0, n1);
+            const uint32_t w0 = ((m0 << 1) + n0) & 0xFFFFu, w1 = ((m1 << 1) + n1) & 0xFFFFu;
             *reinterpret_cast<int2 *>(st + t * 128u + 2u * (uint32_t)i) = make_int2((int)w0, (int)w1);
         }
+    } else if (valid && t == 0u) {
+        st[0] = msb;
     }
 }
 

@@ -26,6 +26,10 @@ enum Kind {
     CMP_BRANCH_T,        // the same, taken (forward over 2 instructions)
     SALU_DEP,            // s_add chain
     SITE_LIKE,           // one call site of the coder, as compiled today (instruction classes and order)
+    CNDMASK_E64_DEP,     // v_cndmask_b32_e64 with an SGPR-pair mask, dependent
+    CNDMASK_VCC_INDEP,   // v_cndmask_b32 (vcc) x8 independent
+    ADD_INDEP, LSHL_OR_INDEP, AND_OR_INDEP, XAD_DEP, ADD3_DEP, CMP_INDEP,
+    SITE_V2,             // the round-2 call site: one reservation round trip, update in every lane
     NKINDS
 };
 static const char *kKindName[NKINDS] = {
@@ -35,10 +39,13 @@ static const char *kKindName[NKINDS] = {
     "v_cndmask_b32 dependent", "v_bfe_u32 x8 independent",
     "v_cmp -> s_and_b64 -> v_cndmask (3 inst round trip)", "v_cmp -> s_and_saveexec -> v_add -> s_or exec (4 inst)",
     "v_cmp -> s_and -> s_cmp -> s_cbranch not taken -> v_add (5 inst)", "v_cmp -> s_and -> s_cmp -> s_cbranch taken -> v_add (5 inst)",
-    "s_add_u32 dependent", "coder call site mix (24 inst: 15 VALU, 9 SALU)" };
+    "s_add_u32 dependent", "coder call site mix (24 inst: 15 VALU, 9 SALU)",
+    "v_cndmask_b32_e64 sgpr mask dependent", "v_cndmask_b32 vcc x8 independent", "v_add_u32 x8 independent",
+    "v_lshl_or_b32 x8 independent", "v_and_or_b32 x8 independent", "v_xad_u32 dependent", "v_add3_u32 dependent",
+    "v_cmp_ne_u32 -> sgpr pair x4 independent", "round-2 call site (21 inst: 17 VALU, 4 SALU)" };
 // instructions per unrolled block (what "per instruction" divides by)
-static const int kBlockInsts[NKINDS] = { 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 64, 32, 32, 24, 32, 40, 40, 32, 24 };
-static const int kBlockValu[NKINDS] = { 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 16, 16, 16, 16, 0, 15 };
+static const int kBlockInsts[NKINDS] = { 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 64, 32, 32, 24, 32, 40, 40, 32, 24, 32, 32, 32, 32, 32, 32, 32, 32, 21 };
+static const int kBlockValu[NKINDS] = { 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 16, 16, 16, 16, 0, 15, 32, 32, 32, 32, 32, 32, 32, 32, 17 };
 
 #define R4(x) x x x x
 #define R8(x) R4(x) R4(x)
@@ -50,9 +57,10 @@ __global__ __launch_bounds__(256) void probe_kernel(uint32_t *out, uint64_t *cyc
 {
     uint32_t a0 = threadIdx.x * 2654435761u + seed, a1 = a0 ^ 0x9E3779B9u, a2 = a0 + 77u, a3 = a1 + 5u;
     uint32_t a4 = a0 * 3u, a5 = a1 * 5u, a6 = a2 * 7u, a7 = a3 * 11u, k = seed | 0x01010101u;
-    uint64_t sm = 0;            // scalar mask scratch
+    uint64_t sm = 0, sm2 = 0x5555aaaa3333ccccull, sm3 = ~0ull, sm4 = 0;            // scalar mask scratch
     uint32_t sc = seed;
     __builtin_amdgcn_s_barrier();
+    const uint64_t r0 = __builtin_amdgcn_s_memrealtime();
     const uint64_t t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; it++) {
         if constexpr (KIND == AND_INDEP) {
@@ -120,11 +128,51 @@ __global__ __launch_bounds__(256) void probe_kernel(uint32_t *out, uint64_t *cyc
                 "v_add_u32 %2, %2, %4\n v_sub_u32 %1, %0, %2\n v_cndmask_b32 %0, %1, %2, vcc\n v_mad_u32_u24 %1, %2, %4, %1\n"
                 "s_or_b64 exec, exec, %3\n v_cmp_ne_u32_e64 %3, 0, %0\n s_and_b64 %3, %3, vcc\n s_and_saveexec_b64 %3, %3\n v_add_u32 %1, %1, %4\n s_or_b64 exec, exec, %3\n"
                 : "+v"(a0), "+v"(a1), "+v"(a2), "+s"(sm) : "v"(k) : "vcc", "scc");
+        } else if constexpr (KIND == CNDMASK_E64_DEP) {
+            asm volatile(R32("v_cndmask_b32_e64 %0, %0, %1, %2\n") : "+v"(a0) : "v"(k), "s"(sm2));
+        } else if constexpr (KIND == CNDMASK_VCC_INDEP) {
+            asm volatile(R4("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                            "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k) : "vcc");
+        } else if constexpr (KIND == ADD_INDEP) {
+            asm volatile(R4("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n"
+                            "v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));
+        } else if constexpr (KIND == LSHL_OR_INDEP) {
+            asm volatile(R4("v_lshl_or_b32 %0, %0, 3, %8\n v_lshl_or_b32 %1, %1, 3, %8\n v_lshl_or_b32 %2, %2, 3, %8\n v_lshl_or_b32 %3, %3, 3, %8\n"
+                            "v_lshl_or_b32 %4, %4, 3, %8\n v_lshl_or_b32 %5, %5, 3, %8\n v_lshl_or_b32 %6, %6, 3, %8\n v_lshl_or_b32 %7, %7, 3, %8\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));
+        } else if constexpr (KIND == AND_OR_INDEP) {
+            asm volatile(R4("v_and_or_b32 %0, %0, %8, %8\n v_and_or_b32 %1, %1, %8, %8\n v_and_or_b32 %2, %2, %8, %8\n v_and_or_b32 %3, %3, %8, %8\n"
+                            "v_and_or_b32 %4, %4, %8, %8\n v_and_or_b32 %5, %5, %8, %8\n v_and_or_b32 %6, %6, %8, %8\n v_and_or_b32 %7, %7, %8, %8\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));
+        } else if constexpr (KIND == XAD_DEP) {
+            asm volatile(R32("v_xad_u32 %0, %0, %1, %1\n") : "+v"(a0) : "v"(k));
+        } else if constexpr (KIND == ADD3_DEP) {
+            asm volatile(R32("v_add3_u32 %0, %0, %1, 1\n") : "+v"(a0) : "v"(k));
+        } else if constexpr (KIND == CMP_INDEP) {
+            asm volatile(R8("v_cmp_ne_u32_e64 %4, %0, %8\n v_cmp_ne_u32_e64 %5, %1, %8\n v_cmp_ne_u32_e64 %6, %2, %8\n v_cmp_ne_u32_e64 %7, %3, %8\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(sm), "+s"(sm2), "+s"(sm3), "+s"(sm4) : "v"(k));
+        } else if constexpr (KIND == SITE_V2) {
+            // two row-bit ballots, need mask + branch, (reservation skipped), probability select for idle lanes,
+            // interval update in every lane, exhausted compare: the round-2 call site
+            asm volatile(
+                "v_and_b32 %2, %5, %0\n v_cmp_eq_u32_e64 %3, 0, %2\n v_and_b32 %2, %5, %1\n v_cmp_ne_u32_e64 %4, 0, %2\n"
+                "s_and_b64 vcc, %6, %3\n s_cmp_eq_u64 vcc, 0\n s_cbranch_scc1 1\n s_nop 0\n"
+                "v_alignbit_b32 %2, %0, %0, 5\n v_and_b32 %2, 1, %2\n v_alignbit_b32 %1, %1, %1, 7\n v_and_or_b32 %2, %1, 2, %2\n v_perm_b32 %2, %0, %1, %2\n"
+                "v_cndmask_b32_e64 %2, %5, %2, %3\n v_mul_u32_u24 %2, %0, %2\n v_lshrrev_b32 %2, 7, %2\n v_xad_u32 %1, %2, -1, %0\n"
+                "v_cndmask_b32_e64 %0, %2, %1, %4\n v_add3_u32 %2, %1, %2, 1\n v_cndmask_b32_e64 %1, %1, %2, %4\n v_cmp_eq_u32_e64 %6, 0, %0\n"
+                : "+v"(a0), "+v"(a1), "+v"(a2), "+s"(sm), "+s"(sm2), "+v"(a3), "+s"(sm3) : : "vcc", "scc");
         }
     }
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    const uint64_t r1 = __builtin_amdgcn_s_memrealtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ (uint32_t)sm ^ sc;
-    if ((threadIdx.x & 63u) == 0u) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+    out[blockIdx.x * blockDim.x + threadIdx.x] ^= (uint32_t)sm2 ^ (uint32_t)sm3 ^ (uint32_t)sm4;
+    if ((threadIdx.x & 63u) == 0u) {
+        uint64_t *c = cyc + 3 * (size_t)(blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64);
+        c[0] = t1 - t0; c[1] = r0; c[2] = r1;
+    }
 }
 
 __global__ void clock_kernel(uint64_t *out)
@@ -139,14 +187,14 @@ __global__ void clock_kernel(uint64_t *out)
 template <int KIND>
 static void run_kind(int ncu, double mhz, uint32_t *d_out, uint64_t *d_cyc, std::string &json)
 {
-    const int iters = 4000;
+    const int iters = 40000;
     char buf[512];
     printf("%-66s", kKindName[KIND]);
     fflush(stdout);
     json += std::string("  {\"pattern\": \"") + kKindName[KIND] + "\", \"rows\": [";
     for (int w = 1; w <= 8; w++) {
         const int blocks = ncu * w;                    // 256-thread workgroups: one wave per SIMD each
-        std::vector<uint64_t> h((size_t)blocks * 4);
+        std::vector<uint64_t> h((size_t)blocks * 4 * 3);
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         probe_kernel<KIND><<<blocks, 256>>>(d_out, d_cyc, 100, 12345u);        // warm-up
@@ -157,15 +205,26 @@ static void run_kind(int ncu, double mhz, uint32_t *d_out, uint64_t *d_cyc, std:
         float ms = 0.f;
         CK(hipEventElapsedTime(&ms, e0, e1));
         CK(hipMemcpy(h.data(), d_cyc, h.size() * 8, hipMemcpyDeviceToHost));
-        double mean = 0;
-        for (uint64_t v : h) mean += (double)v;
-        mean /= (double)h.size();
+        double mean = 0, rsum = 0;
+        uint64_t rmin = ~0ull, rmax = 0;
+        const size_t nw = (size_t)blocks * 4;
+        for (size_t i = 0; i < nw; i++) {
+            mean += (double)h[3 * i];
+            rsum += (double)(h[3 * i + 2] - h[3 * i + 1]);
+            if (h[3 * i + 1] < rmin) rmin = h[3 * i + 1];
+            if (h[3 * i + 2] > rmax) rmax = h[3 * i + 2];
+        }
+        const double load_mhz = mean / rsum * 100.0;                 // shader cycles per 100 MHz tick inside the loops
+        const double resident = rsum / (double)(rmax - rmin) / (ncu * 4.0);      // mean waves per SIMD over the launch's span
+        mean /= (double)nw;
         const double per_wave = mean / ((double)iters * kBlockInsts[KIND]);
-        const double chip = (double)blocks * 4.0 * iters * kBlockInsts[KIND] / (ms * 1e-3 * mhz * 1e6) / (ncu * 4.0);
-        printf(" %5.2f/%4.2f", per_wave, chip);
+        // instructions per shader cycle per SIMD over the span in which waves ran (device timestamps, clock as measured under load)
+        const double chip = (double)nw * iters * kBlockInsts[KIND] / ((double)(rmax - rmin) / 100.0 * load_mhz) / (ncu * 4.0);
+        (void)ms;
+        printf(" %5.2f/%4.3f/%3.1f/%4.0f", per_wave, chip, resident, load_mhz);
         fflush(stdout);
-        snprintf(buf, sizeof buf, "%s{\"waves_per_simd\": %d, \"cycles_per_inst_one_wave\": %.3f, \"insts_per_cycle_per_simd\": %.4f, \"valu_per_cycle_per_simd\": %.4f}",
-                 w == 1 ? "" : ", ", w, per_wave, chip, chip * kBlockValu[KIND] / kBlockInsts[KIND]);
+        snprintf(buf, sizeof buf, "%s{\"waves_per_simd\": %d, \"cycles_per_inst_one_wave\": %.3f, \"insts_per_cycle_per_simd\": %.4f, \"valu_per_cycle_per_simd\": %.4f, \"resident_waves_per_simd\": %.2f, \"shader_mhz_under_load\": %.0f}",
+                 w == 1 ? "" : ", ", w, per_wave, chip, chip * kBlockValu[KIND] / kBlockInsts[KIND], resident, load_mhz);
         json += buf;
         CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
     }
@@ -190,7 +249,7 @@ int main(int argc, char **argv)
     const int ncu = prop.multiProcessorCount;
     uint32_t *d_out; uint64_t *d_cyc, *d_clk;
     CK(hipMalloc(&d_out, (size_t)ncu * 8 * 256 * 4));
-    CK(hipMalloc(&d_cyc, (size_t)ncu * 8 * 4 * 8));
+    CK(hipMalloc(&d_cyc, (size_t)ncu * 8 * 4 * 8 * 3));
     CK(hipMalloc(&d_clk, 16));
     uint64_t clk[2];
     clock_kernel<<<1, 64>>>(d_clk);
@@ -200,7 +259,8 @@ int main(int argc, char **argv)
     const double mhz = (double)clk[0] / (double)clk[1] * 100.0;
     printf("%s: %d CUs, s_memtime runs at %.0f MHz (vs the 100 MHz s_memrealtime), clockRate %d kHz\n", prop.name, ncu, mhz,
            prop.clockRate);
-    printf("columns: waves per SIMD 1..8; each cell = cycles per instruction as one wave sees them / instructions per cycle per SIMD (chip-wide)\n");
+    printf("columns: launched waves per SIMD 1..8; cell = cycles per instruction as one wave sees them / instructions per cycle per SIMD "
+           "(chip-wide, device timestamps) / mean resident waves per SIMD / shader MHz inside the loops\n");
     std::string json = "{\"device\": \"" + std::string(prop.name) + "\", \"cus\": " + std::to_string(ncu) +
                        ", \"shader_mhz\": " + std::to_string(mhz) + ", \"patterns\": [\n";
     run_all<0>(ncu, mhz, d_out, d_cyc, json);
