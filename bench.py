@@ -5,10 +5,13 @@ Metric (BASELINE.json): Mpixels/s, encode (level shift + DWT + BPC + pack), 8K g
 -type 0 (5/3 lossless), device-resident u8 frame in -> device-resident uint16 codestream out;
 decode must round-trip bit-exactly (checked outside the timed region, reported as roundtrip_ok).
 
-A "step" = one 7680x4320 frame per rank through picsong_encode_frame.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) frames are sharded one per rank per step ("weak"), and
-the step ends with the path's only exchange: codestream lengths all-gathered and payloads gathered
-to rank 0 over RCCL; value = pixels all ranks encoded / max-over-ranks time.
+A "step" = one batch of --frames-per-step 7680x4320 frames per rank (default 48: a second of a 48 fps
+video), taken from a pool of --pool distinct device-resident frames (default 16 = 535 MB at 8K, past the
+256 MiB Infinity Cache, so that every frame's input comes from HBM) and coded --batch frames per call of
+picsong_encode_frames, the calls alternating over --streams HIP streams.  With N > 1 (launched by
+torch.distributed.run, one rank per GPU) every rank codes its own frames ("weak"), and each call ends
+with the path's only exchange: codestream lengths all-gathered and payloads gathered to rank 0 over RCCL
+(SURVEY.md 8e); value = pixels all ranks encoded / max-over-ranks time.
 
 Prints ONE JSON line on rank 0.
 """
@@ -106,13 +109,16 @@ def valu_issue(insts, step_s, iso_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # 200 frames = 62 ms of timed region: the pipeline's fill and drain (one frame's latency, 0.5 ms)
-    # weigh 4 % on 40 steps (102-103 Gpixel/s), under 1 % on 200 (106-107; 1000 steps: 108)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=3)
+    # a step = --frames-per-step frames; the default timed region is > 1 s (80 x 48 8K frames at ~0.3 ms)
+    ap.add_argument("--steps", type=int, default=80)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames-per-step", type=int, default=48)
+    ap.add_argument("--batch", type=int, default=0,
+                    help="frames per picsong_encode_frames call (0 = the workload's default)")
+    ap.add_argument("--pool", type=int, default=16, help="distinct device-resident input frames the steps rotate over")
     ap.add_argument("--workload", default="8k_lossless", choices=sorted(WORKLOADS))
-    ap.add_argument("--streams", type=int, default=3,
-                    help="HIP streams (each with its own context) the frames of consecutive steps alternate on")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="HIP streams (each with its own context) consecutive calls alternate on (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=0,
                     help="rows of the frame the CPU baseline encodes (0 = whole frame)")
@@ -145,8 +151,13 @@ def main():
 
     W, H, wl, lossy, qs = WORKLOADS[args.workload]
     lut_dir = os.path.join(orc.LUT_DIR, "n1_lossy" if lossy else "n1_lossless")
-    nstreams = max(1, args.streams)
-    # several frames in flight: the contexts are told so (picsong_ctx_set_pipelined: the frame path then
+    # defaults by workload (measured, tools/ab.sh): an 8K frame is 4080 coder waves, a 4K frame 1020 -- one
+    # per SIMD -- so 4K frames go four to a call
+    batch = args.batch if args.batch > 0 else (4 if W * H <= 3840 * 2160 else 1)
+    nstreams = args.streams if args.streams > 0 else 3
+    fps = max(batch, (args.frames_per_step // batch) * batch)          # frames per step: whole calls
+    pool_n = max(batch, (max(args.pool, 1) + batch - 1) // batch * batch)
+    # several calls in flight: the contexts are told so (picsong_ctx_set_pipelined: the single-frame path then
     # favours the fewest vector instructions over the shortest DWT -- two launches for levels 0 and 1)
     codecs = [pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=lut_dir, device=local_rank,
                        pipelined=nstreams > 1) for _ in range(nstreams)]
@@ -154,36 +165,56 @@ def main():
     codec = codecs[0]
     AW, AH, nCB, P = codec.aw, codec.ah, codec.ncb, codec.P
 
-    # synthetic frames (SURVEY 8d generator), one distinct frame per rank, resident in HBM
-    frame_np = orc.pad_frame(orc.gen_frame(W, H, rank))
-    frame = torch.from_numpy(frame_np).cuda()
-    outs = [torch.empty(codec.max_stream_shorts(), dtype=torch.int16, device="cuda") for _ in range(nstreams)]
-    out = outs[0]
+    # synthetic frames (SURVEY 8d generator), pool_n distinct frames per rank, resident in HBM
+    orc.set_threads(orc.usable_threads())
+    pool_np = np.stack([orc.pad_frame(orc.gen_frame(W, H, rank * pool_n + i)).reshape(-1) for i in range(pool_n)])
+    orc.set_threads(1)
+    pool = torch.from_numpy(pool_np).cuda()                               # [pool_n, P] u8
+    frame_np = pool_np[0].reshape(AH, AW)
+    frame = pool[0]
+    outs = [torch.empty((batch, codec.max_stream_shorts()), dtype=torch.int16, device="cuda") for _ in range(nstreams)]
+    out = outs[0][0]
     gather_bufs = None
     if world > 1 and rank == 0:
-        gather_bufs = [torch.empty(codec.max_stream_shorts(), dtype=torch.int16, device="cuda")
+        gather_bufs = [torch.empty(batch * codec.max_stream_shorts(), dtype=torch.int16, device="cuda")
                        for _ in range(world - 1)]
     dev = torch.device("cuda", local_rank)
 
     dx = pdist.DeferredExchange() if world > 1 else None
+    calls_per_step = fps // batch
+    ncall = [0]
+    last_call = {}
 
-    def step(it):
-        # consecutive frames alternate over the streams: frame i's BPC tail overlaps frame i+1's
-        # DWT/BPC head (each stream has its own context = its own workspace)
-        k = it % nstreams
-        with torch.cuda.stream(streams[k]):
-            codecs[k].encode_frame_async(frame, outs[k], 0 if it == 0 else 1)
-        if world > 1:
-            # the only exchange of the frame-sharded path (picsong_dist.gather_round, covered by
-            # the gloo tests): lengths all-gathered, then payload gatherv to rank 0 over RCCL.  It
-            # needs the length on the host, so it is run one step late (DeferredExchange): the host
-            # waits for frame i only after frame i+1 is queued, and the payload crosses xGMI while
-            # frame i+1 is being coded.  Every step's exchange is inside the timed region (flush).
-            def exchange(k=k):
-                with torch.cuda.stream(streams[k]):
-                    total = codecs[k].last_total()
-                    return pdist.gather_round(outs[k][:total], rank, world, dev, recv_bufs=gather_bufs)
-            dx.submit(exchange)
+    def step(first):
+        # consecutive calls alternate over the streams: call i's coder tail overlaps call i+1's DWT / coder
+        # head (each stream has its own context = its own workspace); `first`: this step holds frame 0 of the
+        # video (the populated header)
+        for j in range(calls_per_step):
+            i = ncall[0]
+            ncall[0] += 1
+            k = i % nstreams
+            f0 = (i * batch) % pool_n
+            with torch.cuda.stream(streams[k]):
+                if batch == 1:
+                    codecs[k].encode_frame_async(pool[f0], outs[k][0], 0 if (first and j == 0) else 1)
+                else:
+                    codecs[k].encode_frames_async(pool[f0:f0 + batch], outs[k], 0 if (first and j == 0) else 1)
+            last_call[k] = f0
+            if world > 1:
+                # the only exchange of the frame-sharded path (picsong_dist.gather_round, covered by the gloo
+                # tests): lengths all-gathered, then payload gatherv to rank 0 over RCCL.  It needs the
+                # lengths on the host, so it runs one call late (DeferredExchange): the host waits for call i
+                # only after call i+1 is queued, and the payload crosses xGMI while call i+1 is being coded.
+                # Every call's exchange is inside the timed region (flush).
+                def exchange(k=k):
+                    with torch.cuda.stream(streams[k]):
+                        if batch == 1:
+                            totals = [codecs[k].last_total()]
+                        else:
+                            totals = codecs[k].last_totals(batch)
+                        payload = torch.cat([outs[k][b, :t] for b, t in enumerate(totals)]) if batch > 1 else outs[k][0, :totals[0]]
+                        return pdist.gather_round(payload, rank, world, dev, recv_bufs=gather_bufs)
+                dx.submit(exchange)
 
     def sync_all():
         if world > 1:
@@ -192,22 +223,32 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        step(i)
+        step(i == 0)
     sync_all()
     for c in codecs:
-        c.profile_begin(args.steps)
+        c.profile_begin(args.steps * calls_per_step)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(1 + i)
+        step(False)
     sync_all()
     dt = time.perf_counter() - t0
-    stage_ms = np.concatenate([c.profile_read(args.steps) for c in codecs], axis=0)
+    stage_ms = np.concatenate([c.profile_read(args.steps * calls_per_step) for c in codecs], axis=0) / batch   # per frame
     for c in codecs:
         c.profile_begin(0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # ---- the timed loop's own last outputs (every stream's last call) against a fresh single-frame encode
+    loop_ok = True
+    for k, f0 in last_call.items():
+        with torch.cuda.stream(streams[k]):
+            totals = [codecs[k].last_total()] if batch == 1 else codecs[k].last_totals(batch)
+            for b, tl in enumerate(totals):
+                ref1 = codec.encode_frame(pool[f0 + b], 1)
+                loop_ok = loop_ok and tl == ref1.numel() and bool(torch.equal(outs[k][b, :tl], ref1))
+    torch.cuda.synchronize()
 
     total_shorts = codec.last_total()
     flag = codec.range_flag()
@@ -265,7 +306,8 @@ def main():
         return
 
     ms_per_step = dt / args.steps * 1e3
-    mpix = (W * H * world * args.steps) / dt / 1e6
+    ms_per_frame = ms_per_step / fps
+    mpix = (W * H * world * args.steps * fps) / dt / 1e6
 
     # ---- roofline of the dominant kernel (bpc_kernel<false>): algorithmic bytes per launch
     # (nCB*16384 coefficient bytes + 4*nCB sizes + 2*sum(ncw) codeword bytes) over the

@@ -55,6 +55,11 @@ struct BpcArgs {
     uint32_t *plane_scratch;       // encoder: kEncScratchDwordsPerWave dwords per wave of the launch
     float k;                       // complexity-scalability factor (-k); > 0 only in BULK kernels
     int n_tables;                  // bit-plane tables laid back to back in `lut` (1 when k = 0)
+    // batched launches (picsong_encode_frames): the grid covers `frames` frames of waves_per_frame waves
+    // each; frame f reads coeffs_in + f * coef_z bytes, codes into staging + f * AW*AH and sizes + f * nCB.
+    // 0 / 1 frames = a single frame (waves_per_frame unused)
+    int frames, waves_per_frame;
+    unsigned long long coef_z;
 };
 
 // ---- cross-lane helpers ---------------------------------------------------------------------
@@ -416,22 +421,54 @@ __device__ __forceinline__ void enc_reserve(EncCoder &c, uint64_t m, uint32_t up
 }
 
 // One call site.  onm = ballot of the lanes that code a symbol here, onem = those of them whose symbol
-// is 1 (both wave-uniform SGPR pairs the callers have anyway).  The interval update runs in EVERY lane:
-// an idle lane multiplies by pone = 1 << prec, (S * pone) >> prec == S, so no exec-masked region and no
-// branch surrounds it; a lane coding a 1 takes  S' = S - a0 - 1, L' = L + a0 + 1  (a = a0 + sym), a lane
-// coding a 0 takes S' = a0.  One dependent round trip VALU -> SGPR -> branch per site (the reservation).
+// is 1 (both wave-uniform SGPR pairs the callers have anyway):  a0 = (S * p) >> prec;  a lane coding a 1
+// takes S' = S - a0 - 1, L' = L + a0 + 1 (a = a0 + sym), a lane coding a 0 takes S' = a0.
+//
+// What this kernel is bound by is vector-instruction ISSUE, and on gfx950 issue cost depends on the
+// instruction (tools/valu_probe, profiles/r02_valu_probe.txt): and / or / xor / add / sub / mov on VGPR,
+// inline or literal operands go at one per ~2.4 cycles per SIMD, but shifts, v_min, every VOP3 form
+// (v_cndmask_e64, v_mad, v_alignbit, v_perm, v_bfe ...), every compare, v_mul_u32_u24, DPP moves and any
+// instruction with an SGPR operand at one per ~4.2.  So the update is written as the instructions
+// themselves, over exec masks instead of selects: 2 half-rate + 4 full-rate + the exhausted compare,
+// where the compiler's select form needs 6 half-rate + 2 full-rate.
+__device__ __forceinline__ void enc_update(EncCoder &c, uint64_t onm, uint64_t onem, uint32_t p, uint32_t prec)
+{
+#if defined(__AMDGCN__)
+    uint32_t a;
+    uint64_t sv, em;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[on]\n\t"
+        "v_mul_u32_u24 %[a], %[S], %[p]\n\t"
+        "v_lshrrev_b32 %[a], %[pr], %[a]\n\t"          // a0, lanes that code
+        "s_mov_b64 exec, %[one]\n\t"
+        "v_add_u32 %[a], 1, %[a]\n\t"                   // lanes coding a 1: a = a0 + 1
+        "v_add_u32 %[L], %[L], %[a]\n\t"                //   L += a
+        "v_sub_u32 %[a], %[S], %[a]\n\t"                //   a = S - a  (their new S)
+        "s_mov_b64 exec, %[on]\n\t"
+        "v_mov_b32 %[S], %[a]\n\t"                      // lanes coding a 0 still hold a0 in a
+        "s_mov_b64 exec, %[sv]\n\t"
+        "v_cmp_eq_u32_e32 vcc, 0, %[S]\n\t"
+        "s_mov_b64 %[em], vcc"
+        : [S] "+v"(c.S), [L] "+v"(c.L), [a] "=&v"(a), [sv] "=&s"(sv), [em] "=s"(em)
+        : [on] "s"(onm), [one] "s"(onem), [p] "v"(p), [pr] "s"(prec)
+        : "vcc");
+    c.emptym = em;
+#else
+    const uint32_t pe = __builtin_amdgcn_inverse_ballot_w64(onm) ? p : c.pone;     // (S * pone) >> prec == S
+    const uint32_t a0 = mul_u24(c.S, pe) >> prec;
+    const bool one = __builtin_amdgcn_inverse_ballot_w64(onem);
+    c.S = one ? c.S + ~a0 : a0;
+    c.L = one ? c.L + a0 + 1u : c.L;
+    c.emptym = zero_mask(c.S);
+#endif
+}
 __device__ __forceinline__ void enc_site2(EncCoder &c, uint64_t onm, uint64_t onem, uint32_t p, uint32_t prec,
                                           uint32_t upper_mask)
 {
     const uint64_t m = c.emptym & onm;
     if (m != 0ull) enc_reserve(c, m, upper_mask);
-    const uint32_t pe = __builtin_amdgcn_inverse_ballot_w64(onm) ? p : c.pone;
-    const uint32_t a0 = mul_u24(c.S, pe) >> prec;
-    const bool one = __builtin_amdgcn_inverse_ballot_w64(onem);
-    c.S = one ? c.S + ~a0 : a0;                  // v_xad_u32 + v_cndmask
-    c.L = one ? c.L + a0 + 1u : c.L;             // v_add3_u32 + v_cndmask
-    // the exhausted-interval mask as the compare's own 64-bit result, opaque to the optimiser
-    c.emptym = zero_mask(c.S);
+    enc_update(c, onm, onem, p, prec);
 }
 // generic form (bulk scan): `inact` = 1 for lanes that sit the site out
 __device__ __forceinline__ void enc_site(EncCoder &c, uint32_t inact, uint32_t sym, uint32_t p, uint32_t prec,
@@ -445,6 +482,19 @@ __device__ __forceinline__ void enc_site(EncCoder &c, uint32_t inact, uint32_t s
 // that one rotate-right by the row index drops each bit where the consumer wants it.
 __device__ __forceinline__ uint32_t rotr32(uint32_t v, uint32_t sh) { return __builtin_amdgcn_alignbit(v, v, sh); }
 __device__ __forceinline__ uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+
+// The row's bit as a VGPR value: `x & rowbit` with the bit in an SGPR issues at half rate (any SGPR operand
+// does), with both operands in VGPRs at full rate; one move per row serves its five to seven mask tests.
+__device__ __forceinline__ uint32_t vgpr_of(uint32_t s)
+{
+#if defined(__AMDGCN__)
+    uint32_t v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return v;
+#else
+    return s;
+#endif
+}
 
 // One coefficient of the significance propagation pass.  rowbit = 1 << ii.  A: significant-before mask
 // of the column's 32 rows (all ones for an idle half: never on); N: becomes significant in this plane
@@ -634,7 +684,7 @@ __device__ __forceinline__ int bulk_setup(const BpcArgs &a, bool coded, int msb,
 // Waves per SIMD the register allocator must leave room for (512 VGPRs per SIMD lane: 8 waves = 64,
 // 7 = 72, 6 = 80, 5 = 96).  Round 1 (8 planes resident): 5.  With one plane resident the kernel fits 64.
 #ifndef PICSONG_BPC_ENC_WAVES
-#define PICSONG_BPC_ENC_WAVES 8
+#define PICSONG_BPC_ENC_WAVES 5
 #endif
 
 // one row (two coefficients of the lane) of the coefficient array as magnitudes and sign bits
@@ -662,8 +712,19 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
 {
     __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
-    const int wave = BULK ? (int)blockIdx.x
-                          : (int)blockIdx.x * kBpcEncWgWaves + (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gwave = BULK ? (int)blockIdx.x
+                           : (int)blockIdx.x * kBpcEncWgWaves + (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int wave = gwave;                                       // wave within its frame
+    if (a.frames > 1) {
+        const int f = gwave / a.waves_per_frame;            // wave-uniform
+        wave = gwave - f * a.waves_per_frame;
+        if (f >= a.frames) { wave = a.waves_per_frame; }    // padding wave of the last workgroup: codes nothing
+        else {
+            a.coeffs_in = (const char *)a.coeffs_in + (unsigned long long)f * a.coef_z;
+            a.staging += (size_t)f * (size_t)a.AW * (size_t)a.AH;
+            a.sizes += (size_t)f * (size_t)(a.nCB - a.cb_base);
+        }
+    }
     const int cb = a.cb_base + 2 * wave + (int)half;
     const bool valid = cb < a.nCB;
     const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
@@ -673,7 +734,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     int32_t *const st = stw + (size_t)half * 4096u;                             // (an invalid upper half never touches it)
     const uint32_t prec = (uint32_t)a.g.prec;
     const uint32_t upper_mask = opaque_mask(half ? 0xFFFFFFFFu : 0u);
-    uint32_t *const pscr = a.plane_scratch + (size_t)wave * (size_t)kEncScratchDwordsPerWave + lane;
+    uint32_t *const pscr = a.plane_scratch + (size_t)gwave * (size_t)kEncScratchDwordsPerWave + lane;
 
     // ---- ONE pass over the coefficients: findMSB (BPCEngine.cu:176-192) and the transposition, plane k
     // of row i -> bit i of the plane's row mask; planes 0..7 of every block are built (a block's planes
@@ -796,7 +857,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
                 uint32_t rows = wave_or32(~(al & ar));
                 while (rows) {
                     const uint32_t ii = (uint32_t)__builtin_ctz(rows);
-                    const uint32_t rowbit = 1u << ii;
+                    const uint32_t rowbit = vgpr_of(1u << ii);
                     rows &= rows - 1u;
                     enc_spp_coeff(c, ii, rowbit, al, nl, cpL, pl, prec, upper_mask);
                     enc_spp_coeff(c, ii, rowbit, ar, nr, cpR, pl, prec, upper_mask);
@@ -813,7 +874,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
             uint32_t rows = wave_or32(ml | mr);
             while (rows) {
                 const uint32_t ii = (uint32_t)__builtin_ctz(rows);
-                const uint32_t rowbit = 1u << ii;
+                const uint32_t rowbit = vgpr_of(1u << ii);
                 rows &= rows - 1u;
                 const uint64_t mL = __builtin_amdgcn_ballot_w64((ml & rowbit) != 0u);
                 if (mL != 0ull) enc_site2(c, mL, __builtin_amdgcn_ballot_w64((bl & rowbit) != 0u), pl.ref, prec, upper_mask);

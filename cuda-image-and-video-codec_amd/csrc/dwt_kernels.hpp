@@ -73,7 +73,19 @@ struct DwtFwdArgs {
     int last;               // last level: LL gets quantised (lossy)
     float qs;
     float q[4];             // quantisation steps of this level: LL, HL, LH, HH
+    // batched launches (grid.z = frames of one picsong_encode_frames call): frame z reads src + z * src_z
+    // and writes ll / mallat + z * dst_z (bytes); 0 for a single frame
+    unsigned long long src_z, dst_z;
 };
+
+// frame blockIdx.z of a batched launch
+__device__ __forceinline__ void dwt_fwd_select_frame(DwtFwdArgs &a)
+{
+    const unsigned long long z = blockIdx.z;
+    a.src = (const char *)a.src + z * a.src_z;
+    a.ll = (char *)a.ll + z * a.dst_z;
+    a.mallat = (char *)a.mallat + z * a.dst_z;
+}
 
 struct DwtInvArgs {
     const int32_t *mallat;  // coded coefficients, int32, row stride AW
@@ -355,6 +367,7 @@ __global__ __launch_bounds__(256) PS_DWT_OCC void dwt_fwd_kernel(DwtFwdArgs a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int strip = blockIdx.x * 4 + wave;
     if (strip * kStripUseful >= a.W) return;               // whole wave idle (no cross-lane use)
+    dwt_fwd_select_frame(a);
     const int c0 = strip * kStripUseful - 4 * kEdgeLanes + 4 * lane;    // first of the lane's 4 columns
     const int m0 = blockIdx.y * (kFwdBandRows / 2);
     int m1 = m0 + kFwdBandRows / 2;
@@ -650,6 +663,8 @@ __global__ __launch_bounds__(256, PICSONG_DWT_F2_WAVES) void dwt_fwd2_kernel(Dwt
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int strip = blockIdx.x * 4 + wave;
     if (strip * kF2Useful >= a2.l0.W) return;
+    dwt_fwd_select_frame(a2.l0);
+    dwt_fwd_select_frame(a2.l1);
     // the wave's 256 columns start at strip * kF2Useful - 4 * kF2Edge: does it hold column 0 or W - 4?
     const int first = strip * kF2Useful - 4 * kF2Edge;
     // (only the 9/7 kernel, which is bound by vector instructions, gets the second instantiation)

@@ -73,6 +73,7 @@ inline std::vector<FwdLaunch> plan_dwt_forward(const void *d_in, bool u8in, void
         a.ll = last ? d_out : (void *)((char *)d_out + off * 4);
         a.ll_stride = last ? aw : (W >> 1);
         a.mallat = d_out; a.AW = aw; a.level = l; a.last = last ? 1 : 0; a.qs = qs;
+        a.src_z = 0; a.dst_z = 0;
         for (int k = 0; k < 4; k++) a.q[k] = kQSteps[l][k];
         const int strips = (W + kStripUseful - 1) / kStripUseful;
         f.band = fwd_band_rows(l, strips, H);

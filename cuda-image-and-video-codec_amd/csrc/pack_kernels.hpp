@@ -16,11 +16,13 @@ namespace picsong {
 struct HeaderArg { uint16_t h[9]; int has; };
 
 // offsets[cb] = sum_{i<cb} (sizes[i] - 1); *total = 9 + 2n + sum(sizes - 1) + 1
-// (BitStreamBuilder.cu:300-305).  One block of 1024 threads.
+// (BitStreamBuilder.cu:300-305).  One block of 1024 threads per frame (blockIdx.x = frame of a batched
+// launch: sizes / offsets advance by n, total by 1).
 __global__ __launch_bounds__(1024) void scan_sizes_kernel(const int32_t *sizes, int n, int32_t *offsets,
                                                           int32_t *total)
 {
     __shared__ int32_t s_wave[16];
+    sizes += (size_t)blockIdx.x * (size_t)n; offsets += (size_t)blockIdx.x * (size_t)n; total += blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = (n + 1023) / 1024;
     const int b = tid * chunk, e = b + chunk < n ? b + chunk : n;
@@ -41,12 +43,20 @@ __global__ __launch_bounds__(1024) void scan_sizes_kernel(const int32_t *sizes, 
     if (tid == 1023) *total = 9 + 2 * n + (base + inc) + 1;
 }
 
-// one workgroup per codeblock (buildBitStreamLUTBS BitStreamBuilder.cu:106-137 layout)
+// one workgroup per codeblock (buildBitStreamLUTBS BitStreamBuilder.cu:106-137 layout); blockIdx.y = frame
+// of a batched launch (staging advances by frame_words, sizes / offsets by n, total by 1, out by
+// out_stride shorts; only the frame hdr.has - 1 == blockIdx.y carries the populated header -- has = 0: none)
 __global__ __launch_bounds__(256) void pack_kernel(const int32_t *staging, const int32_t *sizes,
                                                    const int32_t *offsets, const int32_t *total, int n,
-                                                   HeaderArg hdr, uint16_t *out)
+                                                   HeaderArg hdr, uint16_t *out, size_t frame_words = 0,
+                                                   size_t out_stride = 0)
 {
     const int cb = blockIdx.x, tid = threadIdx.x;
+    {
+        const size_t f = blockIdx.y;
+        staging += f * frame_words; sizes += f * (size_t)n; offsets += f * (size_t)n; total += f; out += f * out_stride;
+        hdr.has = (hdr.has != 0 && (size_t)(hdr.has - 1) == f) ? 1 : 0;
+    }
     const int32_t *st = staging + (size_t)cb * 4096u;
     const int len = sizes[cb];
     uint16_t *dst = out + 9 + 2 * (size_t)n + (size_t)offsets[cb];

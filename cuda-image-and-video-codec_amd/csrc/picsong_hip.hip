@@ -67,6 +67,12 @@ struct picsong_ctx {
     int32_t *d_staging;   // int32[P]
     int32_t *d_sizes;     // int32[nCB]
     int32_t *d_coef_i;    // int32[P] (decode)
+    // batched frame path (picsong_encode_frames): workspaces for batch_cap frames, laid frame after frame
+    int batch_cap;
+    void *b_coef; int32_t *b_staging, *b_sizes, *b_offsets, *b_total;
+    uint32_t *b_plane_scratch;
+    int32_t *h_totals;    // pinned, batch_cap
+    int last_batch;       // frames of the most recent picsong_encode_frames
     // stage profiling (HIP events on the launch stream)
     std::vector<hipEvent_t> *prof_ev;   // 4 per frame
     int prof_cap, prof_n;
@@ -105,9 +111,9 @@ static void launch_fwd_v(bool lossy, const FwdLaunch &f, dim3 grid, hipStream_t 
 }
 
 template <int BAND>
-static void launch_fwd(const picsong_ctx *c, const FwdLaunch &f, hipStream_t s)
+static void launch_fwd(const picsong_ctx *c, const FwdLaunch &f, hipStream_t s, unsigned frames = 1)
 {
-    dim3 grid(f.gx, f.gy);
+    dim3 grid(f.gx, f.gy, frames);
     if (f.vec) launch_fwd_v<BAND, true>(c->p.lossy != 0, f, grid, s);
     else launch_fwd_v<BAND, false>(c->p.lossy != 0, f, grid, s);
 }
@@ -351,6 +357,13 @@ void picsong_ctx_destroy(picsong_ctx *c)
     if (c->d_staging) (void)hipFree(c->d_staging);
     if (c->d_sizes) (void)hipFree(c->d_sizes);
     if (c->d_coef_i) (void)hipFree(c->d_coef_i);
+    if (c->b_coef) (void)hipFree(c->b_coef);
+    if (c->b_staging) (void)hipFree(c->b_staging);
+    if (c->b_sizes) (void)hipFree(c->b_sizes);
+    if (c->b_offsets) (void)hipFree(c->b_offsets);
+    if (c->b_total) (void)hipFree(c->b_total);
+    if (c->b_plane_scratch) (void)hipFree(c->b_plane_scratch);
+    if (c->h_totals) (void)hipHostFree(c->h_totals);
     if (c->prof_ev) {
         for (hipEvent_t e : *c->prof_ev) (void)hipEventDestroy(e);
         delete c->prof_ev;
@@ -799,6 +812,131 @@ int picsong_encode_frame_stripe(picsong_ctx *c, const uint8_t *d_frame, int cb_b
     if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, s, cb_begin, cb_count))) return rc;
     return pack_range(c, c->d_staging + (size_t)cb_begin * PICSONG_CB_WORDS, c->d_sizes + cb_begin, cb_count, nullptr,
                       d_stream, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// batched frames: n frames of a video in ONE launch per stage (grid.z = frame for the DWT levels, n x the
+// codeblock waves for the coder, grid.y = frame for the pack).  A 4K frame alone is 1020 coder waves -- one
+// per SIMD, a quarter of what the coder needs to keep the vector pipes busy ("batch several
+// frames per launch"); the reference's answer is -numberOfStreams worker threads with a stream each
+// (Engines/CodingEngine.cu:990-1061), this is the same frames-in-flight idea without depending on the
+// runtime's queues.
+// ---------------------------------------------------------------------------------------------
+static void free_batch(picsong_ctx *c)
+{
+    if (c->b_coef) (void)hipFree(c->b_coef);
+    if (c->b_staging) (void)hipFree(c->b_staging);
+    if (c->b_sizes) (void)hipFree(c->b_sizes);
+    if (c->b_offsets) (void)hipFree(c->b_offsets);
+    if (c->b_total) (void)hipFree(c->b_total);
+    if (c->b_plane_scratch) (void)hipFree(c->b_plane_scratch);
+    if (c->h_totals) (void)hipHostFree(c->h_totals);
+    c->b_coef = nullptr; c->b_staging = c->b_sizes = c->b_offsets = c->b_total = nullptr;
+    c->b_plane_scratch = nullptr; c->h_totals = nullptr; c->batch_cap = 0;
+}
+
+static int ensure_batch(picsong_ctx *c, int n)
+{
+    if (n <= c->batch_cap) return PICSONG_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());                 // a smaller batch may still be running on the old buffers
+    free_batch(c);
+    const size_t waves = ((size_t)n * (size_t)((c->ncb + 1) / 2) + kBpcEncWgWaves - 1) / kBpcEncWgWaves * kBpcEncWgWaves;
+    HIP_TRY(hipMalloc(&c->b_coef, (size_t)n * (c->P + c->extra) * 4));
+    HIP_TRY(hipMalloc(&c->b_staging, (size_t)n * c->P * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&c->b_sizes, (size_t)n * (size_t)c->ncb * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&c->b_offsets, (size_t)n * (size_t)c->ncb * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&c->b_total, (size_t)n * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&c->b_plane_scratch, waves * kEncScratchDwordsPerWave * sizeof(uint32_t)));
+    HIP_TRY(hipHostMalloc(&c->h_totals, (size_t)n * sizeof(int32_t)));
+    c->batch_cap = n;
+    return PICSONG_OK;
+}
+
+int picsong_encode_frames(picsong_ctx *c, int n, const uint8_t *d_frames, size_t frame_stride, int first_iter,
+                          uint16_t *d_streams, size_t stream_stride, void *stream)
+{
+    if (!c || !d_frames || !d_streams) return fail(PICSONG_ERR_ARG, "encode_frames: null argument");
+    if (n < 1 || n > 64) return fail(PICSONG_ERR_ARG, "encode_frames: %d frames outside 1..64", n);
+    if (n > 1 && (frame_stride < c->P || stream_stride < picsong_max_stream_shorts(c->aw, c->ah)))
+        return fail(PICSONG_ERR_ARG, "encode_frames: strides smaller than a padded frame / a worst-case codestream");
+    if (c->p.k > 0.0f) return fail(PICSONG_ERR_ARG, "encode_frames: -k > 0 is coded frame by frame (picsong_encode_frame)");
+    if (((uintptr_t)d_frames | frame_stride) & 15u) return fail(PICSONG_ERR_ARG, "encode_frames: frames must be 16-byte aligned");
+    BpcArgs a;
+    int rc = bpc_args(c, a, 0);
+    if (rc) return rc;
+    if ((rc = ensure_batch(c, n))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t coef_z = (c->P + c->extra) * 4;
+    hipEvent_t *ev = nullptr;                             // stage timers: one set per batch (picsong_profile_begin)
+    if (c->prof_cap > 0 && c->prof_n < c->prof_cap) ev = c->prof_ev->data() + 4 * (c->prof_n++);
+    if (ev) HIP_TRY(hipEventRecord(ev[0], s));
+
+    // ---- DWT: the single-frame plan of frame 0 with grid.z = n
+    std::vector<FwdLaunch> plan = plan_dwt_forward(d_frames, true, c->b_coef, c->aw, c->ah, c->p.wl, c->p.qs);
+    for (size_t l = 0; l < plan.size(); l++) {
+        plan[l].a.src_z = l == 0 ? (unsigned long long)frame_stride : (unsigned long long)coef_z;
+        plan[l].a.dst_z = (unsigned long long)coef_z;
+    }
+    Fwd2Launch f2;
+    const bool fused01 = plan_dwt_fwd2(plan, f2, true);
+    if (fused01) {
+        dim3 grid(f2.gx, f2.gy, (unsigned)n);
+        if (c->p.lossy) dwt_fwd2_kernel<float, true, true, kF2Pairs><<<grid, 256, 0, s>>>(f2.a);
+        else dwt_fwd2_kernel<int, false, true, kF2Pairs><<<grid, 256, 0, s>>>(f2.a);
+        HIP_TRY(hipGetLastError());
+    }
+    for (size_t l = fused01 ? 2 : 0; l < plan.size(); l++) {
+        const FwdLaunch &f = plan[l];
+        switch (f.band) {
+        case 32: launch_fwd<32>(c, f, s, (unsigned)n); break;
+        case 16: launch_fwd<16>(c, f, s, (unsigned)n); break;
+        case 8: launch_fwd<8>(c, f, s, (unsigned)n); break;
+        default: launch_fwd<4>(c, f, s, (unsigned)n); break;
+        }
+        HIP_TRY(hipGetLastError());
+    }
+
+    if (ev) HIP_TRY(hipEventRecord(ev[1], s));
+    // ---- coder: one grid over the n frames' codeblock pairs
+    const int wpf = (c->ncb + 1) / 2;
+    a.cb_base = 0; a.nCB = c->ncb;
+    a.coeffs_in = c->b_coef; a.is_float = c->p.lossy ? 1 : 0;
+    a.staging = c->b_staging; a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch;
+    a.frames = n; a.waves_per_frame = wpf; a.coef_z = coef_z;
+    const size_t waves = (size_t)n * (size_t)wpf;
+    bpc_encode_kernel<false><<<(unsigned)((waves + kBpcEncWgWaves - 1) / kBpcEncWgWaves), 64 * kBpcEncWgWaves, 0, s>>>(a);
+    HIP_TRY(hipGetLastError());
+
+    if (ev) HIP_TRY(hipEventRecord(ev[2], s));
+    // ---- pack
+    HeaderArg h;
+    memset(&h, 0, sizeof h);
+    if (first_iter <= 0 && first_iter + n > 0) {          // the batch holds the video's frame 0
+        uint16_t hdr[PICSONG_HDR_SHORTS];
+        picsong_header_pack(&c->p, hdr);
+        memcpy(h.h, hdr, sizeof h.h);
+        h.has = -first_iter + 1;
+    }
+    scan_sizes_kernel<<<(unsigned)n, 1024, 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
+    HIP_TRY(hipGetLastError());
+    pack_kernel<<<dim3((unsigned)c->ncb, (unsigned)n), 256, 0, s>>>(c->b_staging, c->b_sizes, c->b_offsets, c->b_total,
+                                                                    c->ncb, h, d_streams, c->P, stream_stride);
+    HIP_TRY(hipGetLastError());
+    if (ev) HIP_TRY(hipEventRecord(ev[3], s));
+    c->last_batch = n;
+    return PICSONG_OK;
+}
+
+int picsong_last_totals(picsong_ctx *c, void *stream, int n, int *h_totals)
+{
+    if (!c || !h_totals) return fail(PICSONG_ERR_ARG, "last_totals: null argument");
+    if (n < 1 || n > c->last_batch) return fail(PICSONG_ERR_ARG, "last_totals: %d frames, the last batch had %d", n, c->last_batch);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(c->h_totals, c->b_total, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int i = 0; i < n; i++) h_totals[i] = c->h_totals[i];
+    return PICSONG_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -41,6 +41,7 @@ EXPORTS = [
     "picsong_encode_frame_stripe", "picsong_ctx_set_lut_component", "picsong_rgb_forward", "picsong_rgb_inverse",
     "picsong_encode_plane", "picsong_decode_plane",
     "picsong_ctx_set_lut_device", "picsong_bpc_encode_component", "picsong_bpc_decode_component",
+    "picsong_encode_frames", "picsong_last_totals",
 ]
 
 _lib = None
@@ -99,6 +100,12 @@ def load():
     L.picsong_range_flag.argtypes = [vp, vp, C.POINTER(i)]
     L.picsong_profile_begin.argtypes = [vp, i]
     L.picsong_profile_read.argtypes = [vp, C.POINTER(i), vp, i]
+    if hasattr(L, "picsong_encode_frames"):          # (A/B runs load older variant libraries through PICSONG_SO)
+        L.picsong_encode_frames.argtypes = [vp, i, vp, C.c_size_t, i, vp, C.c_size_t, vp]
+        L.picsong_last_totals.argtypes = [vp, vp, i, C.POINTER(i)]
+        L.picsong_ctx_set_lut_device.argtypes = [vp, i, C.POINTER(LutInfo), vp]
+        L.picsong_bpc_encode_component.argtypes = [vp, i, vp, vp, vp, vp]
+        L.picsong_bpc_decode_component.argtypes = [vp, i, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -315,6 +322,27 @@ class Codec:
         out = self.torch.empty(self.max_stream_shorts(), dtype=self.torch.int16, device=self.dev)
         self.encode_frame_async(frame_u8_padded, out, iter_)
         return out[:self.last_total()]
+
+    # ---- batched frames: n frames, one launch per stage (picsong_encode_frames) ----
+    def encode_frames_async(self, frames_u8_padded, out_streams, first_iter=0):
+        """frames_u8_padded: uint8 [n, AH*AW] (rows contiguous, any row stride that is a multiple of 16);
+        out_streams: int16 [n, >= max_stream_shorts()]."""
+        n = frames_u8_padded.shape[0]
+        assert out_streams.shape[0] >= n and frames_u8_padded.stride(-1) == 1 and out_streams.stride(-1) == 1
+        _check(self.L.picsong_encode_frames(self.h, n, self._p(frames_u8_padded), frames_u8_padded.stride(0),
+                                            first_iter, self._p(out_streams), out_streams.stride(0), self._stream()))
+        return n
+
+    def last_totals(self, n):
+        t = (C.c_int * n)()
+        _check(self.L.picsong_last_totals(self.h, self._stream(), n, t))
+        return list(t)
+
+    def encode_frames(self, frames_u8_padded, first_iter=0):
+        n = frames_u8_padded.shape[0]
+        out = self.torch.empty((n, self.max_stream_shorts()), dtype=self.torch.int16, device=self.dev)
+        self.encode_frames_async(frames_u8_padded, out, first_iter)
+        return [out[i, :t] for i, t in enumerate(self.last_totals(n))]
 
     def encode_frame_stripe(self, frame_u8_padded, cb_begin, cb_count):
         """Mini-stream (9 x 0xFFFF | pairs | payload | 0xFFFF) of codeblocks [cb_begin, +cb_count)."""

@@ -175,6 +175,20 @@ int picsong_encode_frame(picsong_ctx *ctx, const uint8_t *d_frame, int iter, uin
                          void *stream);
 int picsong_decode_frame(picsong_ctx *ctx, const uint16_t *d_stream, uint8_t *d_frame_out,
                          void *stream);
+/* ---- batched frames: n consecutive frames of a video through ONE launch per stage (grid.z = frame for the
+ *      DWT levels, one coder grid over n x nCB codeblocks, one pack grid) -- CodingEngine::runVideo's call
+ *      sequence (Engines/CodingEngine.cu:819-872) for frames first_iter .. first_iter + n - 1, which the
+ *      reference spreads over -numberOfStreams worker threads (:990-1061).  Frame f is the padded
+ *      u8[AW*AH] at d_frames + f * frame_stride (bytes, 16-byte aligned), its codestream lands at
+ *      d_streams + f * stream_stride (shorts, >= picsong_max_stream_shorts); only the video's frame 0
+ *      (first_iter + f == 0) carries the populated header.  n = 1..64; the context grows its workspace to
+ *      the largest n seen (about 10 bytes per pixel per frame).  Asynchronous; picsong_last_totals
+ *      synchronises `stream` and returns the n lengths in shorts.  Byte-identical to n calls of
+ *      picsong_encode_frame.  k > 0 contexts are refused (code those frame by frame). ---- */
+int picsong_encode_frames(picsong_ctx *ctx, int n, const uint8_t *d_frames, size_t frame_stride, int first_iter,
+                          uint16_t *d_streams, size_t stream_stride, void *stream);
+int picsong_last_totals(picsong_ctx *ctx, void *stream, int n, int *h_totals);
+
 /* ---- RGB path: RGBTransformLossless / RGBTransformLossy with the level shift
  *      fused (Engines/CodingEngine.cu:357-403,408-449; Engines/DecodingEngine.cu:599-701), then each
  *      component is coded as a frame of its own with its own LUT (CodingEngine.cu:598-633,676-712).

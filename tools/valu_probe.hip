@@ -30,6 +30,13 @@ enum Kind {
     CNDMASK_VCC_INDEP,   // v_cndmask_b32 (vcc) x8 independent
     ADD_INDEP, LSHL_OR_INDEP, AND_OR_INDEP, XAD_DEP, ADD3_DEP, CMP_INDEP,
     SITE_V2,             // the round-2 call site: one reservation round trip, update in every lane
+    OR_INDEP, XOR_INDEP, LSHL_INDEP, LSHR_SGPR_INDEP, SUB_INDEP, MOV_INDEP, MIN_INDEP, NOT_INDEP, FFBL_INDEP, BCNT_INDEP,
+    CMP_E32_INDEP,       // v_cmp_eq_u32_e32 -> vcc
+    CMP_CND_E32_PAIR,    // v_cmp_e32 vcc ; v_cndmask_e32 vcc
+    CND_E32_AFTER_SMOV,  // s_mov_b64 vcc once per block, then v_cndmask_e32 x8 independent
+    ADDCO_DEP,           // v_add_co_u32 x, vcc, x, x (shift left by one, bit out to vcc)
+    AND_SGPR_INDEP, AND_LIT_INDEP, EXEC_MOV,      // s_mov exec, m ; v_mov ; s_mov exec, -1
+    SDWA_AND_INDEP, PK_ADD_INDEP, MUL_LO_INDEP, MAD24_INDEP, BFI_INDEP, LSHL_ADD_INDEP,
     NKINDS
 };
 static const char *kKindName[NKINDS] = {
@@ -42,15 +49,36 @@ static const char *kKindName[NKINDS] = {
     "s_add_u32 dependent", "coder call site mix (24 inst: 15 VALU, 9 SALU)",
     "v_cndmask_b32_e64 sgpr mask dependent", "v_cndmask_b32 vcc x8 independent", "v_add_u32 x8 independent",
     "v_lshl_or_b32 x8 independent", "v_and_or_b32 x8 independent", "v_xad_u32 dependent", "v_add3_u32 dependent",
-    "v_cmp_ne_u32 -> sgpr pair x4 independent", "round-2 call site (21 inst: 17 VALU, 4 SALU)" };
+    "v_cmp_ne_u32 -> sgpr pair x4 independent", "round-2 call site (21 inst: 17 VALU, 4 SALU)",
+    "v_or_b32 x8 independent", "v_xor_b32 x8 independent", "v_lshlrev_b32 (inline shift) x8 independent",
+    "v_lshrrev_b32 (sgpr shift) x8 independent", "v_sub_u32 x8 independent", "v_mov_b32 x8 independent",
+    "v_min_u32 x8 independent", "v_not_b32 x8 independent", "v_ffbl_b32 x8 independent", "v_bcnt_u32_b32 x8 independent",
+    "v_cmp_eq_u32_e32 -> vcc x8 independent", "v_cmp_e32 vcc ; v_cndmask_e32 vcc (pairs, x8 independent)",
+    "s_mov vcc ; 8 x v_cndmask_e32 vcc independent (9 inst)", "v_add_co_u32 x, vcc, x, x dependent",
+    "v_and_b32 v, s, v x8 independent", "v_and_b32 v, literal, v x8 independent",
+    "s_mov exec, m ; v_mov ; s_mov exec, -1 (3 inst)", "v_and_b32_sdwa x8 independent", "v_pk_add_u16 x8 independent",
+    "v_mul_lo_u32 x8 independent", "v_mad_u32_u24 x8 independent", "v_bfi_b32 x8 independent", "v_lshl_add_u32 x8 independent" };
 // instructions per unrolled block (what "per instruction" divides by)
-static const int kBlockInsts[NKINDS] = { 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 64, 32, 32, 24, 32, 40, 40, 32, 24, 32, 32, 32, 32, 32, 32, 32, 32, 21 };
-static const int kBlockValu[NKINDS] = { 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 16, 16, 16, 16, 0, 15, 32, 32, 32, 32, 32, 32, 32, 32, 17 };
+static const int kBlockInsts[NKINDS] = { 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 64, 32, 32, 24, 32, 40, 40, 32, 24, 32, 32, 32, 32, 32, 32, 32, 32, 21, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 64, 36, 32, 32, 32, 24, 32, 32, 32, 32, 32, 32 };
+static const int kBlockValu[NKINDS] = { 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 16, 16, 16, 16, 0, 15, 32, 32, 32, 32, 32, 32, 32, 32, 17, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 64, 32, 32, 32, 32, 8, 32, 32, 32, 32, 32, 32 };
 
 #define R4(x) x x x x
 #define R8(x) R4(x) R4(x)
 #define R16(x) R8(x) R8(x)
 #define R32(x) R16(x) R16(x)
+
+#define IND8_2(op) asm volatile(R4(op " %0, %0, %8\n" op " %1, %1, %8\n" op " %2, %2, %8\n" op " %3, %3, %8\n" \
+                                    op " %4, %4, %8\n" op " %5, %5, %8\n" op " %6, %6, %8\n" op " %7, %7, %8\n") \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k))
+#define IND8_2R(op) asm volatile(R4(op " %0, %8, %0\n" op " %1, %8, %1\n" op " %2, %8, %2\n" op " %3, %8, %3\n" \
+                                     op " %4, %8, %4\n" op " %5, %8, %5\n" op " %6, %8, %6\n" op " %7, %8, %7\n") \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(sc))
+#define IND8_1(op) asm volatile(R4(op " %0, %0\n" op " %1, %1\n" op " %2, %2\n" op " %3, %3\n" \
+                                    op " %4, %4\n" op " %5, %5\n" op " %6, %6\n" op " %7, %7\n") \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7))
+#define IND8_3(op, tail) asm volatile(R4(op " %0, %0, %8" tail "\n" op " %1, %1, %8" tail "\n" op " %2, %2, %8" tail "\n" op " %3, %3, %8" tail "\n" \
+                                    op " %4, %4, %8" tail "\n" op " %5, %5, %8" tail "\n" op " %6, %6, %8" tail "\n" op " %7, %7, %8" tail "\n") \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k))
 
 template <int KIND>
 __global__ __launch_bounds__(256) void probe_kernel(uint32_t *out, uint64_t *cyc, int iters, uint32_t seed)
@@ -163,6 +191,50 @@ __global__ __launch_bounds__(256) void probe_kernel(uint32_t *out, uint64_t *cyc
                 "v_cndmask_b32_e64 %2, %5, %2, %3\n v_mul_u32_u24 %2, %0, %2\n v_lshrrev_b32 %2, 7, %2\n v_xad_u32 %1, %2, -1, %0\n"
                 "v_cndmask_b32_e64 %0, %2, %1, %4\n v_add3_u32 %2, %1, %2, 1\n v_cndmask_b32_e64 %1, %1, %2, %4\n v_cmp_eq_u32_e64 %6, 0, %0\n"
                 : "+v"(a0), "+v"(a1), "+v"(a2), "+s"(sm), "+s"(sm2), "+v"(a3), "+s"(sm3) : : "vcc", "scc");
+        } else if constexpr (KIND == OR_INDEP) { IND8_2("v_or_b32");
+        } else if constexpr (KIND == XOR_INDEP) { IND8_2("v_xor_b32");
+        } else if constexpr (KIND == LSHL_INDEP) {
+            asm volatile(R4("v_lshlrev_b32 %0, 3, %0\n v_lshlrev_b32 %1, 3, %1\n v_lshlrev_b32 %2, 3, %2\n v_lshlrev_b32 %3, 3, %3\n"
+                            "v_lshlrev_b32 %4, 3, %4\n v_lshlrev_b32 %5, 3, %5\n v_lshlrev_b32 %6, 3, %6\n v_lshlrev_b32 %7, 3, %7\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if constexpr (KIND == LSHR_SGPR_INDEP) { IND8_2R("v_lshrrev_b32");
+        } else if constexpr (KIND == SUB_INDEP) { IND8_2("v_sub_u32");
+        } else if constexpr (KIND == MOV_INDEP) {
+            asm volatile(R4("v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k));
+        } else if constexpr (KIND == MIN_INDEP) { IND8_2("v_min_u32");
+        } else if constexpr (KIND == NOT_INDEP) { IND8_1("v_not_b32");
+        } else if constexpr (KIND == FFBL_INDEP) { IND8_1("v_ffbl_b32");
+        } else if constexpr (KIND == BCNT_INDEP) { IND8_2("v_bcnt_u32_b32");
+        } else if constexpr (KIND == CMP_E32_INDEP) {
+            asm volatile(R4("v_cmp_eq_u32_e32 vcc, %0, %8\n v_cmp_eq_u32_e32 vcc, %1, %8\n v_cmp_eq_u32_e32 vcc, %2, %8\n v_cmp_eq_u32_e32 vcc, %3, %8\n"
+                            "v_cmp_eq_u32_e32 vcc, %4, %8\n v_cmp_eq_u32_e32 vcc, %5, %8\n v_cmp_eq_u32_e32 vcc, %6, %8\n v_cmp_eq_u32_e32 vcc, %7, %8\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k) : "vcc");
+        } else if constexpr (KIND == CMP_CND_E32_PAIR) {
+            asm volatile(R4("v_cmp_eq_u32_e32 vcc, %0, %8\n v_cndmask_b32 %0, %0, %8, vcc\n v_cmp_eq_u32_e32 vcc, %1, %8\n v_cndmask_b32 %1, %1, %8, vcc\n"
+                            "v_cmp_eq_u32_e32 vcc, %2, %8\n v_cndmask_b32 %2, %2, %8, vcc\n v_cmp_eq_u32_e32 vcc, %3, %8\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                            "v_cmp_eq_u32_e32 vcc, %4, %8\n v_cndmask_b32 %4, %4, %8, vcc\n v_cmp_eq_u32_e32 vcc, %5, %8\n v_cndmask_b32 %5, %5, %8, vcc\n"
+                            "v_cmp_eq_u32_e32 vcc, %6, %8\n v_cndmask_b32 %6, %6, %8, vcc\n v_cmp_eq_u32_e32 vcc, %7, %8\n v_cndmask_b32 %7, %7, %8, vcc\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k) : "vcc");
+        } else if constexpr (KIND == CND_E32_AFTER_SMOV) {
+            asm volatile(R4("s_mov_b64 vcc, %9\n v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                            "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k), "s"(sm2) : "vcc");
+        } else if constexpr (KIND == ADDCO_DEP) {
+            asm volatile(R32("v_add_co_u32 %0, vcc, %0, %0\n") : "+v"(a0) : : "vcc");
+        } else if constexpr (KIND == AND_SGPR_INDEP) { IND8_2R("v_and_b32");
+        } else if constexpr (KIND == AND_LIT_INDEP) {
+            asm volatile(R4("v_and_b32 %0, 0x12345678, %0\n v_and_b32 %1, 0x12345678, %1\n v_and_b32 %2, 0x12345678, %2\n v_and_b32 %3, 0x12345678, %3\n"
+                            "v_and_b32 %4, 0x12345678, %4\n v_and_b32 %5, 0x12345678, %5\n v_and_b32 %6, 0x12345678, %6\n v_and_b32 %7, 0x12345678, %7\n")
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+        } else if constexpr (KIND == EXEC_MOV) {
+            asm volatile(R8("s_mov_b64 exec, %1\n v_mov_b32 %0, %2\n s_mov_b64 exec, -1\n") : "+v"(a0) : "s"(sm2), "v"(k));
+        } else if constexpr (KIND == SDWA_AND_INDEP) { IND8_3("v_and_b32_sdwa", " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD");
+        } else if constexpr (KIND == PK_ADD_INDEP) { IND8_2("v_pk_add_u16");
+        } else if constexpr (KIND == MUL_LO_INDEP) { IND8_2("v_mul_lo_u32");
+        } else if constexpr (KIND == MAD24_INDEP) { IND8_3("v_mad_u32_u24", ", %8");
+        } else if constexpr (KIND == BFI_INDEP) { IND8_3("v_bfi_b32", ", %8");
+        } else if constexpr (KIND == LSHL_ADD_INDEP) { IND8_3("v_lshl_add_u32", ", %8");
         }
     }
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
@@ -184,6 +256,8 @@ __global__ void clock_kernel(uint64_t *out)
     out[0] = c1 - c0; out[1] = r1 - r0;
 }
 
+static int g_first = 0;
+
 template <int KIND>
 static void run_kind(int ncu, double mhz, uint32_t *d_out, uint64_t *d_cyc, std::string &json)
 {
@@ -193,6 +267,7 @@ static void run_kind(int ncu, double mhz, uint32_t *d_out, uint64_t *d_cyc, std:
     fflush(stdout);
     json += std::string("  {\"pattern\": \"") + kKindName[KIND] + "\", \"rows\": [";
     for (int w = 1; w <= 8; w++) {
+        if (KIND >= OR_INDEP && w != 1 && w != 4 && w != 8) continue;
         const int blocks = ncu * w;                    // 256-thread workgroups: one wave per SIMD each
         std::vector<uint64_t> h((size_t)blocks * 4 * 3);
         hipEvent_t e0, e1;
@@ -236,8 +311,10 @@ template <int K>
 static void run_all(int ncu, double mhz, uint32_t *d_out, uint64_t *d_cyc, std::string &json)
 {
     if constexpr (K < NKINDS) {
-        if (K) json += ",\n";
-        run_kind<K>(ncu, mhz, d_out, d_cyc, json);
+        if (K >= g_first) {
+            if (K > g_first) json += ",\n";
+            run_kind<K>(ncu, mhz, d_out, d_cyc, json);
+        }
         run_all<K + 1>(ncu, mhz, d_out, d_cyc, json);
     }
 }
@@ -263,6 +340,7 @@ int main(int argc, char **argv)
            "(chip-wide, device timestamps) / mean resident waves per SIMD / shader MHz inside the loops\n");
     std::string json = "{\"device\": \"" + std::string(prop.name) + "\", \"cus\": " + std::to_string(ncu) +
                        ", \"shader_mhz\": " + std::to_string(mhz) + ", \"patterns\": [\n";
+    if (argc > 2) g_first = atoi(argv[2]);
     run_all<0>(ncu, mhz, d_out, d_cyc, json);
     json += "\n]}\n";
     if (argc > 1) {
