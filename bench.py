@@ -49,13 +49,17 @@ def host_cores():
     return n
 
 
-def pmc_traffic(workload):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_hbm.csv:
-    FETCH_SIZE and WRITE_SIZE collected in separate runs of this command with --streams 1, unit
-    1024 B; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note -- calibrated on the DWT
-    kernels' known read bytes).  None when no summary for this workload is committed."""
+PROFILE_TAG = "r02"          # profiles/<tag>_pmc_hbm.csv, <tag>_pmc_sq.csv, <tag>_valu_probe.json (tools/collect_profiles.sh)
+
+
+def pmc_traffic(workload, batch=1):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_hbm.csv: FETCH_SIZE and
+    WRITE_SIZE collected in separate runs of this command with --streams 1 --batch 1, unit 1024 B;
+    FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note -- calibrated on the DWT kernels' known read
+    bytes), scaled to the `batch` frames of a launch.  OFFLINE figures: they describe the build the
+    profiles were taken from.  None when no summary for this workload is committed."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_final_pmc_hbm.csv")
+    path = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_hbm.csv")
     if workload != "8k_lossless" or not os.path.exists(path):
         return None, None
     bpc = dwt = 0.0
@@ -70,23 +74,66 @@ def pmc_traffic(workload):
         if "bpc_encode_kernel" in r["Kernel_Name"]:
             bpc += b
         elif "dwt_fwd" in r["Kernel_Name"] and frames:
-            # all levels of one frame; the counter passes run --streams 1, i.e. the context that is not
-            # set pipelined: dwt_fwd2_kernel (levels 0 + 1) + dwt_fwd_kernel (the rest)
-            dwt += b * int(r["Dispatches"]) / frames
-    return (int(bpc) if bpc else None), (int(dwt) if dwt else None)
+            dwt += b * int(r["Dispatches"]) / frames          # all levels of one frame
+    return (int(bpc * batch) if bpc else None), (int(dwt * batch) if dwt else None)
 
 
 def pmc_valu(workload):
-    """VALU wave-instructions per launch of the BPC encoder from the committed SQ counter pass
-    (profiles/*_pmc_sq.csv, SQ_INSTS_VALU): the kernel's real bound is vector-instruction issue."""
+    """VALU wave-instructions per FRAME of the BPC encoder from the committed SQ counter pass
+    (profiles/*_pmc_sq.csv, SQ_INSTS_VALU)."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_final_pmc_sq.csv")
+    path = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_sq.csv")
     if workload != "8k_lossless" or not os.path.exists(path):
         return None
     for r in csv.DictReader(open(path)):
         if "bpc_encode_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "SQ_INSTS_VALU":
             return float(r["MeanValue"])
     return None
+
+
+def probe_rates():
+    """Issue rates measured by tools/valu_probe on an MI355X (profiles/*_valu_probe.json): wave64
+    instructions per cycle per SIMD with 8 waves resident, for a full-rate and a half-rate class."""
+    path = os.path.join(ROOT, "profiles", PROFILE_TAG + "_valu_probe.json")
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    out = {"shader_mhz": d.get("shader_mhz")}
+    for pat in d["patterns"]:
+        best = max(r["insts_per_cycle_per_simd"] for r in pat["rows"])
+        if pat["pattern"].startswith("v_and_b32 x8"):
+            out["full_rate"] = best
+        elif pat["pattern"].startswith("v_alignbit_b32 dependent"):
+            out["half_rate"] = best
+        elif pat["pattern"].startswith("coder call site mix"):
+            out["call_site_mix_valu"] = max(r["valu_per_cycle_per_simd"] for r in pat["rows"])
+    return out
+
+
+def valu_issue(insts, step_s, iso_s):
+    """The encoder is bound by vector-instruction issue.  Peaks, wave64 instructions per second on 256 CUs x
+    4 SIMDs at 2.4 GHz: (a) the guide's 2 cycles per instruction on a SIMD-32 (MI355X_MICROARCH.md l.53),
+    (b) what tools/valu_probe measures on the box: and / or / add / mov on VGPR operands reach ~0.41 per
+    cycle per SIMD, every other class this kernel is made of -- shifts, v_min, compares, every VOP3 form
+    (v_alignbit, v_perm, v_bfe, v_mbcnt, v_cndmask_e64, v_mad), v_mul_u32_u24, DPP moves, any SGPR operand
+    -- ~0.24, i.e. one per 4.2 cycles however many waves are resident."""
+    if not insts:
+        return None
+    simd_hz = 256 * 4 * 2.4e9
+    pr = probe_rates() or {}
+    res = {"valu_wave_insts_per_frame": int(insts),
+           "achieved_per_cycle_per_simd": {"single_stream": round(insts / iso_s / simd_hz, 4),
+                                           "pipelined": round(insts / step_s / simd_hz, 4)},
+           "peak_guide_per_cycle_per_simd": 0.5,
+           "frac_of_guide_peak": {"single_stream": round(insts / iso_s / simd_hz / 0.5, 4),
+                                  "pipelined": round(insts / step_s / simd_hz / 0.5, 4)},
+           "source": "profiles/%s_pmc_sq.csv (SQ_INSTS_VALU, rocprofv3 --pmc pass, offline) / tools/valu_probe" % PROFILE_TAG}
+    if "half_rate" in pr:
+        res["probe"] = pr
+        res["frac_of_probe_half_rate_peak"] = {"single_stream": round(insts / iso_s / simd_hz / pr["half_rate"], 4),
+                                               "pipelined": round(insts / step_s / simd_hz / pr["half_rate"], 4)}
+    return res
 
 
 def dwt_bytes(P, wl, s0):
@@ -225,14 +272,15 @@ def main():
     for i in range(args.warmup):
         step(i == 0)
     sync_all()
+    prof_cap = min(256, (args.steps * calls_per_step + nstreams - 1) // nstreams)      # calls timed per stream
     for c in codecs:
-        c.profile_begin(args.steps * calls_per_step)
+        c.profile_begin(prof_cap)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(False)
     sync_all()
     dt = time.perf_counter() - t0
-    stage_ms = np.concatenate([c.profile_read(args.steps * calls_per_step) for c in codecs], axis=0) / batch   # per frame
+    stage_ms = np.concatenate([c.profile_read(prof_cap) for c in codecs], axis=0) / batch   # per frame
     for c in codecs:
         c.profile_begin(0)
     if world > 1:
@@ -255,17 +303,24 @@ def main():
 
     # ---- the same frames on ONE stream, nothing else on the GPU: per-stage kernel time in isolation
     # (a context of its own, not told that anything shares the GPU: what a single-stream caller gets)
-    iso_n = min(args.steps, 10)
+    iso_n = 12
     iso = codec if nstreams == 1 else pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=lut_dir,
                                                 device=local_rank)
+
+    def iso_call(i):
+        f0 = (i * batch) % pool_n
+        if batch == 1:
+            iso.encode_frame_async(pool[f0], outs[0][0], 1)
+        else:
+            iso.encode_frames_async(pool[f0:f0 + batch], outs[0], 1)
     for i in range(2):
-        iso.encode_frame_async(frame, out, 1)
+        iso_call(i)
     torch.cuda.synchronize()
     iso.profile_begin(iso_n)
     for i in range(iso_n):
-        iso.encode_frame_async(frame, out, 1)
+        iso_call(2 + i)
     torch.cuda.synchronize()
-    iso_ms = iso.profile_read(iso_n).mean(axis=0)
+    iso_ms = iso.profile_read(iso_n).mean(axis=0) / batch              # per frame
     iso.profile_begin(0)
 
     # ---- measured device-copy roof ("use the measured device copy bandwidth as the roof
@@ -309,48 +364,47 @@ def main():
     ms_per_frame = ms_per_step / fps
     mpix = (W * H * world * args.steps * fps) / dt / 1e6
 
-    # ---- roofline of the dominant kernel (bpc_kernel<false>): algorithmic bytes per launch
-    # (nCB*16384 coefficient bytes + 4*nCB sizes + 2*sum(ncw) codeword bytes) over the
-    # kernel's mean duration measured with HIP events on the launch stream inside the timed region.
+    # ---- roofline of the dominant kernel (bpc_encode_kernel): algorithmic bytes per launch
+    # (nCB*16384 coefficient bytes + 4*nCB sizes + 2*sum(ncw) codeword bytes per frame, x the
+    # `batch` frames of a launch) over the kernel's mean duration measured with HIP events on the launch
+    # stream inside the timed region.
     sizes = stream0.cpu().numpy().view(np.uint16)[10:10 + 2 * nCB:2].astype(np.int64)
     ncw = int((sizes - 1).sum())
-    bpc_bytes = nCB * 16384 + 4 * nCB + 2 * ncw
-    dwt_ms, bpc_ms, pack_ms = [float(x) for x in stage_ms.mean(axis=0)]
-    bpc_gbs = bpc_bytes / (bpc_ms * 1e-3) / 1e9
-    dwt_b = dwt_bytes(P, wl, 1)
-    bpc_traffic, dwt_traffic = pmc_traffic(args.workload)
+    bpc_bytes = (nCB * 16384 + 4 * nCB + 2 * ncw) * batch
+    dwt_ms, bpc_ms, pack_ms = [float(x) for x in stage_ms.mean(axis=0)]        # per frame
+    bpc_launch_ms, dwt_launch_ms = bpc_ms * batch, dwt_ms * batch
+    bpc_gbs = bpc_bytes / (bpc_launch_ms * 1e-3) / 1e9
+    dwt_b = dwt_bytes(P, wl, 1) * batch
+    bpc_traffic, dwt_traffic = pmc_traffic(args.workload, batch)
     roofline = {"kernel": "bpc_encode_kernel (BPC-PaCo encode)", "bound": "hbm",
                 "achieved": round(bpc_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(bpc_gbs / HBM_PEAK_GBS, 5), "traffic": bpc_traffic,
-                "algorithmic_bytes_per_launch": bpc_bytes, "avg_launch_ms": round(bpc_ms, 4),
-                "codeblocks_per_s": round(nCB / (bpc_ms * 1e-3), 1),
-                "single_stream": {"avg_launch_ms": round(float(iso_ms[1]), 4),
+                "algorithmic_bytes_per_launch": bpc_bytes, "frames_per_launch": batch,
+                "avg_launch_ms": round(bpc_launch_ms, 4),
+                "codeblocks_per_s": round(nCB * batch / (bpc_launch_ms * 1e-3), 1),
+                "single_stream": {"avg_launch_ms": round(float(iso_ms[1]) * batch, 4),
                                   "codeblocks_per_s": round(nCB / (float(iso_ms[1]) * 1e-3), 1)},
-                "valu_issue": valu_issue(pmc_valu(args.workload), dt / args.steps, float(iso_ms[1]) * 1e-3),
+                "valu_issue": valu_issue(pmc_valu(args.workload), ms_per_frame * 1e-3, float(iso_ms[1]) * 1e-3),
                 "note": "BPC is bound by vector-instruction issue, not HBM (SURVEY 8d): codeblocks/s and "
-                        "valu_issue are the figures of merit, the HBM fraction is reported for completeness; "
-                        "`traffic` (PMC) exceeds the algorithmic bytes because the coefficients are read twice "
-                        "(MSB search, then bit-plane transposition); the 96-VGPR build (5 waves/SIMD, the "
-                        "faster one when frames are pipelined) spills 17 dwords per lane to scratch and "
-                        "parks the bit-planes below the 8 it keeps in registers in an HBM scratch"}
+                        "valu_issue are the figures of merit, the HBM fraction is reported for completeness. "
+                        "`traffic` is the PMC figure of the committed counter passes (profiles/): the coefficients "
+                        "are read once, the transposed bit-planes go through a 16 KB-per-wave scratch"}
     roofline_dwt = {"kernel": "dwt_fwd_kernel / dwt_fwd2_kernel (all levels, u8 ingest fused)", "bound": "hbm",
-                    "achieved": round(dwt_b / (dwt_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(dwt_b / (dwt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "traffic": dwt_traffic, "algorithmic_bytes_per_launch": int(dwt_b),
-                    "avg_launch_ms": round(dwt_ms, 4),
-                    "single_stream": {"avg_launch_ms": round(float(iso_ms[0]), 4),
-                                      "achieved": round(dwt_b / (float(iso_ms[0]) * 1e-3) / 1e9, 2),
-                                      "frac": round(dwt_b / (float(iso_ms[0]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                    "achieved": round(dwt_b / (dwt_launch_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(dwt_b / (dwt_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "traffic": dwt_traffic, "algorithmic_bytes_per_launch": int(dwt_b), "frames_per_launch": batch,
+                    "avg_launch_ms": round(dwt_launch_ms, 4),
+                    "single_stream": {"avg_launch_ms": round(float(iso_ms[0]) * batch, 4),
+                                      "achieved": round(dwt_b / (float(iso_ms[0]) * batch * 1e-3) / 1e9, 2),
+                                      "frac": round(dwt_b / (float(iso_ms[0]) * batch * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
                     "measured_roof": {"copy_i32_GBps": round(copy_gbs, 1), "fill_i32_GBps": round(fill_gbs, 1),
                                       "frac_of_copy_single_stream":
-                                          round(dwt_b / (float(iso_ms[0]) * 1e-3) / 1e9 / copy_gbs, 5)},
+                                          round(dwt_b / (float(iso_ms[0]) * batch * 1e-3) / 1e9 / copy_gbs, 5)},
                     "note": "all of a frame's level launches counted as one; `achieved` uses HIP-event times "
-                            "inside the timed region, where frames of the other stream(s) share the GPU and the "
-                            f"contexts are set pipelined (levels 0 and 1 as two launches: {wl} launches); "
-                            "`single_stream` is the same frame on one stream with nothing else running, on a "
-                            f"context that is not (levels 0 and 1 in one launch, LL1 never leaves the registers: "
-                            f"{wl - 1} launches); `measured_roof` is a plain device copy / fill of one "
-                            "coefficient plane"}
+                            "inside the timed region, where the calls of the other stream(s) share the GPU; "
+                            "`single_stream` is the same call shape on one stream with nothing else running; the "
+                            "input frames rotate over a pool larger than the Infinity Cache, so every frame's "
+                            "pixels come from HBM; `measured_roof` is a plain device copy / fill of a 134 MB plane"}
 
     # ---- CPU baseline: the oracle (C port, OpenMP over codeblocks / DWT rows+columns) on the
     # box's host cores, rank 0, N = 1 only.  Same stage boundaries as the GPU step (level shift +
@@ -413,15 +467,19 @@ def main():
         "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32" if lossy else "int32", "data": "synthetic",
-        "config": {"workload": f"{W}x{H} greyscale u8 frame (padded {AW}x{AH}), "
+        "config": {"workload": f"{W}x{H} greyscale u8 frames (padded {AW}x{AH}), "
                                f"-type {int(lossy)} {'9/7 qs=%g' % qs if lossy else '5/3 lossless'}, "
-                               f"wl={wl}, cp=2, k=0, LUT {'n1_lossy' if lossy else 'n1_lossless'}, "
-                               f"1 frame/step/GPU, frames sharded over {world} GPU(s), "
-                               f"{nstreams} HIP stream(s) per GPU",
+                               f"wl={wl}, cp=2, k=0, LUT {'n1_lossy' if lossy else 'n1_lossless'}; "
+                               f"a step = {fps} frames per GPU from a pool of {pool_n} distinct HBM-resident frames "
+                               f"({pool_n * P / 1e6:.0f} MB), {batch} frame(s) per call, calls alternating over "
+                               f"{nstreams} HIP stream(s); frames sharded over {world} GPU(s)",
+                   "frames_per_step": fps, "frames_per_call": batch, "streams": nstreams, "pool_frames": pool_n,
                    "codeblocks": nCB, "stream_shorts": int(total_shorts),
                    "bits_per_pixel": round(total_shorts * 16 / (W * H), 4)},
-        "roundtrip_ok": roundtrip_ok, "range_flag": flag,
-        "stage_ms": {"dwt": round(dwt_ms, 4), "bpc": round(bpc_ms, 4), "pack": round(pack_ms, 4)},
+        "ms_per_frame": round(ms_per_frame, 5), "timed_seconds": round(dt, 3),
+        "roundtrip_ok": roundtrip_ok, "timed_loop_outputs_ok": loop_ok, "range_flag": flag,
+        "stage_ms": {"dwt": round(dwt_ms, 4), "bpc": round(bpc_ms, 4), "pack": round(pack_ms, 4),
+                     "note": "per frame, HIP events on the launch streams inside the timed region"},
         "stage_ms_single_stream": {"dwt": round(float(iso_ms[0]), 4), "bpc": round(float(iso_ms[1]), 4),
                                    "pack": round(float(iso_ms[2]), 4)},
         "roofline": roofline, "roofline_dwt": roofline_dwt, "cpu_baseline": cpu,

@@ -210,6 +210,16 @@ __device__ __forceinline__ void lut_to_lds(const int32_t *lut, int total, uint8_
 #define PICSONG_BPC_DEC_WG 4
 #endif
 constexpr int kBpcEncWgWaves = PICSONG_BPC_ENC_WG, kBpcDecWgWaves = PICSONG_BPC_DEC_WG;
+// LDS operations of the wave's other lanes have completed
+__device__ __forceinline__ void wave_lds_done()
+{
+#if defined(__AMDGCN__)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#else
+    (void)__builtin_amdgcn_ballot_w64(true);
+#endif
+}
 // stores of the wave's other lanes to addresses this lane is about to overwrite have completed
 __device__ __forceinline__ void wave_stores_issued()
 {
@@ -387,8 +397,30 @@ __device__ __forceinline__ void reserve_enc(Coder &c, bool need, uint64_t m, uin
 // Per-lane state of the encoder: interval (L, S) and the BYTE offset `off`, from the wave's staging
 // base, of the codeword slot the lane has reserved.  Wave state: the two codeblocks' codeword counters
 // (SGPRs), the ballot of exhausted intervals, and constants of the wave.
+// PICSONG_ENC_LDS_RESERVE (default 1): a codeword slot is taken with ONE LDS atomic -- ds_add_rtn_u32 on the
+// codeblock's codeword counter, every requesting lane adding 1 -- instead of ballot popcounts, v_mbcnt ranks
+// and scalar counters.  The reference's order (requesting lanes of a call site in ascending lane order,
+// BPCEngine.cu:380-393) is the order in which the LDS hands the pre-add values back to the lanes of one
+// instruction that hit one address; that is how gfx950 resolves the conflict, it is checked against the
+// v_mbcnt form by tests/test_gpu_parity.py::test_lds_atomic_reservation_order and by every codestream
+// comparison with the oracle, and PICSONG_ENC_LDS_RESERVE=0 builds the v_mbcnt form.  The returned value is
+// not needed until the lane's NEXT reservation (it only addresses the deferred store), so no wait for the
+// LDS sits in the call site's dependent chain.
+#ifndef PICSONG_ENC_LDS_RESERVE
+#define PICSONG_ENC_LDS_RESERVE 1
+#endif
+// (the CPU wave emulator of the tests runs lanes as coroutines, not in lane order between two cross-lane
+// operations: it builds the v_mbcnt form, which states the order explicitly)
+#if PICSONG_ENC_LDS_RESERVE && defined(__AMDGCN__)
+#define PS_ENC_LDS 1
+#else
+#define PS_ENC_LDS 0
+#endif
+
 struct EncCoder {
     uint32_t L, S, off;
+    uint32_t slot;              // LDS form: raw pre-add value of the lane's reservation (clamped when used)
+    uint32_t *ldscnt;           // LDS form: the lane's codeblock's codeword counter
     uint32_t cnt_lo, cnt_hi;
     uint64_t emptym;            // ballot(S == 0) as of the end of the previous call site
     uint32_t halfoff4;          // byte offset of slot 0 of the lane's codeblock: half * 16384 + 4
@@ -405,6 +437,17 @@ struct EncCoder {
 // overwrites with the MSB after the wave's stores have drained.
 __device__ __forceinline__ void enc_reserve(EncCoder &c, uint64_t m, uint32_t upper_mask)
 {
+#if PS_ENC_LDS
+    (void)upper_mask;
+    if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+        // the codeword this lane has just finished goes to the slot it reserved last time (slot starts at
+        // -1: word 0 of the staging, see above)
+        const uint32_t sl = (int32_t)c.slot > 4094 ? 4094u : c.slot;
+        *reinterpret_cast<int32_t *>(c.stw + ((sl << 2) + c.halfoff4)) = (int32_t)c.L;
+        c.slot = __hip_atomic_fetch_add(c.ldscnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        c.L = 0u; c.S = 0xFFFFu;
+    }
+#else
     const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
     const uint32_t nlo = (uint32_t)__builtin_popcount(mlo), nhi = (uint32_t)__builtin_popcount(mhi);
     const uint32_t base = c.cnt_lo + (upper_mask & (c.cnt_hi - nlo - c.cnt_lo));
@@ -418,6 +461,7 @@ __device__ __forceinline__ void enc_reserve(EncCoder &c, uint64_t m, uint32_t up
     const uint32_t a = c.cnt_lo + nlo, b = c.cnt_hi + nhi;
     c.cnt_lo = __builtin_amdgcn_readfirstlane(a > 4095u ? 4095u : a);
     c.cnt_hi = __builtin_amdgcn_readfirstlane(b > 4095u ? 4095u : b);
+#endif
 }
 
 // One call site.  onm = ballot of the lanes that code a symbol here, onem = those of them whose symbol
@@ -711,7 +755,9 @@ template <bool BULK>
 __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(BpcArgs a)
 {
     __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
+    __shared__ uint32_t lds_cnt[2 * (BULK ? 1 : kBpcEncWgWaves)];      // codeword counters of the workgroup's codeblocks
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
+    if (t == 0u) lds_cnt[(threadIdx.x >> 6) * 2u + half] = 0u;        // (the table copy below ends with a barrier)
     const int gwave = BULK ? (int)blockIdx.x
                            : (int)blockIdx.x * kBpcEncWgWaves + (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int wave = gwave;                                       // wave within its frame
@@ -820,6 +866,8 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     EncCoder c;
     c.L = 0u; c.S = 0u; c.off = half * 16384u;                // a first reservation "stores" L = 0 to word 0 (see enc_reserve)
     c.cnt_lo = 0u; c.cnt_hi = 0u; c.emptym = ~0ull;
+    c.slot = 0xFFFFFFFFu;                                  // -1: (slot << 2) + halfoff4 = word 0 of the lane's codeblock
+    c.ldscnt = &lds_cnt[(threadIdx.x >> 6) * 2u + half];
     c.halfoff4 = half * 16384u + 4u; c.pone = 1u << prec;
     c.stw = reinterpret_cast<char *>(stw);
     U64 AL = { 0u, 0u }, AR = { 0u, 0u };                 // significant before the current plane
@@ -916,8 +964,18 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     }
 
     // flush (Encode BPCEngine.cu:1719) + sizeArray (:2010) + MSB slot (:1998)
+#if PS_ENC_LDS
+    if (coded) {
+        const uint32_t sl = (int32_t)c.slot > 4094 ? 4094u : c.slot;
+        *reinterpret_cast<int32_t *>(c.stw + ((sl << 2) + c.halfoff4)) = (int32_t)c.L;
+    }
+    wave_lds_done();                                       // every lane's last atomic has landed
+    const uint32_t cw_count = *c.ldscnt;
+    const uint32_t size = (cw_count > 4095u ? 4095u : cw_count) + 1u;
+#else
     if (coded) *reinterpret_cast<int32_t *>(c.stw + c.off) = (int32_t)c.L;
     const uint32_t size = (half ? c.cnt_hi : c.cnt_lo) + 1u;
+#endif
     if (valid && t == 0u) a.sizes[cb] = (int32_t)size;
     // word 0 (the MSB) and expansionFix :1905-1912 (which overwrites the whole block) must land after every
     // codeword store of the block, the lanes' first-reservation stores to word 0 included
@@ -934,6 +992,39 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     }
 }
 
+
+// Self-test of the property the LDS form of the slot reservation rests on: when several lanes of ONE
+// ds_add_rtn_u32 hit one address, the pre-add values come back in ascending lane order.  Every wave draws
+// `iters` pseudo-random 64-bit lane masks, lets the lanes in the mask add 1 to their half's counter and
+// compares what they get with the counter's value before the instruction plus their v_mbcnt rank.
+__global__ __launch_bounds__(256) void lds_order_selftest_kernel(int iters, uint32_t seed, uint32_t *mismatches)
+{
+    __shared__ uint32_t cnt[8];
+    const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, w = threadIdx.x >> 6;
+    if ((lane & 31u) == 0u) cnt[w * 2u + half] = 0u;
+    __syncthreads();
+    uint32_t z = seed ^ (blockIdx.x * 0x9E3779B9u) ^ (w * 0x85EBCA6Bu), bad = 0u, expect_lo = 0u, expect_hi = 0u;
+    for (int i = 0; i < iters; i++) {
+        z = 1664525u * z + 1013904223u;
+        uint32_t mlo = z;
+        z = 1664525u * z + 1013904223u;
+        uint32_t mhi = z;
+        // every density occurs: all lanes, sparse masks, one half only
+        if ((i & 7) == 1) { mlo &= mlo >> 3; mhi &= mhi << 5; }
+        if ((i & 7) == 2) { mlo = ~0u; mhi = ~0u; }
+        if ((i & 7) == 3) mlo = 0u;
+        mlo = __builtin_amdgcn_readfirstlane(mlo); mhi = __builtin_amdgcn_readfirstlane(mhi);
+        const uint64_t m = ((uint64_t)mhi << 32) | mlo;
+        uint32_t got = 0u;
+        const bool in = __builtin_amdgcn_inverse_ballot_w64(m);
+        if (in) got = __hip_atomic_fetch_add(&cnt[w * 2u + half], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const uint32_t rank = half ? __builtin_amdgcn_mbcnt_hi(mhi, 0u) : __builtin_amdgcn_mbcnt_lo(mlo, 0u);
+        if (in && got != (half ? expect_hi : expect_lo) + rank) bad++;
+        expect_lo += (uint32_t)__builtin_popcount(mlo);
+        expect_hi += (uint32_t)__builtin_popcount(mhi);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
 
 // =============================================================================================
 // Decoder (kernelBPCDecoder BPCEngine.cu:2126-2215, Decode :1777-1837, SPPDecoder :559-594,

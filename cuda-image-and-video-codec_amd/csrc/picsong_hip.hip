@@ -647,6 +647,26 @@ int picsong_bpc_decode_component(picsong_ctx *c, int comp, const int32_t *d_stag
     return bpc_decode_impl(c, d_staging, d_sizes, d_coeffs, (hipStream_t)stream, comp);
 }
 
+int picsong_selftest_lds_order(int device, int *mismatches)
+{
+    if (!mismatches) return fail(PICSONG_ERR_ARG, "selftest: null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(PICSONG_ERR_NODEVICE, "no HIP device: this library has no CPU path");
+    if (device < 0 || device >= ndev) return fail(PICSONG_ERR_ARG, "device %d of %d", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    uint32_t *d = nullptr, h = 0;
+    HIP_TRY(hipMalloc(&d, sizeof(uint32_t)));
+    HIP_TRY(hipMemset(d, 0, sizeof(uint32_t)));
+    lds_order_selftest_kernel<<<2048, 256>>>(2000, 0x5EED1234u, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(PICSONG_ERR_HIP, "selftest: %s", hipGetErrorString(e));
+    *mismatches = (int)h;
+    return PICSONG_OK;
+}
+
 int picsong_range_flag(picsong_ctx *c, void *stream, int *h_flag)
 {
     if (!c || !h_flag) return fail(PICSONG_ERR_ARG, "range_flag: null argument");

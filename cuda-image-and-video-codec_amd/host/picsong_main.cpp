@@ -43,6 +43,8 @@ struct Options {
     int cd = 2, x = 0, y = 0, cb_width = 64, cb_height = 18, wl = 5, cp = 2, endianess = 0, bps = 8;
     int signed_or_unsigned = 0, video = 0, frames = 0, avoid_size_check = 0, components = 1, streams = 2;
     int is_rgb = 0, type = 0, device = 0, lut_fill = 0;
+    int gpus = 1, frames_per_launch = 0;        // -gpus N: frames sharded over N devices; -framesPerLaunch B (0 = by frame size)
+    std::string devices;                        // --devices a,b,..: explicit device list (a device may repeat)
     float qs = 1.0f, k = 0.0f;
     std::string metrics;
 };
@@ -93,6 +95,10 @@ void help()
         " -isRGB 1 -components 3  planar R,G,B planes per frame (RCT lossless / ICT lossy)\n"
         " -k 0..65.535        complexity-scalable factor (needs the bit-plane LUT files _0.._14)\n"
         " -device D           GPU index (default 0);  --metrics <file>  JSON stage timings\n"
+        " -gpus N             video coding: groups of frames sharded round-robin over devices D .. D+N-1 of this node\n"
+        "                     (--devices a,b,c names them explicitly); every device copies its codestreams to the\n"
+        "                     writer's pinned ring over its own host link, the output file is the 1-GPU file\n"
+        " -framesPerLaunch B  frames coded per launch (default: 4 up to 4K frames, 1 above)\n"
         " --lut-fill V        value of LUT entries the loader never writes (default 0)\n";
 }
 
@@ -111,6 +117,7 @@ Options parse(const Args &a)
     gets("-i", o.input); gets("-o", o.output); gets("-LUTFolder", o.lut_folder);
     geti("-numberOfStreams", o.streams); geti("-video", o.video);
     geti("-device", o.device); geti("--lut-fill", o.lut_fill); gets("--metrics", o.metrics);
+    geti("-gpus", o.gpus); geti("-framesPerLaunch", o.frames_per_launch); gets("--devices", o.devices);
     if (o.cd == 0) {
         geti("-xSize", o.x); geti("-ySize", o.y); geti("-cbWidth", o.cb_width); geti("-cbHeight", o.cb_height);
         geti("-wl", o.wl); geti("-cp", o.cp); geti("-endianess", o.endianess); geti("-bps", o.bps);
@@ -155,6 +162,7 @@ bool read_frame(std::ifstream &f, size_t base, size_t frame, int w, int h, uint8
 struct Worker {
     picsong_ctx *ctx = nullptr;
     hipStream_t stream = nullptr;
+    int device = 0;                                // the GPU this slot's context, stream and buffers live on
     uint8_t *h_in = nullptr, *d_in = nullptr;      // padded frame, pinned / device
     uint16_t *h_out = nullptr, *d_out = nullptr;   // codestream, pinned / device
     uint8_t *h_raw = nullptr;                      // unpadded frame (host)
@@ -280,29 +288,59 @@ int run_encode(Options o)
     const long nframes = o.video ? o.frames : 1;
     if (nframes <= 0) die("Incorrect parameters. Please choose valid values. (-frames)");
     if (o.is_rgb) return run_encode_rgb(o, pgm.is_pgm ? pgm.offset : 0, nframes);
-    // slots of the pipeline: at least 6 for a video (2 readers | launch | run | collect | 2 writers overlap)
-    const int nstreams = o.video ? ((o.streams < 3 ? 3 : o.streams) + 3) : 1;
-
-    HIPCK(hipSetDevice(o.device));
+    // ---- devices: -gpus N takes devices D .. D+N-1, --devices names them (a device may repeat: several
+    // worker sets on one GPU, which is also how the sharded path is exercised on a one-GPU box)
+    std::vector<int> devs;
+    {
+        int ndev = 0;
+        HIPCK(hipGetDeviceCount(&ndev));
+        if (!o.devices.empty()) {
+            std::stringstream ss(o.devices);
+            std::string tok;
+            while (std::getline(ss, tok, ',')) if (!tok.empty()) devs.push_back(std::stoi(tok));
+        } else {
+            for (int i = 0; i < (o.gpus < 1 ? 1 : o.gpus); i++) devs.push_back(o.device + i);
+        }
+        if (devs.empty()) die("Incorrect parameters. Please choose valid values. (--devices)");
+        for (int d : devs)
+            if (d < 0 || d >= ndev) die("Incorrect parameters. -gpus / --devices name GPU " + std::to_string(d) + ", this node has " + std::to_string(ndev));
+        if (!o.video && devs.size() > 1) devs.resize(1);           // one image = one frame = one GPU
+    }
+    const int ndevs = (int)devs.size();
     const int aw = picsong_pad_dim(o.x), ah = picsong_pad_dim(o.y);
     const size_t P = (size_t)aw * ah, max_shorts = picsong_max_stream_shorts(aw, ah);
+    // frames per launch: a 4K frame is 1020 coder waves, one per SIMD; four of them fill the GPU like an 8K frame
+    int B = o.frames_per_launch > 0 ? o.frames_per_launch : (P <= (size_t)3840 * 2176 ? 4 : 1);
+    if (!o.video || o.k > 0.0f) B = 1;
+    if (B > 16) B = 16;
+    if ((long)B > nframes) B = (int)nframes;
+    const long ngroups = (nframes + B - 1) / B;
+    // slots of the pipeline: at least 6 for a video (2 readers | launch | run | collect | 2 writers overlap),
+    // a multiple of the device count so that slot i always belongs to device i mod ndevs
+    int nstreams = o.video ? ((o.streams < 3 ? 3 : o.streams) + 3) : 1;
+    if (o.video) nstreams = (nstreams + ndevs - 1) / ndevs * ndevs;
+    if (nstreams < ndevs) nstreams = ndevs;
+
     const size_t frame_bytes = (size_t)o.x * o.y, file_base = pgm.is_pgm ? pgm.offset : 0;
     const bool padded_already = (o.x == aw && o.y == ah);
     picsong_params params = make_params(o);
     std::vector<Worker> w((size_t)nstreams);
-    for (auto &k : w) {
-        CK(picsong_ctx_create(&params, o.device, &k.ctx));
+    for (int i = 0; i < nstreams; i++) {
+        Worker &k = w[(size_t)i];
+        k.device = devs[(size_t)(i % ndevs)];
+        HIPCK(hipSetDevice(k.device));
+        CK(picsong_ctx_create(&params, k.device, &k.ctx));
         if (nstreams > 1) CK(picsong_ctx_set_pipelined(k.ctx, 1));     // the video engine keeps frames in flight
         load_lut(k.ctx, o, o.wl, 1, o.k);
         HIPCK(hipStreamCreate(&k.stream));
-        HIPCK(hipHostMalloc(&k.h_in, P));
-        HIPCK(hipMalloc(&k.d_in, P));
-        HIPCK(hipHostMalloc(&k.h_out, max_shorts * 2));
-        HIPCK(hipMalloc(&k.d_out, max_shorts * 2));
+        HIPCK(hipHostMalloc(&k.h_in, P * B));
+        HIPCK(hipMalloc(&k.d_in, P * B));
+        HIPCK(hipHostMalloc(&k.h_out, max_shorts * 2 * B));
+        HIPCK(hipMalloc(&k.d_out, max_shorts * 2 * B));
         k.h_raw = (uint8_t *)malloc(frame_bytes);
-        // stage timers (HIP events): at most kProfFrames frames per slot are timed, so the event count does
+        // stage timers (HIP events): at most kProfFrames launches per slot are timed, so the event count does
         // not grow with the video; "BPC acum time" scales their mean to all frames
-        CK(picsong_profile_begin(k.ctx, (int)std::min<long>((nframes + nstreams - 1) / nstreams, kProfFrames)));
+        CK(picsong_profile_begin(k.ctx, (int)std::min<long>((ngroups + nstreams - 1) / nstreams, kProfFrames)));
     }
     const int fd = open(o.input.c_str(), O_RDONLY);
     if (fd < 0) die("Cannot open input file " + o.input);
@@ -315,11 +353,13 @@ int run_encode(Options o)
     auto t0 = std::chrono::steady_clock::now();
 
     // slot state machine: FREE -(reader)-> FILLED -(main)-> LAUNCHED -(collector)-> COLLECTED
-    // -(writer)-> FREE; `expect` is the frame the slot takes next, so frames f and f + S never race
+    // -(writer)-> FREE; a slot carries one GROUP of up to B consecutive frames; `expect` is the group the
+    // slot takes next, so groups g and g + S never race
     enum { FREE = 0, FILLED = 1, LAUNCHED = 2, COLLECTED = 3 };
-    struct SlotState { int state = FREE; long expect = 0; off_t offset = 0; int total = 0; };
+    struct SlotState { int state = FREE; long expect = 0; int n = 0; off_t offset[16]; int total[16]; };
     std::vector<SlotState> st((size_t)nstreams);
     for (int i = 0; i < nstreams; i++) st[(size_t)i].expect = i;
+    auto group_frames = [&](long g) { return (int)std::min<long>(B, nframes - g * B); };
     std::mutex mu;
     std::condition_variable cv;
     std::string failure;                      // first error of a helper thread (reported by main)
@@ -331,120 +371,134 @@ int run_encode(Options o)
         return std::chrono::duration<double>(b - a).count(); };
 
     auto reader = [&](int r, int nreaders) {
-        for (long f = r; f < nframes; f += nreaders) {
-            const size_t si = (size_t)(f % nstreams);
+        for (long g = r; g < ngroups; g += nreaders) {
+            const size_t si = (size_t)(g % nstreams);
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !failure.empty() || (st[si].state == FREE && st[si].expect == f); });
+                cv.wait(lk, [&] { return !failure.empty() || (st[si].state == FREE && st[si].expect == g); });
                 if (!failure.empty()) return;
             }
             Worker &k = w[si];
-            uint8_t *dst = padded_already ? k.h_in : k.h_raw;
+            const int n = group_frames(g);
             const auto tr0 = now();
-            size_t got = 0;
-            while (got < frame_bytes) {
-                ssize_t n = pread(fd, dst + got, frame_bytes - got, (off_t)(file_base + (size_t)f * frame_bytes + got));
-                if (n <= 0) break;
-                got += (size_t)n;
-            }
             std::string err;
-            if (got != frame_bytes) err = "Input file is shorter than the requested frames.";
-            else if (!padded_already && picsong_pad_frame_host(k.h_raw, o.x, o.y, k.h_in, aw, ah) != PICSONG_OK)
-                err = picsong_last_error();
+            for (int j = 0; j < n && err.empty(); j++) {
+                const long f = g * B + j;
+                uint8_t *dst = padded_already ? k.h_in + (size_t)j * P : k.h_raw;
+                size_t got = 0;
+                while (got < frame_bytes) {
+                    ssize_t m = pread(fd, dst + got, frame_bytes - got, (off_t)(file_base + (size_t)f * frame_bytes + got));
+                    if (m <= 0) break;
+                    got += (size_t)m;
+                }
+                if (got != frame_bytes) err = "Input file is shorter than the requested frames.";
+                else if (!padded_already && picsong_pad_frame_host(k.h_raw, o.x, o.y, k.h_in + (size_t)j * P, aw, ah) != PICSONG_OK)
+                    err = picsong_last_error();
+            }
             t_read[(size_t)r] += secs(tr0, now());
             std::lock_guard<std::mutex> lk(mu);
             if (!err.empty() && failure.empty()) failure = err;
+            st[si].n = n;
             st[si].state = FILLED;
             cv.notify_all();
         }
     };
-    // collector (one thread, frame order): waits for the frame's length and fixes its place in the
-    // file; writers (any order): copy the codestream back, pwrite it there and free the slot
+    // collector (one thread, group order): waits for the group's lengths and fixes every frame's place in
+    // the file; writers (any order): copy the codestreams back over the slot's device's own host link,
+    // pwrite them there and free the slot
     auto collector = [&] {
-        (void)hipSetDevice(o.device);
         off_t offset = out_base;
-        for (long f = 0; f < nframes; f++) {
-            const size_t si = (size_t)(f % nstreams);
+        for (long g = 0; g < ngroups; g++) {
+            const size_t si = (size_t)(g % nstreams);
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !failure.empty() || (st[si].state == LAUNCHED && st[si].expect == f); });
+                cv.wait(lk, [&] { return !failure.empty() || (st[si].state == LAUNCHED && st[si].expect == g); });
                 if (!failure.empty()) return;
             }
             Worker &k = w[si];
-            int total = 0;
+            (void)hipSetDevice(k.device);
+            const int n = st[si].n;
+            int totals[16] = { 0 };
             std::string err;
             const auto tw0 = now();
-            if (picsong_last_total(k.ctx, k.stream, &total) != PICSONG_OK) err = picsong_last_error();
+            if (B == 1) { if (picsong_last_total(k.ctx, k.stream, &totals[0]) != PICSONG_OK) err = picsong_last_error(); }
+            else if (picsong_last_totals(k.ctx, k.stream, n, totals) != PICSONG_OK) err = picsong_last_error();
             t_wait_gpu += secs(tw0, now());
             std::lock_guard<std::mutex> lk(mu);
             if (!err.empty() && failure.empty()) failure = err;
-            frame_totals[(size_t)f] = total;
-            total_shorts += total;
-            st[si].offset = offset;
-            st[si].total = total;
+            for (int j = 0; j < n; j++) {
+                frame_totals[(size_t)(g * B + j)] = totals[j];
+                total_shorts += totals[j];
+                st[si].offset[j] = offset;
+                st[si].total[j] = totals[j];
+                offset += (off_t)totals[j] * 2;
+            }
             st[si].state = COLLECTED;
-            offset += (off_t)total * 2;
             cv.notify_all();
         }
     };
     std::vector<double> t_write_v(8, 0.0);
     auto writer = [&](int r, int nwriters) {
-        (void)hipSetDevice(o.device);
-        for (long f = r; f < nframes; f += nwriters) {
-            const size_t si = (size_t)(f % nstreams);
-            off_t offset;
-            int total;
+        for (long g = r; g < ngroups; g += nwriters) {
+            const size_t si = (size_t)(g % nstreams);
+            SlotState ss;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !failure.empty() || (st[si].state == COLLECTED && st[si].expect == f); });
+                cv.wait(lk, [&] { return !failure.empty() || (st[si].state == COLLECTED && st[si].expect == g); });
                 if (!failure.empty()) return;
-                offset = st[si].offset; total = st[si].total;
+                ss = st[si];
             }
             const auto tw1 = now();
-            const char *src = reinterpret_cast<const char *>(w[si].h_out);
-            size_t left = (size_t)total * 2, done = 0;
             std::string err;
-            if (hipMemcpyAsync(w[si].h_out, w[si].d_out, left, hipMemcpyDeviceToHost, w[si].stream) != hipSuccess ||
-                hipStreamSynchronize(w[si].stream) != hipSuccess) {
-                err = "HIP error while copying a codestream back";
-                left = 0;
-            }
-            while (left) {
-                ssize_t n = pwrite(ofd, src + done, left, offset + (off_t)done);
-                if (n <= 0) { err = "Cannot write the output file " + o.output; break; }
-                done += (size_t)n; left -= (size_t)n;
+            (void)hipSetDevice(w[si].device);
+            for (int j = 0; j < ss.n && err.empty(); j++)
+                if (hipMemcpyAsync(w[si].h_out + (size_t)j * max_shorts, w[si].d_out + (size_t)j * max_shorts,
+                                   (size_t)ss.total[j] * 2, hipMemcpyDeviceToHost, w[si].stream) != hipSuccess)
+                    err = "HIP error while copying a codestream back";
+            if (err.empty() && hipStreamSynchronize(w[si].stream) != hipSuccess) err = "HIP error while copying a codestream back";
+            for (int j = 0; j < ss.n && err.empty(); j++) {
+                const char *src = reinterpret_cast<const char *>(w[si].h_out + (size_t)j * max_shorts);
+                size_t left = (size_t)ss.total[j] * 2, done = 0;
+                while (left) {
+                    ssize_t m = pwrite(ofd, src + done, left, ss.offset[j] + (off_t)done);
+                    if (m <= 0) { err = "Cannot write the output file " + o.output; break; }
+                    done += (size_t)m; left -= (size_t)m;
+                }
             }
             t_write_v[(size_t)r] += secs(tw1, now());
             std::lock_guard<std::mutex> lk(mu);
             if (!err.empty() && failure.empty()) failure = err;
             st[si].state = FREE;
-            st[si].expect = f + nstreams;
+            st[si].expect = g + nstreams;
             cv.notify_all();
         }
     };
-    int nreaders = nframes > 1 ? 2 : 1;
+    int nreaders = ngroups > 1 ? 2 : 1;
     if (const char *e = getenv("PICSONG_READERS")) { int v = atoi(e); if (v >= 1 && v <= 16) nreaders = v; }
     if (nreaders > nstreams - 1 && nstreams > 1) nreaders = nstreams - 1;
     std::vector<std::thread> threads;
     for (int r = 0; r < nreaders; r++) threads.emplace_back(reader, r, nreaders);
-    int nwriters = nframes > 1 ? 2 : 1;
+    int nwriters = ngroups > 1 ? 2 : 1;
     if (const char *e = getenv("PICSONG_WRITERS")) { int v = atoi(e); if (v >= 1 && v <= 8) nwriters = v; }
     threads.emplace_back(collector);
     for (int r = 0; r < nwriters; r++) threads.emplace_back(writer, r, nwriters);
-    for (long f = 0; f < nframes; f++) {
-        const size_t si = (size_t)(f % nstreams);
+    for (long g = 0; g < ngroups; g++) {
+        const size_t si = (size_t)(g % nstreams);
         const auto tm0 = now();
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return !failure.empty() || (st[si].state == FILLED && st[si].expect == f); });
+            cv.wait(lk, [&] { return !failure.empty() || (st[si].state == FILLED && st[si].expect == g); });
             if (!failure.empty()) break;
         }
         const auto tm1 = now();
         t_main_wait += secs(tm0, tm1);
         Worker &k = w[si];
+        const int n = st[si].n;
         std::string err;
-        if (hipMemcpyAsync(k.d_in, k.h_in, P, hipMemcpyHostToDevice, k.stream) != hipSuccess) err = "HIP error in the frame upload";
-        else if (picsong_encode_frame(k.ctx, k.d_in, f == 0 ? 0 : 1, k.d_out, k.stream) != PICSONG_OK) err = picsong_last_error();
+        if (hipSetDevice(k.device) != hipSuccess ||
+            hipMemcpyAsync(k.d_in, k.h_in, P * (size_t)n, hipMemcpyHostToDevice, k.stream) != hipSuccess) err = "HIP error in the frame upload";
+        else if (B == 1) { if (picsong_encode_frame(k.ctx, k.d_in, g == 0 ? 0 : 1, k.d_out, k.stream) != PICSONG_OK) err = picsong_last_error(); }
+        else if (picsong_encode_frames(k.ctx, n, k.d_in, P, (int)(g * B), k.d_out, max_shorts, k.stream) != PICSONG_OK) err = picsong_last_error();
         t_launch += secs(tm1, now());
         std::lock_guard<std::mutex> lk(mu);
         if (!err.empty() && failure.empty()) failure = err;
@@ -466,22 +520,24 @@ int run_encode(Options o)
         double rd = 0; for (double v : t_read) rd += v;
         std::cout << "host pipeline seconds: read(sum of " << nreaders << " readers) " << rd << ", main waiting for frames "
                   << t_main_wait << ", main launching " << t_launch << ", writer waiting for the GPU " << t_wait_gpu
-                  << ", writer writing " << t_write << std::endl;
+                  << ", writer writing " << t_write << "; " << ndevs << " device(s), " << B << " frame(s) per launch" << std::endl;
     }
 
     double dwt = 0, bpc = 0, pack = 0;
     long counted = 0;
     for (auto &k : w) {
         int n = 0;
-        std::vector<float> ms(3 * (size_t)std::min<long>((nframes + nstreams - 1) / nstreams, kProfFrames) + 3);
+        std::vector<float> ms(3 * (size_t)std::min<long>((ngroups + nstreams - 1) / nstreams, kProfFrames) + 3);
+        (void)hipSetDevice(k.device);
         CK(picsong_profile_read(k.ctx, &n, ms.data(), (int)(ms.size() / 3)));
         for (int i = 0; i < n; i++) { dwt += ms[3 * i]; bpc += ms[3 * i + 1]; pack += ms[3 * i + 2]; counted++; }
     }
     std::cout << "The time spent with the app without considering allocation periods is: " << sec << std::endl;
-    std::cout << "BPC acum time is: " << (counted ? bpc / counted * (double)nframes : 0.0) / 1e3 << std::endl;
-    write_metrics(o, "encode", nframes, sec, counted ? dwt / counted : 0, counted ? bpc / counted : 0,
-                  counted ? pack / counted : 0, total_shorts);
+    std::cout << "BPC acum time is: " << (counted ? bpc / counted * (double)ngroups : 0.0) / 1e3 << std::endl;
+    write_metrics(o, "encode", nframes, sec, counted ? dwt / counted / B : 0, counted ? bpc / counted / B : 0,
+                  counted ? pack / counted / B : 0, total_shorts);
     for (auto &k : w) {
+        (void)hipSetDevice(k.device);
         picsong_ctx_destroy(k.ctx);
         (void)hipStreamDestroy(k.stream);
         (void)hipHostFree(k.h_in); (void)hipFree(k.d_in); (void)hipHostFree(k.h_out); (void)hipFree(k.d_out);

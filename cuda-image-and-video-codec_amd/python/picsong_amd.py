@@ -41,7 +41,7 @@ EXPORTS = [
     "picsong_encode_frame_stripe", "picsong_ctx_set_lut_component", "picsong_rgb_forward", "picsong_rgb_inverse",
     "picsong_encode_plane", "picsong_decode_plane",
     "picsong_ctx_set_lut_device", "picsong_bpc_encode_component", "picsong_bpc_decode_component",
-    "picsong_encode_frames", "picsong_last_totals",
+    "picsong_encode_frames", "picsong_last_totals", "picsong_selftest_lds_order",
 ]
 
 _lib = None

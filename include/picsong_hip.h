@@ -228,6 +228,13 @@ int picsong_pad_frame_host(const uint8_t *in, int w, int h, uint8_t *out, int aw
 int picsong_profile_begin(picsong_ctx *ctx, int capacity);
 int picsong_profile_read(picsong_ctx *ctx, int *n_frames, float *ms, int ms_capacity_frames);
 
+/* ---- self-test of the hardware property the coder's slot reservation uses (one LDS atomic add per
+ *      codeword; lanes of one instruction that hit one counter are served in ascending lane order, the
+ *      order of arithmeticEncoder's __activemask reservation, BPC/BPCEngine.cu:380-393): 16 M random lane
+ *      masks against the v_mbcnt ranks.  *mismatches must come back 0; a build with
+ *      -DPICSONG_ENC_LDS_RESERVE=0 does not depend on it. ---- */
+int picsong_selftest_lds_order(int device, int *mismatches);
+
 /* ---- diagnostics: nonzero if, since the previous query (reading clears it), any codeblock of a
  *      bpc call on ctx had MSB > 15 (outside the LUT's 15 bit-planes), or if
  *      picsong_bitstream_unpack / picsong_decode_frame

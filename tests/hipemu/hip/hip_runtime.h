@@ -154,6 +154,10 @@ static inline unsigned atomicOr(unsigned *p, unsigned v) { unsigned o = *p; *p =
 static inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
 static inline unsigned atomicAdd(unsigned *p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline int atomicMax(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
+#define __ATOMIC_RELAXED_EMU 0
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+template <typename T> static inline T __hip_atomic_fetch_add(T *p, T v, int, int) { T o = *p; *p = o + v; return o; }
 static inline void __threadfence() {}
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
 static inline void __builtin_amdgcn_s_setprio(int) {}

@@ -85,6 +85,43 @@ def test_video_files_roundtrip(oracle, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("extra", [
+    ["-framesPerLaunch", 3],                                   # groups of 3 frames per launch, 11 = 3+3+3+2
+    ["-framesPerLaunch", 2, "--devices", "0,0"],               # two worker sets (the -gpus sharding, on one GPU)
+    ["-framesPerLaunch", 1, "--devices", "0,0,0", "-numberOfStreams", 4],
+])
+def test_video_sharded_and_batched_equals_oracle(oracle, tmp_path, extra):
+    """The video engine with groups of frames per launch and with the groups sharded round-robin over several
+    worker sets (-gpus N / --devices): the output file and _SIZE are the 1-GPU, frame-by-frame ones
+    (CodingEngine::engineManager Engines/CodingEngine.cu:990-1061 round-robins frames over its workers the
+    same way, iteration % N)."""
+    W, H, wl, F = 320, 256, 3, 11
+    frames = [oracle.gen_frame(W, H, 40 + f) for f in range(F)]
+    lutdir = os.path.join(oracle.LUT_DIR, "n1_lossless")
+    raw, enc, dec = tmp_path / "v.raw", tmp_path / "v.enc", tmp_path / "v.dec"
+    np.concatenate([f.ravel() for f in frames]).tofile(raw)
+    r = _run("-cd", 0, "-i", raw, "-o", enc, "-xSize", W, "-ySize", H, "-wl", wl, "-type", 0,
+             "-video", 1, "-frames", F, "-LUTFolder", lutdir, *extra)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lut = oracle.lut_for(False, wl)
+    ref = [oracle.encode_frame(frames[f], wl, False, 1.0, lut, 0 if f == 0 else 1, F) for f in range(F)]
+    assert np.array_equal(np.fromfile(enc, np.uint16), np.concatenate(ref))
+    assert open(str(enc) + "_SIZE").read() == ",".join(str(x.size) for x in ref)
+    r = _run("-cd", 1, "-i", enc, "-o", dec, "-video", 1, "-LUTFolder", lutdir)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(np.fromfile(dec, np.uint8), np.fromfile(raw, np.uint8))
+
+
+@pytest.mark.gpu
+def test_more_gpus_than_the_node_has_is_refused(oracle, tmp_path):
+    raw = tmp_path / "v.raw"
+    oracle.gen_frame(256, 256, 0).tofile(raw)
+    r = _run("-cd", 0, "-i", raw, "-o", tmp_path / "v.enc", "-xSize", 256, "-ySize", 256, "-wl", 2, "-video", 1,
+             "-frames", 1, "-gpus", 64, "-LUTFolder", os.path.join(oracle.LUT_DIR, "n1_lossless"))
+    assert r.returncode != 0 and "this node has" in r.stdout
+
+
+@pytest.mark.gpu
 def test_4k_video_file_equals_oracle_frame_by_frame(oracle, tmp_path):
     """BASELINE configs[3] on one GPU through the CLI: a 4K (3840x2160) greyscale video, -type 0, wl 5,
     -numberOfStreams 3; every frame's codestream equals the oracle's (header on frame 0 only,

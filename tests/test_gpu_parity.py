@@ -203,6 +203,58 @@ def test_full_size_codestream_equals_oracle(oracle, pa, torch, W, H, wl, lossy, 
         oracle.set_threads(1)
 
 
+@pytest.mark.parametrize("W,H,wl,lossy,qs,n,first", [
+    (640, 448, 3, False, 1.0, 5, 0),       # frame 0 of the video in the batch: header on it alone
+    (640, 448, 3, False, 1.0, 3, 7),       # later frames: no header
+    (576, 320, 3, False, 1.0, 4, -2),      # 45 codeblocks (odd: the last wave of a frame is half empty), frame 0 third
+    (512, 512, 4, True, 0.5, 2, 0),
+    (3840, 2160, 5, False, 1.0, 4, 0),     # BASELINE configs[3]'s frames, four to a launch
+])
+def test_batched_frames_equal_oracle(oracle, pa, torch, W, H, wl, lossy, qs, n, first):
+    """picsong_encode_frames: n frames through one launch per stage == the oracle's frame-by-frame streams
+    (CodingEngine::runVideo Engines/CodingEngine.cu:819-872; header on the video's frame 0 only,
+    BitStreamBuilder.cu:277-278)."""
+    oracle.set_threads(oracle.usable_threads())
+    try:
+        lut = oracle.lut_for(lossy, wl)
+        imgs = [oracle.gen_frame(W, H, 20 + i) for i in range(n)]
+        c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=_lutdir(oracle, lossy))
+        frames = _dev(torch, np.stack([oracle.pad_frame(im).reshape(-1) for im in imgs]))
+        got = c.encode_frames(frames, first)
+        assert c.range_flag() == 0
+        for i in range(n):
+            ref = oracle.encode_frame(imgs[i], wl, lossy, qs, lut, 0 if first + i == 0 else 1)
+            g = got[i].cpu().numpy().view(np.uint16)
+            assert g.size == ref.size and np.array_equal(g, ref), f"frame {i} of the batch differs from the oracle"
+        # a smaller batch on the same context afterwards, and the single-frame path, still agree
+        one = c.encode_frame(frames[1], 1).cpu().numpy().view(np.uint16)
+        two = c.encode_frames(frames[:2], 5)
+        assert np.array_equal(two[1].cpu().numpy().view(np.uint16), one)
+        c.close()
+    finally:
+        oracle.set_threads(1)
+
+
+def test_lds_atomic_reservation_order(pa, torch):
+    """The coder takes codeword slots with one LDS atomic add per requesting lane; lanes of one instruction
+    that hit one counter must be served in ascending lane order (== v_mbcnt rank).  16 M random lane masks."""
+    import ctypes as C
+    bad = C.c_int(-1)
+    assert pa.load().picsong_selftest_lds_order(0, C.byref(bad)) == 0
+    assert bad.value == 0
+
+
+def test_batched_frames_argument_checks(oracle, pa, torch):
+    c = pa.Codec(256, 256, wl=2, lut_folder=_lutdir(oracle, False))
+    frames = torch.zeros((2, c.P), dtype=torch.uint8, device="cuda")
+    out = torch.empty((2, c.max_stream_shorts() - 1), dtype=torch.int16, device="cuda")      # too short a stride
+    with pytest.raises(pa.PicsongError):
+        c.encode_frames_async(frames, out, 0)
+    with pytest.raises(pa.PicsongError):
+        c.last_totals(3)
+    c.close()
+
+
 @pytest.mark.parametrize("W,H,wl", [(3840, 2160, 5), (7680, 4320, 5)])
 def test_full_size_lossless_roundtrip(oracle, pa, torch, W, H, wl):
     """configs[1] (4K) and the headline 8K lossless workload: encode -> decode is the identity."""

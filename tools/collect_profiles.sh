@@ -1,23 +1,32 @@
 #!/bin/bash
 # Collects the judged measurements of a round on the GPU box (run from the repo root through gpurun):
-# the default bench line, rocprofv3 kernel stats of the same command and of a single-stream run,
-# the 8K lossy variant, and the FETCH_SIZE / WRITE_SIZE / SQ counter passes (each in its own run,
-# never combined with sys/runtime traces).
+# the default bench line, rocprofv3 kernel stats of the same command (shortened) and of a single-stream run,
+# the 8K lossy and 4K variants, the FETCH_SIZE / WRITE_SIZE / SQ counter passes (each in its own run, never
+# combined with sys/runtime traces), and the issue-rate probe.  tools/summarize_pmc.py turns the counter
+# CSVs into the profiles/<tag>_pmc_*.csv summaries bench.py reads.
 set -e
 out=gpurun_out/${1:-final}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python3 bench.py > $out/bench.json 2> $out/bench.err
 echo "bench done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_default -- python3 bench.py --no-cpu-baseline > $out/bench_prof_default.json 2> $out/prof_default.err
+S="--steps 2 --warmup 1 --frames-per-step 12 --no-cpu-baseline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_default -- python3 bench.py $S > $out/bench_prof_default.json 2> $out/prof_default.err
 echo "prof default done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_single -- python3 bench.py --steps 30 --warmup 3 --streams 1 --no-cpu-baseline > $out/bench_prof_single.json 2> $out/prof_single.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_single -- python3 bench.py $S --streams 1 > $out/bench_prof_single.json 2> $out/prof_single.err
 echo "prof single done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_lossy -- python3 bench.py --steps 30 --warmup 3 --streams 1 --workload 8k_lossy --no-cpu-baseline > $out/bench_prof_lossy.json 2> $out/prof_lossy.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_lossy -- python3 bench.py $S --streams 1 --workload 8k_lossy > $out/bench_prof_lossy.json 2> $out/prof_lossy.err
 echo "prof lossy done"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > $out/pmc_fetch.json 2> $out/pmc_fetch.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_4k -- python3 bench.py $S --workload 4k_lossless > $out/bench_prof_4k.json 2> $out/prof_4k.err
+echo "prof 4k done"
+P="--steps 1 --warmup 1 --frames-per-step 4 --pool 4 --streams 1 --batch 1 --no-cpu-baseline"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py $P > $out/pmc_fetch.json 2> $out/pmc_fetch.err
 echo "pmc fetch done"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > $out/pmc_write.json 2> $out/pmc_write.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py $P > $out/pmc_write.json 2> $out/pmc_write.err
 echo "pmc write done"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d $out/pmc_sq -- python3 bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > $out/pmc_sq.json 2> $out/pmc_sq.err
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d $out/pmc_sq -- python3 bench.py $P > $out/pmc_sq.json 2> $out/pmc_sq.err
 echo "pmc sq done"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --output-format csv -d $out/pmc_sq2 -- python3 bench.py $P > $out/pmc_sq2.json 2> $out/pmc_sq2.err || echo "pmc sq2 pass failed (a counter of the list is not available on this box)"
+echo "pmc sq2 done"
+timeout -k 10 240 tools/valu_probe $out/valu_probe.json > $out/valu_probe.txt 2>&1 || echo "probe failed"
+echo "probe done"
