@@ -162,7 +162,7 @@ struct Coder {
 };
 
 // significance probabilities for contexts 0..8 packed as bytes: w0 = ctx 0-3, w1 = ctx 4-7, p8.
-struct PlaneLut { uint32_t sig0, sig1, sig8, sign, ref; };
+struct PlaneLut { uint32_t sig0, sig1, sig8, sign, ref, sig8x4; };
 
 // The probability table of a codeblock sits in LDS as bytes (3360 at wl = 5): a plane's 14 entries
 // are read with LDS latency.  Read from global memory instead, every plane would wait behind the
@@ -190,6 +190,7 @@ __device__ __forceinline__ PlaneLut plane_lut(const LutView &v, const LutGeo &g,
     pl.sig1 = lut_get(v, si + 4) | (lut_get(v, si + 5) << 8) | (lut_get(v, si + 6) << 16) | (lut_get(v, si + 7) << 24);
     pl.sig8 = lut_get(v, si + 8);
     pl.sign = lut_get(v, gi + 0) | (lut_get(v, gi + 1) << 8) | (lut_get(v, gi + 2) << 16) | (lut_get(v, gi + 3) << 24);
+    pl.sig8x4 = pl.sig8 * 0x01010101u;
     return pl;
 }
 // k = 0: every codeblock of the workgroup uses table 0; every thread copies its share of it
@@ -293,9 +294,6 @@ __device__ __forceinline__ ColHalf make_col(uint32_t x1, uint32_t x2, uint32_t x
     fa32(c1, c2, c3, t1, d1);
     r.n1 = t1 ^ c4; d2 = t1 & c4;
     r.n2 = d1 ^ d2; r.n3 = d1 & d2;
-    r.n1 = __builtin_amdgcn_alignbit(r.n1, r.n1, 31u);      // rotate left by 1 (see enc_spp_coeff)
-    r.n2 = __builtin_amdgcn_alignbit(r.n2, r.n2, 30u);      // rotate left by 2
-    r.n3 = __builtin_amdgcn_alignbit(r.n3, r.n3, 30u);      // rotate left by 2
     // contributions: +1 significant & positive, -1 significant & negative (BPCEngine.cu:302-305)
     uint32_t pu = us & ~ug, nu = us & ug, pd = ds & ~dg, nd = ds & dg;
     uint32_t pl = ls & ~lg, nl = ls & lg, pr = rs & ~rg, nr = rs & rg;
@@ -306,8 +304,6 @@ __device__ __forceinline__ ColHalf make_col(uint32_t x1, uint32_t x2, uint32_t x
     uint32_t c0 = hn | (vn & ~hp);
     r.c1 = (~(hp | hn) & (vp | vn)) | same;
     r.c2 = ((hp | hn) & ~(vp | vn)) | same;
-    r.c1 = __builtin_amdgcn_alignbit(r.c1, r.c1, 29u);      // rotate left by 3
-    r.c2 = __builtin_amdgcn_alignbit(r.c2, r.c2, 28u);      // rotate left by 4
     r.s2 = self_sgn ^ c0;
     return r;
 }
@@ -522,10 +518,35 @@ __device__ __forceinline__ void enc_site(EncCoder &c, uint32_t inact, uint32_t s
     enc_site2(c, onm, onm & __builtin_amdgcn_ballot_w64(sym != 0u), p, prec, upper_mask);
 }
 
-// Context masks are kept pre-rotated (n1 by 1, n2 and n3 by 2 bits; sign bits c1 by 3, c2 by 4) so
-// that one rotate-right by the row index drops each bit where the consumer wants it.
 __device__ __forceinline__ uint32_t rotr32(uint32_t v, uint32_t sh) { return __builtin_amdgcn_alignbit(v, v, sh); }
 __device__ __forceinline__ uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+
+// ---- probabilities of FOUR rows at a time -----------------------------------------------------------
+// The context of a row is spread over the bit-sliced masks n0..n3 (c1, c2 for the sign); gathered row by
+// row it costs three or four rotates, as many selects and two byte permutes per coefficient (11 half-rate
+// instructions).  Gathered for rows 4g .. 4g+3 at once: a mask's nibble times 0x204081 puts bit i at bit 8i
+// (the four shifted copies land on 16 distinct bits, so no carry forms), three such words make the four
+// rows' byte selectors, ONE v_perm looks up four probabilities, and a row takes its byte with one v_bfe.
+__device__ __forceinline__ uint32_t spread4(uint32_t mask, uint32_t g4)
+{
+    return mul_u24((mask >> g4) & 0xFu, 0x204081u) & 0x01010101u;
+}
+// significance probabilities (computeContext BPCEngine.cu:222-230 + the LUT read) of rows g4 .. g4+3
+__device__ __forceinline__ uint32_t sig_probs4(const ColHalf &cp, const PlaneLut &pl, uint32_t g4)
+{
+    const uint32_t s0 = spread4(cp.n0, g4), s1 = spread4(cp.n1, g4), s2 = spread4(cp.n2, g4), s3 = spread4(cp.n3, g4);
+    const uint32_t sel = s0 | (s1 << 1) | (s2 << 2);                      // bytes 0..7: the context
+    const uint32_t p07 = __builtin_amdgcn_perm(pl.sig1, pl.sig0, sel);
+    // context 8 (n3 set => n0 = n1 = n2 = 0): those bytes take p8.  s3 * 255 as a shift and a subtraction: the
+    // flag of row 3 sits at bit 24, beyond a 24-bit multiply
+    return bfi32((s3 << 8) - s3, pl.sig8x4, p07);
+}
+// sign probabilities (computeSignContext :252-308: LUT index c >> 1 = c2 c1) of rows g4 .. g4+3
+__device__ __forceinline__ uint32_t sign_probs4(const ColHalf &cp, const PlaneLut &pl, uint32_t g4)
+{
+    const uint32_t sel = spread4(cp.c1, g4) | (spread4(cp.c2, g4) << 1);
+    return __builtin_amdgcn_perm(0u, pl.sign, sel);
+}
 
 // The row's bit as a VGPR value: `x & rowbit` with the bit in an SGPR issues at half rate (any SGPR operand
 // does), with both operands in VGPRs at full rate; one move per row serves its five to seven mask tests.
@@ -540,29 +561,19 @@ __device__ __forceinline__ uint32_t vgpr_of(uint32_t s)
 #endif
 }
 
-// One coefficient of the significance propagation pass.  rowbit = 1 << ii.  A: significant-before mask
-// of the column's 32 rows (all ones for an idle half: never on); N: becomes significant in this plane
-// (0 for an idle half).
-__device__ __forceinline__ void enc_spp_coeff(EncCoder &c, uint32_t ii, uint32_t rowbit, uint32_t A, uint32_t N,
-                                              const ColHalf &cp, const PlaneLut &pl, uint32_t prec, uint32_t upper_mask)
+// One coefficient of the significance propagation pass.  rowbit = 1 << ii (VGPR); sh = 8 * (ii & 3): the
+// row's byte in the group's probability words P4 (significance) and Q4 (sign).  A: significant-before mask
+// of the column's 32 rows (all ones for an idle half: never on); N: becomes significant in this plane (0
+// for an idle half).
+__device__ __forceinline__ void enc_spp_coeff(EncCoder &c, uint32_t sh, uint32_t rowbit, uint32_t A, uint32_t N,
+                                              uint32_t s2, uint32_t P4, uint32_t Q4, uint32_t prec, uint32_t upper_mask)
 {
     const uint64_t onm = __builtin_amdgcn_ballot_w64((A & rowbit) == 0u);
     if (onm == 0ull) return;                                // no lane has this column's coefficient to code
     const uint64_t onem = __builtin_amdgcn_ballot_w64((N & rowbit) != 0u);       // N is a subset of ~A
-    // byte selector of v_perm: bits 0..2 = context 0..7, other selector bytes = 0x0C (constant 0)
-    uint32_t sel = (rotr32(cp.n0, ii) & 1u) | 0x0C0C0C00u;
-    sel = bfi32(2u, rotr32(cp.n1, ii), sel);
-    sel = bfi32(4u, rotr32(cp.n2, ii), sel);
-    const uint32_t p07 = __builtin_amdgcn_perm(pl.sig1, pl.sig0, sel);
-    // context 8 (n3 set => n0 = n1 = n2 = 0): a second byte select takes p8 (byte 4) instead of p07
-    const uint32_t p = __builtin_amdgcn_perm(pl.sig8, p07, (rotr32(cp.n3, ii) & 4u) | 0x0C0C0C00u);
-    enc_site2(c, onm, onem, p, prec, upper_mask);
-    if (onem != 0ull) {
-        // bit offset of the sign probability inside pl.sign = 8 * (c >> 1)
-        const uint32_t off = (rotr32(cp.c2, ii) & 16u) | (rotr32(cp.c1, ii) & 8u);
-        const uint32_t p2 = (pl.sign >> off) & 0xFFu;
-        enc_site2(c, onem, onem & __builtin_amdgcn_ballot_w64((cp.s2 & rowbit) != 0u), p2, prec, upper_mask);
-    }
+    enc_site2(c, onm, onem, (P4 >> sh) & 0xFFu, prec, upper_mask);
+    if (onem != 0ull)
+        enc_site2(c, onem, onem & __builtin_amdgcn_ballot_w64((s2 & rowbit) != 0u), (Q4 >> sh) & 0xFFu, prec, upper_mask);
 }
 
 __device__ __forceinline__ uint32_t dec_site(Coder &c, uint32_t inact, uint32_t p, uint32_t prec,
@@ -878,7 +889,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
         const int bp = msb - p;
         const bool act = coded && bp >= cbp;
 
-        PlaneLut pl = { 0u, 0u, 0u, 0u, 0u };
+        PlaneLut pl = { 0u, 0u, 0u, 0u, 0u, 0u };
         if (act) pl = plane_lut(lv, a.g, grp, bp);
 
         const U64 BL = BLn, BR = BRn;
@@ -904,11 +915,19 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
                 const uint32_t nl = w_of(BL, hw) & ~al, nr = w_of(BR, hw) & ~ar;      // become significant in this plane
                 uint32_t rows = wave_or32(~(al & ar));
                 while (rows) {
-                    const uint32_t ii = (uint32_t)__builtin_ctz(rows);
-                    const uint32_t rowbit = vgpr_of(1u << ii);
-                    rows &= rows - 1u;
-                    enc_spp_coeff(c, ii, rowbit, al, nl, cpL, pl, prec, upper_mask);
-                    enc_spp_coeff(c, ii, rowbit, ar, nr, cpR, pl, prec, upper_mask);
+                    // a group of four rows: their probabilities are gathered together (sig_probs4)
+                    const uint32_t g4 = (uint32_t)__builtin_ctz(rows) & ~3u;
+                    uint32_t sub = (rows >> g4) & 0xFu;
+                    rows &= ~(0xFu << g4);
+                    const uint32_t P4L = sig_probs4(cpL, pl, g4), P4R = sig_probs4(cpR, pl, g4);
+                    const uint32_t Q4L = sign_probs4(cpL, pl, g4), Q4R = sign_probs4(cpR, pl, g4);
+                    while (sub) {
+                        const uint32_t j = (uint32_t)__builtin_ctz(sub);
+                        sub &= sub - 1u;
+                        const uint32_t rowbit = vgpr_of(1u << (g4 + j)), sh = 8u * j;
+                        enc_spp_coeff(c, sh, rowbit, al, nl, cpL.s2, P4L, Q4L, prec, upper_mask);
+                        enc_spp_coeff(c, sh, rowbit, ar, nr, cpR.s2, P4R, Q4R, prec, upper_mask);
+                    }
                 }
             }
         }
@@ -1234,7 +1253,7 @@ void bpc_decode_kernel(BpcArgs a)
             PLlo[0] = PLhi[0] = PRlo[0] = PRhi[0] = 0u;
         }
 
-        PlaneLut pl = { 0u, 0u, 0u, 0u, 0u };
+        PlaneLut pl = { 0u, 0u, 0u, 0u, 0u, 0u };
         if (act) pl = plane_lut(lv, a.g, grp, bp);
 
         // ---- significance propagation pass (SPPDecoderLauncher), rows with an insignificant coeff

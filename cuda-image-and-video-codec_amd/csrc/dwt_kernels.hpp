@@ -76,6 +76,10 @@ struct DwtFwdArgs {
     // batched launches (grid.z = frames of one picsong_encode_frames call): frame z reads src + z * src_z
     // and writes ll / mallat + z * dst_z (bytes); 0 for a single frame
     unsigned long long src_z, dst_z;
+    // row band (picsong_dwt_forward_band, intra-frame sharding): the launch produces the row pairs
+    // [pair_base, pair_end) of this level only; 0, 0 = the whole level.  Input rows are still addressed in
+    // frame coordinates: the band's rows and its halo (2 rows either side for 5/3, 4 for 9/7) must be there.
+    int pair_base, pair_end;
 };
 
 // frame blockIdx.z of a batched launch
@@ -369,9 +373,10 @@ __global__ __launch_bounds__(256) PS_DWT_OCC void dwt_fwd_kernel(DwtFwdArgs a)
     if (strip * kStripUseful >= a.W) return;               // whole wave idle (no cross-lane use)
     dwt_fwd_select_frame(a);
     const int c0 = strip * kStripUseful - 4 * kEdgeLanes + 4 * lane;    // first of the lane's 4 columns
-    const int m0 = blockIdx.y * (kFwdBandRows / 2);
+    const int m0 = a.pair_base + blockIdx.y * (kFwdBandRows / 2);
     int m1 = m0 + kFwdBandRows / 2;
-    if (m1 > (a.H >> 1)) m1 = a.H >> 1;
+    const int mend = a.pair_end > 0 ? a.pair_end : (a.H >> 1);
+    if (m1 > mend) m1 = mend;
     const bool wr = lane >= kEdgeLanes && lane <= 63 - kEdgeLanes && c0 >= 0 && c0 < a.W;
     // VEC: every lane loads a whole in-image vector (out-of-image lanes a clamped one they never
     // use); the lanes owning columns 0 / W-4 mirror in registers (hfwd).  !VEC: per-column mirrors.

@@ -73,7 +73,7 @@ inline std::vector<FwdLaunch> plan_dwt_forward(const void *d_in, bool u8in, void
         a.ll = last ? d_out : (void *)((char *)d_out + off * 4);
         a.ll_stride = last ? aw : (W >> 1);
         a.mallat = d_out; a.AW = aw; a.level = l; a.last = last ? 1 : 0; a.qs = qs;
-        a.src_z = 0; a.dst_z = 0;
+        a.src_z = 0; a.dst_z = 0; a.pair_base = 0; a.pair_end = 0;
         for (int k = 0; k < 4; k++) a.q[k] = kQSteps[l][k];
         const int strips = (W + kStripUseful - 1) / kStripUseful;
         f.band = fwd_band_rows(l, strips, H);
@@ -89,6 +89,15 @@ inline std::vector<FwdLaunch> plan_dwt_forward(const void *d_in, bool u8in, void
         W >>= 1; H >>= 1;
     }
     return v;
+}
+
+// Level 0 restricted to the input rows [row0, row0 + rows) (both even): the launch then produces the row
+// pairs [row0 / 2, (row0 + rows) / 2) of HL / LH / HH (Mallat) and of LL (scratch, or Mallat when wl = 1).
+inline void plan_restrict_band(FwdLaunch &f, int row0, int rows)
+{
+    f.a.pair_base = row0 >> 1;
+    f.a.pair_end = (row0 + rows) >> 1;
+    f.gy = (unsigned)(((rows >> 1) + f.band / 2 - 1) / (f.band / 2));
 }
 
 // May the 9/7 synthesis of a context with this qs use the reciprocal form of its divisions

@@ -512,6 +512,40 @@ int picsong_dwt_forward_u8(picsong_ctx *c, const uint8_t *d_in, void *d_out, voi
     return dwt_forward_impl(c, d_in, true, d_out, (hipStream_t)stream);
 }
 
+static void launch_fwd_any(picsong_ctx *c, const FwdLaunch &f, hipStream_t s)
+{
+    switch (f.band) {
+    case 32: launch_fwd<32>(c, f, s); break;
+    case 16: launch_fwd<16>(c, f, s); break;
+    case 8: launch_fwd<8>(c, f, s); break;
+    default: launch_fwd<4>(c, f, s); break;
+    }
+}
+
+int picsong_dwt_forward_band(picsong_ctx *c, const uint8_t *d_frame, int row0, int rows, void *d_out, void *stream)
+{
+    if (!c || !d_frame || !d_out) return fail(PICSONG_ERR_ARG, "dwt_forward_band: null argument");
+    if (row0 < 0 || rows <= 0 || (row0 & 1) || (rows & 1) || row0 + rows > c->ah)
+        return fail(PICSONG_ERR_ARG, "dwt_forward_band: rows [%d, %d) must be even and inside [0, %d)", row0, row0 + rows, c->ah);
+    std::vector<FwdLaunch> plan = plan_dwt_forward(d_frame, true, d_out, c->aw, c->ah, c->p.wl, c->p.qs);
+    plan_restrict_band(plan[0], row0, rows);
+    launch_fwd_any(c, plan[0], (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return PICSONG_OK;
+}
+
+int picsong_dwt_forward_tail(picsong_ctx *c, void *d_out, void *stream)
+{
+    if (!c || !d_out) return fail(PICSONG_ERR_ARG, "dwt_forward_tail: null argument");
+    // (the level-0 source is irrelevant here: only the launches of levels >= 1 are used)
+    const std::vector<FwdLaunch> plan = plan_dwt_forward(d_out, false, d_out, c->aw, c->ah, c->p.wl, c->p.qs);
+    for (size_t l = 1; l < plan.size(); l++) {
+        launch_fwd_any(c, plan[l], (hipStream_t)stream);
+        HIP_TRY(hipGetLastError());
+    }
+    return PICSONG_OK;
+}
+
 // d_pixels != nullptr: the finest level writes clamped u8 pixels there (level shift + clamp fused,
 // when its vector kernel applies) instead of T samples into d_out; returns 1 in *fused then.
 static int dwt_inverse_impl(picsong_ctx *c, const int32_t *d_in, void *d_out, uint8_t *d_pixels, bool *fused,
@@ -816,6 +850,21 @@ int picsong_decode_frame(picsong_ctx *c, const uint16_t *d_stream, uint8_t *d_fr
     else clamp_to_u8_i32_kernel<<<grid, 256, 0, s>>>((const int32_t *)img, d_frame_out, n4, off);
     HIP_TRY(hipGetLastError());
     return PICSONG_OK;
+}
+
+int picsong_encode_stripe_coded(picsong_ctx *c, const void *d_coeffs, int cb_begin, int cb_count, uint16_t *d_stream,
+                                void *stream)
+{
+    if (!c || !d_coeffs || !d_stream) return fail(PICSONG_ERR_ARG, "encode_stripe_coded: null argument");
+    if (cb_begin < 0 || cb_count <= 0 || cb_begin + cb_count > c->ncb)
+        return fail(PICSONG_ERR_ARG, "encode_stripe_coded: codeblocks [%d, %d) outside [0, %d)", cb_begin,
+                    cb_begin + cb_count, c->ncb);
+    int rc = ensure_workspace(c, false);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = bpc_encode_impl(c, d_coeffs, c->d_staging, c->d_sizes, false, s, cb_begin, cb_count))) return rc;
+    return pack_range(c, c->d_staging + (size_t)cb_begin * PICSONG_CB_WORDS, c->d_sizes + cb_begin, cb_count, nullptr,
+                      d_stream, s);
 }
 
 int picsong_encode_frame_stripe(picsong_ctx *c, const uint8_t *d_frame, int cb_begin, int cb_count,

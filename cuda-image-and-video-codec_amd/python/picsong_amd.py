@@ -42,6 +42,7 @@ EXPORTS = [
     "picsong_encode_plane", "picsong_decode_plane",
     "picsong_ctx_set_lut_device", "picsong_bpc_encode_component", "picsong_bpc_decode_component",
     "picsong_encode_frames", "picsong_last_totals", "picsong_selftest_lds_order",
+    "picsong_dwt_forward_band", "picsong_dwt_forward_tail", "picsong_encode_stripe_coded",
 ]
 
 _lib = None
@@ -106,6 +107,10 @@ def load():
         L.picsong_ctx_set_lut_device.argtypes = [vp, i, C.POINTER(LutInfo), vp]
         L.picsong_bpc_encode_component.argtypes = [vp, i, vp, vp, vp, vp]
         L.picsong_bpc_decode_component.argtypes = [vp, i, vp, vp, vp, vp]
+    if hasattr(L, "picsong_dwt_forward_band"):
+        L.picsong_dwt_forward_band.argtypes = [vp, vp, i, i, vp, vp]
+        L.picsong_dwt_forward_tail.argtypes = [vp, vp, vp]
+        L.picsong_encode_stripe_coded.argtypes = [vp, vp, i, i, vp, vp]
     _lib = L
     return L
 
@@ -349,6 +354,24 @@ class Codec:
         out = self.torch.empty(9 + 2 * cb_count + cb_count * 4096 + 1, dtype=self.torch.int16, device=self.dev)
         _check(self.L.picsong_encode_frame_stripe(self.h, self._p(frame_u8_padded), cb_begin, cb_count,
                                                   self._p(out), self._stream()))
+        return out[:self.last_total()]
+
+    # ---- row-band sharding of the transform (intra-frame split) ----
+    def new_coef_buffer(self):
+        return self.torch.zeros(self.P + self.extra, dtype=self.torch.float32 if self.lossy else self.torch.int32,
+                                device=self.dev)
+
+    def dwt_forward_band(self, frame_u8_frame_coords, row0, rows, coef):
+        _check(self.L.picsong_dwt_forward_band(self.h, self._p(frame_u8_frame_coords), row0, rows, self._p(coef),
+                                               self._stream()))
+
+    def dwt_forward_tail(self, coef):
+        _check(self.L.picsong_dwt_forward_tail(self.h, self._p(coef), self._stream()))
+
+    def encode_stripe_coded(self, coef, cb_begin, cb_count):
+        out = self.torch.empty(9 + 2 * cb_count + cb_count * 4096 + 1, dtype=self.torch.int16, device=self.dev)
+        _check(self.L.picsong_encode_stripe_coded(self.h, self._p(coef), cb_begin, cb_count, self._p(out),
+                                                  self._stream()))
         return out[:self.last_total()]
 
     def decode_frame(self, stream):

@@ -168,3 +168,49 @@ def encode_frame_striped(n_cb, encode_stripe_fn, header9, rank, world, device, g
     minis = [g for g, (_, cnt) in zip(got, ranges) if cnt > 0]
     counts = [cnt for _, cnt in ranges if cnt > 0]
     return splice_stripes(header9, minis, counts)
+
+
+# ---- intra-frame sharding with a row-band transform (second form) ------------------
+def band_plan(aw, ah, world):
+    """Rank k's share of ONE frame when the transform is sharded too: input rows [row0, row0 + rows), the
+    LL1 rows it produces (a contiguous chunk of the packed LL1 plane), and the two codeblock ranges made of
+    exactly the coefficients its own band and the shared levels >= 1 produce: Mallat codeblock rows
+    [k R, (k+1) R) (LL pyramid | HL1) and [AH/128 + k R, ...) (LH1 | HH1).  None when AH is not a multiple
+    of 128 * world (use the stripes over a replicated transform then)."""
+    if ah % (128 * world) != 0:
+        return None
+    rows = ah // world
+    R = ah // (128 * world)
+    ncx = aw // 64
+    plan = []
+    for k in range(world):
+        plan.append({"row0": k * rows, "rows": rows,
+                     "ll1_begin": (aw // 2) * (k * rows // 2), "ll1_count": (aw // 2) * (rows // 2),
+                     "stripes": [(k * R * ncx, R * ncx), ((ah // 128 + k * R) * ncx, R * ncx)]})
+    return plan
+
+
+def encode_frame_banded(aw, ah, ops, header9, rank, world, device, group=None):
+    """One frame over `world` ranks, transform included: every rank runs level 0 on its row band only
+    (`ops.dwt_band(row0, rows)`), the ranks all-gather their LL1 row bands in place (`ops.ll1()` = the packed
+    LL1 plane as a 1-D tensor view: the one collective of the transform, P/4 samples), run levels >= 1
+    redundantly (`ops.dwt_tail()`), code their two codeblock stripes (`ops.encode_stripe(begin, count)` ->
+    mini-stream) and rank 0 splices header + pair tables + payloads in raster order.  Rank 0 returns the full
+    codestream -- byte-identical to the 1-GPU one -- other ranks None."""
+    plan = band_plan(aw, ah, world)
+    assert plan is not None, "AH must be a multiple of 128 * world for the banded transform"
+    me = plan[rank]
+    ops.dwt_band(me["row0"], me["rows"])
+    ll1 = ops.ll1()
+    if world > 1:
+        mine = ll1[me["ll1_begin"]:me["ll1_begin"] + me["ll1_count"]].clone()
+        dist.all_gather_into_tensor(ll1, mine, group=group)
+    ops.dwt_tail()
+    minis = [ops.encode_stripe(b, n) for b, n in me["stripes"]]
+    # two gathers, one per half of the Mallat image, so that the root receives the stripes in raster order
+    got = [gather_round(m, rank, world, device, group=group) for m in minis]
+    if rank != 0:
+        return None
+    ordered = got[0] + got[1]
+    counts = [p["stripes"][0][1] for p in plan] + [p["stripes"][1][1] for p in plan]
+    return splice_stripes(header9, ordered, counts)

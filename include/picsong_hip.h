@@ -215,6 +215,27 @@ int picsong_decode_plane(picsong_ctx *ctx, const uint16_t *d_stream, int compone
  *      Asynchronous; length via picsong_last_total(). ---- */
 int picsong_encode_frame_stripe(picsong_ctx *ctx, const uint8_t *d_frame, int cb_begin, int cb_count,
                                 uint16_t *d_stream, void *stream);
+/* Row-band sharding of the transform for the same split ("partition level 0 by row bands
+ * with a halo of 2 (5/3) or 4 (9/7) rows per side ... then all-gather LL1 and compute levels >= 1
+ * redundantly"): no rank transforms or even holds the whole frame.
+ *   picsong_dwt_forward_band: level 0 (u8 ingest, level shift fused) of the input rows [row0, row0 + rows)
+ *     only -- row0 and rows even; d_frame is addressed in frame coordinates (row y at d_frame + y * AW) but
+ *     only the band's rows and its halo need to be present.  Writes rows [row0/2, (row0+rows)/2) of HL, LH and
+ *     HH into the Mallat array at d_out and of LL1 into the scratch behind it (d_out + AW*AH elements, row
+ *     stride AW/2) -- the same places picsong_dwt_forward_u8 writes them (DWTEngine::DWTForward's buffer
+ *     contract, DWT/DWTGenerator.cu:1268-1342).
+ *   picsong_dwt_forward_tail: levels 1 .. wl-1 from the complete LL1 in that scratch (after the ranks have
+ *     all-gathered their LL1 row bands in place).
+ *   picsong_encode_stripe_coded: coder + pack of the codeblocks [cb_begin, cb_begin + cb_count) from a
+ *     coefficient array (picsong_encode_frame_stripe without its transform); mini-stream as above.
+ * With N ranks and AH a multiple of 128 N, rank k transforms input rows [k AH/N, (k+1) AH/N) and codes the
+ * codeblock rows [k R, (k+1) R) and [AH/128 + k R, ...), R = AH / (128 N): exactly the coefficients its own
+ * band and the shared tail produce.  Asynchronous. */
+int picsong_dwt_forward_band(picsong_ctx *ctx, const uint8_t *d_frame, int row0, int rows, void *d_out,
+                             void *stream);
+int picsong_dwt_forward_tail(picsong_ctx *ctx, void *d_out, void *stream);
+int picsong_encode_stripe_coded(picsong_ctx *ctx, const void *d_coeffs, int cb_begin, int cb_count,
+                                uint16_t *d_stream, void *stream);
 /* host helper: IOManager::loadFrameCAdaptedSizes' mirror padding (IO/IOManager.ipp:72-112).
  * PICSONG_ERR_ARG when aw - w > w or ah - h > h: the reference's loop is undefined there. */
 int picsong_pad_frame_host(const uint8_t *in, int w, int h, uint8_t *out, int aw, int ah);

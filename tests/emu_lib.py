@@ -68,6 +68,31 @@ def dwt_forward(x, wl, lossy, qs=1.0, extra=0):
     return out
 
 
+def dwt_forward_band(x_u8, out, wl, lossy, qs, row0, rows):
+    """Level 0 of the input rows [row0, row0 + rows) of the (AH, AW) uint8 frame into `out` (Mallat + scratch)."""
+    AH, AW = x_u8.shape
+    assert x_u8.dtype == np.uint8 and x_u8.flags["C_CONTIGUOUS"]
+    lib().emu_dwt_forward_band(_p(x_u8), _p(out), AW, AH, wl, int(lossy), C.c_float(qs), row0, rows)
+
+
+def dwt_forward_tail(out, AW, AH, wl, lossy, qs=1.0):
+    lib().emu_dwt_forward_tail(_p(out), AW, AH, wl, int(lossy), C.c_float(qs))
+
+
+def bpc_encode_range(coef, wl, lut, cb_begin, cb_count):
+    """Staging / sizes of the whole frame with only the codeblocks [cb_begin, +cb_count) coded."""
+    AH, AW = coef.shape
+    coef = np.ascontiguousarray(coef)
+    staging = np.full(AW * AH, -1, np.int32)
+    sizes = np.zeros((AW // 64) * (AH // 64), np.int32)
+    flag = np.zeros(1, np.int32)
+    tab = np.ascontiguousarray(lut.table, np.int32)
+    geo = _geo(lut)
+    lib().emu_bpc_encode_range(_p(coef), int(coef.dtype == np.float32), AW, AH, wl, _p(tab), _p(geo),
+                               _p(staging), _p(sizes), _p(flag), cb_begin, cb_count)
+    return staging, sizes, int(flag[0])
+
+
 def dwt_inverse(coef, wl, lossy, qs=1.0, extra=0):
     AH, AW = coef.shape
     coef = aligned_copy(np.ascontiguousarray(coef, np.int32))

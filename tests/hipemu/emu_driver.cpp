@@ -110,6 +110,30 @@ int emu_dwt_forward(const void *in, int u8in, void *out, int aw, int ah, int wl,
     return fused01 ? 1 : 0;
 }
 
+static void emu_fwd_any(const FwdLaunch &f, int lossy)
+{
+    switch (f.band) {
+    case 32: emu_fwd<32>(f, lossy); break;
+    case 16: emu_fwd<16>(f, lossy); break;
+    case 8: emu_fwd<8>(f, lossy); break;
+    default: emu_fwd<4>(f, lossy); break;
+    }
+}
+
+// mirror picsong_dwt_forward_band / picsong_dwt_forward_tail (picsong_hip.hip)
+void emu_dwt_forward_band(const void *in, void *out, int aw, int ah, int wl, int lossy, float qs, int row0, int rows)
+{
+    std::vector<FwdLaunch> plan = plan_dwt_forward(in, true, out, aw, ah, wl, qs);
+    plan_restrict_band(plan[0], row0, rows);
+    emu_fwd_any(plan[0], lossy);
+}
+
+void emu_dwt_forward_tail(void *out, int aw, int ah, int wl, int lossy, float qs)
+{
+    const std::vector<FwdLaunch> plan = plan_dwt_forward(out, false, out, aw, ah, wl, qs);
+    for (size_t l = 1; l < plan.size(); l++) emu_fwd_any(plan[l], lossy);
+}
+
 void emu_dwt_inverse(const int32_t *in, void *out, int aw, int ah, int wl, int lossy, float qs)
 {
     for (const InvLaunch &f : plan_dwt_inverse(in, out, aw, ah, wl, qs, emu_fast_div(lossy, qs, wl))) {
@@ -184,6 +208,21 @@ static BpcArgs mk(int aw, int ah, int wl, const int32_t *lut, const int *geo, in
 }
 
 // k > 0 (n_tables bit-plane tables in lut) runs the BULK instantiations, like picsong_hip.hip
+// codeblocks [cb_begin, cb_begin + cb_count) of the frame (cb_count < 0: all), like bpc_encode_impl
+void emu_bpc_encode_range(const void *coeffs, int is_float, int aw, int ah, int wl, const int32_t *lut, const int *geo,
+                          int32_t *staging, int32_t *sizes, int *flag, int cb_begin, int cb_count)
+{
+    BpcArgs a = mk(aw, ah, wl, lut, geo, staging, sizes, flag);
+    a.coeffs_in = coeffs; a.is_float = is_float;
+    a.k = 0.0f; a.n_tables = 1;
+    if (cb_count < 0) cb_count = a.nCB - cb_begin;
+    a.cb_base = cb_begin; a.nCB = cb_begin + cb_count;
+    const unsigned wgs = (unsigned)(((cb_count + 1) / 2 + kBpcEncWgWaves - 1) / kBpcEncWgWaves);
+    std::vector<uint32_t> plane_scratch((size_t)wgs * kBpcEncWgWaves * kEncScratchDwordsPerWave, 0xDEADBEEFu);
+    a.plane_scratch = plane_scratch.data();
+    emu::launch(dim3(wgs), dim3(64 * kBpcEncWgWaves), [&] { bpc_encode_kernel<false>(a); });
+}
+
 void emu_bpc_encode(const void *coeffs, int is_float, int aw, int ah, int wl, const int32_t *lut, const int *geo,
                     int32_t *staging, int32_t *sizes, int *flag, float k, int n_tables)
 {

@@ -156,3 +156,84 @@ def test_stripe_ranges():
     assert pd.stripe_ranges(12, 5) == [(0, 3), (3, 3), (6, 2), (8, 2), (10, 2)]
     assert pd.stripe_ranges(3, 4) == [(0, 1), (1, 1), (2, 1), (3, 0)]
     assert sum(n for _, n in pd.stripe_ranges(65536, 8)) == 65536
+
+
+# ---- intra-frame sharding WITH a row-band transform: the product's own kernels (CPU wave emulator) ----
+BW, BH, BWL = 256, 256, 3          # 4 x 4 = 16 codeblocks; 2 ranks: 128 input rows each
+
+
+def _banded_worker(rank, world, port, outdir, lossy):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(ROOT, "cuda-image-and-video-codec_amd", "python"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import emu_lib as E
+    import oracle_lib as orc
+    import picsong_dist as pd
+    qs = 0.5 if lossy else 1.0
+    lut = orc.lut_for(lossy, BWL)
+    img = orc.pad_frame(orc.gen_frame(BW, BH, 11))
+    AH, AW = img.shape
+    P, extra = AW * AH, orc.dwt_extra(AW, AH, BWL)
+    plan = pd.band_plan(AW, AH, world)
+    me = plan[rank]
+    # this rank holds ONLY its band and the 4-row halo of the input
+    x = np.full((AH, AW), 0x5A, np.uint8)
+    lo, hi = max(0, me["row0"] - 4), min(AH, me["row0"] + me["rows"] + 4)
+    x[lo:hi] = img[lo:hi]
+    x = E.aligned_copy(x)
+    coef = E.aligned_zeros(P + extra, np.float32 if lossy else np.int32)
+    coef[:] = 777                                    # what the rank never computes stays poison
+
+    class Ops:
+        def dwt_band(self, row0, rows):
+            E.dwt_forward_band(x, coef, BWL, lossy, qs, row0, rows)
+
+        def ll1(self):
+            return torch.from_numpy(coef[P:P + (AW // 2) * (AH // 2)])      # a view: the gather lands in place
+
+        def dwt_tail(self):
+            E.dwt_forward_tail(coef, AW, AH, BWL, lossy, qs)
+
+        def encode_stripe(self, b, n):
+            staging, sizes, flag = E.bpc_encode_range(coef[:P].reshape(AH, AW), BWL, lut, b, n)
+            assert flag == 0
+            mini = E.pack(staging[b * 4096:(b + n) * 4096], sizes[b:b + n], None)
+            return torch.from_numpy(mini.view(np.int16).copy())
+
+    hdr = orc.header_pack(n_samples=BW * BH, cp=2, cb_height=18, cb_width=64, wl=BWL, bit_depth=8, lossy=int(lossy),
+                          qs_1e4=int(qs * 10000), components=1, is_rgb=0, height=BH, endianess=0, bps=8, is_signed=0,
+                          frames=0, k_1e3=0)
+    full = pd.encode_frame_banded(AW, AH, Ops(), torch.from_numpy(hdr.view(np.int16).copy()), rank, world,
+                                  torch.device("cpu"))
+    if rank == 0:
+        np.save(os.path.join(outdir, "banded.npy"), full.numpy().view(np.uint16))
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lossy", [False, True])
+def test_banded_transform_and_stripes_splice_to_single_gpu_stream(oracle, tmp_path, lossy):
+    """World size 2, the product's kernels through the wave emulator: each rank transforms its row band from
+    an input that holds nothing else, the LL1 bands are all-gathered over gloo, each rank codes the two
+    codeblock stripes its coefficients cover, rank 0 splices: the oracle's whole-frame codestream."""
+    port = _free_port()
+    mp.spawn(_banded_worker, args=(2, port, str(tmp_path), lossy), nprocs=2, join=True)
+    qs = 0.5 if lossy else 1.0
+    ref = oracle.encode_frame(oracle.gen_frame(BW, BH, 11), BWL, lossy, qs, oracle.lut_for(lossy, BWL), 0, 0)
+    assert np.array_equal(np.load(os.path.join(tmp_path, "banded.npy")), ref)
+
+
+def test_band_plan():
+    sys.path.insert(0, os.path.join(ROOT, "cuda-image-and-video-codec_amd", "python"))
+    import picsong_dist as pd
+    p = pd.band_plan(16384, 16384, 8)                 # BASELINE config 5
+    assert [q["rows"] for q in p] == [2048] * 8 and p[3]["row0"] == 6144
+    assert p[1]["stripes"] == [(16 * 256, 16 * 256), ((128 + 16) * 256, 16 * 256)]
+    covered = sorted(b for q in p for s in q["stripes"] for b in range(s[0], s[0] + s[1]))
+    assert covered == list(range(65536))
+    assert sum(q["ll1_count"] for q in p) == 8192 * 8192
+    assert pd.band_plan(7680, 4352, 8) is None        # 4352 is not a multiple of 1024

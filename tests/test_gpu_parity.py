@@ -346,6 +346,50 @@ def test_config5_16k_single_frame_roundtrip(oracle, pa, torch):
     c.close()
 
 
+@pytest.mark.parametrize("W,H,wl,lossy,world", [(512, 512, 3, False, 4), (384, 256, 2, True, 2), (16384, 16384, 5, False, 8)])
+def test_banded_transform_sharding_equals_full_frame(oracle, pa, torch, W, H, wl, lossy, world):
+    """SURVEY 8e / BASELINE config 5 with the transform sharded too, the `world` ranks played one after the
+    other on one GPU: rank k transforms only its row band (picsong_dwt_forward_band) from a buffer that holds
+    nothing but the band and its 4-row halo, the LL1 bands are exchanged (here: device copies, on a node:
+    one all-gather), every rank runs levels >= 1 (picsong_dwt_forward_tail) and codes its two stripes
+    (picsong_encode_stripe_coded); the splice equals picsong_encode_frame's stream byte for byte."""
+    import picsong_dist as pd
+    qs = 0.5 if lossy else 1.0
+    c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=_lutdir(oracle, lossy))
+    AW, AH, P = c.aw, c.ah, c.P
+    if W * H > (1 << 24):
+        tile = torch.from_numpy(oracle.gen_frame(2048, 2048, 1)).cuda()
+        frame = tile.repeat(AH // 2048, AW // 2048).contiguous()
+    else:
+        frame = _dev(torch, oracle.pad_frame(oracle.gen_frame(W, H, 6)))
+    full = c.encode_frame(frame.view(-1), 0).clone()
+    plan = pd.band_plan(AW, AH, world)
+    assert plan is not None
+    n_ll1 = (AW // 2) * (AH // 2)
+    coefs = []
+    for k, p in enumerate(plan):
+        x = torch.full((AH, AW), 0xA5, dtype=torch.uint8, device="cuda")
+        lo, hi = max(0, p["row0"] - 4), min(AH, p["row0"] + p["rows"] + 4)
+        x[lo:hi] = frame.view(AH, AW)[lo:hi]
+        coef = c.new_coef_buffer()
+        c.dwt_forward_band(x.view(-1), p["row0"], p["rows"], coef)
+        torch.cuda.synchronize()
+        coefs.append(coef)
+    ll1 = torch.cat([coefs[k][P + p["ll1_begin"]:P + p["ll1_begin"] + p["ll1_count"]] for k, p in enumerate(plan)])
+    minis = [[], []]
+    for k, p in enumerate(plan):
+        coefs[k][P:P + n_ll1] = ll1                              # the all-gather
+        c.dwt_forward_tail(coefs[k])
+        for h, (b, n) in enumerate(p["stripes"]):
+            minis[h].append(c.encode_stripe_coded(coefs[k], b, n).clone())
+        coefs[k] = None
+    hdr = torch.from_numpy(pa.header_pack(c.params).view(np.int16).copy()).cuda()
+    counts = [p["stripes"][0][1] for p in plan] + [p["stripes"][1][1] for p in plan]
+    spliced = pd.splice_stripes(hdr, minis[0] + minis[1], counts)
+    assert torch.equal(spliced, full)
+    c.close()
+
+
 @pytest.mark.parametrize("lossy,qs", [(False, 1.0), (True, 0.5)])
 def test_rgb_components_parity(oracle, pa, torch, lossy, qs):
     """RGB row: colour transform + per-component LUT streams identical to the oracle, decode_plane +

@@ -2,6 +2,8 @@
 CPU wave emulator (tests/hipemu) and compared bit-for-bit with the oracle.  This is kernel-logic
 coverage for the no-GPU suite; the `-m gpu` tests repeat the same comparisons through the C ABI on
 a real MI355X."""
+import os
+
 import numpy as np
 import pytest
 
@@ -428,3 +430,48 @@ def test_dwt_fused_levels_0_and_1(oracle, E, monkeypatch, W, H, wl, lossy, qs):
     two = E.dwt_forward(img, wl, lossy, qs, extra=extra)
     assert not E.dwt_forward.fused01
     assert np.array_equal(two[:W * H].view(np.uint32), ref[:W * H].view(np.uint32))
+
+
+@pytest.mark.parametrize("lossy,wl,world,W,H", [(False, 3, 2, 320, 256), (True, 3, 2, 256, 256), (False, 2, 4, 192, 512),
+                                                (False, 1, 2, 128, 256)])
+def test_banded_transform_equals_full_on_every_ranks_stripes(oracle, E, lossy, wl, world, W, H):
+    """picsong_dwt_forward_band / _tail: each rank transforms its row band from an input in which
+    only the band and a 4-row halo exist, the LL1 bands are exchanged, levels >= 1 are computed by everyone,
+    and the coefficients under the codeblocks the rank codes equal the whole-frame transform's."""
+    import picsong_dist as pd
+    qs = 0.5
+    img = oracle.gen_frame(W, H, 3)
+    AH, AW = img.shape
+    extra = oracle.dwt_extra(AW, AH, wl)
+    os.environ["PICSONG_DWT_NOFUSE01"] = "1"          # the per-level form writes LL1 to the scratch (the fused one keeps it in registers)
+    try:
+        full = E.dwt_forward(E.aligned_copy(img), wl, lossy, qs, extra)
+    finally:
+        del os.environ["PICSONG_DWT_NOFUSE01"]
+    plan = pd.band_plan(AW, AH, world)
+    outs = []
+    for k, p in enumerate(plan):
+        x = np.full((AH, AW), 0xA5, np.uint8)                      # rows outside band +- halo: poison
+        lo, hi = max(0, p["row0"] - 4), min(AH, p["row0"] + p["rows"] + 4)
+        x[lo:hi] = img[lo:hi]
+        x = E.aligned_copy(x)
+        out = E.aligned_zeros(AW * AH + extra, np.float32 if lossy else np.int32)
+        out[:] = 12345
+        E.dwt_forward_band(x, out, wl, lossy, qs, p["row0"], p["rows"])
+        outs.append(out)
+    if wl > 1:
+        ll1 = np.concatenate([outs[k][AW * AH + p["ll1_begin"]:AW * AH + p["ll1_begin"] + p["ll1_count"]]
+                              for k, p in enumerate(plan)])
+        assert np.array_equal(ll1, full[AW * AH:AW * AH + (AW // 2) * (AH // 2)])
+    for k, p in enumerate(plan):
+        if wl > 1:
+            outs[k][AW * AH:AW * AH + ll1.size] = ll1                  # the all-gather
+            E.dwt_forward_tail(outs[k], AW, AH, wl, lossy, qs)
+        got, ref = outs[k][:AW * AH].reshape(AH, AW), full[:AW * AH].reshape(AH, AW)
+        for b, n in p["stripes"]:
+            r0, r1 = (b // (AW // 64)) * 64, ((b + n) // (AW // 64)) * 64
+            if wl == 1 and r0 < AH // 2:
+                # one level: the top-left quadrant is LL1 itself, of which a rank holds only its own rows
+                assert np.array_equal(got[r0:r1], ref[r0:r1])
+            else:
+                assert np.array_equal(got[r0:r1], ref[r0:r1]), f"rank {k}, codeblock rows {r0 // 64}..{r1 // 64}"
