@@ -471,30 +471,57 @@ __device__ __forceinline__ void enc_reserve(EncCoder &c, uint64_t m, uint32_t up
 // instruction with an SGPR operand at one per ~4.2.  So the update is written as the instructions
 // themselves, over exec masks instead of selects: 2 half-rate + 4 full-rate + the exhausted compare,
 // where the compiler's select form needs 6 half-rate + 2 full-rate.
+// J >= 0: `p` is a word of four probabilities and this site takes its byte J -- selected by the multiply itself
+// (SDWA src1_sel), so no extraction instruction exists; J < 0: `p` is the probability.
+template <int J = -1>
 __device__ __forceinline__ void enc_update(EncCoder &c, uint64_t onm, uint64_t onem, uint32_t p, uint32_t prec)
 {
 #if defined(__AMDGCN__)
+    // Call sites sit in wave-uniform control flow of kernels launched with whole waves: exec is all ones on
+    // entry, so it is not saved, the product and the shift run in every lane (an idle lane's `a` is never
+    // used), and exec goes back to all ones.  Scalar instructions are not free either -- the CU's one
+    // scalar unit issues about one per cycle for its four SIMDs (tools/valu_probe) -- so: three exec writes.
     uint32_t a;
-    uint64_t sv, em;
+    uint64_t em;
+#define PS_ENC_UPDATE_TAIL                                                                           \
+        "v_lshrrev_b32 %[a], %[pr], %[a]\n\t"          /* a0 */                                          \
+        "s_mov_b64 exec, %[one]\n\t"                                                                    \
+        "v_add_u32 %[a], 1, %[a]\n\t"                   /* lanes coding a 1: a = a0 + 1 */               \
+        "v_add_u32 %[L], %[L], %[a]\n\t"                /*   L += a */                                   \
+        "v_sub_u32 %[a], %[S], %[a]\n\t"                /*   a = S - a  (their new S) */                 \
+        "s_mov_b64 exec, %[on]\n\t"                                                                     \
+        "v_mov_b32 %[S], %[a]\n\t"                      /* lanes coding a 0 still hold a0 in a */        \
+        "s_mov_b64 exec, -1\n\t"                                                                        \
+        "v_cmp_eq_u32_e64 %[em], 0, %[S]"
+#define PS_ENC_UPDATE(MUL)                                                                           \
+    asm volatile(MUL PS_ENC_UPDATE_TAIL                                                              \
+                 : [S] "+v"(c.S), [L] "+v"(c.L), [a] "=&v"(a), [em] "=s"(em)                         \
+                 : [on] "s"(onm), [one] "s"(onem), [p] "v"(p), [pr] "s"(prec))
+    if constexpr (J == 0) PS_ENC_UPDATE("v_mul_u32_u24_sdwa %[a], %[S], %[p] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n\t");
+    else if constexpr (J == 1) PS_ENC_UPDATE("v_mul_u32_u24_sdwa %[a], %[S], %[p] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t");
+    else if constexpr (J == 2) PS_ENC_UPDATE("v_mul_u32_u24_sdwa %[a], %[S], %[p] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t");
+    else if constexpr (J == 3) PS_ENC_UPDATE("v_mul_u32_u24_sdwa %[a], %[S], %[p] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3\n\t");
+    else PS_ENC_UPDATE("v_mul_u32_u24 %[a], %[S], %[p]\n\t");
+#undef PS_ENC_UPDATE
+#undef PS_ENC_UPDATE_TAIL
+    c.emptym = em;
+#if 0
     asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_mov_b64 exec, %[on]\n\t"
         "v_mul_u32_u24 %[a], %[S], %[p]\n\t"
-        "v_lshrrev_b32 %[a], %[pr], %[a]\n\t"          // a0, lanes that code
+        "v_lshrrev_b32 %[a], %[pr], %[a]\n\t"          // a0
         "s_mov_b64 exec, %[one]\n\t"
         "v_add_u32 %[a], 1, %[a]\n\t"                   // lanes coding a 1: a = a0 + 1
         "v_add_u32 %[L], %[L], %[a]\n\t"                //   L += a
         "v_sub_u32 %[a], %[S], %[a]\n\t"                //   a = S - a  (their new S)
         "s_mov_b64 exec, %[on]\n\t"
         "v_mov_b32 %[S], %[a]\n\t"                      // lanes coding a 0 still hold a0 in a
-        "s_mov_b64 exec, %[sv]\n\t"
-        "v_cmp_eq_u32_e32 vcc, 0, %[S]\n\t"
-        "s_mov_b64 %[em], vcc"
-        : [S] "+v"(c.S), [L] "+v"(c.L), [a] "=&v"(a), [sv] "=&s"(sv), [em] "=s"(em)
-        : [on] "s"(onm), [one] "s"(onem), [p] "v"(p), [pr] "s"(prec)
-        : "vcc");
-    c.emptym = em;
+        "s_mov_b64 exec, -1\n\t"
+        "v_cmp_eq_u32_e64 %[em], 0, %[S]"
+        : [S] "+v"(c.S), [L] "+v"(c.L), [a] "=&v"(a), [em] "=s"(em)
+        : [on] "s"(onm), [one] "s"(onem), [p] "v"(p), [pr] "s"(prec));
+#endif
 #else
+    if (J >= 0) p = (p >> (8 * (J < 0 ? 0 : J))) & 0xFFu;
     const uint32_t pe = __builtin_amdgcn_inverse_ballot_w64(onm) ? p : c.pone;     // (S * pone) >> prec == S
     const uint32_t a0 = mul_u24(c.S, pe) >> prec;
     const bool one = __builtin_amdgcn_inverse_ballot_w64(onem);
@@ -503,12 +530,13 @@ __device__ __forceinline__ void enc_update(EncCoder &c, uint64_t onm, uint64_t o
     c.emptym = zero_mask(c.S);
 #endif
 }
+template <int J = -1>
 __device__ __forceinline__ void enc_site2(EncCoder &c, uint64_t onm, uint64_t onem, uint32_t p, uint32_t prec,
                                           uint32_t upper_mask)
 {
     const uint64_t m = c.emptym & onm;
     if (m != 0ull) enc_reserve(c, m, upper_mask);
-    enc_update(c, onm, onem, p, prec);
+    enc_update<J>(c, onm, onem, p, prec);
 }
 // generic form (bulk scan): `inact` = 1 for lanes that sit the site out
 __device__ __forceinline__ void enc_site(EncCoder &c, uint32_t inact, uint32_t sym, uint32_t p, uint32_t prec,
@@ -561,19 +589,20 @@ __device__ __forceinline__ uint32_t vgpr_of(uint32_t s)
 #endif
 }
 
-// One coefficient of the significance propagation pass.  rowbit = 1 << ii (VGPR); sh = 8 * (ii & 3): the
-// row's byte in the group's probability words P4 (significance) and Q4 (sign).  A: significant-before mask
+// One coefficient of the significance propagation pass.  rowbit = 1 << ii (VGPR); J = ii & 3: the row's
+// byte in the group's probability words P4 (significance) and Q4 (sign).  A: significant-before mask
 // of the column's 32 rows (all ones for an idle half: never on); N: becomes significant in this plane (0
 // for an idle half).
-__device__ __forceinline__ void enc_spp_coeff(EncCoder &c, uint32_t sh, uint32_t rowbit, uint32_t A, uint32_t N,
+template <int J>
+__device__ __forceinline__ void enc_spp_coeff(EncCoder &c, uint32_t rowbit, uint32_t A, uint32_t N,
                                               uint32_t s2, uint32_t P4, uint32_t Q4, uint32_t prec, uint32_t upper_mask)
 {
     const uint64_t onm = __builtin_amdgcn_ballot_w64((A & rowbit) == 0u);
     if (onm == 0ull) return;                                // no lane has this column's coefficient to code
     const uint64_t onem = __builtin_amdgcn_ballot_w64((N & rowbit) != 0u);       // N is a subset of ~A
-    enc_site2(c, onm, onem, (P4 >> sh) & 0xFFu, prec, upper_mask);
+    enc_site2<J>(c, onm, onem, P4, prec, upper_mask);
     if (onem != 0ull)
-        enc_site2(c, onem, onem & __builtin_amdgcn_ballot_w64((s2 & rowbit) != 0u), (Q4 >> sh) & 0xFFu, prec, upper_mask);
+        enc_site2<J>(c, onem, onem & __builtin_amdgcn_ballot_w64((s2 & rowbit) != 0u), Q4, prec, upper_mask);
 }
 
 __device__ __forceinline__ uint32_t dec_site(Coder &c, uint32_t inact, uint32_t p, uint32_t prec,
@@ -921,13 +950,17 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
                     rows &= ~(0xFu << g4);
                     const uint32_t P4L = sig_probs4(cpL, pl, g4), P4R = sig_probs4(cpR, pl, g4);
                     const uint32_t Q4L = sign_probs4(cpL, pl, g4), Q4R = sign_probs4(cpR, pl, g4);
-                    while (sub) {
-                        const uint32_t j = (uint32_t)__builtin_ctz(sub);
-                        sub &= sub - 1u;
-                        const uint32_t rowbit = vgpr_of(1u << (g4 + j)), sh = 8u * j;
-                        enc_spp_coeff(c, sh, rowbit, al, nl, cpL.s2, P4L, Q4L, prec, upper_mask);
-                        enc_spp_coeff(c, sh, rowbit, ar, nr, cpR.s2, P4R, Q4R, prec, upper_mask);
+                    // the group's rows, unrolled: the byte of P4 / Q4 a row takes is then a constant of the
+                    // instruction (SDWA), and a row costs two scalar instructions of loop control, not six
+                    const uint32_t gbit = 1u << g4;
+#define PS_SPP_ROW(J)                                                                                    \
+                    if (sub & (1u << J)) {                                                                \
+                        const uint32_t rowbit = vgpr_of(gbit << J);                                       \
+                        enc_spp_coeff<J>(c, rowbit, al, nl, cpL.s2, P4L, Q4L, prec, upper_mask);          \
+                        enc_spp_coeff<J>(c, rowbit, ar, nr, cpR.s2, P4R, Q4R, prec, upper_mask);          \
                     }
+                    PS_SPP_ROW(0) PS_SPP_ROW(1) PS_SPP_ROW(2) PS_SPP_ROW(3)
+#undef PS_SPP_ROW
                 }
             }
         }
