@@ -159,7 +159,53 @@ struct Coder {
     uint32_t cnt_lo, cnt_hi;   // codeword counters (codeStreamShared) of the codeblocks in lanes 0-31 /
                                // 32-63: wave-uniform, they live in SGPRs and are updated by SALU
     uint64_t emptym;           // encoder: ballot(S == 0) as of the end of the previous call site
+    // decoder: the codeblocks' next codewords wait in an LDS ring (see dec_ring_*): window edges of the two
+    // codeblocks (wave-uniform), the lane's ring (its codeblock's) and lane index inside its half
+    uint32_t next_lo, next_hi;
+    uint32_t *ring;
+    uint32_t t;
 };
+
+// LDS operations of the wave's other lanes have completed
+__device__ __forceinline__ void wave_lds_done()
+{
+#if defined(__AMDGCN__)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#else
+    (void)__builtin_amdgcn_ballot_w64(true);
+#endif
+}
+
+// ---- decoder: codeword ring ------------------------------------------------------------------------
+// A reservation of the decoder is followed at once by the use of the codeword it reserved
+// (arithmeticDecoder BPCEngine.cu:420-428), so a load from the staging array puts an L2 / HBM round trip
+// (500-900 cycles) into the dependent chain of every call site that starts a codeword -- about 1100 times
+// per wave.  Codewords are consumed in slot order, so the wave keeps a window of its two codeblocks'
+// streams in LDS: 128 entries per codeblock, of which [cnt, cnt + 64) are always there; whenever a counter
+// passes a multiple of 64 the lanes of that half fetch the next 64 (two coalesced loads), which will not be
+// needed for at least 32 more reservations.  A reservation then reads its codeword with LDS latency.
+constexpr int kDecRing = 128;
+__device__ __forceinline__ void dec_ring_fill(const int32_t *cwarr, uint32_t *ring, uint32_t first, uint32_t t)
+{   // entries first .. first + 63 of the lane's codeblock (cwarr[k] = codeword k; k <= 4094 exists)
+    const uint32_t e0 = first + t, e1 = first + 32u + t;
+    const int32_t v0 = cwarr[e0 > 4094u ? 4094u : e0], v1 = cwarr[e1 > 4094u ? 4094u : e1];
+    ring[e0 & (kDecRing - 1)] = (uint32_t)v0;
+    ring[e1 & (kDecRing - 1)] = (uint32_t)v1;
+}
+// after a reservation: refill the half whose counter passed its window edge
+__device__ __forceinline__ void dec_ring_advance(Coder &c, const int32_t *cwarr, uint32_t upper_mask)
+{
+    const bool lo = c.cnt_lo >= c.next_lo, hi = c.cnt_hi >= c.next_hi;        // wave-uniform
+    if (lo || hi) {
+        wave_lds_done();                                   // every lane has read this site's codeword
+        const uint32_t edge = upper_mask ? c.next_hi : c.next_lo;
+        if (upper_mask ? hi : lo) dec_ring_fill(cwarr, c.ring, edge + 64u, c.t);
+        wave_lds_done();                                   // (a later reservation of another lane reads them)
+        if (lo) c.next_lo = __builtin_amdgcn_readfirstlane(c.next_lo + 64u);
+        if (hi) c.next_hi = __builtin_amdgcn_readfirstlane(c.next_hi + 64u);
+    }
+}
 
 // significance probabilities for contexts 0..8 packed as bytes: w0 = ctx 0-3, w1 = ctx 4-7, p8.
 struct PlaneLut { uint32_t sig0, sig1, sig8, sign, ref, sig8x4; };
@@ -211,16 +257,6 @@ __device__ __forceinline__ void lut_to_lds(const int32_t *lut, int total, uint8_
 #define PICSONG_BPC_DEC_WG 4
 #endif
 constexpr int kBpcEncWgWaves = PICSONG_BPC_ENC_WG, kBpcDecWgWaves = PICSONG_BPC_DEC_WG;
-// LDS operations of the wave's other lanes have completed
-__device__ __forceinline__ void wave_lds_done()
-{
-#if defined(__AMDGCN__)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-#else
-    (void)__builtin_amdgcn_ballot_w64(true);
-#endif
-}
 // stores of the wave's other lanes to addresses this lane is about to overwrite have completed
 __device__ __forceinline__ void wave_stores_issued()
 {
@@ -1101,7 +1137,8 @@ __device__ __forceinline__ uint64_t dec_site_m(Coder &c, bool on, uint64_t onm, 
     const uint64_t m = __builtin_amdgcn_ballot_w64(empty) & onm;
     if (m != 0ull) {
         reserve_enc(c, on && empty, m, upper_mask);
-        if (on && empty) c.cw = (uint32_t)stage[c.slot];   // stage = the codeword array (staging + 1)
+        if (on && empty) c.cw = c.ring[c.slot & (kDecRing - 1)];
+        dec_ring_advance(c, stage, upper_mask);            // stage = the codeword array (staging + 1)
     }
     const uint32_t a = (mul_u24(c.S, p) >> prec) + 1u;
     const uint32_t a2 = c.L + a;
@@ -1226,6 +1263,7 @@ void bpc_decode_kernel(BpcArgs a)
     static_assert(NP == kDecSmallPlanes || NP == kMaxPlanes, "two classes");
     __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
     __shared__ uint8_t sign_tab[256];
+    __shared__ uint32_t cw_ring[(BULK ? 1 : kBpcDecWgWaves) * 2 * kDecRing];
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
     sign_table_fill(sign_tab, lane);                        // (the LUT copy below ends with the barrier)
     const int wave = BULK ? (int)blockIdx.x : (int)blockIdx.x * kBpcDecWgWaves + (int)(threadIdx.x >> 6);
@@ -1255,7 +1293,13 @@ void bpc_decode_kernel(BpcArgs a)
     find_subband(cbx * 64 + 2 * (int)t, cby * 64, a.AW, a.AH, a.wl, level, sb);
     const int grp = level * a.g.nSub + sb;
 
-    Coder c = { 0u, 0u, 0u, 0u, 0u, 0u, ~0ull };
+    Coder c = { 0u, 0u, 0u, 0u, 0u, 0u, ~0ull, 64u, 64u, nullptr, t };
+    c.ring = cw_ring + ((threadIdx.x >> 6) * 2u + half) * kDecRing;
+    // codewords 0 .. 127 of both codeblocks (reads stay inside the codeblock's 4096 staging words whatever
+    // its length; what lies beyond the length is never used)
+    dec_ring_fill(cw, c.ring, 0u, t);
+    dec_ring_fill(cw, c.ring, 64u, t);
+    wave_lds_done();
     M64 sigL = { 0u, 0u }, sigR = { 0u, 0u }, refL = { 0u, 0u }, refR = { 0u, 0u };
 
     int cbp = 0, loff = 0;
