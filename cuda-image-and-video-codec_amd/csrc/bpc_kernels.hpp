@@ -164,6 +164,7 @@ struct Coder {
     uint32_t next_lo, next_hi;
     uint32_t *ring;
     uint32_t t;
+    uint32_t *ldscnt;          // LDS form of the reservation: the lane's codeblock's codeword counter
 };
 
 // LDS operations of the wave's other lanes have completed
@@ -1136,10 +1137,48 @@ __device__ __forceinline__ uint64_t dec_site_m(Coder &c, bool on, uint64_t onm, 
     const bool empty = c.S == 0u;
     const uint64_t m = __builtin_amdgcn_ballot_w64(empty) & onm;
     if (m != 0ull) {
+#if PS_ENC_LDS
+        // the slot by one LDS atomic add per requesting lane (see the encoder's enc_reserve); the scalar
+        // counters only steer the codeword ring
+        if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+            const uint32_t slot = __hip_atomic_fetch_add(c.ldscnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            c.cw = c.ring[slot & (kDecRing - 1)];
+            c.L = 0u; c.S = 0xFFFFu;
+        }
+        c.cnt_lo = __builtin_amdgcn_readfirstlane(c.cnt_lo + (uint32_t)__builtin_popcount((uint32_t)m));
+        c.cnt_hi = __builtin_amdgcn_readfirstlane(c.cnt_hi + (uint32_t)__builtin_popcount((uint32_t)(m >> 32)));
+#else
         reserve_enc(c, on && empty, m, upper_mask);
         if (on && empty) c.cw = c.ring[c.slot & (kDecRing - 1)];
+#endif
         dec_ring_advance(c, stage, upper_mask);            // stage = the codeword array (staging + 1)
     }
+#if defined(__AMDGCN__)
+    // a = ((S * p) >> prec) + 1;  cw >= L + a decodes a 1: S' = S - a, L' = L + a;  else S' = a - 1
+    // (arithmeticDecoder BPCEngine.cu:405-442).  As the encoder's update: the instructions themselves over
+    // exec masks (exec is all ones on entry), full-rate moves and adds where the compiler's form selects.
+    uint32_t a, t2;
+    uint64_t gem, onem;
+    asm volatile(
+        "v_mul_u32_u24 %[a], %[S], %[p]\n\t"
+        "v_lshrrev_b32 %[a], %[pr], %[a]\n\t"          // a0 = a - 1
+        "v_add3_u32 %[t2], %[L], %[a], 1\n\t"           // L + a
+        "v_cmp_ge_u32_e64 %[gem], %[cw], %[t2]\n\t"
+        "s_and_b64 %[onem], %[gem], %[on]\n\t"
+        "s_mov_b64 exec, %[onem]\n\t"                   // lanes decoding a 1
+        "v_add_u32 %[a], 1, %[a]\n\t"
+        "v_mov_b32 %[L], %[t2]\n\t"
+        "v_sub_u32 %[a], %[S], %[a]\n\t"                //   a = S - a (their new S)
+        "s_mov_b64 exec, %[on]\n\t"
+        "v_mov_b32 %[S], %[a]\n\t"                      // lanes decoding a 0 still hold a0 = a - 1
+        "s_mov_b64 exec, -1"
+        : [S] "+v"(c.S), [L] "+v"(c.L), [a] "=&v"(a), [t2] "=&v"(t2), [gem] "=&s"(gem), [onem] "=&s"(onem)
+        : [on] "s"(onm), [p] "v"(p), [pr] "s"(prec), [cw] "v"(c.cw)
+        : "scc");
+    (void)on;
+    one = __builtin_amdgcn_inverse_ballot_w64(onem);
+    return onem;
+#else
     const uint32_t a = (mul_u24(c.S, p) >> prec) + 1u;
     const uint32_t a2 = c.L + a;
     const bool ge = c.cw >= a2;
@@ -1150,6 +1189,7 @@ __device__ __forceinline__ uint64_t dec_site_m(Coder &c, bool on, uint64_t onm, 
     }
     one = ge && on;
     return gem & onm;
+#endif
 }
 __device__ __forceinline__ bool dec_site_on(Coder &c, bool on, uint64_t onm, uint32_t p, uint32_t prec,
                                             uint32_t upper_mask, const int32_t *stage)
@@ -1264,7 +1304,9 @@ void bpc_decode_kernel(BpcArgs a)
     __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
     __shared__ uint8_t sign_tab[256];
     __shared__ uint32_t cw_ring[(BULK ? 1 : kBpcDecWgWaves) * 2 * kDecRing];
+    __shared__ uint32_t lds_cnt[(BULK ? 1 : kBpcDecWgWaves) * 2];
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
+    if (t == 0u) lds_cnt[(threadIdx.x >> 6) * 2u + half] = 0u;        // (barrier: below, with the table copy)
     sign_table_fill(sign_tab, lane);                        // (the LUT copy below ends with the barrier)
     const int wave = BULK ? (int)blockIdx.x : (int)blockIdx.x * kBpcDecWgWaves + (int)(threadIdx.x >> 6);
     const int cb = a.cb_base + 2 * wave + (int)half;
@@ -1293,7 +1335,8 @@ void bpc_decode_kernel(BpcArgs a)
     find_subband(cbx * 64 + 2 * (int)t, cby * 64, a.AW, a.AH, a.wl, level, sb);
     const int grp = level * a.g.nSub + sb;
 
-    Coder c = { 0u, 0u, 0u, 0u, 0u, 0u, ~0ull, 64u, 64u, nullptr, t };
+    Coder c = { 0u, 0u, 0u, 0u, 0u, 0u, ~0ull, 64u, 64u, nullptr, t, nullptr };
+    c.ldscnt = &lds_cnt[(threadIdx.x >> 6) * 2u + half];
     c.ring = cw_ring + ((threadIdx.x >> 6) * 2u + half) * kDecRing;
     // codewords 0 .. 127 of both codeblocks (reads stay inside the codeblock's 4096 staging words whatever
     // its length; what lies beyond the length is never used)
