@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace picsong {
 
@@ -1478,6 +1479,326 @@ void bpc_decode_kernel(BpcArgs a)
         // NP.. do not exist in this instantiation (its waves have at most NP coded planes).
         write_rows<NP>(PLlo, PRlo, sgnL.lo, sgnR.lo, 0, valid, sz, stage, t, a.coeffs_out + cbase, a.AW);
         write_rows<NP>(PLhi, PRhi, sgnL.hi, sgnR.hi, 32, valid, sz, stage, t, a.coeffs_out + cbase, a.AW);
+    }
+}
+
+
+// =============================================================================================
+// -cp 3: three coding passes (kernelBPCCoder3CP / kernelBPCDecoder3CP BPC/BPCEngine.cu:2029-2121,
+// 2221-2299; Encode3CP :1727-1776, Decode3CP :1844-1900; SPPEncoder3CP :521-553, SPPDecoder3CP :599-640,
+// CPEncoder :645-680, CPDecoder :686-719 and their launchers :850-925, :1010-1243).  Deprecated in the
+// reference (IO/CommandLineParser.cpp:34) and not tuned here: one kernel for both directions over LIVE
+// row masks, as the 2-pass decoder keeps them -- in this mode even the encoder cannot form its contexts
+// ahead of the scan, because whether the significance pass codes a coefficient at all (one of its eight
+// neighbours is significant when the scan reaches it) depends on what the pass did to the coefficients
+// before it.
+//   plane MSB      : cleanup pass over every coefficient (all are flagged at the start)
+//   planes below   : significance pass (insignificant coefficients with a significant neighbour; the others
+//                    get the cleanup flag), refinement pass (significant before this plane), cleanup pass (the
+//                    flagged ones, cp_sig / cp_sign tables = the ordinary LUT pointers + nSig + nSign)
+// The table is [ref | sig | sign | cp_sig | cp_sign]; the call sites are the 2-pass kernels' (enc_site2 /
+// dec_site_m), so slot order, LDS reservation and the decoder's codeword ring are shared.
+// =============================================================================================
+constexpr int kLutLdsMax3 = 2 * kLutLdsMax;        // bytes of one 5-section table
+
+__device__ __forceinline__ PlaneLut plane_lut_aux(const LutView &v, const LutGeo &g, int grp, int bp, int aux)
+{
+    PlaneLut pl;
+    const int ri = (grp * g.nBp + bp) * g.cRef;
+    const int si = (grp * g.nBp + bp) * g.cSig + g.nRef + aux;
+    const int gi = (grp * g.nBp + bp) * g.cSign + g.nRef + g.nSig + aux;
+    pl.ref = lut_get(v, ri);
+    pl.sig0 = lut_get(v, si + 0) | (lut_get(v, si + 1) << 8) | (lut_get(v, si + 2) << 16) | (lut_get(v, si + 3) << 24);
+    pl.sig1 = lut_get(v, si + 4) | (lut_get(v, si + 5) << 8) | (lut_get(v, si + 6) << 16) | (lut_get(v, si + 7) << 24);
+    pl.sig8 = lut_get(v, si + 8);
+    pl.sign = lut_get(v, gi + 0) | (lut_get(v, gi + 1) << 8) | (lut_get(v, gi + 2) << 16) | (lut_get(v, gi + 3) << 24);
+    pl.sig8x4 = pl.sig8 * 0x01010101u;
+    return pl;
+}
+
+// One coefficient of the significance pass (CLEANUP = false) or of the cleanup pass (true), encoder
+// (DEC = false: `cur` holds the plane's bits, `so` every coefficient's sign) or decoder (`cur` and `so`
+// receive them).  wo/wl/wr: W-form significance of the own / left / right column, so/sl/sr: signs.  flag:
+// the 32 rows' cleanup flags of this column half; elig: rows that become eligible for refinement at once
+// (cleanup pass, :669-670).  Returns the ballot of the lanes whose coefficient became significant.
+template <bool DEC, bool CLEANUP, class CT>
+__device__ __forceinline__ uint64_t cp3_coeff(CT &c, bool idle, uint32_t ii, M64 &wo, const M64 &wl, const M64 &wr,
+                                              M64 &so, const M64 &sl, const M64 &sr, uint32_t &cur, uint32_t &flag,
+                                              uint32_t &elig, const PlaneLut &pl, uint32_t prec, uint32_t upper_mask,
+                                              const int32_t *cwarr, const uint8_t *sgt)
+{
+    const uint32_t to = triple(wo, ii), tl = triple(wl, ii), tr = triple(wr, ii);
+    const uint32_t ctx = (uint32_t)__builtin_popcount(to & 5u) + (uint32_t)__builtin_popcount(tl) +
+                         (uint32_t)__builtin_popcount(tr);
+    bool on;
+    if constexpr (CLEANUP) {
+        on = !idle && ((flag >> ii) & 1u) != 0u;
+    } else {
+        const bool cand = !idle && (to & 2u) == 0u;
+        on = cand && ctx != 0u;
+        if (cand && ctx == 0u) flag |= 1u << ii;                       // left to the cleanup pass (:551 / :638)
+    }
+    const uint64_t onm = __builtin_amdgcn_ballot_w64(on);
+    if (onm == 0ull) return 0ull;
+    const uint32_t p07 = __builtin_amdgcn_perm(pl.sig1, pl.sig0, ctx | 0x0C0C0C00u);
+    const uint32_t p = ctx >= 8u ? pl.sig8 : p07;
+    bool one;
+    uint64_t onem;
+    if constexpr (DEC) {
+        onem = dec_site_m(c, on, onm, p, prec, upper_mask, cwarr, one);
+    } else {
+        one = on && ((cur >> ii) & 1u) != 0u;
+        onem = __builtin_amdgcn_ballot_w64(one);
+        enc_site2(c, onm, onem, p, prec, upper_mask);
+    }
+    if constexpr (CLEANUP) { if (on) flag &= ~(1u << ii); }            // :664 / :703
+    if (onem != 0ull) {
+        // sign context from the four neighbours' (significant, sign) pairs; the encoder holds the signs
+        // of coefficients that are not significant yet, which must not count
+        const uint32_t xo = triple(so, ii) & to, xl = triple(sl, ii) & tl, xr = triple(sr, ii) & tr;
+        uint32_t idx = (to & 5u) | ((xo & 5u) << 1);
+        idx |= ((tl & 2u) << 3) | ((xl & 2u) << 4) | ((tr & 2u) << 5) | ((xr & 2u) << 6);
+        const uint32_t tv = sgt[idx];
+        const uint32_t p2 = (pl.sign >> (tv >> 3)) & 0xFFu;
+        if constexpr (DEC) {
+            const bool s2 = dec_site_on(c, one, onem, p2, prec, upper_mask, cwarr);
+            if (one) w_set(so, ii, (s2 ? 1u : 0u) ^ (tv & 1u));
+        } else {
+            const uint32_t sgn = (triple(so, ii) >> 1) & 1u;            // the coefficient's own sign
+            enc_site2(c, onem, onem & __builtin_amdgcn_ballot_w64(((sgn ^ tv) & 1u) != 0u), p2, prec, upper_mask);
+        }
+        if (one) {
+            w_set(wo, ii, 1u);
+            if constexpr (DEC) cur |= 1u << ii;
+            if constexpr (CLEANUP) elig |= 1u << ii;
+        }
+    }
+    return onem;
+}
+
+#ifndef PICSONG_BPC3_WG
+#define PICSONG_BPC3_WG 2
+#endif
+constexpr int kBpc3WgWaves = PICSONG_BPC3_WG;
+
+template <bool DEC>
+__global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
+{
+    using CT = typename std::conditional<DEC, Coder, EncCoder>::type;
+    constexpr int NP = kMaxPlanes;
+    __shared__ uint8_t lds_lut[kLutLdsMax3];
+    __shared__ uint8_t sign_tab[256];
+    __shared__ uint32_t cw_ring[kBpc3WgWaves * 2 * kDecRing];
+    __shared__ uint32_t lds_cnt[kBpc3WgWaves * 2];
+    const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
+    sign_table_fill(sign_tab, lane);
+    if (t == 0u) lds_cnt[(threadIdx.x >> 6) * 2u + half] = 0u;
+    const int wave = (int)blockIdx.x * kBpc3WgWaves + (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cb = a.cb_base + 2 * wave + (int)half;
+    const bool valid = cb < a.nCB;
+    const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
+    const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
+    const uint32_t cbyte = (uint32_t)cbase * 4u, rstride = (uint32_t)a.AW * 4u;
+    int32_t *const stw = a.staging + (size_t)(a.cb_base + 2 * wave) * 4096u;
+    int32_t *const st = stw + (size_t)half * 4096u;
+    const int32_t *const cw = st + 1;
+    const uint32_t prec = (uint32_t)a.g.prec;
+    const uint32_t upper_mask = opaque_mask(half ? 0xFFFFFFFFu : 0u);
+    const int total = a.g.nRef + 2 * (a.g.nSig + a.g.nSign), aux = a.g.nSig + a.g.nSign;
+
+    uint32_t PLlo[NP], PLhi[NP], PRlo[NP], PRhi[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) { PLlo[k] = PLhi[k] = PRlo[k] = PRhi[k] = 0u; }
+    M64 sgnL = { 0u, 0u }, sgnR = { 0u, 0u };              // X-form here: lo = rows 0-31, hi = rows 32-63
+    int msb = 32;
+    int32_t sz = 0;
+    if constexpr (DEC) {
+        if (valid) { msb = st[0]; sz = a.sizes[cb]; }
+        if (valid && sz != 4096 && msb != 32 && (msb < 0 || msb > kMaxPlanes - 1)) { atomicOr(a.range_flag, 1); msb = kMaxPlanes - 1; }
+    } else {
+        // findMSB3CP :198-216 (the cleanup flag does not count) and the planes, plane msb - k in register k
+        uint32_t ormag = 0u;
+        if (valid)
+            for (int i = 0; i < 64; i++) {
+                uint32_t m0, m1, n0, n1;
+                load_row(a, cbyte + (uint32_t)i * rstride, m0, m1, n0, n1);
+                ormag |= m0 | m1;
+            }
+        ormag = half_or_dpp(ormag, upper_mask);
+        msb = ormag ? 31 - __builtin_clz(ormag) : 32;
+        if (valid && msb != 32 && msb > kMaxPlanes - 1) { atomicOr(a.range_flag, 1); msb = kMaxPlanes - 1; }
+        if (valid && msb != 32) {
+            const uint32_t up = (uint32_t)(kMaxPlanes - 1 - msb);
+#pragma unroll
+            for (int hw = 0; hw < 2; hw++)
+                for (int ii = 0; ii < 32; ii++) {
+                    uint32_t m0, m1, n0, n1;
+                    load_row(a, cbyte + (uint32_t)(hw * 32 + ii) * rstride, m0, m1, n0, n1);
+                    m0 = (m0 << up) & 0xFFFFu; m1 = (m1 << up) & 0xFFFFu;
+                    if (hw == 0) { sgnL.lo |= n0 << ii; sgnR.lo |= n1 << ii; }
+                    else         { sgnL.hi |= n0 << ii; sgnR.hi |= n1 << ii; }
+#pragma unroll
+                    for (int k = 0; k < NP; k++) {
+                        const uint32_t b0 = (m0 >> (kMaxPlanes - 1 - k)) & 1u, b1 = (m1 >> (kMaxPlanes - 1 - k)) & 1u;
+                        if (hw == 0) { PLlo[k] |= b0 << ii; PRlo[k] |= b1 << ii; }
+                        else         { PLhi[k] |= b0 << ii; PRhi[k] |= b1 << ii; }
+                    }
+                }
+        }
+    }
+    const bool coded = valid && msb != 32 && sz != 4096;
+
+    int level, sb;
+    find_subband(cbx * 64 + 2 * (int)t, cby * 64, a.AW, a.AH, a.wl, level, sb);
+    const int grp = level * a.g.nSub + sb;
+    lut_to_lds(a.lut, total, lds_lut);                     // (ends with the workgroup barrier)
+    const LutView lv = { lds_lut, a.lut, total, total, 0 };
+
+    CT c;
+    if constexpr (DEC) {
+        c = Coder{ 0u, 0u, 0u, 0u, 0u, 0u, ~0ull, 64u, 64u, nullptr, t, nullptr };
+        c.ldscnt = &lds_cnt[(threadIdx.x >> 6) * 2u + half];
+        c.ring = cw_ring + ((threadIdx.x >> 6) * 2u + half) * kDecRing;
+        dec_ring_fill(cw, c.ring, 0u, t);
+        dec_ring_fill(cw, c.ring, 64u, t);
+        wave_lds_done();
+    } else {
+        c.L = 0u; c.S = 0u; c.off = half * 16384u;
+        c.cnt_lo = 0u; c.cnt_hi = 0u; c.emptym = ~0ull;
+        c.slot = 0xFFFFFFFFu;
+        c.ldscnt = &lds_cnt[(threadIdx.x >> 6) * 2u + half];
+        c.halfoff4 = half * 16384u + 4u; c.pone = 1u << prec;
+        c.stw = reinterpret_cast<char *>(stw);
+    }
+
+    int np = coded ? msb + 1 : 0;
+    { int o = __shfl_xor(np, 32); np = np > o ? np : o; }
+    np = (int)__builtin_amdgcn_readfirstlane((uint32_t)np);
+
+    M64 sigL = { 0u, 0u }, sigR = { 0u, 0u }, refL = { 0u, 0u }, refR = { 0u, 0u };
+    M64 flgL = { ~0u, ~0u }, flgR = { ~0u, ~0u };          // readCoefficients3CP :84-86: every coefficient flagged
+
+    for (int p = 0; p < np; p++) {
+        const int bp = msb - p;
+        const bool act = coded && bp >= 0;
+        const bool idle = !act;
+        if constexpr (DEC) {
+            if (act && p > 0) {                            // make room: index 0 = the plane being decoded
+#pragma unroll
+                for (int k = NP - 1; k > 0; k--) { PLlo[k] = PLlo[k - 1]; PLhi[k] = PLhi[k - 1]; PRlo[k] = PRlo[k - 1]; PRhi[k] = PRhi[k - 1]; }
+                PLlo[0] = PLhi[0] = PRlo[0] = PRhi[0] = 0u;
+            }
+        }
+        PlaneLut pl = { 0u, 0u, 0u, 0u, 0u, 0u }, plc = pl;
+        if (act) { pl = plane_lut_aux(lv, a.g, grp, bp, 0); plc = plane_lut_aux(lv, a.g, grp, bp, aux); }
+
+        // ---- significance pass, then refinement pass (not on a codeblock's top plane, Encode3CP :1744-1751)
+        const bool top = act && p == 0 && bp == msb;       // this lane's codeblock is at its MSB plane
+        const bool spp_idle = idle || top;
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            // pass 0: significance, pass 1 (after the refinement loop below): cleanup -- same scan
+            if (pass == 1) {
+                // refinement pass: coefficients significant before this plane (bit 29), :726-736 / :743-762
+#pragma unroll
+                for (int hw = 0; hw < 2; hw++) {
+                    uint32_t curL = hw ? PLhi[0] : PLlo[0], curR = hw ? PRhi[0] : PRlo[0];
+                    const uint32_t rL = spp_idle ? 0u : (hw ? refL.hi : refL.lo), rR = spp_idle ? 0u : (hw ? refR.hi : refR.lo);
+                    uint32_t rows = wave_or32(rL | rR);
+                    while (rows) {
+                        const uint32_t ii = (uint32_t)__builtin_ctz(rows);
+                        rows &= rows - 1u;
+                        const bool oL = ((rL >> ii) & 1u) != 0u, oR = ((rR >> ii) & 1u) != 0u;
+                        const uint64_t mL = __builtin_amdgcn_ballot_w64(oL), mR = __builtin_amdgcn_ballot_w64(oR);
+                        if constexpr (DEC) {
+                            if (mL != 0ull) curL |= dec_site_on(c, oL, mL, pl.ref, prec, upper_mask, cw) ? (1u << ii) : 0u;
+                            if (mR != 0ull) curR |= dec_site_on(c, oR, mR, pl.ref, prec, upper_mask, cw) ? (1u << ii) : 0u;
+                        } else {
+                            if (mL != 0ull) enc_site2(c, mL, mL & __builtin_amdgcn_ballot_w64(((curL >> ii) & 1u) != 0u), pl.ref, prec, upper_mask);
+                            if (mR != 0ull) enc_site2(c, mR, mR & __builtin_amdgcn_ballot_w64(((curR >> ii) & 1u) != 0u), pl.ref, prec, upper_mask);
+                        }
+                    }
+                    if constexpr (DEC) { if (hw == 0) { PLlo[0] = curL; PRlo[0] = curR; } else { PLhi[0] = curL; PRhi[0] = curR; } }
+                }
+                // coefficients the significance pass made significant become eligible now (MRP's else branch)
+                if (!spp_idle) { refL.lo |= sigL.lo; refL.hi |= sigL.hi; refR.lo |= sigR.lo; refR.hi |= sigR.hi; }
+            }
+            const bool pidle = pass == 0 ? spp_idle : idle;
+            const PlaneLut &plp = pass == 0 ? pl : plc;
+#pragma unroll
+            for (int hw = 0; hw < 2; hw++) {
+                M64 wL = to_w(sigL, hw), wR = to_w(sigR, hw);
+                M64 sL = to_w(sgnL, hw), sR = to_w(sgnR, hw);
+                M64 wPR = { from_prev32(wR.lo, t), from_prev32(wR.hi, t) };
+                M64 wNL = { from_next32(wL.lo, t), from_next32(wL.hi, t) };
+                M64 sPR = { from_prev32(sR.lo, t), from_prev32(sR.hi, t) };
+                M64 sNL = { from_next32(sL.lo, t), from_next32(sL.hi, t) };
+                uint32_t curL = hw ? PLhi[0] : PLlo[0], curR = hw ? PRhi[0] : PRlo[0];
+                uint32_t fL = hw ? flgL.hi : flgL.lo, fR = hw ? flgR.hi : flgR.lo;
+                uint32_t eL = 0u, eR = 0u;
+                const uint32_t xl = hw ? sigL.hi : sigL.lo, xr = hw ? sigR.hi : sigR.lo;
+                uint32_t rows = wave_or32(pidle ? 0u : (pass == 0 ? ~(xl & xr) : (fL | fR)));
+                while (rows) {
+                    const uint32_t ii = (uint32_t)__builtin_ctz(rows);
+                    rows &= rows - 1u;
+                    uint64_t bL, bR;
+                    if (pass == 0) bL = cp3_coeff<DEC, false>(c, pidle, ii, wL, wPR, wR, sL, sPR, sR, curL, fL, eL, plp, prec, upper_mask, cw, sign_tab);
+                    else           bL = cp3_coeff<DEC, true>(c, pidle, ii, wL, wPR, wR, sL, sPR, sR, curL, fL, eL, plp, prec, upper_mask, cw, sign_tab);
+                    if (bL != 0ull) {                      // lane+1's left column as it is after the left phase
+                        wNL.lo = from_next32(wL.lo, t); wNL.hi = from_next32(wL.hi, t);
+                        if constexpr (DEC) { sNL.lo = from_next32(sL.lo, t); sNL.hi = from_next32(sL.hi, t); }
+                    }
+                    if (pass == 0) bR = cp3_coeff<DEC, false>(c, pidle, ii, wR, wL, wNL, sR, sL, sNL, curR, fR, eR, plp, prec, upper_mask, cw, sign_tab);
+                    else           bR = cp3_coeff<DEC, true>(c, pidle, ii, wR, wL, wNL, sR, sL, sNL, curR, fR, eR, plp, prec, upper_mask, cw, sign_tab);
+                    if (bR != 0ull) {                      // lane-1's right column after the right phase
+                        wPR.lo = from_prev32(wR.lo, t); wPR.hi = from_prev32(wR.hi, t);
+                        if constexpr (DEC) { sPR.lo = from_prev32(sR.lo, t); sPR.hi = from_prev32(sR.hi, t); }
+                    }
+                }
+                if (hw == 0) { sigL.lo = w_rows(wL); sigR.lo = w_rows(wR); flgL.lo = fL; flgR.lo = fR; refL.lo |= eL; refR.lo |= eR; }
+                else         { sigL.hi = w_rows(wL); sigR.hi = w_rows(wR); flgL.hi = fL; flgR.hi = fR; refL.hi |= eL; refR.hi |= eR; }
+                if constexpr (DEC) {
+                    if (hw == 0) { sgnL.lo = w_rows(sL); sgnR.lo = w_rows(sR); PLlo[0] = curL; PRlo[0] = curR; }
+                    else         { sgnL.hi = w_rows(sL); sgnR.hi = w_rows(sR); PLhi[0] = curL; PRhi[0] = curR; }
+                }
+            }
+        }
+        if constexpr (!DEC) {                              // the next plane moves into register 0
+#pragma unroll
+            for (int k = 0; k < NP - 1; k++) { PLlo[k] = PLlo[k + 1]; PLhi[k] = PLhi[k + 1]; PRlo[k] = PRlo[k + 1]; PRhi[k] = PRhi[k + 1]; }
+            PLlo[NP - 1] = PLhi[NP - 1] = PRlo[NP - 1] = PRhi[NP - 1] = 0u;
+        }
+    }
+
+    if constexpr (DEC) {
+        write_rows<NP>(PLlo, PRlo, sgnL.lo, sgnR.lo, 0, valid, sz, st, t, a.coeffs_out + cbase, a.AW);
+        write_rows<NP>(PLhi, PRhi, sgnL.hi, sgnR.hi, 32, valid, sz, st, t, a.coeffs_out + cbase, a.AW);
+    } else {
+        // flush + sizeArray + MSB word + expansion fallback, as bpc_encode_kernel
+#if PS_ENC_LDS
+        if (coded) {
+            const uint32_t sl = (int32_t)c.slot > 4094 ? 4094u : c.slot;
+            *reinterpret_cast<int32_t *>(c.stw + ((sl << 2) + c.halfoff4)) = (int32_t)c.L;
+        }
+        wave_lds_done();
+        const uint32_t cw_count = *c.ldscnt;
+        const uint32_t size = (cw_count > 4095u ? 4095u : cw_count) + 1u;
+#else
+        if (coded) *reinterpret_cast<int32_t *>(c.stw + c.off) = (int32_t)c.L;
+        const uint32_t size = (half ? c.cnt_hi : c.cnt_lo) + 1u;
+#endif
+        if (valid && t == 0u) a.sizes[cb] = (int32_t)size;
+        wave_stores_issued();
+        if (valid && size == 4096u) {
+            for (int i = 0; i < 64; i++) {
+                uint32_t m0, m1, n0, n1;
+                load_row(a, cbyte + (uint32_t)i * rstride, m0, m1, n0, n1);
+                const uint32_t w0 = ((m0 << 1) + n0) & 0xFFFFu, w1 = ((m1 << 1) + n1) & 0xFFFFu;
+                *reinterpret_cast<int2 *>(st + t * 128u + 2u * (uint32_t)i) = make_int2((int)w0, (int)w1);
+            }
+        } else if (valid && t == 0u) {
+            st[0] = msb;
+        }
     }
 }
 

@@ -261,6 +261,7 @@ int picsong_lut_load_k(const char *folder_c, int component, int wl, int fill, in
     if (n_tables <= 0) n_tables = info->n_bp_files;
     if (n_tables < 1) n_tables = 1;
     info->n_tables = n_tables;
+    info->cp = 2;
     if (!table) return PICSONG_OK;
     const size_t total = (size_t)info->n_ref + info->n_sig + info->n_sign;
     if (cap < total * (size_t)n_tables)
@@ -282,6 +283,33 @@ int picsong_lut_load_k(const char *folder_c, int component, int wl, int fill, in
     return PICSONG_OK;
 }
 
+int picsong_lut_load_cp(const char *folder_c, int component, int wl, int fill, int cp, picsong_lut_info *info,
+                        int32_t *table, size_t cap)
+{
+    if (cp != 3) {
+        const int rc = picsong_lut_load_k(folder_c, component, wl, fill, 1, info, table, cap);
+        if (rc == PICSONG_OK) info->cp = 2;
+        return rc;
+    }
+    if (!folder_c || !info) return fail(PICSONG_ERR_ARG, "lut_load: null argument");
+    int rc = picsong_lut_load_k(folder_c, component, wl, fill, 1, info, nullptr, 0);      // header + section sizes
+    if (rc) return rc;
+    info->cp = 3;
+    if (!table) return PICSONG_OK;
+    const size_t b3 = (size_t)info->n_ref + info->n_sig + info->n_sign, total = b3 + info->n_sig + info->n_sign;
+    if (cap < total) return fail(PICSONG_ERR_ARG, "lut_load: table capacity %zu < %zu", cap, total);
+    std::string folder(folder_c);
+    if (!folder.empty() && folder.back() != '/') folder += '/';
+    for (size_t i = 0; i < total; i++) table[i] = fill;
+    const int nBp = info->n_bitplanes;
+    if ((rc = lut_section(folder, "ref", component, 0, info->ctx_ref, nBp, wl, table, 0, total))) return rc;
+    if ((rc = lut_section(folder, "sig", component, 0, info->ctx_sig, nBp, wl, table, info->n_ref, total))) return rc;
+    if ((rc = lut_section(folder, "sign", component, 0, info->ctx_sign, nBp, wl, table, info->n_ref + info->n_sig, total))) return rc;
+    if ((rc = lut_section(folder, "cp_sig", component, 0, info->ctx_sig, nBp, wl, table, (int)b3, total))) return rc;
+    if ((rc = lut_section(folder, "cp_sign", component, 0, info->ctx_sign, nBp, wl, table, (int)b3 + info->n_sig, total))) return rc;
+    return PICSONG_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------
@@ -292,7 +320,8 @@ int picsong_ctx_create(const picsong_params *p, int device, picsong_ctx **out)
     // Launcher.cu:132 validation + header limits
     if (p->width <= 0 || p->height <= 0) return fail(PICSONG_ERR_ARG, "xSize/ySize must be positive");
     if (p->wl < 1 || p->wl > 7) return fail(PICSONG_ERR_ARG, "wl %d outside 1..7", p->wl);
-    if (p->cp != 2) return fail(PICSONG_ERR_ARG, "only -cp 2 is implemented (got %d)", p->cp);
+    if (p->cp != 2 && p->cp != 3) return fail(PICSONG_ERR_ARG, "cp %d: 2 or 3 coding passes", p->cp);
+    if (p->cp == 3 && p->k > 0.0f) return fail(PICSONG_ERR_ARG, "-cp 3 has no complexity-scalable mode (k must be 0)");
     if (!(p->k >= 0.0f && p->k <= 65.535f)) return fail(PICSONG_ERR_ARG, "k %g outside [0, 65.535]", p->k);
     if (p->lossy && !(p->qs > 0.0f && p->qs <= 1.0f)) return fail(PICSONG_ERR_ARG, "qs %g outside (0,1]", p->qs);
     if (p->bit_depth != 8) return fail(PICSONG_ERR_ARG, "only 8-bit samples are implemented");
@@ -380,11 +409,15 @@ int picsong_ctx_set_lut_component(picsong_ctx *c, int comp, const picsong_lut_in
         return fail(PICSONG_ERR_ARG, "LUT contexts must be 9/4/1 (sig/sign/ref), got %d/%d/%d", info->ctx_sig,
                     info->ctx_sign, info->ctx_ref);
     if (info->precision < 1 || info->precision > 8) return fail(PICSONG_ERR_ARG, "LUT precision %d", info->precision);
-    const size_t one = (size_t)info->n_ref + info->n_sig + info->n_sign;
+    const bool cp3 = c->p.cp == 3;
+    if (cp3 != (info->cp == 3))
+        return fail(PICSONG_ERR_ARG, "the context codes %d passes, the table is laid out for %d (picsong_lut_load_cp)",
+                    c->p.cp, info->cp == 3 ? 3 : 2);
+    const size_t one = (size_t)info->n_ref + (cp3 ? 2 : 1) * ((size_t)info->n_sig + info->n_sign);
     const int n_tables = info->n_tables > 0 ? info->n_tables : 1;
-    if (one > (size_t)kLutLdsMax)
+    if (one > (size_t)(cp3 ? kLutLdsMax3 : kLutLdsMax))
         return fail(PICSONG_ERR_ARG, "LUT table of %zu entries exceeds the %d the coder kernels hold in LDS", one,
-                    kLutLdsMax);
+                    cp3 ? kLutLdsMax3 : kLutLdsMax);
     const size_t total = one * (size_t)n_tables;
     for (size_t i = 0; i < total; i++)
         if (host_table[i] < 0 || host_table[i] > 255)
@@ -624,6 +657,11 @@ static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_stag
     // BPCEngine::deviceMemoryAllocator BPCEngine.cu:2429-2441.  Slots beyond a codeblock's length
     // are never read downstream, so the fused frame path skips this 4*AW*AH-byte fill.
     if (memset_staging) HIP_TRY(hipMemsetAsync(d_staging, 0xFF, c->P * sizeof(int32_t), s));
+    if (c->p.cp == 3) {        // three coding passes: one kernel for both directions (bpc3_kernel)
+        bpc3_kernel<false><<<(unsigned)(((cb_count + 1) / 2 + kBpc3WgWaves - 1) / kBpc3WgWaves), 64 * kBpc3WgWaves, 0, s>>>(a);
+        HIP_TRY(hipGetLastError());
+        return PICSONG_OK;
+    }
     // -k > 0: the BULK instantiation (bulk scan below the consecutive bit-planes, table s in LDS)
     if (a.k > 0.0f) bpc_encode_kernel<true><<<(unsigned)((cb_count + 1) / 2), 64, 0, s>>>(a);
     else bpc_encode_kernel<false><<<(unsigned)(((cb_count + 1) / 2 + kBpcEncWgWaves - 1) / kBpcEncWgWaves), 64 * kBpcEncWgWaves, 0, s>>>(a);
@@ -648,6 +686,11 @@ static int bpc_decode_impl(picsong_ctx *c, const int32_t *d_staging, const int32
     a.sizes = const_cast<int32_t *>(d_sizes);
     // both plane-count classes over the same grid: each wave is taken by exactly one of them
     const unsigned waves = (unsigned)((c->ncb + 1) / 2);
+    if (c->p.cp == 3) {
+        bpc3_kernel<true><<<(waves + kBpc3WgWaves - 1) / kBpc3WgWaves, 64 * kBpc3WgWaves, 0, s>>>(a);
+        HIP_TRY(hipGetLastError());
+        return PICSONG_OK;
+    }
     if (a.k > 0.0f) {
         bpc_decode_kernel<true, kDecSmallPlanes><<<waves, 64, 0, s>>>(a);
         bpc_decode_kernel<true, kMaxPlanes><<<waves, 64, 0, s>>>(a);
@@ -929,7 +972,8 @@ int picsong_encode_frames(picsong_ctx *c, int n, const uint8_t *d_frames, size_t
     if (n < 1 || n > 64) return fail(PICSONG_ERR_ARG, "encode_frames: %d frames outside 1..64", n);
     if (n > 1 && (frame_stride < c->P || stream_stride < picsong_max_stream_shorts(c->aw, c->ah)))
         return fail(PICSONG_ERR_ARG, "encode_frames: strides smaller than a padded frame / a worst-case codestream");
-    if (c->p.k > 0.0f) return fail(PICSONG_ERR_ARG, "encode_frames: -k > 0 is coded frame by frame (picsong_encode_frame)");
+    if (c->p.k > 0.0f || c->p.cp == 3)
+        return fail(PICSONG_ERR_ARG, "encode_frames: -k > 0 and -cp 3 are coded frame by frame (picsong_encode_frame)");
     if (((uintptr_t)d_frames | frame_stride) & 15u) return fail(PICSONG_ERR_ARG, "encode_frames: frames must be 16-byte aligned");
     BpcArgs a;
     int rc = bpc_args(c, a, 0);

@@ -2,9 +2,8 @@
 // of include/picsong_hip.h.  It keeps the reference's flags, defaults, validation, file formats and
 // console vocabulary (Launcher.cu:8-29,36-163; IO/IOManager.ipp:72-112,176-231,267-344,615-620) so
 // it is a drop-in for the greyscale and RGB (planar R,G,B; RCT / ICT) image / video encode + decode
-// paths, including the complexity-scalable mode -k > 0.  The reference's -cp 3 (deprecated, LUT files
-// not shipped) is not built
-// and are refused with a message instead of being silently ignored.
+// paths, including the complexity-scalable mode -k > 0 and the three-coding-pass mode -cp 3 (deprecated in
+// the reference, whose tree ships no cp_sig / cp_sign tables for it: -LUTFolder must hold them).
 //
 // Pipeline (video encode): the reference's reader / worker / writer structure
 // (CodingEngine.cu:212-262,463-498,758-1069) with condition variables instead of its spin-wait flag
@@ -87,7 +86,7 @@ void help()
         " -xSize W -ySize H   frame dimensions (coding; optional when the input is a P5 PGM)\n"
         " -wl N               wavelet levels (1..7, default 5)\n"
         " -type 0|1           0 = lossless 5/3, 1 = lossy 9/7 (+ -qs in (0,1])\n"
-        " -cp 2               coding passes (3 is deprecated in the reference and not built here)\n"
+        " -cp 2|3             coding passes (3: deprecated in the reference; needs cp_sig / cp_sign tables in -LUTFolder)\n"
         " -cbWidth 64 -cbHeight 18  kept for header compatibility\n"
         " -video 0|1 -frames F  video mode (raw planar frames; output + <o>_SIZE sidecar)\n"
         " -LUTFolder <dir>    probability tables (header.txt, {ref,sig,sign}R.txt_0)\n"
@@ -171,12 +170,20 @@ struct Worker {
 
 // component c uses the {ref,sig,sign}{R,G,B}.txt_0 files (Engine::initLUT Engines/Engine.cu:124-136);
 // with k > 0 every bit-plane file _0 .. _(AMOUNT_OF_BITPLANE_FILES-1) (Engines/Engine.cu:12-56)
-void load_lut(picsong_ctx *ctx, const Options &o, int wl, int components = 1, float k = 0.0f)
+// -cp 3: the five sections ref, sig, sign, cp_sig, cp_sign of file _0 (IO/IOManager.ipp:539-606)
+void load_lut(picsong_ctx *ctx, const Options &o, int wl, int components = 1, float k = 0.0f, int cp = 2)
 {
     if (o.lut_folder.empty()) die("Incorrect parameters. Please choose valid values. (-LUTFolder is required)");
     const int n_tables = k > 0.0f ? 0 : 1;
     for (int c = 0; c < components; c++) {
         picsong_lut_info info;
+        if (cp == 3) {
+            CK(picsong_lut_load_cp(o.lut_folder.c_str(), c + 1, wl, o.lut_fill, 3, &info, nullptr, 0));
+            std::vector<int32_t> table((size_t)info.n_ref + 2 * ((size_t)info.n_sig + info.n_sign));
+            CK(picsong_lut_load_cp(o.lut_folder.c_str(), c + 1, wl, o.lut_fill, 3, &info, table.data(), table.size()));
+            CK(picsong_ctx_set_lut_component(ctx, c, &info, table.data()));
+            continue;
+        }
         CK(picsong_lut_load_k(o.lut_folder.c_str(), c + 1, wl, o.lut_fill, n_tables, &info, nullptr, 0));
         std::vector<int32_t> table(((size_t)info.n_ref + info.n_sig + info.n_sign) * (size_t)info.n_tables);
         CK(picsong_lut_load_k(o.lut_folder.c_str(), c + 1, wl, o.lut_fill, n_tables, &info, table.data(), table.size()));
@@ -219,7 +226,7 @@ int run_encode_rgb(const Options &o, size_t file_base, long nframes)
     picsong_params params = make_params(o);
     picsong_ctx *ctx = nullptr;
     CK(picsong_ctx_create(&params, o.device, &ctx));
-    load_lut(ctx, o, o.wl, 3, o.k);
+    load_lut(ctx, o, o.wl, 3, o.k, o.cp);
     hipStream_t s;
     HIPCK(hipStreamCreate(&s));
     uint8_t *h_in, *d_in[3];
@@ -283,7 +290,7 @@ int run_encode(Options o)
         die("Incorrect parameters. Please choose valid values.");
     if (!((o.is_rgb && o.components == 3) || (!o.is_rgb && o.components == 1)))
         die("Incorrect parameters. Use -components 1, or -isRGB 1 -components 3 (planar R,G,B planes).");
-    if (o.cp != 2) die("-cp 3 (deprecated in the reference) is not built in this MI355X hot-path build.");
+    if (o.cp == 3 && o.k > 0) die("Incorrect parameters. -cp 3 has no complexity-scalable mode (-k must be 0).");
     if (o.signed_or_unsigned != 0 || o.bps != 8) die("Only unsigned 8-bit samples are built in this MI355X hot-path build.");
     const long nframes = o.video ? o.frames : 1;
     if (nframes <= 0) die("Incorrect parameters. Please choose valid values. (-frames)");
@@ -311,7 +318,7 @@ int run_encode(Options o)
     const size_t P = (size_t)aw * ah, max_shorts = picsong_max_stream_shorts(aw, ah);
     // frames per launch: a 4K frame is 1020 coder waves, one per SIMD; four of them fill the GPU like an 8K frame
     int B = o.frames_per_launch > 0 ? o.frames_per_launch : (P <= (size_t)3840 * 2176 ? 4 : 1);
-    if (!o.video || o.k > 0.0f) B = 1;
+    if (!o.video || o.k > 0.0f || o.cp == 3) B = 1;
     if (B > 16) B = 16;
     if ((long)B > nframes) B = (int)nframes;
     const long ngroups = (nframes + B - 1) / B;
@@ -331,7 +338,7 @@ int run_encode(Options o)
         HIPCK(hipSetDevice(k.device));
         CK(picsong_ctx_create(&params, k.device, &k.ctx));
         if (nstreams > 1) CK(picsong_ctx_set_pipelined(k.ctx, 1));     // the video engine keeps frames in flight
-        load_lut(k.ctx, o, o.wl, 1, o.k);
+        load_lut(k.ctx, o, o.wl, 1, o.k, o.cp);
         HIPCK(hipStreamCreate(&k.stream));
         HIPCK(hipHostMalloc(&k.h_in, P * B));
         HIPCK(hipMalloc(&k.d_in, P * B));
@@ -632,7 +639,7 @@ int run_decode_video(const Options &o, const picsong_params &p, const std::vecto
     for (int i = 0; i < nslots; i++) {
         Slot &k = sl[(size_t)i];
         CK(picsong_ctx_create(&p, o.device, &k.ctx));
-        load_lut(k.ctx, o, p.wl, 1, p.k);
+        load_lut(k.ctx, o, p.wl, 1, p.k, p.cp);
         HIPCK(hipStreamCreate(&k.stream));
         HIPCK(hipHostMalloc(&k.h_in, max_shorts * 2));
         HIPCK(hipMalloc(&k.d_in, max_shorts * 2));
@@ -755,8 +762,8 @@ int run_decode(const Options &o)
     if ((size_t)in.gcount() != sizeof hdr) die("Input file too short for a PICSONG header.");
     picsong_params p;
     CK(picsong_header_unpack(hdr, &p));
-    if (p.cp != 2 || !((p.components == 1 && !p.is_rgb) || (p.components == 3 && p.is_rgb)))
-        die("This stream uses -cp 3 / a component layout not built here.");
+    if (!((p.components == 1 && !p.is_rgb) || (p.components == 3 && p.is_rgb)))
+        die("This stream uses a component layout not built here.");
     const long nframes = o.video ? p.frames : 1;
     std::vector<long> frame_shorts;
     if (o.video || p.is_rgb) {
@@ -774,7 +781,7 @@ int run_decode(const Options &o)
     picsong_ctx *ctx = nullptr;
     CK(picsong_ctx_create(&p, o.device, &ctx));
     Options lo = o;
-    load_lut(ctx, lo, p.wl, p.components, p.k);
+    load_lut(ctx, lo, p.wl, p.components, p.k, p.cp);
     int aw, ah, ncb;
     CK(picsong_ctx_padded_dims(ctx, &aw, &ah, &ncb));
     if (p.is_rgb) return run_decode_rgb(o, p, ctx, in, frame_shorts, nframes, aw, ah);

@@ -25,7 +25,7 @@ class Params(C.Structure):
 class LutInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("n_bitplanes", "n_subbands", "ctx_ref", "ctx_sign", "ctx_sig",
                                        "precision", "n_files", "n_bp_files", "n_ref", "n_sig", "n_sign",
-                                       "n_tables")]
+                                       "n_tables", "cp")]
 
 
 EXPORTS = [
@@ -42,7 +42,7 @@ EXPORTS = [
     "picsong_encode_plane", "picsong_decode_plane",
     "picsong_ctx_set_lut_device", "picsong_bpc_encode_component", "picsong_bpc_decode_component",
     "picsong_encode_frames", "picsong_last_totals", "picsong_selftest_lds_order",
-    "picsong_dwt_forward_band", "picsong_dwt_forward_tail", "picsong_encode_stripe_coded",
+    "picsong_dwt_forward_band", "picsong_dwt_forward_tail", "picsong_encode_stripe_coded", "picsong_lut_load_cp",
 ]
 
 _lib = None
@@ -107,6 +107,8 @@ def load():
         L.picsong_ctx_set_lut_device.argtypes = [vp, i, C.POINTER(LutInfo), vp]
         L.picsong_bpc_encode_component.argtypes = [vp, i, vp, vp, vp, vp]
         L.picsong_bpc_decode_component.argtypes = [vp, i, vp, vp, vp, vp]
+    if hasattr(L, "picsong_lut_load_cp"):
+        L.picsong_lut_load_cp.argtypes = [C.c_char_p, i, i, i, i, C.POINTER(LutInfo), vp, C.c_size_t]
     if hasattr(L, "picsong_dwt_forward_band"):
         L.picsong_dwt_forward_band.argtypes = [vp, vp, i, i, vp, vp]
         L.picsong_dwt_forward_tail.argtypes = [vp, vp, vp]
@@ -132,11 +134,18 @@ def dwt_extra(aw, ah, wl):
     return load().picsong_dwt_extra(aw, ah, wl)
 
 
-def lut_load(folder, wl, component=1, fill=0, n_tables=1):
+def lut_load(folder, wl, component=1, fill=0, n_tables=1, cp=2):
     """Returns (LutInfo, np.int32 table) parsed by the library's own host parser.
-    n_tables = 1: file _0 (k = 0); n_tables = 0: every bit-plane file (the -k > 0 layout)."""
+    n_tables = 1: file _0 (k = 0); n_tables = 0: every bit-plane file (the -k > 0 layout);
+    cp = 3: the five sections of the 3-coding-pass mode."""
     L = load()
     info = LutInfo()
+    if cp == 3:
+        _check(L.picsong_lut_load_cp(folder.encode(), component, wl, fill, 3, C.byref(info), None, 0))
+        table = np.empty(info.n_ref + 2 * (info.n_sig + info.n_sign), np.int32)
+        _check(L.picsong_lut_load_cp(folder.encode(), component, wl, fill, 3, C.byref(info),
+                                     table.ctypes.data_as(C.c_void_p), table.size))
+        return info, table
     _check(L.picsong_lut_load_k(folder.encode(), component, wl, fill, n_tables, C.byref(info), None, 0))
     table = np.empty((info.n_ref + info.n_sig + info.n_sign) * info.n_tables, np.int32)
     _check(L.picsong_lut_load_k(folder.encode(), component, wl, fill, n_tables, C.byref(info),
@@ -144,8 +153,8 @@ def lut_load(folder, wl, component=1, fill=0, n_tables=1):
     return info, table
 
 
-def make_params(width, height, wl=5, lossy=False, qs=1.0, frames=0, rgb=False, k=0.0):
-    return Params(width=width, height=height, wl=wl, cp=2, lossy=int(lossy), qs=qs, k=k,
+def make_params(width, height, wl=5, lossy=False, qs=1.0, frames=0, rgb=False, k=0.0, cp=2):
+    return Params(width=width, height=height, wl=wl, cp=cp, lossy=int(lossy), qs=qs, k=k,
                   cb_width=64, cb_height=18, bit_depth=8, frames=frames, components=3 if rgb else 1,
                   is_rgb=int(rgb))
 
@@ -168,13 +177,13 @@ class Codec:
     objects + the LUT upload of Engine::initLUT).  All tensor arguments are torch CUDA tensors."""
 
     def __init__(self, width, height, wl=5, lossy=False, qs=1.0, lut_folder=None, lut_fill=0,
-                 device=0, frames=0, rgb=False, k=0.0, pipelined=False):
+                 device=0, frames=0, rgb=False, k=0.0, pipelined=False, cp=2):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("no GPU visible: the picsong HIP path has no CPU fallback")
         self.torch = torch
         self.L = load()
-        self.params = make_params(width, height, wl, lossy, qs, frames, rgb, k)
+        self.params = make_params(width, height, wl, lossy, qs, frames, rgb, k, cp)
         self.rgb = bool(rgb)
         self.device = device
         h = C.c_void_p()
@@ -193,7 +202,7 @@ class Codec:
         if lut_folder is not None:
             for comp in range(3 if rgb else 1):
                 # files ...R/G/B.txt_0 (k = 0) or every bit-plane file ...txt_0.._14 (k > 0)
-                info, table = lut_load(lut_folder, wl, comp + 1, lut_fill, 0 if k > 0 else 1)
+                info, table = lut_load(lut_folder, wl, comp + 1, lut_fill, 0 if k > 0 else 1, cp)
                 self.set_lut(info, table, comp)
 
     def close(self):

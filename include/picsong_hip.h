@@ -42,7 +42,7 @@ extern "C" {
 typedef struct picsong_params {
     int width, height;      /* -xSize / -ySize (unpadded) */
     int wl;                 /* -wl, 1..7 (header limit) */
-    int cp;                 /* -cp, only 2 is implemented */
+    int cp;                 /* -cp: 2 coding passes, or 3 (deprecated in the reference; needs the cp_sig / cp_sign tables) */
     int lossy;              /* -type: 0 = 5/3 reversible, 1 = 9/7 + quantisation */
     float qs;               /* -qs */
     float k;                /* -k: 0 = two coding passes on every plane; > 0 = complexity-scalable bulk mode */
@@ -60,6 +60,8 @@ typedef struct picsong_lut_info {
     int n_ref, n_sig, n_sign;       /* section sizes in ints; table = [ref | sig | sign] */
     int n_tables;                   /* tables laid back to back: 1 (k = 0, file _0) or the bit-plane
                                      * files _0.._(n-1) of -k > 0 (Engines/Engine.cu:12-56); 0 == 1 */
+    int cp;                         /* coding passes the table is laid out for: 2 (or 0) = [ref | sig | sign];
+                                     * 3 = that followed by [cp_sig | cp_sign] (IO/IOManager.ipp:539-606) */
 } picsong_lut_info;
 
 typedef struct picsong_ctx picsong_ctx;
@@ -90,6 +92,12 @@ int picsong_lut_load(const char *folder, int component, int wl, int fill,
  * (query with table == NULL: info->n_tables is filled in). */
 int picsong_lut_load_k(const char *folder, int component, int wl, int fill, int n_tables,
                        picsong_lut_info *info, int32_t *table, size_t table_capacity);
+
+/* -cp 3 (Engine::initLUT with codingPasses == 3, Engines/Engine.cu:56-100; loader IO/IOManager.ipp:539-606):
+ * file _0 of ref, sig, sign, cp_sig and cp_sign; table needs n_ref + 2 (n_sig + n_sign) ints.  cp = 2 is
+ * picsong_lut_load. */
+int picsong_lut_load_cp(const char *folder, int component, int wl, int fill, int cp,
+                        picsong_lut_info *info, int32_t *table, size_t table_capacity);
 
 /* ---- context: replaces `new DWT<T,Y>(...)` / `new BPCCuda<T>(...)` + Engine::initLUT's
  *      cudaMalloc/cudaMemcpy of the table (Engines/Engine.cu:111-136).  Owns only the LUT copy

@@ -551,6 +551,39 @@ int po_lut_load(const char *folder, int component, int wl, int fill, po_lut *l)
     return po_lut_load_k(folder, component, wl, fill, 1, l);
 }
 
+/* -cp 3, k = 0: the table is [ref | sig | sign | cp_sig | cp_sign]; the last two sections have the
+ * geometry of sig and sign and are parsed by the same loop (IO/IOManager.ipp:539-606: bases
+ * refinementNumber + significanceNumber + signNumber and that + significanceNumber). */
+int po_lut_load_cp(const char *folder, int component, int wl, int fill, int cp, po_lut *l)
+{
+    if (cp != 3) { int rc = po_lut_load_k(folder, component, wl, fill, 1, l); if (!rc) l->cp = 2; return rc; }
+    memset(l, 0, sizeof *l);
+    if (po_lut_header(folder, l)) return -1;
+    l->wl = wl; l->n_tables = 1; l->cp = 3;
+    int nBp = l->n_bitplanes, nS = l->n_subbands;
+    l->n_ref = nS * nBp * l->ctx_ref * wl + nBp * l->ctx_ref;
+    l->n_sig = nS * nBp * l->ctx_sig * wl + nBp * l->ctx_sig;
+    l->n_sign = nS * nBp * l->ctx_sign * wl + nBp * l->ctx_sign;
+    size_t n = (size_t)l->n_ref + 2 * ((size_t)l->n_sig + l->n_sign) + (size_t)nBp * 16;
+    l->table = (int32_t *)malloc(n * sizeof(int32_t));
+    if (!l->table) return -3;
+    for (size_t i = 0; i < n; i++) l->table[i] = fill;
+    int32_t *T = l->table;
+    const int b3 = l->n_ref + l->n_sig + l->n_sign;
+    if (po_lut_section(folder, "ref", component, 0, l->ctx_ref, nBp, wl, T, 0)) return -4;
+    if (po_lut_section(folder, "sig", component, 0, l->ctx_sig, nBp, wl, T, l->n_ref)) return -5;
+    if (po_lut_section(folder, "sign", component, 0, l->ctx_sign, nBp, wl, T, l->n_ref + l->n_sig)) return -6;
+    if (po_lut_section(folder, "cp_sig", component, 0, l->ctx_sig, nBp, wl, T, b3)) return -7;
+    if (po_lut_section(folder, "cp_sign", component, 0, l->ctx_sign, nBp, wl, T, b3 + l->n_sig)) return -8;
+    return 0;
+}
+
+/* ints of one table of the array */
+static int po_lut_table_ints(const po_lut *l)
+{
+    return l->n_ref + (l->cp == 3 ? 2 : 1) * (l->n_sig + l->n_sign);
+}
+
 void po_lut_free(po_lut *l) { free(l->table); l->table = NULL; }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -794,6 +827,118 @@ static void po_mrp(po_cb *cb, int bp, int decode, uint32_t mask)
         }
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* -cp 3: three coding passes (deprecated in the reference, IO/CommandLineParser.cpp:34)        */
+/* ------------------------------------------------------------------------------------------ */
+/* Bit 30 of a coefficient word is the cleanup flag: set on every word before coding
+ * (readCoefficients3CP BPCEngine.cu:65-90 / initializeCoefficients3CP :124-137), set again by the
+ * significance pass on a coefficient it leaves to the cleanup pass, cleared by the cleanup pass. */
+
+/* Significance propagation pass of the 3-pass mode: SPPEncoderLauncher3CP BPCEngine.cu:850-925 +
+ * SPPEncoder3CP :521-553 / SPPDecoderLauncher3CP :1010-1085 + SPPDecoder3CP :599-640.  Scan order and
+ * neighbour exchange as in po_spp; an insignificant coefficient is coded only if one of its eight
+ * neighbours is significant when the scan reaches it, otherwise it is flagged for the cleanup pass. */
+static void po_spp3(po_cb *cb, int bp, int decode, uint32_t mask)
+{
+    uint8_t act[32], sym[32], act2[32], sym2[32];
+    int prob[32], prob2[32], sctx[32];
+    for (int i = 0; i < 64; i++)
+        for (int side = 0; side < 2; side++) {
+            for (int t = 0; t < 32; t++) {
+                int col = 2 * t + side;
+                uint32_t *w = &cb->TD[t][2 * i + side];
+                act[t] = 0; act2[t] = 0; sym[t] = 0;
+                if ((*w) >> 31) continue;
+                uint32_t n1 = po_w(cb, i - 1, col - 1), n2 = po_w(cb, i - 1, col),
+                         n3 = po_w(cb, i - 1, col + 1), n4 = po_w(cb, i, col - 1),
+                         n5 = po_w(cb, i, col + 1), n6 = po_w(cb, i + 1, col - 1),
+                         n7 = po_w(cb, i + 1, col), n8 = po_w(cb, i + 1, col + 1);
+                int ctx = (int)((n1 >> 31) + (n2 >> 31) + (n3 >> 31) + (n4 >> 31) + (n5 >> 31) +
+                                (n6 >> 31) + (n7 >> 31) + (n8 >> 31));
+                if (ctx == 0) { *w |= (1u << 30); continue; }     /* :551 / :638 */
+                act[t] = 1;
+                prob[t] = po_lut_at(cb, cb->sig_p[t] + ctx);
+                sym[t] = (uint8_t)(((*w) >> (bp + 1)) & 1u);
+                sctx[t] = po_sign_ctx(n2, n4, n5, n7);
+            }
+            if (decode) po_dec_site(cb, act, sym, prob);
+            else po_enc_site(cb, act, sym, prob);
+            for (int t = 0; t < 32; t++) {
+                if (!act[t] || sym[t] != 1) continue;
+                uint32_t *w = &cb->TD[t][2 * i + side];
+                if (decode) *w |= mask;                       /* :620 */
+                *w |= (1u << 31);                             /* :541 / :622 */
+                *w |= ((uint32_t)bp << 24);                   /* :543 / :624 */
+                act2[t] = 1;
+                prob2[t] = po_lut_at(cb, cb->sign_p[t] + (sctx[t] >> 1));
+                sym2[t] = (uint8_t)((((*w) & 1u) == (uint32_t)(sctx[t] & 1)) ? 0 : 1);  /* :547 */
+            }
+            if (decode) {
+                po_dec_site(cb, act2, sym2, prob2);
+                for (int t = 0; t < 32; t++)
+                    if (act2[t]) {
+                        uint32_t s = ((sym2[t] & 1u) == (uint32_t)(sctx[t] & 1)) ? 0u : 1u;  /* :630 */
+                        cb->TD[t][2 * i + side] |= s;
+                    }
+            } else {
+                po_enc_site(cb, act2, sym2, prob2);
+            }
+        }
+}
+
+/* Cleanup pass: CPEncoderLauncher BPCEngine.cu:1090-1165 + CPEncoder :645-680 / CPDecoderLauncher
+ * :1170-1243 + CPDecoder :686-719.  Codes the flagged coefficients with the cp_sig / cp_sign tables (the
+ * ordinary pointers + section sizes of sig and sign, Encode3CP :1744-1748); a coefficient that becomes
+ * significant here is at once eligible for refinement (bit 29). */
+static void po_cp(po_cb *cb, int bp, int decode, uint32_t mask)
+{
+    uint8_t act[32], sym[32], act2[32], sym2[32];
+    int prob[32], prob2[32], sctx[32];
+    const int aux = cb->lut->n_sig + cb->lut->n_sign;
+    for (int i = 0; i < 64; i++)
+        for (int side = 0; side < 2; side++) {
+            for (int t = 0; t < 32; t++) {
+                int col = 2 * t + side;
+                uint32_t w = cb->TD[t][2 * i + side];
+                act[t] = (uint8_t)((w >> 30) & 1u); act2[t] = 0; sym[t] = 0;
+                if (!act[t]) continue;
+                uint32_t n1 = po_w(cb, i - 1, col - 1), n2 = po_w(cb, i - 1, col),
+                         n3 = po_w(cb, i - 1, col + 1), n4 = po_w(cb, i, col - 1),
+                         n5 = po_w(cb, i, col + 1), n6 = po_w(cb, i + 1, col - 1),
+                         n7 = po_w(cb, i + 1, col), n8 = po_w(cb, i + 1, col + 1);
+                int ctx = (int)((n1 >> 31) + (n2 >> 31) + (n3 >> 31) + (n4 >> 31) + (n5 >> 31) +
+                                (n6 >> 31) + (n7 >> 31) + (n8 >> 31));
+                prob[t] = po_lut_at(cb, cb->sig_p[t] + aux + ctx);
+                sym[t] = (uint8_t)((w >> (bp + 1)) & 1u);
+                sctx[t] = po_sign_ctx(n2, n4, n5, n7);
+            }
+            if (decode) po_dec_site(cb, act, sym, prob);
+            else po_enc_site(cb, act, sym, prob);
+            for (int t = 0; t < 32; t++) {
+                if (!act[t]) continue;
+                uint32_t *w = &cb->TD[t][2 * i + side];
+                *w &= 0xBFFFFFFFu;                            /* :664 / :703 */
+                if (sym[t] != 1) continue;
+                if (decode) *w |= mask;                       /* :708 */
+                *w |= (1u << 31) | (1u << 29);                /* :669-670 / :710-711 */
+                *w |= ((uint32_t)bp << 24);
+                act2[t] = 1;
+                prob2[t] = po_lut_at(cb, cb->sign_p[t] + aux + (sctx[t] >> 1));
+                sym2[t] = (uint8_t)((((*w) & 1u) == (uint32_t)(sctx[t] & 1)) ? 0 : 1);
+            }
+            if (decode) {
+                po_dec_site(cb, act2, sym2, prob2);
+                for (int t = 0; t < 32; t++)
+                    if (act2[t]) {
+                        uint32_t s = ((sym2[t] & 1u) == (uint32_t)(sctx[t] & 1)) ? 0u : 1u;
+                        cb->TD[t][2 * i + side] |= s;
+                    }
+            } else {
+                po_enc_site(cb, act2, sym2, prob2);
+            }
+        }
+}
+
 /* computeContextBulk BPCEngine.cu:236-243 */
 static int po_ctx_bulk(const uint32_t n[8], int B)
 {
@@ -942,6 +1087,52 @@ static void po_cb_decode(po_cb *cb, int msb, int cbp)
     if (bp >= 0) po_bulk(cb, bp, 1, mask);   /* :1831-1835 */
 }
 
+/* Encode3CP BPCEngine.cu:1727-1776: the top plane takes the cleanup pass only */
+static void po_cb_encode3(po_cb *cb, int msb)
+{
+    for (int t = 0; t < 32; t++) {
+        cb->L[t] = 0; cb->S[t] = 0; cb->slot[t] = -1;
+        for (int i = 0; i < 128; i++) cb->TD[t][i] |= (1u << 30);     /* readCoefficients3CP :84-86 */
+    }
+    int bp = msb;
+    po_cp(cb, bp, 0, 0);
+    bp--;
+    po_lut_step(cb);
+    for (; bp >= 0; bp--) {
+        po_spp3(cb, bp, 0, 0);
+        po_mrp(cb, bp, 0, 0);
+        po_cp(cb, bp, 0, 0);
+        po_lut_step(cb);
+    }
+    for (int t = 0; t < 32; t++)
+        if (cb->slot[t] >= 0) cb->stage[1 + cb->slot[t]] = (int32_t)cb->L[t];
+}
+
+/* Decode3CP BPCEngine.cu:1844-1900 */
+static void po_cb_decode3(po_cb *cb, int msb)
+{
+    for (int t = 0; t < 32; t++) {
+        cb->L[t] = 0; cb->S[t] = 0; cb->cw[t] = 0;
+        for (int i = 0; i < 128; i++) cb->TD[t][i] = (1u << 30);      /* initializeCoefficients3CP :124-137 */
+    }
+    uint32_t mask = 0x3u << msb;
+    int bp = msb;
+    if (bp == 0) mask &= 0x2u;
+    po_cp(cb, bp, 1, mask);
+    bp--;
+    mask >>= 1;
+    if (bp == 0) mask = 0x2u;
+    po_lut_step(cb);
+    for (; bp >= 0; bp--) {
+        po_spp3(cb, bp, 1, mask);
+        po_mrp(cb, bp, 1, mask);
+        po_cp(cb, bp, 1, mask);
+        mask >>= 1;
+        if (bp == 1) mask = 0x2u;
+        po_lut_step(cb);
+    }
+}
+
 /* table index s = min(consecutiveBitplanes, MSB) (:1694-1697 / :1807-1810), clamped to the tables
  * that were loaded */
 static void po_cb_select_table(po_cb *cb, int msb, int cbp, float k)
@@ -950,7 +1141,7 @@ static void po_cb_select_table(po_cb *cb, int msb, int cbp, float k)
     if (k > 0.0f) s = cbp < msb ? cbp : msb;
     int nt = cb->lut->n_tables > 0 ? cb->lut->n_tables : 1;
     if (s > nt - 1) s = nt - 1;
-    cb->lut_off = s * (cb->lut->n_ref + cb->lut->n_sig + cb->lut->n_sign);
+    cb->lut_off = s * po_lut_table_ints(cb->lut);
 }
 
 static int po_msb_of(const po_cb *cb)
@@ -992,7 +1183,7 @@ void po_bpc_encode_k(const void *coeffs, int is_float, int AW, int AH, int wl, c
     {
     po_cb *cb = (po_cb *)malloc(sizeof(po_cb));
     cb->lut = lut;
-    cb->lut_total = (lut->n_ref + lut->n_sig + lut->n_sign) * (lut->n_tables > 0 ? lut->n_tables : 1);
+    cb->lut_total = po_lut_table_ints(lut) * (lut->n_tables > 0 ? lut->n_tables : 1);
     cb->lut_off = 0;
     _Pragma("omp for schedule(dynamic, 4)")
     for (int id = 0; id < ncx * ncy; id++) {
@@ -1020,7 +1211,8 @@ void po_bpc_encode_k(const void *coeffs, int is_float, int AW, int AH, int wl, c
                 int cbp = po_consecutive_bitplanes(msb, k, level[0], sb[0], wl);
                 po_cb_select_table(cb, msb, cbp, k);
                 for (int t = 0; t < 32; t++) po_lut_init(cb, t, level[t], sb[t], msb);
-                po_cb_encode(cb, msb, cbp);
+                if (lut->cp == 3) po_cb_encode3(cb, msb);        /* kernelBPCCoder3CP :2029-2121 (k is ignored there) */
+                else po_cb_encode(cb, msb, cbp);
             }
             sizes[id] = po_cb_finish_encode(cb);
     }
@@ -1034,7 +1226,7 @@ int po_bpc_encode_block_uniform(const int32_t *block, int level, int sb, int wl,
     (void)wl;
     po_cb *cb = (po_cb *)malloc(sizeof(po_cb));
     cb->lut = lut;
-    cb->lut_total = (lut->n_ref + lut->n_sig + lut->n_sign) * (lut->n_tables > 0 ? lut->n_tables : 1);
+    cb->lut_total = po_lut_table_ints(lut) * (lut->n_tables > 0 ? lut->n_tables : 1);
     cb->lut_off = 0;
     cb->stage = staging4096;
     memset(staging4096, 0xFF, PO_CB_WORDS * sizeof(int32_t));
@@ -1072,7 +1264,7 @@ void po_bpc_decode_k(const int32_t *staging, const int32_t *sizes, int AW, int A
     int ncx = AW / PO_CB, ncy = AH / PO_CB;
     po_cb *cb = (po_cb *)malloc(sizeof(po_cb));
     cb->lut = lut;
-    cb->lut_total = (lut->n_ref + lut->n_sig + lut->n_sign) * (lut->n_tables > 0 ? lut->n_tables : 1);
+    cb->lut_total = po_lut_table_ints(lut) * (lut->n_tables > 0 ? lut->n_tables : 1);
     cb->lut_off = 0;
     for (int cy = 0; cy < ncy; cy++)
         for (int cx = 0; cx < ncx; cx++) {
@@ -1094,7 +1286,8 @@ void po_bpc_decode_k(const int32_t *staging, const int32_t *sizes, int AW, int A
                     po_find_subband(cx * 64 + 2 * t, cy * 64, AW, AH, wl, &level, &sb);
                     po_lut_init(cb, t, level, sb, msb);
                 }
-                po_cb_decode(cb, msb, cbp);
+                if (lut->cp == 3) po_cb_decode3(cb, msb);        /* kernelBPCDecoder3CP :2221-2299 */
+                else po_cb_decode(cb, msb, cbp);
             }
             for (int t = 0; t < 32; t++)
                 for (int i = 0; i < 64; i++)
@@ -1233,7 +1426,7 @@ size_t po_encode_frame_k(const uint8_t *frame, int W, int H, int wl, int lossy, 
     po_header h;
     memset(&h, 0, sizeof h);
     h.n_samples = (uint32_t)W * (uint32_t)H;
-    h.cp = 2; h.cb_height = 18; h.cb_width = 64; h.wl = wl; h.bit_depth = 8; h.lossy = lossy;
+    h.cp = lut->cp == 3 ? 3 : 2; h.cb_height = 18; h.cb_width = 64; h.wl = wl; h.bit_depth = 8; h.lossy = lossy;
     h.qs_1e4 = (int)(qs * 10000); h.components = 1; h.is_rgb = 0; h.height = H; h.endianess = 0;
     h.bps = 8; h.is_signed = 0; h.frames = frames; h.k_1e3 = (int)(k * 1000);
     po_header_pack(&h, hdr);

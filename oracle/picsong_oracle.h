@@ -41,6 +41,8 @@ typedef struct po_lut {
     int n_ref, n_sig, n_sign;  /* section sizes in ints */
     int32_t *table;    /* n_tables x [ref | sig | sign], malloc'd */
     int n_tables;      /* 1 for k = 0; the bit-plane files _0.._(n-1) for k > 0 (Engine.cu:12-56) */
+    int cp;            /* coding passes the table was loaded for: 2 = [ref | sig | sign]; 3 = the same followed by
+                        * [cp_sig | cp_sign], the cleanup pass's tables (IO/IOManager.ipp:539-606); 0 == 2 */
 } po_lut;
 
 /* Header fields (BitStreamBuilder.cpp:35-94 <-> Engines/DecodingEngine.cu:567-585). */
@@ -106,6 +108,10 @@ void po_dwt97_inverse(const int32_t *in, float *out, int AW, int AH, int wl, flo
 int  po_lut_load(const char *folder, int component, int wl, int fill, po_lut *out);
 /* k > 0: tables of files _0 .. _(n_tables-1) back to back (n_tables <= 0: all of them) */
 int  po_lut_load_k(const char *folder, int component, int wl, int fill, int n_tables, po_lut *out);
+/* -cp 3: file _0 of ref / sig / sign / cp_sig / cp_sign (Engine::initLUT's codingPasses == 3 sizes,
+ * Engines/Engine.cu:66-68; loader IO/IOManager.ipp:539-606).  The BPC functions below take the three
+ * coding passes (Encode3CP / Decode3CP, BPC/BPCEngine.cu:1727-1776,1844-1900) whenever lut->cp == 3. */
+int  po_lut_load_cp(const char *folder, int component, int wl, int fill, int cp, po_lut *out);
 /* consecutiveBitplanes of a codeblock, BPC/BPCEngine.cu:1684-1692 */
 int  po_consecutive_bitplanes(int msb, float k, int level, int sb, int wl);
 void po_lut_free(po_lut *lut);

@@ -159,6 +159,31 @@ def bpc_encode(coef, wl, lut, k=0.0):
     return staging, sizes, int(flag[0])
 
 
+def bpc3_encode(coef, wl, lut):
+    """-cp 3 (lut: oracle_lib.lut_for_cp3)."""
+    AH, AW = coef.shape
+    coef = np.ascontiguousarray(coef)
+    staging = np.empty(AW * AH, np.int32)
+    sizes = np.empty((AW // 64) * (AH // 64), np.int32)
+    flag = np.zeros(1, np.int32)
+    tab = np.ascontiguousarray(lut.table, np.int32)
+    geo = _geo(lut)
+    lib().emu_bpc3_encode(_p(coef), int(coef.dtype == np.float32), AW, AH, wl, _p(tab), _p(geo), _p(staging),
+                          _p(sizes), _p(flag))
+    return staging, sizes, int(flag[0])
+
+
+def bpc3_decode(staging, sizes, AW, AH, wl, lut):
+    staging = np.ascontiguousarray(staging, np.int32)
+    sizes = np.ascontiguousarray(sizes, np.int32)
+    coef = np.empty((AH, AW), np.int32)
+    flag = np.zeros(1, np.int32)
+    tab = np.ascontiguousarray(lut.table, np.int32)
+    geo = _geo(lut)
+    lib().emu_bpc3_decode(_p(staging), _p(sizes), AW, AH, wl, _p(tab), _p(geo), _p(coef), _p(flag))
+    return coef
+
+
 def bpc_decode(staging, sizes, AW, AH, wl, lut, k=0.0):
     staging = np.ascontiguousarray(staging, np.int32)
     sizes = np.ascontiguousarray(sizes, np.int32)

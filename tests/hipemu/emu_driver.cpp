@@ -253,6 +253,24 @@ void emu_bpc_decode(const int32_t *staging, const int32_t *sizes, int aw, int ah
     }
 }
 
+// -cp 3: geo[6..8] = nRef, nSig, nSign; lut = [ref | sig | sign | cp_sig | cp_sign]
+void emu_bpc3_encode(const void *coeffs, int is_float, int aw, int ah, int wl, const int32_t *lut, const int *geo,
+                     int32_t *staging, int32_t *sizes, int *flag)
+{
+    BpcArgs a = mk(aw, ah, wl, lut, geo, staging, sizes, flag);
+    a.coeffs_in = coeffs; a.is_float = is_float; a.n_tables = 1;
+    memset(staging, 0xFF, (size_t)aw * ah * 4);
+    emu::launch(dim3((unsigned)(((a.nCB + 1) / 2 + kBpc3WgWaves - 1) / kBpc3WgWaves)), dim3(64 * kBpc3WgWaves), [&] { bpc3_kernel<false>(a); });
+}
+
+void emu_bpc3_decode(const int32_t *staging, const int32_t *sizes, int aw, int ah, int wl, const int32_t *lut,
+                     const int *geo, int32_t *coeffs, int *flag)
+{
+    BpcArgs a = mk(aw, ah, wl, lut, geo, const_cast<int32_t *>(staging), const_cast<int32_t *>(sizes), flag);
+    a.coeffs_out = coeffs; a.n_tables = 1;
+    emu::launch(dim3((unsigned)(((a.nCB + 1) / 2 + kBpc3WgWaves - 1) / kBpc3WgWaves)), dim3(64 * kBpc3WgWaves), [&] { bpc3_kernel<true>(a); });
+}
+
 int emu_pack(const int32_t *staging, const int32_t *sizes, int ncb, const uint16_t *header, uint16_t *out)
 {
     std::vector<int32_t> offsets(ncb);

@@ -28,7 +28,7 @@ class PoLut(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "n_bitplanes", "n_subbands", "ctx_ref", "ctx_sign", "ctx_sig", "precision", "n_files",
         "n_bp_files", "wl", "n_ref", "n_sig", "n_sign")] + [("table", C.POINTER(C.c_int32)),
-                                                              ("n_tables", C.c_int)]
+                                                              ("n_tables", C.c_int), ("cp", C.c_int)]
 
 
 class PoHeader(C.Structure):
@@ -70,6 +70,7 @@ def lib():
     L.po_lut_load.argtypes = [C.c_char_p, i32, i32, i32, C.POINTER(PoLut)]
     L.po_lut_load_k.restype = i32
     L.po_lut_load_k.argtypes = [C.c_char_p, i32, i32, i32, i32, C.POINTER(PoLut)]
+    L.po_lut_load_cp.argtypes = [C.c_char_p, i32, i32, i32, i32, C.POINTER(PoLut)]
     L.po_consecutive_bitplanes.restype = i32
     L.po_consecutive_bitplanes.argtypes = [i32, f32, i32, i32, i32]
     L.po_lut_free.argtypes = [C.POINTER(PoLut)]
@@ -136,14 +137,19 @@ def usable_threads():
 class Lut:
     """Loaded LUT (keeps the C struct alive; .table is a numpy copy)."""
 
-    def __init__(self, folder, wl, component=1, fill=0, n_tables=1):
-        """n_tables = 1: file _0 (k = 0); n_tables = 0: every bit-plane file (k > 0)."""
+    def __init__(self, folder, wl, component=1, fill=0, n_tables=1, cp=2):
+        """n_tables = 1: file _0 (k = 0); n_tables = 0: every bit-plane file (k > 0); cp = 3: the five
+        sections of the 3-coding-pass mode (file _0 of ref, sig, sign, cp_sig, cp_sign)."""
         self.c = PoLut()
         f = folder if folder.endswith("/") else folder + "/"
-        rc = lib().po_lut_load_k(f.encode(), component, wl, fill, n_tables, C.byref(self.c))
+        if cp == 3:
+            rc = lib().po_lut_load_cp(f.encode(), component, wl, fill, 3, C.byref(self.c))
+        else:
+            rc = lib().po_lut_load_k(f.encode(), component, wl, fill, n_tables, C.byref(self.c))
         if rc != 0:
-            raise RuntimeError(f"po_lut_load_k({folder}) failed: {rc}")
-        self.total = self.c.n_ref + self.c.n_sig + self.c.n_sign      # one table
+            raise RuntimeError(f"po_lut_load({folder}, cp={cp}) failed: {rc}")
+        self.cp = cp
+        self.total = self.c.n_ref + (2 if cp == 3 else 1) * (self.c.n_sig + self.c.n_sign)      # one table
         self.n_tables = self.c.n_tables
         self.table = np.ctypeslib.as_array(self.c.table, shape=(self.total * self.n_tables,)).copy()
         self.wl = wl
@@ -163,6 +169,14 @@ class Lut:
 
 def lut_for(lossy, wl, fill=0):
     return Lut(os.path.join(LUT_DIR, "n1_lossy" if lossy else "n1_lossless"), wl, 1, fill)
+
+
+LUT_CP3_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lut_cp3")
+
+
+def lut_for_cp3(lossy, wl, fill=0):
+    """Tables of the 3-coding-pass mode (tests/golden/make_cp3_tables.py)."""
+    return Lut(os.path.join(LUT_CP3_DIR, "n1_lossy" if lossy else "n1_lossless"), wl, 1, fill, cp=3)
 
 
 def lut_for_k(lossy, wl, fill=0):

@@ -63,6 +63,16 @@ def test_lut_parser_bit_plane_tables_match_oracle(oracle):
     assert info1.n_tables == 1 and np.array_equal(table1, table[:table1.size])
 
 
+def test_lut_parser_cp3_matches_oracle(oracle):
+    path = os.path.join(oracle.LUT_CP3_DIR, "n1_lossless")
+    info, table = pa.lut_load(path, 4, component=1, fill=0, cp=3)
+    ref = oracle.lut_for_cp3(False, 4)
+    assert info.cp == 3 and table.size == ref.table.size
+    assert np.array_equal(table, ref.table)
+    info2, _ = pa.lut_load(path, 4, component=1, fill=0)
+    assert info2.cp == 2
+
+
 def test_lut_missing_folder_reports_error():
     info = pa.LutInfo()
     rc = pa.load().picsong_lut_load(b"/nonexistent/", 1, 5, 0, C.byref(info), None, 0)
@@ -134,7 +144,10 @@ def test_invalid_parameters_are_rejected_without_exit():
         p = pa.make_params(kw.get("width", 512), 512, wl=kw.get("wl", 3))
         assert L.picsong_ctx_create(C.byref(p), 0, C.byref(h)) == -1
     p = pa.make_params(512, 512, wl=3)
-    p.cp = 3
+    p.cp = 4
+    assert L.picsong_ctx_create(C.byref(p), 0, C.byref(h)) == -1
+    p = pa.make_params(512, 512, wl=3, k=0.5)
+    p.cp = 3                                               # -cp 3 has no complexity-scalable mode
     assert L.picsong_ctx_create(C.byref(p), 0, C.byref(h)) == -1
     p = pa.make_params(64, 64, wl=6)
     assert L.picsong_ctx_create(C.byref(p), 0, C.byref(h)) == -1        # too small for 6 levels (2x2 at the last)

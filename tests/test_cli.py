@@ -29,7 +29,8 @@ def test_help_and_validation():
     for extra, msg in ((("-wl", 11), "Incorrect parameters"), (("-cbWidth", 65), "Incorrect parameters"),
                        (("-cbHeight", 21), "Incorrect parameters"), (("-qs", 1.5), "Incorrect parameters"),
                        (("-isRGB", 1), "Incorrect parameters"), (("-components", 3), "Incorrect parameters"),
-                       (("-cp", 3), "not built"), (("-k", 70), "Incorrect parameters"),
+                       (("-cp", 4), "Incorrect parameters"), (("-cp", 3, "-k", 1), "no complexity-scalable mode"),
+                       (("-k", 70), "Incorrect parameters"),
                        (("-k", -1), "Incorrect parameters")):
         base = () if extra[0] == "-wl" else ("-wl", 1)
         r = _run("-cd", 0, "-i", "/etc/hostname", "-o", "/tmp/x", "-xSize", 64, "-ySize", 64, *base, *extra)
@@ -110,6 +111,25 @@ def test_video_sharded_and_batched_equals_oracle(oracle, tmp_path, extra):
     r = _run("-cd", 1, "-i", enc, "-o", dec, "-video", 1, "-LUTFolder", lutdir)
     assert r.returncode == 0, r.stdout + r.stderr
     assert np.array_equal(np.fromfile(dec, np.uint8), np.fromfile(raw, np.uint8))
+
+
+@pytest.mark.gpu
+def test_three_coding_passes_files(oracle, tmp_path):
+    """-cp 3 through the CLI: the coded file equals the oracle's stream, the decoder takes the mode from the
+    header (Engines/DecodingEngine.cu:567-585) and returns the image."""
+    W, H, wl = 520, 390, 3
+    img = oracle.gen_frame(W, H, 12)
+    lutdir = os.path.join(oracle.LUT_CP3_DIR, "n1_lossless")
+    raw, enc, dec = tmp_path / "i.raw", tmp_path / "i.enc", tmp_path / "i.pgm"
+    img.tofile(raw)
+    r = _run("-cd", 0, "-i", raw, "-o", enc, "-xSize", W, "-ySize", H, "-wl", wl, "-type", 0, "-cp", 3, "-LUTFolder", lutdir)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = oracle.encode_frame(img, wl, False, 1.0, oracle.lut_for_cp3(False, wl))
+    assert np.array_equal(np.fromfile(enc, np.uint16), ref)
+    r = _run("-cd", 1, "-i", enc, "-o", dec, "-LUTFolder", lutdir)
+    assert r.returncode == 0, r.stdout + r.stderr
+    data = open(dec, "rb").read()
+    assert np.array_equal(np.frombuffer(data[-W * H:], np.uint8).reshape(H, W), img)
 
 
 @pytest.mark.gpu

@@ -235,6 +235,30 @@ def test_batched_frames_equal_oracle(oracle, pa, torch, W, H, wl, lossy, qs, n, 
         oracle.set_threads(1)
 
 
+@pytest.mark.parametrize("W,H,wl,lossy", [(512, 512, 3, False), (1000, 300, 4, False), (832, 192, 4, True),
+                                          (3840, 2160, 5, False)])
+def test_three_coding_passes_equal_oracle(oracle, pa, torch, W, H, wl, lossy):
+    """-cp 3 (kernelBPCCoder3CP / kernelBPCDecoder3CP BPC/BPCEngine.cu:2029-2121,2221-2299): the HIP codestream
+    equals the oracle's, and the HIP decode of it the oracle's decode."""
+    oracle.set_threads(oracle.usable_threads())
+    try:
+        qs = 0.5 if lossy else 1.0
+        img = oracle.gen_frame(W, H, 3)
+        lut = oracle.lut_for_cp3(lossy, wl)
+        ref = oracle.encode_frame(img, wl, lossy, qs, lut)
+        c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, cp=3,
+                     lut_folder=os.path.join(oracle.LUT_CP3_DIR, "n1_lossy" if lossy else "n1_lossless"))
+        s = c.encode_frame(_dev(torch, oracle.pad_frame(img)), 0)
+        got = s.cpu().numpy().view(np.uint16)
+        assert c.range_flag() == 0
+        assert got.size == ref.size and np.array_equal(got, ref)
+        dec = c.decode_frame(s).cpu().numpy()
+        assert np.array_equal(dec[:H, :W], oracle.decode_frame(ref, W, H, wl, lossy, qs, lut))
+        c.close()
+    finally:
+        oracle.set_threads(1)
+
+
 def test_lds_atomic_reservation_order(pa, torch):
     """The coder takes codeword slots with one LDS atomic add per requesting lane; lanes of one instruction
     that hit one counter must be served in ascending lane order (== v_mbcnt rank).  16 M random lane masks."""

@@ -475,3 +475,43 @@ def test_banded_transform_equals_full_on_every_ranks_stripes(oracle, E, lossy, w
                 assert np.array_equal(got[r0:r1], ref[r0:r1])
             else:
                 assert np.array_equal(got[r0:r1], ref[r0:r1]), f"rank {k}, codeblock rows {r0 // 64}..{r1 // 64}"
+
+
+@pytest.mark.parametrize("W,H,wl,lossy", [(192, 128, 2, False), (128, 128, 3, True), (64, 64, 1, False)])
+def test_three_coding_passes_bit_exact(oracle, E, W, H, wl, lossy):
+    """-cp 3: bpc3_kernel (encode and decode through the wave emulator) against the oracle's restatement of
+    Encode3CP / Decode3CP -- per-codeblock staging, sizes and the decoded coefficients."""
+    qs = 0.5
+    lut = oracle.lut_for_cp3(lossy, wl)
+    img = oracle.pad_frame(oracle.gen_frame(W, H, 2))
+    AH, AW = img.shape
+    coef = oracle.dwt_forward(oracle.level_shift_fwd(img, lossy), wl, qs)[:AW * AH].reshape(AH, AW)
+    st_ref, sz_ref = oracle.bpc_encode(coef, wl, lut)
+    st, sz, flag = E.bpc3_encode(coef, wl, lut)
+    assert flag == 0
+    assert np.array_equal(sz, sz_ref)
+    for cb in range(sz.size):                                    # words beyond a codeblock's length are unspecified
+        n = int(sz[cb])
+        assert np.array_equal(st[cb * 4096:cb * 4096 + n], st_ref[cb * 4096:cb * 4096 + n]), f"codeblock {cb}"
+    dec = E.bpc3_decode(st_ref, sz_ref, AW, AH, wl, lut)
+    ref_dec = oracle.bpc_decode(st_ref, sz_ref, AW, AH, wl, lut)
+    assert np.array_equal(dec, ref_dec)
+    if not lossy:
+        assert np.array_equal(dec, coef)
+
+
+def test_three_coding_passes_stress_blocks(oracle, E):
+    """-cp 3 corner cases: an all-zero codeblock, an impulse, noise that takes the raw fallback."""
+    lut = oracle.lut_for_cp3(False, 1)
+    rng = np.random.default_rng(7)
+    coef = np.zeros((64, 256), np.int32)
+    coef[10, 64 + 20] = -37                                      # impulse in codeblock 1
+    coef[:, 128:192] = rng.integers(-255, 256, (64, 64))         # noise: expands -> raw fallback (size 4096)
+    coef[:, 192:256] = rng.integers(-3, 4, (64, 64))
+    st_ref, sz_ref = oracle.bpc_encode(coef, 1, lut)
+    st, sz, flag = E.bpc3_encode(coef, 1, lut)
+    assert flag == 0 and np.array_equal(sz, sz_ref) and sz_ref[0] == 1
+    for cb in range(sz.size):
+        n = int(sz[cb])
+        assert np.array_equal(st[cb * 4096:cb * 4096 + n], st_ref[cb * 4096:cb * 4096 + n]), f"codeblock {cb}"
+    assert np.array_equal(E.bpc3_decode(st_ref, sz_ref, 256, 64, 1, lut), oracle.bpc_decode(st_ref, sz_ref, 256, 64, 1, lut))

@@ -313,3 +313,34 @@ def test_bulk_mode_frame_round_trip_and_header(oracle):
     d = O.decode_frame(sl, W, H, wl, True, 0.5, lutl, k=0.5).astype(np.float64)
     mse = np.mean((d - img) ** 2)
     assert 10 * np.log10(255 ** 2 / mse) > 35
+
+
+# ---- -cp 3: three coding passes (Encode3CP / Decode3CP, BPC/BPCEngine.cu:1727-1776,1844-1900) ----------
+@pytest.mark.parametrize("W,H,wl,lossy", [(320, 192, 3, False), (256, 128, 2, True)])
+def test_cp3_round_trip_and_header(oracle, W, H, wl, lossy):
+    """The oracle's 3-pass restatement decodes what it encodes (identity for 5/3; for 9/7 the same pixels the
+    2-pass stream decodes to: both carry the same quantised coefficients), the streams of the two modes differ,
+    and header bit 0 of word 2 says which one it is (BitStreamBuilder.cpp:59)."""
+    qs = 0.5
+    img = oracle.gen_frame(W, H, 5)
+    l3, l2 = oracle.lut_for_cp3(lossy, wl), oracle.lut_for(lossy, wl)
+    s3, s2 = oracle.encode_frame(img, wl, lossy, qs, l3), oracle.encode_frame(img, wl, lossy, qs, l2)
+    assert s3[2] & 1 == 1 and s2[2] & 1 == 0
+    assert s3.size != s2.size or not np.array_equal(s3, s2)
+    d3 = oracle.decode_frame(s3, W, H, wl, lossy, qs, l3)
+    assert np.array_equal(d3, oracle.decode_frame(s2, W, H, wl, lossy, qs, l2))
+    if not lossy:
+        assert np.array_equal(d3, img)
+
+
+def test_cp3_table_layout(oracle):
+    """[ref | sig | sign | cp_sig | cp_sign]: the cleanup tables sit nSig + nSign entries after the ordinary
+    ones (Encode3CP's LUTPointerAux, :1744-1745), parsed by the same loop (IO/IOManager.ipp:539-606)."""
+    l3, l2 = oracle.lut_for_cp3(False, 3), oracle.lut_for(False, 3)
+    g = l3.geometry()
+    b3 = g["n_ref"] + g["n_sig"] + g["n_sign"]
+    assert l3.table.size == b3 + g["n_sig"] + g["n_sign"]
+    assert np.array_equal(l3.table[:b3], l2.table)
+    sig, cps = l3.table[g["n_ref"]:g["n_ref"] + g["n_sig"]], l3.table[b3:b3 + g["n_sig"]]
+    written = sig > 0
+    assert np.array_equal(cps[written & (sig != 64)], np.minimum(127, (3 * sig[written & (sig != 64)] + 127) // 4))
