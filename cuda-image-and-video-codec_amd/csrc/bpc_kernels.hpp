@@ -593,24 +593,31 @@ __device__ __forceinline__ uint32_t bfi32(uint32_t mask, uint32_t a, uint32_t b)
 // instructions).  Gathered for rows 4g .. 4g+3 at once: a mask's nibble times 0x204081 puts bit i at bit 8i
 // (the four shifted copies land on 16 distinct bits, so no carry forms), three such words make the four
 // rows' byte selectors, ONE v_perm looks up four probabilities, and a row takes its byte with one v_bfe.
-__device__ __forceinline__ uint32_t spread4(uint32_t mask, uint32_t g4)
+// nibble g4/4 of `mask`, bit i of it at bit 8i + SH of the result (SH = 0, 1, 2); the other product bits are
+// strays the callers mask off
+template <int SH>
+__device__ __forceinline__ uint32_t spread4_raw(uint32_t mask, uint32_t g4)
 {
-    return mul_u24((mask >> g4) & 0xFu, 0x204081u) & 0x01010101u;
+    return mul_u24((mask >> g4) & 0xFu, 0x204081u << SH);              // 0x810204 still fits 24 bits
 }
+__device__ __forceinline__ uint32_t spread4(uint32_t mask, uint32_t g4) { return spread4_raw<0>(mask, g4) & 0x01010101u; }
 // significance probabilities (computeContext BPCEngine.cu:222-230 + the LUT read) of rows g4 .. g4+3
 __device__ __forceinline__ uint32_t sig_probs4(const ColHalf &cp, const PlaneLut &pl, uint32_t g4)
 {
-    const uint32_t s0 = spread4(cp.n0, g4), s1 = spread4(cp.n1, g4), s2 = spread4(cp.n2, g4), s3 = spread4(cp.n3, g4);
-    const uint32_t sel = s0 | (s1 << 1) | (s2 << 2);                      // bytes 0..7: the context
+    // the three context bits land on bits 0, 1, 2 of the rows' bytes by the multiplier's own shift; two
+    // bit-field inserts keep exactly those (strays of one product never reach the bits taken from another)
+    uint32_t sel = bfi32(0x01010101u, spread4_raw<0>(cp.n0, g4), spread4_raw<1>(cp.n1, g4));
+    sel = bfi32(0x03030303u, sel, spread4_raw<2>(cp.n2, g4)) & 0x07070707u;      // bytes 0..7: the context
     const uint32_t p07 = __builtin_amdgcn_perm(pl.sig1, pl.sig0, sel);
-    // context 8 (n3 set => n0 = n1 = n2 = 0): those bytes take p8.  s3 * 255 as a shift and a subtraction: the
-    // flag of row 3 sits at bit 24, beyond a 24-bit multiply
-    return bfi32((s3 << 8) - s3, pl.sig8x4, p07);
+    // context 8 (n3 set => n0 = n1 = n2 = 0): those bytes take p8 -- a second permute whose selector is the
+    // identity (bytes 0..3 = p07's) plus 4 where n3 is set (bytes 4..7 = p8 four times)
+    const uint32_t sel8 = (spread4(cp.n3, g4) << 2) | 0x03020100u;
+    return __builtin_amdgcn_perm(pl.sig8x4, p07, sel8);
 }
 // sign probabilities (computeSignContext :252-308: LUT index c >> 1 = c2 c1) of rows g4 .. g4+3
 __device__ __forceinline__ uint32_t sign_probs4(const ColHalf &cp, const PlaneLut &pl, uint32_t g4)
 {
-    const uint32_t sel = spread4(cp.c1, g4) | (spread4(cp.c2, g4) << 1);
+    const uint32_t sel = bfi32(0x01010101u, spread4_raw<0>(cp.c1, g4), spread4_raw<1>(cp.c2, g4)) & 0x03030303u;
     return __builtin_amdgcn_perm(0u, pl.sign, sel);
 }
 

@@ -1,0 +1,20 @@
+#!/bin/bash
+# usage: tools/publish_profiles.sh <gpurun_out subdir> <tag>   -- copies the summaries of a tools/collect_profiles.sh run
+# into profiles/<tag>_* (the files bench.py and DESIGN.md cite).  Run on the development box after the GPU call.
+set -e
+src=gpurun_out/$1; tag=$2; dst=profiles
+ks() { ls $src/$1/*/*kernel_stats.csv | head -1; }
+cp $(ks prof_default) $dst/${tag}_kernel_stats.csv
+cp $(ks prof_single) $dst/${tag}_kernel_stats_single_stream.csv
+cp $(ks prof_lossy) $dst/${tag}_kernel_stats_8k_lossy.csv
+cp $(ks prof_4k) $dst/${tag}_kernel_stats_4k.csv
+python3 tools/summarize_pmc.py $src/pmc_fetch/*/*counter_collection.csv $src/pmc_write/*/*counter_collection.csv > $dst/${tag}_pmc_hbm.csv
+python3 tools/summarize_pmc.py $src/pmc_sq/*/*counter_collection.csv $src/pmc_sq2/*/*counter_collection.csv > $dst/${tag}_pmc_sq.csv
+# keep the library's own kernels only (the bench also runs torch fills and copies)
+for f in $dst/${tag}_pmc_hbm.csv $dst/${tag}_pmc_sq.csv; do { head -1 $f; grep picsong $f; } > $f.tmp && mv $f.tmp $f; done
+cp $src/valu_probe.txt $dst/${tag}_valu_probe.txt
+cp $src/valu_probe.json $dst/${tag}_valu_probe.json
+cp $src/bench.json $dst/${tag}_bench.json
+for f in bench_4k bench_8k_lossy bench_8k_b3 bench_8k_lossy_b3; do [ -f $src/$f.json ] && cp $src/$f.json $dst/${tag}_$f.json; done
+[ -f $src/decode.txt ] && cp $src/decode.txt $dst/${tag}_decode.txt
+ls -la $dst | grep $tag
