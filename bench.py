@@ -141,18 +141,6 @@ def dwt_bytes(P, wl, s0):
     return P * (s0 + 4) + 8 * P * sum(4.0 ** -l for l in range(1, wl))
 
 
-def valu_issue(insts, step_s, iso_s):
-    """The encoder is bound by vector-instruction issue: one wave64 VALU instruction occupies a SIMD
-    for 4 cycles; 256 CUs x 4 SIMDs at the 2.4 GHz peak clock.  Fractions: in isolation (one kernel
-    on the GPU) and in the pipelined bench (one BPC launch per step, other kernels ignored)."""
-    if not insts:
-        return None
-    peak = 256 * 4 * 2.4e9 / 4.0                       # wave-instructions per second
-    return {"valu_wave_insts_per_launch": int(insts), "peak_wave_insts_per_s": peak,
-            "frac_single_stream": round(insts / iso_s / peak, 4), "frac_pipelined": round(insts / step_s / peak, 4),
-            "source": "profiles/r01_final_pmc_sq.csv (SQ_INSTS_VALU, rocprofv3 --pmc pass)"}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)

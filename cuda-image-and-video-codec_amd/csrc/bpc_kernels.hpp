@@ -1608,7 +1608,8 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
     const uint32_t cbyte = (uint32_t)cbase * 4u, rstride = (uint32_t)a.AW * 4u;
     int32_t *const stw = a.staging + (size_t)(a.cb_base + 2 * wave) * 4096u;
     int32_t *const st = stw + (size_t)half * 4096u;
-    const int32_t *const cw = st + 1;
+    // (a half beyond the last codeblock reads the launch's first codeblock: its ring is never used)
+    const int32_t *const cw = (valid ? st : a.staging + (size_t)a.cb_base * 4096u) + 1;
     const uint32_t prec = (uint32_t)a.g.prec;
     const uint32_t upper_mask = opaque_mask(half ? 0xFFFFFFFFu : 0u);
     const int total = a.g.nRef + 2 * (a.g.nSig + a.g.nSign), aux = a.g.nSig + a.g.nSign;
