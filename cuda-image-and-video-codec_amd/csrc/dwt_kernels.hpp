@@ -145,6 +145,85 @@ template <> __device__ __forceinline__ float dpp_prev<float>(float v)
 template <> __device__ __forceinline__ float dpp_next<float>(float v)
 { return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x130, 0xf, 0xf, false)); }
 
+// ---- wave-uniform row offset + per-lane byte offset addressing ---------------------------------
+// A plane addressed as base + row offset (an SGPR: 32-bit scalar arithmetic, P * 4 < 2^32) + lane offset (one
+// VGPR per column position, computed once per wave): buffer instructions, so a row's address costs one or
+// two scalar instructions and no vector instruction at all (per-row 64-bit pointers cost the fused kernel
+// a v_mad_u64 or two per access and 40 % of its instructions were scalar address arithmetic).  A lane that
+// must not store gets the offset kRbDrop: past the resource's num_records, the hardware drops the access
+// (raw buffer range check: lane offset against num_records), so stores need no exec mask.
+constexpr uint32_t kRbDrop = 0x80000000u;
+struct RowBuf {
+#if defined(__AMDGCN__)
+    __amdgpu_buffer_rsrc_t rs;
+#else
+    char *base;
+#endif
+};
+__device__ __forceinline__ RowBuf rowbuf(const void *p)
+{
+    RowBuf b;
+#if defined(__AMDGCN__)
+    b.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0x7FFFFFFF, 0x00020000);
+#else
+    b.base = const_cast<char *>((const char *)p);
+#endif
+    return b;
+}
+__device__ __forceinline__ uint32_t rb_load32(const RowBuf &b, uint32_t lane_off, uint32_t row_off)
+{
+#if defined(__AMDGCN__)
+    return __builtin_amdgcn_raw_buffer_load_b32(b.rs, lane_off, row_off, 0);
+#else
+    uint32_t v = 0;
+    if (lane_off < kRbDrop) memcpy(&v, b.base + row_off + lane_off, 4);
+    return v;
+#endif
+}
+__device__ __forceinline__ uint4 rb_load128(const RowBuf &b, uint32_t lane_off, uint32_t row_off)
+{
+#if defined(__AMDGCN__)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(b.rs, lane_off, row_off, 0);
+    uint4 r; r.x = w.x; r.y = w.y; r.z = w.z; r.w = w.w;
+    return r;
+#else
+    uint4 r = { 0u, 0u, 0u, 0u };
+    if (lane_off < kRbDrop) memcpy(&r, b.base + row_off + lane_off, 16);
+    return r;
+#endif
+}
+__device__ __forceinline__ void rb_store32(const RowBuf &b, uint32_t lane_off, uint32_t row_off, uint32_t x)
+{
+#if defined(__AMDGCN__)
+    __builtin_amdgcn_raw_buffer_store_b32(x, b.rs, lane_off, row_off, 0);
+#else
+    if (lane_off < kRbDrop) memcpy(b.base + row_off + lane_off, &x, 4);
+#endif
+}
+__device__ __forceinline__ void rb_store64(const RowBuf &b, uint32_t lane_off, uint32_t row_off, uint32_t x, uint32_t y)
+{
+#if defined(__AMDGCN__)
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 w; w.x = x; w.y = y;
+    __builtin_amdgcn_raw_buffer_store_b64(w, b.rs, lane_off, row_off, 0);
+#else
+    if (lane_off < kRbDrop) { memcpy(b.base + row_off + lane_off, &x, 4); memcpy(b.base + row_off + lane_off + 4, &y, 4); }
+#endif
+}
+
+// ---- time-resolved trace (variant builds only: -DPICSONG_DWT_TRACE) ------------------------------
+// Each wave of the fused head stamps s_memrealtime (100 MHz, chip-wide) at six points into a buffer the
+// tool sets with picsong_debug_set_trace (tools/dwt_trace.py).  Not compiled into the product library.
+#ifdef PICSONG_DWT_TRACE
+__device__ unsigned long long *g_dwt_trace = nullptr;
+#define PS_TRACE(slot) do { if (g_dwt_trace && (threadIdx.x & 63) == 0) g_dwt_trace[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x * 4 + blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define PS_TRACE_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define PS_TRACE(slot) do { } while (0)
+#define PS_TRACE_WAIT() do { } while (0)
+#endif
+
 // ---- division by a constant ------------------------------------------------------------------
 // The 9/7 synthesis divides (the reference writes x / K, x / 0.812893066, (m / Q) / qs; the forward
 // transform multiplies), and a correctly rounded fp32 division is ~11 instructions.  With the
@@ -502,7 +581,17 @@ constexpr int kF2Useful = kStripCols - 8 * kF2Edge;          // 232 columns writ
 // rows fetched before the first store like dwt_fwd_kernel (8K 5/3, 32-row bands: 31.5 us; 3 / 5 / 6
 // iterations ahead: 42.9 / 34.4 / 37.4; 64-row bands 34.3, 16-row bands 33.9)
 constexpr int kF2GroupSet = PICSONG_DWT_F2_GROUP;
-constexpr int kF2Pairs = 8;                                  // level-1 row pairs per band (32 input rows)
+// level-1 row pairs per band (8 = 32 input rows), by transform: the 9/7 band's run-in is 21 input rows, the 5/3 band's 9
+#ifndef PICSONG_DWT_F2_PAIRS
+#define PICSONG_DWT_F2_PAIRS 8
+#endif
+#ifndef PICSONG_DWT_F2_PAIRS_LOSSY
+#define PICSONG_DWT_F2_PAIRS_LOSSY 8
+#endif
+#ifndef PICSONG_DWT_F2_WAVES_LOSSY
+#define PICSONG_DWT_F2_WAVES_LOSSY PICSONG_DWT_F2_WAVES
+#endif
+constexpr int kF2Pairs = PICSONG_DWT_F2_PAIRS, kF2PairsLossy = PICSONG_DWT_F2_PAIRS_LOSSY;
 struct DwtFwd2Args { DwtFwdArgs l0, l1; };
 
 __device__ __forceinline__ void hfwd2(int v[2], bool le, bool re)
@@ -594,7 +683,7 @@ __device__ __forceinline__ void emit_pair1(const DwtFwdArgs &a, int n, int pc, b
 // substitutes its own mirror sample for a neighbour's; the other waves (all but the outermost strips)
 // run the instantiation without those per-use selects (15 % of the 9/7 kernel's vector instructions).
 template <typename T, bool LOSSY, bool U8IN, int NB, bool EDGE>
-__device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdArgs &a1, int strip, int lane)
+__device__ __forceinline__ void dwt_fwd2_band_v1(const DwtFwdArgs &a, const DwtFwdArgs &a1, int strip, int lane)
 {
     constexpr int kIters0 = NB + (LOSSY ? 5 : 2);
     constexpr int kF2Group = kF2GroupSet > 0 && kF2GroupSet < kIters0 ? kF2GroupSet : kIters0;
@@ -661,21 +750,149 @@ __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdA
     }
 }
 
-// grid.x = ceil(strips / 4) with strips of kF2Useful columns, grid.y = bands of NB level-1 row pairs
+template <bool LOSSY, int NB> constexpr int f2_iters() { return NB + (LOSSY ? 5 : 2); }
+
+// The same band, lean (round 2): the whole band unrolled, every row address a scalar offset into a buffer
+// resource (RowBuf), store conditions resolved at compile time (bands are whole: plan_dwt_fwd2 takes the fused
+// launch only when the level-1 row pairs are a multiple of NB, so pair `rel` of a band is stored iff
+// 0 <= rel < 2 NB), lanes that own no output column parked on the dropped offset instead of an exec mask per
+// store, level 1's bottom mirror looked at only in the iterations that can reach it.  u8 input.
+// Measured and not kept: the band's rows staged through LDS by 16-byte-per-lane loads shared by the workgroup's
+// four waves (a quarter of the load instructions, no prefetched rows in registers; one phase of 51 KB, or two of
+// 28 KB with the second half's rows waiting in registers): 36-41 us against 35.6 for 9/7, 30.2-31.1 against 30.4
+// for 5/3 -- the launch's first 6-7 us are the frame's 45-55 MB of input arriving at HBM speed whoever issues the
+// loads, and the rest is its 135 MB of output leaving at the 6.3 TB/s the memory takes writes at.
+template <typename T, bool LOSSY, int NB, bool EDGE>
+__device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdArgs &a1, int strip, int lane)
+{
+    constexpr int kIters = f2_iters<LOSSY, NB>();
+    constexpr int kRel0 = LOSSY ? 7 : 3;                     // iteration i delivers the level-0 pairs 2 n0 + 2 i - kRel0, + 1
+    constexpr int kLag1 = LOSSY ? 5 : 2;                     // ... and the level-1 pair n0 + i - kLag1
+    constexpr int kHist = LOSSY ? 6 : 2;                     // LL rows kept for level 1's bottom mirror
+    const int c0 = strip * kF2Useful - 4 * kF2Edge + 4 * lane;
+    const int n0 = blockIdx.y * NB;
+    const bool wr = lane >= kF2Edge && lane <= 63 - kF2Edge && c0 >= 0 && c0 < a.W;
+    const bool le = EDGE && c0 == 0, re = EDGE && c0 + 4 == a.W;
+    const int cl = c0 < 0 ? 0 : (c0 > a.W - 4 ? a.W - 4 : c0);
+    const int hW = a.W >> 1, hH = a.H >> 1, hW1 = a1.W >> 1, hH1 = a1.H >> 1;
+    const bool lastb = 2 * (n0 + NB) >= a1.H;                // the band that ends at the bottom of the image
+    const int y0 = 2 * (2 * n0 - (LOSSY ? 6 : 3));           // first input row (2 S0)
+
+    const RowBuf in = rowbuf(a.src), mal = rowbuf(a.mallat), ll2 = rowbuf(a1.ll);
+    const uint32_t vin = (uint32_t)cl;
+    const uint32_t vlh = wr ? (uint32_t)(cl >> 1) * 4u : kRbDrop, vhl = wr ? (uint32_t)(hW + (cl >> 1)) * 4u : kRbDrop;
+    const uint32_t vlh1 = wr ? (uint32_t)(cl >> 2) * 4u : kRbDrop, vhl1 = wr ? (uint32_t)(hW1 + (cl >> 2)) * 4u : kRbDrop;
+    const uint32_t aw4 = (uint32_t)a.AW * 4u, ll4 = (uint32_t)a1.ll_stride * 4u;
+    // level-1 LL: quantised on the transform's last level only; x * 1.0f * 1.0f is x
+    const float qll = LOSSY && a1.last ? a1.q[0] : 1.0f, qsll = LOSSY && a1.last ? a1.qs : 1.0f;
+
+    T xe[4], st0[3][4], xe1[2], st1[3][2], hist[kHist][2];
+#pragma unroll
+    for (int k = 0; k < kHist; k++) { hist[k][0] = hist[k][1] = (T)0; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) { st0[0][k] = st0[1][k] = st0[2][k] = (T)0; }
+#pragma unroll
+    for (int k = 0; k < 2; k++) { xe1[k] = st1[0][k] = st1[1][k] = st1[2][k] = (T)0; }
+
+    // all of the band's input rows go out before the first store (one in-order memory pipe), at raised priority
+    RawRow<true> r0, raw[kIters][4];
+    PS_TRACE(0);
+    __builtin_amdgcn_s_setprio(3);
+    r0.w = rb_load32(in, vin, (uint32_t)reflect(y0, a.H) * (uint32_t)a.src_stride);
+#pragma unroll
+    for (int p = 0; p < kIters; p++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            raw[p][q].w = rb_load32(in, vin, (uint32_t)reflect(y0 + 1 + 4 * p + q, a.H) * (uint32_t)a.src_stride);
+    __builtin_amdgcn_s_setprio(0);
+    PS_TRACE(1);
+    unpack_row<T, true>(r0, xe);
+    PS_TRACE(2);
+
+#pragma unroll
+    for (int i = 0; i < kIters; i++) {
+        if (i == kIters / 2) PS_TRACE(3);
+        T x[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) unpack_row<T, true>(raw[i][q], x[q]);
+        const int rel = 2 * i - kRel0;                       // (compile-time after unrolling)
+        T LA[4], HA[4], LB[4], HB[4];
+        vstep<T, LOSSY, 4>(xe, st0, x[0], x[1], LA, HA);
+        vstep<T, LOSSY, 4>(xe, st0, x[2], x[3], LB, HB);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {                        // the two level-0 pairs of this iteration
+            T *Lr = h ? LB : LA, *Hr = h ? HB : HA;
+            const int r = rel + h;
+            hfwd(Lr, le, re);
+            if (r >= 0 && r < 2 * NB) {
+                hfwd(Hr, le, re);
+                T hl0 = Lr[1], hl1 = Lr[3], lh0 = Hr[0], lh1 = Hr[2], hh0 = Hr[1], hh1 = Hr[3];
+                if (LOSSY) {
+                    hl0 = (T)(((float)hl0 * a.q[1]) * a.qs); hl1 = (T)(((float)hl1 * a.q[1]) * a.qs);
+                    lh0 = (T)(((float)lh0 * a.q[2]) * a.qs); lh1 = (T)(((float)lh1 * a.q[2]) * a.qs);
+                    hh0 = (T)(((float)hh0 * a.q[3]) * a.qs); hh1 = (T)(((float)hh1 * a.q[3]) * a.qs);
+                }
+                const uint32_t row0 = (uint32_t)(2 * n0 + r) * aw4, row1 = (uint32_t)(2 * n0 + r + hH) * aw4;
+                rb_store64(mal, vhl, row0, as_u32(hl0), as_u32(hl1));
+                rb_store64(mal, vlh, row1, as_u32(lh0), as_u32(lh1));
+                rb_store64(mal, vhl, row1, as_u32(hh0), as_u32(hh1));
+            }
+        }
+        // level 1: LL rows 2 n0 + rel (odd row of its pair) and + 1 (the even row after it).  Past the bottom
+        // of the image they are level 1's OWN mirror, LL[N + k] = LL[N - 2 - k]: mirrored input rows do not give
+        // that (the input's mirror centre H - 1 is an odd row, so the even-row subsequence comes out half-sample
+        // symmetric) -- taken from the rows kept in `hist`; only the last band's last iterations get there.
+        T la[2] = { LA[0], LA[2] }, lb[2] = { LB[0], LB[2] };
+        ll_row_or_mirror<T, kHist>(la, hist, rel >= 2 * NB && lastb ? rel - 2 * NB : -1);
+        ll_row_or_mirror<T, kHist>(lb, hist, rel + 1 >= 2 * NB && lastb ? rel + 1 - 2 * NB : -1);
+        T L1[2], H1[2];
+        vstep<T, LOSSY, 2>(xe1, st1, la, lb, L1, H1);
+        if (i >= kLag1) {
+            hfwd2(L1, le, re);
+            hfwd2(H1, le, re);
+            T ll = L1[0], hl = L1[1], lh = H1[0], hh = H1[1];
+            if (LOSSY) {
+                ll = (T)(((float)ll * qll) * qsll);
+                hl = (T)(((float)hl * a1.q[1]) * a1.qs);
+                lh = (T)(((float)lh * a1.q[2]) * a1.qs);
+                hh = (T)(((float)hh * a1.q[3]) * a1.qs);
+            }
+            const uint32_t n = (uint32_t)(n0 + i - kLag1);
+            rb_store32(ll2, vlh1, n * ll4, as_u32(ll));
+            rb_store32(mal, vhl1, n * aw4, as_u32(hl));
+            rb_store32(mal, vlh1, (n + (uint32_t)hH1) * aw4, as_u32(lh));
+            rb_store32(mal, vhl1, (n + (uint32_t)hH1) * aw4, as_u32(hh));
+        }
+    }
+    PS_TRACE(4);
+#ifdef PICSONG_DWT_TRACE
+    PS_TRACE_WAIT();
+    PS_TRACE(5);
+#endif
+}
+
 template <typename T, bool LOSSY, bool U8IN, int NB>
-__global__ __launch_bounds__(256, PICSONG_DWT_F2_WAVES) void dwt_fwd2_kernel(DwtFwd2Args a2)
+__global__ __launch_bounds__(256, (LOSSY ? PICSONG_DWT_F2_WAVES_LOSSY : PICSONG_DWT_F2_WAVES)) void dwt_fwd2_kernel(DwtFwd2Args a2)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int strip = blockIdx.x * 4 + wave;
-    if (strip * kF2Useful >= a2.l0.W) return;
     dwt_fwd_select_frame(a2.l0);
     dwt_fwd_select_frame(a2.l1);
     // the wave's 256 columns start at strip * kF2Useful - 4 * kF2Edge: does it hold column 0 or W - 4?
     const int first = strip * kF2Useful - 4 * kF2Edge;
     // (only the 9/7 kernel, which is bound by vector instructions, gets the second instantiation)
+#ifdef PICSONG_DWT_F2_V1
+    if (strip * kF2Useful >= a2.l0.W) return;
     if (!LOSSY || first <= 0 || first + kStripCols >= a2.l0.W)
-        dwt_fwd2_band<T, LOSSY, U8IN, NB, true>(a2.l0, a2.l1, strip, lane);
-    else dwt_fwd2_band<T, LOSSY, U8IN, NB, LOSSY ? false : true>(a2.l0, a2.l1, strip, lane);
+        dwt_fwd2_band_v1<T, LOSSY, U8IN, NB, true>(a2.l0, a2.l1, strip, lane);
+    else dwt_fwd2_band_v1<T, LOSSY, U8IN, NB, LOSSY ? false : true>(a2.l0, a2.l1, strip, lane);
+#else
+    static_assert(U8IN, "the fused head ingests u8 frames");
+    if (strip * kF2Useful >= a2.l0.W) return;               // whole wave idle (no cross-lane use)
+    if (!LOSSY || first <= 0 || first + kStripCols >= a2.l0.W)
+        dwt_fwd2_band<T, LOSSY, NB, true>(a2.l0, a2.l1, strip, lane);
+    else dwt_fwd2_band<T, LOSSY, NB, LOSSY ? false : true>(a2.l0, a2.l1, strip, lane);
+#endif
 }
 
 // ---- inverse --------------------------------------------------------------------------------

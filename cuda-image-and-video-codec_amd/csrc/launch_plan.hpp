@@ -136,7 +136,7 @@ inline bool dequant_fast_ok(float qs, int wl)
 // frames share the GPU, picsong_ctx_set_pipelined); PICSONG_DWT_NOFUSE01=1 / PICSONG_DWT_FUSE01=1 force
 // two launches / the fused one (the tests cross-check both).
 struct Fwd2Launch { DwtFwd2Args a; unsigned gx, gy; };
-inline bool plan_dwt_fwd2(const std::vector<FwdLaunch> &plan, Fwd2Launch &f, bool wanted = true)
+inline bool plan_dwt_fwd2(const std::vector<FwdLaunch> &plan, Fwd2Launch &f, bool wanted = true, bool lossy = false)
 {
     if (const char *e = getenv("PICSONG_DWT_NOFUSE01")) if (atoi(e) != 0) return false;
     if (const char *e = getenv("PICSONG_DWT_FUSE01")) wanted = wanted || atoi(e) != 0;
@@ -144,11 +144,13 @@ inline bool plan_dwt_fwd2(const std::vector<FwdLaunch> &plan, Fwd2Launch &f, boo
     if (plan.size() < 2 || !plan[0].vec || !plan[1].vec || !plan[0].u8) return false;
     const DwtFwdArgs &l0 = plan[0].a;
     if (l0.H < 64 || (l0.H & 3) || l0.W < 8 || (l0.W & 7)) return false;
+    const int pairs1 = l0.H >> 2;                                   // level-1 row pairs
     f.a.l0 = l0; f.a.l1 = plan[1].a;
     const int strips = (l0.W + kF2Useful - 1) / kF2Useful;
     f.gx = (unsigned)((strips + 3) / 4);
-    const int pairs1 = l0.H >> 2;                                   // level-1 row pairs
-    f.gy = (unsigned)((pairs1 + kF2Pairs - 1) / kF2Pairs);
+    const int nb = lossy ? kF2PairsLossy : kF2Pairs;
+    if (pairs1 % nb) return false;                                  // whole bands only (dwt_fwd2_band)
+    f.gy = (unsigned)((pairs1 + nb - 1) / nb);
     return true;
 }
 

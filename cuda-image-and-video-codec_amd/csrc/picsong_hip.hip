@@ -121,7 +121,7 @@ static void launch_fwd(const picsong_ctx *c, const FwdLaunch &f, hipStream_t s, 
 static void launch_fwd2(bool lossy, const Fwd2Launch &f, hipStream_t s)
 {
     dim3 grid(f.gx, f.gy);
-    if (lossy) dwt_fwd2_kernel<float, true, true, kF2Pairs><<<grid, 256, 0, s>>>(f.a);
+    if (lossy) dwt_fwd2_kernel<float, true, true, kF2PairsLossy><<<grid, 256, 0, s>>>(f.a);
     else dwt_fwd2_kernel<int, false, true, kF2Pairs><<<grid, 256, 0, s>>>(f.a);
 }
 
@@ -515,7 +515,7 @@ static int dwt_forward_impl(picsong_ctx *c, const void *d_in, bool u8in, void *d
 {
     const std::vector<FwdLaunch> plan = plan_dwt_forward(d_in, u8in, d_out, c->aw, c->ah, c->p.wl, c->p.qs);
     Fwd2Launch f2;
-    const bool fused01 = plan_dwt_fwd2(plan, f2, !c->pipelined);
+    const bool fused01 = plan_dwt_fwd2(plan, f2, !c->pipelined, c->p.lossy != 0);
     if (fused01) {                       // levels 0 and 1 in one launch, LL1 stays in registers
         launch_fwd2(c->p.lossy != 0, f2, s);
         HIP_TRY(hipGetLastError());
@@ -992,10 +992,10 @@ int picsong_encode_frames(picsong_ctx *c, int n, const uint8_t *d_frames, size_t
         plan[l].a.dst_z = (unsigned long long)coef_z;
     }
     Fwd2Launch f2;
-    const bool fused01 = plan_dwt_fwd2(plan, f2, true);
+    const bool fused01 = plan_dwt_fwd2(plan, f2, true, c->p.lossy != 0);
     if (fused01) {
         dim3 grid(f2.gx, f2.gy, (unsigned)n);
-        if (c->p.lossy) dwt_fwd2_kernel<float, true, true, kF2Pairs><<<grid, 256, 0, s>>>(f2.a);
+        if (c->p.lossy) dwt_fwd2_kernel<float, true, true, kF2PairsLossy><<<grid, 256, 0, s>>>(f2.a);
         else dwt_fwd2_kernel<int, false, true, kF2Pairs><<<grid, 256, 0, s>>>(f2.a);
         HIP_TRY(hipGetLastError());
     }
@@ -1124,3 +1124,12 @@ int picsong_pad_frame_host(const uint8_t *in, int w, int h, uint8_t *out, int aw
 }
 
 }  // extern "C"
+
+#ifdef PICSONG_DWT_TRACE
+// variant builds only (tools/dwt_trace.py): device buffer the fused DWT head's waves stamp their phases into
+extern "C" int picsong_debug_set_trace(void *d_buf)
+{
+    unsigned long long *p = (unsigned long long *)d_buf;
+    return hipMemcpyToSymbol(HIP_SYMBOL(picsong::g_dwt_trace), &p, sizeof p) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -74,7 +74,7 @@ static void emu_fwd2(const Fwd2Launch &f, int lossy)
 {
     DwtFwd2Args a = f.a;
     const dim3 grid(f.gx, f.gy);
-    if (lossy) emu::launch(grid, dim3(256), [&] { dwt_fwd2_kernel<float, true, true, kF2Pairs>(a); });
+    if (lossy) emu::launch(grid, dim3(256), [&] { dwt_fwd2_kernel<float, true, true, kF2PairsLossy>(a); });
     else emu::launch(grid, dim3(256), [&] { dwt_fwd2_kernel<int, false, true, kF2Pairs>(a); });
 }
 
@@ -94,7 +94,7 @@ int emu_dwt_forward(const void *in, int u8in, void *out, int aw, int ah, int wl,
 {
     const std::vector<FwdLaunch> plan = plan_dwt_forward(in, u8in != 0, out, aw, ah, wl, qs);
     Fwd2Launch f2;
-    const bool fused01 = plan_dwt_fwd2(plan, f2);
+    const bool fused01 = plan_dwt_fwd2(plan, f2, true, lossy != 0);
     if (fused01) {
         emu_fwd2(f2, lossy);
     }

@@ -37,6 +37,9 @@ enum Kind {
     ADDCO_DEP,           // v_add_co_u32 x, vcc, x, x (shift left by one, bit out to vcc)
     AND_SGPR_INDEP, AND_LIT_INDEP, EXEC_MOV,      // s_mov exec, m ; v_mov ; s_mov exec, -1
     SDWA_AND_INDEP, PK_ADD_INDEP, MUL_LO_INDEP, MAD24_INDEP, BFI_INDEP, LSHL_ADD_INDEP,
+    // fp32 classes of the 9/7 DWT kernels (dwt_kernels.hpp)
+    F_ADD_INDEP, F_MUL_INDEP, F_FMAC_INDEP, F_FMA_INDEP, F_FMAMK_INDEP, F_ADD_DPP_INDEP, F_CVT_UBYTE_INDEP, F_CVT_I32_INDEP,
+    PK_FMA_INDEP, PK_ADDF_INDEP, PK_MULF_INDEP, PK_FMA_SGPR_INDEP, MOV_B64_INDEP, F_ADD_DEP, PK_FMA_DEP,
     NKINDS
 };
 static const char *kKindName[NKINDS] = {
@@ -57,10 +60,16 @@ static const char *kKindName[NKINDS] = {
     "s_mov vcc ; 8 x v_cndmask_e32 vcc independent (9 inst)", "v_add_co_u32 x, vcc, x, x dependent",
     "v_and_b32 v, s, v x8 independent", "v_and_b32 v, literal, v x8 independent",
     "s_mov exec, m ; v_mov ; s_mov exec, -1 (3 inst)", "v_and_b32_sdwa x8 independent", "v_pk_add_u16 x8 independent",
-    "v_mul_lo_u32 x8 independent", "v_mad_u32_u24 x8 independent", "v_bfi_b32 x8 independent", "v_lshl_add_u32 x8 independent" };
+    "v_mul_lo_u32 x8 independent", "v_mad_u32_u24 x8 independent", "v_bfi_b32 x8 independent", "v_lshl_add_u32 x8 independent",
+    "v_add_f32 x8 independent", "v_mul_f32 x8 independent", "v_fmac_f32 x8 independent", "v_fma_f32 x8 independent",
+    "v_fmaak_f32 (literal) x8 independent", "v_add_f32_dpp wave_shl:1 x8 independent", "v_cvt_f32_ubyte1 x8 independent",
+    "v_cvt_f32_i32 x8 independent", "v_pk_fma_f32 x8 independent", "v_pk_add_f32 x8 independent", "v_pk_mul_f32 x8 independent",
+    "v_pk_fma_f32 v, s, v x8 independent", "v_mov_b64 x8 independent", "v_add_f32 dependent", "v_pk_fma_f32 dependent" };
 // instructions per unrolled block (what "per instruction" divides by)
-static const int kBlockInsts[NKINDS] = { 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 64, 32, 32, 24, 32, 40, 40, 32, 24, 32, 32, 32, 32, 32, 32, 32, 32, 21, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 64, 36, 32, 32, 32, 24, 32, 32, 32, 32, 32, 32 };
-static const int kBlockValu[NKINDS] = { 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 16, 16, 16, 16, 0, 15, 32, 32, 32, 32, 32, 32, 32, 32, 17, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 64, 32, 32, 32, 32, 8, 32, 32, 32, 32, 32, 32 };
+static const int kBlockInsts[NKINDS] = { 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 64, 32, 32, 24, 32, 40, 40, 32, 24, 32, 32, 32, 32, 32, 32, 32, 32, 21, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 64, 36, 32, 32, 32, 24, 32, 32, 32, 32, 32, 32,
+    32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32 };
+static const int kBlockValu[NKINDS] = { 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 16, 16, 16, 16, 0, 15, 32, 32, 32, 32, 32, 32, 32, 32, 17, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 64, 32, 32, 32, 32, 8, 32, 32, 32, 32, 32, 32,
+    32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32 };
 
 #define R4(x) x x x x
 #define R8(x) R4(x) R4(x)
@@ -80,6 +89,9 @@ static const int kBlockValu[NKINDS] = { 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 
                                     op " %4, %4, %8" tail "\n" op " %5, %5, %8" tail "\n" op " %6, %6, %8" tail "\n" op " %7, %7, %8" tail "\n") \
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(k))
 
+#define PK8(o0, o1, o2, o3, o4, o5, o6, o7, cls) asm volatile(R4(o0 o1 o2 o3 o4 o5 o6 o7) \
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : cls(pk))
+
 template <int KIND>
 __global__ __launch_bounds__(256) void probe_kernel(uint32_t *out, uint64_t *cyc, int iters, uint32_t seed)
 {
@@ -87,6 +99,9 @@ __global__ __launch_bounds__(256) void probe_kernel(uint32_t *out, uint64_t *cyc
     uint32_t a4 = a0 * 3u, a5 = a1 * 5u, a6 = a2 * 7u, a7 = a3 * 11u, k = seed | 0x01010101u;
     uint64_t sm = 0, sm2 = 0x5555aaaa3333ccccull, sm3 = ~0ull, sm4 = 0;            // scalar mask scratch
     uint32_t sc = seed;
+    // 64-bit operands of the packed fp32 classes (finite, non-trivial floats in both halves)
+    uint64_t p0 = 0x3f8000013f800003ull + threadIdx.x, p1 = p0 + 17u, p2 = p0 + 33u, p3 = p0 + 49u, p4 = p0 + 65u, p5 = p0 + 81u,
+             p6 = p0 + 97u, p7 = p0 + 113u, pk = 0x3f7fff003f7ffe00ull;
     __builtin_amdgcn_s_barrier();
     const uint64_t r0 = __builtin_amdgcn_s_memrealtime();
     const uint64_t t0 = __builtin_amdgcn_s_memtime();
@@ -235,12 +250,28 @@ __global__ __launch_bounds__(256) void probe_kernel(uint32_t *out, uint64_t *cyc
         } else if constexpr (KIND == MAD24_INDEP) { IND8_3("v_mad_u32_u24", ", %8");
         } else if constexpr (KIND == BFI_INDEP) { IND8_3("v_bfi_b32", ", %8");
         } else if constexpr (KIND == LSHL_ADD_INDEP) { IND8_3("v_lshl_add_u32", ", %8");
+        } else if constexpr (KIND == F_ADD_INDEP) { IND8_2("v_add_f32");
+        } else if constexpr (KIND == F_MUL_INDEP) { IND8_2("v_mul_f32");
+        } else if constexpr (KIND == F_FMAC_INDEP) { IND8_2("v_fmac_f32");
+        } else if constexpr (KIND == F_FMA_INDEP) { IND8_3("v_fma_f32", ", %8");
+        } else if constexpr (KIND == F_FMAMK_INDEP) { IND8_3("v_fmaak_f32", ", 0x3f99999a");
+        } else if constexpr (KIND == F_ADD_DPP_INDEP) { IND8_3("v_add_f32_dpp", " wave_shl:1 row_mask:0xf bank_mask:0xf");
+        } else if constexpr (KIND == F_CVT_UBYTE_INDEP) { IND8_1("v_cvt_f32_ubyte1");
+        } else if constexpr (KIND == F_CVT_I32_INDEP) { IND8_1("v_cvt_f32_i32");
+        } else if constexpr (KIND == PK_FMA_INDEP) { PK8("v_pk_fma_f32 %0, %0, %8, %0\n", "v_pk_fma_f32 %1, %1, %8, %1\n", "v_pk_fma_f32 %2, %2, %8, %2\n", "v_pk_fma_f32 %3, %3, %8, %3\n", "v_pk_fma_f32 %4, %4, %8, %4\n", "v_pk_fma_f32 %5, %5, %8, %5\n", "v_pk_fma_f32 %6, %6, %8, %6\n", "v_pk_fma_f32 %7, %7, %8, %7\n", "v");
+        } else if constexpr (KIND == PK_ADDF_INDEP) { PK8("v_pk_add_f32 %0, %0, %8\n", "v_pk_add_f32 %1, %1, %8\n", "v_pk_add_f32 %2, %2, %8\n", "v_pk_add_f32 %3, %3, %8\n", "v_pk_add_f32 %4, %4, %8\n", "v_pk_add_f32 %5, %5, %8\n", "v_pk_add_f32 %6, %6, %8\n", "v_pk_add_f32 %7, %7, %8\n", "v");
+        } else if constexpr (KIND == PK_MULF_INDEP) { PK8("v_pk_mul_f32 %0, %0, %8\n", "v_pk_mul_f32 %1, %1, %8\n", "v_pk_mul_f32 %2, %2, %8\n", "v_pk_mul_f32 %3, %3, %8\n", "v_pk_mul_f32 %4, %4, %8\n", "v_pk_mul_f32 %5, %5, %8\n", "v_pk_mul_f32 %6, %6, %8\n", "v_pk_mul_f32 %7, %7, %8\n", "v");
+        } else if constexpr (KIND == PK_FMA_SGPR_INDEP) { PK8("v_pk_fma_f32 %0, %0, %8, %0\n", "v_pk_fma_f32 %1, %1, %8, %1\n", "v_pk_fma_f32 %2, %2, %8, %2\n", "v_pk_fma_f32 %3, %3, %8, %3\n", "v_pk_fma_f32 %4, %4, %8, %4\n", "v_pk_fma_f32 %5, %5, %8, %5\n", "v_pk_fma_f32 %6, %6, %8, %6\n", "v_pk_fma_f32 %7, %7, %8, %7\n", "s");
+        } else if constexpr (KIND == MOV_B64_INDEP) { PK8("v_mov_b64 %0, %8\n", "v_mov_b64 %1, %8\n", "v_mov_b64 %2, %8\n", "v_mov_b64 %3, %8\n", "v_mov_b64 %4, %8\n", "v_mov_b64 %5, %8\n", "v_mov_b64 %6, %8\n", "v_mov_b64 %7, %8\n", "v");
+        } else if constexpr (KIND == F_ADD_DEP) { asm volatile(R32("v_add_f32 %0, %0, %1\n") : "+v"(a0) : "v"(k));
+        } else if constexpr (KIND == PK_FMA_DEP) { asm volatile(R32("v_pk_fma_f32 %0, %0, %1, %0\n") : "+v"(p0) : "v"(pk));
         }
     }
     const uint64_t t1 = __builtin_amdgcn_s_memtime();
     const uint64_t r1 = __builtin_amdgcn_s_memrealtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ (uint32_t)sm ^ sc;
     out[blockIdx.x * blockDim.x + threadIdx.x] ^= (uint32_t)sm2 ^ (uint32_t)sm3 ^ (uint32_t)sm4;
+    out[blockIdx.x * blockDim.x + threadIdx.x] ^= (uint32_t)((p0 ^ p1 ^ p2 ^ p3 ^ p4 ^ p5 ^ p6 ^ p7) >> 7);
     if ((threadIdx.x & 63u) == 0u) {
         uint64_t *c = cyc + 3 * (size_t)(blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64);
         c[0] = t1 - t0; c[1] = r0; c[2] = r1;
