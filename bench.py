@@ -192,8 +192,7 @@ def main():
     nstreams = args.streams if args.streams > 0 else 3
     fps = max(batch, (args.frames_per_step // batch) * batch)          # frames per step: whole calls
     pool_n = max(batch, (max(args.pool, 1) + batch - 1) // batch * batch)
-    # several calls in flight: the contexts are told so (picsong_ctx_set_pipelined: the single-frame path then
-    # favours the fewest vector instructions over the shortest DWT -- two launches for levels 0 and 1)
+    # several calls in flight: the contexts are told so (picsong_ctx_set_pipelined, a hint)
     codecs = [pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=lut_dir, device=local_rank,
                        pipelined=nstreams > 1) for _ in range(nstreams)]
     streams = [torch.cuda.Stream(device=local_rank) for _ in range(nstreams)]

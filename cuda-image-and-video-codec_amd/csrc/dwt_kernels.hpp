@@ -895,6 +895,18 @@ __global__ __launch_bounds__(256, (LOSSY ? PICSONG_DWT_F2_WAVES_LOSSY : PICSONG_
 #endif
 }
 
+// ---- the small levels of the forward transform ---------------------------------------------------------
+// Past level 2 of an 8K frame a level is 2 MB and less and a launch costs 4-5 us, most of it the dependency drain
+// and one wave's serial chain.  Measured in round 2 and not kept: ONE launch for levels 3..5 (3..4 at wl = 5) --
+// 64 x 32-sample tiles with the 32 (16)-sample halo three (two) levels of lifting reach, all levels in LDS in
+// place at stride 2^j, a thread lifting a segment of 8 >> j pairs in registers between two barriers, level 1's
+// and 2's mirrors re-made from the tile's own LL samples; bit-identical on the emulator and on the GPU.  9.9 us
+// against 3 x 4.7 (9/7), 6.6 against 2 x 5 (5/3): the input's round trip to memory 2.7 us, level 0's two passes
+// 2.3, emit + mirror 1.1, level 1 1.9, level 2 1.1 (time-resolved trace).  A lone frame gained 2-4 us of 55, and
+// frames in flight LOST 9-14 % (137.6 against 150.9 Gpixel/s at 8K, 126.6 against 147.5 at 4K): a 1024-thread
+// workgroup with 50 KB of LDS waits for a whole CU's worth of resources among the coder's waves.  The levels
+// stay one launch each.
+
 // ---- inverse --------------------------------------------------------------------------------
 // readSubbands* DWTGenerator.cu:477-553: de-quantisation (|v| + 0.5) * sgn(v) / Q / qs, 0 -> 0
 template <bool FAST>

@@ -118,11 +118,28 @@ static void launch_fwd(const picsong_ctx *c, const FwdLaunch &f, hipStream_t s, 
     else launch_fwd_v<BAND, false>(c->p.lossy != 0, f, grid, s);
 }
 
-static void launch_fwd2(bool lossy, const Fwd2Launch &f, hipStream_t s)
+static void launch_fwd2(bool lossy, const Fwd2Launch &f, hipStream_t s, unsigned frames = 1)
 {
-    dim3 grid(f.gx, f.gy);
+    dim3 grid(f.gx, f.gy, frames);
     if (lossy) dwt_fwd2_kernel<float, true, true, kF2PairsLossy><<<grid, 256, 0, s>>>(f.a);
     else dwt_fwd2_kernel<int, false, true, kF2Pairs><<<grid, 256, 0, s>>>(f.a);
+}
+
+// Levels [from, end) of a forward plan, one launch each.  `frames` = grid.z of a batched call.
+static int launch_fwd_levels(const picsong_ctx *c, const std::vector<FwdLaunch> &plan, size_t from, hipStream_t s,
+                             unsigned frames = 1)
+{
+    for (size_t l = from; l < plan.size(); l++) {
+        const FwdLaunch &f = plan[l];
+        switch (f.band) {
+        case 32: launch_fwd<32>(c, f, s, frames); break;
+        case 16: launch_fwd<16>(c, f, s, frames); break;
+        case 8: launch_fwd<8>(c, f, s, frames); break;
+        default: launch_fwd<4>(c, f, s, frames); break;
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    return PICSONG_OK;
 }
 
 
@@ -515,22 +532,12 @@ static int dwt_forward_impl(picsong_ctx *c, const void *d_in, bool u8in, void *d
 {
     const std::vector<FwdLaunch> plan = plan_dwt_forward(d_in, u8in, d_out, c->aw, c->ah, c->p.wl, c->p.qs);
     Fwd2Launch f2;
-    const bool fused01 = plan_dwt_fwd2(plan, f2, !c->pipelined, c->p.lossy != 0);
+    const bool fused01 = plan_dwt_fwd2(plan, f2, true, c->p.lossy != 0);
     if (fused01) {                       // levels 0 and 1 in one launch, LL1 stays in registers
         launch_fwd2(c->p.lossy != 0, f2, s);
         HIP_TRY(hipGetLastError());
     }
-    for (size_t l = fused01 ? 2 : 0; l < plan.size(); l++) {
-        const FwdLaunch &f = plan[l];
-        switch (f.band) {
-        case 32: launch_fwd<32>(c, f, s); break;
-        case 16: launch_fwd<16>(c, f, s); break;
-        case 8: launch_fwd<8>(c, f, s); break;
-        default: launch_fwd<4>(c, f, s); break;
-        }
-        HIP_TRY(hipGetLastError());
-    }
-    return PICSONG_OK;
+    return launch_fwd_levels(c, plan, fused01 ? 2 : 0, s);
 }
 
 int picsong_dwt_forward(picsong_ctx *c, const void *d_in, void *d_out, void *stream)
@@ -572,11 +579,7 @@ int picsong_dwt_forward_tail(picsong_ctx *c, void *d_out, void *stream)
     if (!c || !d_out) return fail(PICSONG_ERR_ARG, "dwt_forward_tail: null argument");
     // (the level-0 source is irrelevant here: only the launches of levels >= 1 are used)
     const std::vector<FwdLaunch> plan = plan_dwt_forward(d_out, false, d_out, c->aw, c->ah, c->p.wl, c->p.qs);
-    for (size_t l = 1; l < plan.size(); l++) {
-        launch_fwd_any(c, plan[l], (hipStream_t)stream);
-        HIP_TRY(hipGetLastError());
-    }
-    return PICSONG_OK;
+    return launch_fwd_levels(c, plan, 1, (hipStream_t)stream);
 }
 
 // d_pixels != nullptr: the finest level writes clamped u8 pixels there (level shift + clamp fused,
@@ -994,21 +997,10 @@ int picsong_encode_frames(picsong_ctx *c, int n, const uint8_t *d_frames, size_t
     Fwd2Launch f2;
     const bool fused01 = plan_dwt_fwd2(plan, f2, true, c->p.lossy != 0);
     if (fused01) {
-        dim3 grid(f2.gx, f2.gy, (unsigned)n);
-        if (c->p.lossy) dwt_fwd2_kernel<float, true, true, kF2PairsLossy><<<grid, 256, 0, s>>>(f2.a);
-        else dwt_fwd2_kernel<int, false, true, kF2Pairs><<<grid, 256, 0, s>>>(f2.a);
+        launch_fwd2(c->p.lossy != 0, f2, s, (unsigned)n);
         HIP_TRY(hipGetLastError());
     }
-    for (size_t l = fused01 ? 2 : 0; l < plan.size(); l++) {
-        const FwdLaunch &f = plan[l];
-        switch (f.band) {
-        case 32: launch_fwd<32>(c, f, s, (unsigned)n); break;
-        case 16: launch_fwd<16>(c, f, s, (unsigned)n); break;
-        case 8: launch_fwd<8>(c, f, s, (unsigned)n); break;
-        default: launch_fwd<4>(c, f, s, (unsigned)n); break;
-        }
-        HIP_TRY(hipGetLastError());
-    }
+    if (int rc = launch_fwd_levels(c, plan, fused01 ? 2 : 0, s, (unsigned)n)) return rc;
 
     if (ev) HIP_TRY(hipEventRecord(ev[1], s));
     // ---- coder: one grid over the n frames' codeblock pairs

@@ -89,6 +89,22 @@ int emu_dwt_vec_levels(const void *in, void *out, int aw, int ah, int wl)
     return n;
 }
 
+static void emu_fwd_any(const FwdLaunch &f, int lossy)
+{
+    switch (f.band) {
+    case 32: emu_fwd<32>(f, lossy); break;
+    case 16: emu_fwd<16>(f, lossy); break;
+    case 8: emu_fwd<8>(f, lossy); break;
+    default: emu_fwd<4>(f, lossy); break;
+    }
+}
+
+// mirrors launch_fwd_levels (picsong_hip.hip)
+static void emu_fwd_levels(const std::vector<FwdLaunch> &plan, size_t from, int lossy)
+{
+    for (size_t l = from; l < plan.size(); l++) emu_fwd_any(plan[l], lossy);
+}
+
 // mirrors dwt_forward_impl (picsong_hip.hip); returns 1 when levels 0 and 1 went through the fused kernel
 int emu_dwt_forward(const void *in, int u8in, void *out, int aw, int ah, int wl, int lossy, float qs)
 {
@@ -98,26 +114,8 @@ int emu_dwt_forward(const void *in, int u8in, void *out, int aw, int ah, int wl,
     if (fused01) {
         emu_fwd2(f2, lossy);
     }
-    for (size_t l = fused01 ? 2 : 0; l < plan.size(); l++) {
-        const FwdLaunch &f = plan[l];
-        switch (f.band) {
-        case 32: emu_fwd<32>(f, lossy); break;
-        case 16: emu_fwd<16>(f, lossy); break;
-        case 8: emu_fwd<8>(f, lossy); break;
-        default: emu_fwd<4>(f, lossy); break;
-        }
-    }
+    emu_fwd_levels(plan, fused01 ? 2 : 0, lossy);
     return fused01 ? 1 : 0;
-}
-
-static void emu_fwd_any(const FwdLaunch &f, int lossy)
-{
-    switch (f.band) {
-    case 32: emu_fwd<32>(f, lossy); break;
-    case 16: emu_fwd<16>(f, lossy); break;
-    case 8: emu_fwd<8>(f, lossy); break;
-    default: emu_fwd<4>(f, lossy); break;
-    }
 }
 
 // mirror picsong_dwt_forward_band / picsong_dwt_forward_tail (picsong_hip.hip)
@@ -131,7 +129,7 @@ void emu_dwt_forward_band(const void *in, void *out, int aw, int ah, int wl, int
 void emu_dwt_forward_tail(void *out, int aw, int ah, int wl, int lossy, float qs)
 {
     const std::vector<FwdLaunch> plan = plan_dwt_forward(out, false, out, aw, ah, wl, qs);
-    for (size_t l = 1; l < plan.size(); l++) emu_fwd_any(plan[l], lossy);
+    emu_fwd_levels(plan, 1, lossy);
 }
 
 void emu_dwt_inverse(const int32_t *in, void *out, int aw, int ah, int wl, int lossy, float qs)

@@ -511,8 +511,8 @@ def test_deep_planes_beyond_the_register_file(oracle, pa, torch, k):
 
 
 def test_pipelined_hint_changes_launches_not_results(oracle, pa, torch):
-    """picsong_ctx_set_pipelined: the frame path runs DWT levels 0 and 1 as two launches instead of the
-    fused kernel; the codestream is the same, and both equal the oracle's."""
+    """picsong_ctx_set_pipelined is a hint: the codestream is the same with and without it, and equals the
+    oracle's (until round 2 the hint selected two launches for DWT levels 0 and 1)."""
     for (W, H, wl, lossy, qs) in ((1920, 1080, 5, False, 1.0), (1024, 768, 4, True, 0.5)):
         img = oracle.gen_frame(W, H, 9)
         ref = oracle.encode_frame(img, wl, lossy, qs, oracle.lut_for(lossy, wl), 0, 0)
