@@ -7,6 +7,12 @@
 // one thread per staged value and binary-searches the prefix array through a 256-entry index;
 // here one workgroup owns one codeblock, so both sides of the copy are contiguous bursts and no
 // search exists.  The scan is a single-workgroup wave scan (nCB <= 65,536).
+// (Round 2 measured the scan folded away -- a workgroup per group of 1..16 codeblocks summing the lengths before
+// its group itself, sixteen loads in flight, the group's payload copied as one run: bit-identical, one launch
+// instead of two (three on the decoder's side), and SLOWER: 31 us against 8 + 14.5 for an 8K frame, 146 against
+// 150 Gpixel/s with frames in flight.  Every workgroup then starts with the same chain of round trips -- lengths,
+// wave reduction, LDS, barrier, group scan, barrier -- before it copies a byte, and a launch of 2040 such
+// workgroups is one round of them; 8160 small workgroups behind a scan that costs one round trip overlap better.)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -412,7 +412,7 @@ def test_dwt97_inverse_fast_and_dividing_kernels_agree(oracle, E, monkeypatch, W
 @pytest.mark.parametrize("W,H,wl,lossy,qs", [(320, 192, 3, False, 1.0), (64, 64, 5, False, 1.0), (256, 64, 2, False, 1.0),
                                              (1024, 320, 4, False, 1.0), (768, 128, 2, True, 0.5),
                                              (64, 128, 5, True, 0.3), (512, 256, 6, True, 1.0),
-                                             # widths that are 8 mod 16 (the staged rows' clamped vectors land 8-byte aligned), two workgroups
+                                             # widths that are 8 mod 16, two workgroups
                                              (328, 192, 3, False, 1.0), (1864, 64, 2, True, 0.7), (936, 128, 3, False, 1.0)])
 def test_dwt_fused_levels_0_and_1(oracle, E, monkeypatch, W, H, wl, lossy, qs):
     """The frame path's first two levels as one launch: LL1 stays in registers, level 1's own mirror at
