@@ -834,6 +834,106 @@ __device__ __forceinline__ void load_row(const BpcArgs &a, uint32_t off, uint32_
     n0 = (uint32_t)v0 >> 31; n1 = (uint32_t)v1 >> 31;
 }
 
+// a value the optimiser cannot see through (no hoisting of what is computed from it)
+__device__ __forceinline__ void opaque32(uint32_t &x)
+{
+#if defined(__AMDGCN__)
+    asm volatile("" : "+v"(x));
+#else
+    (void)x;
+#endif
+}
+// nothing is scheduled across this point
+__device__ __forceinline__ void sched_fence()
+{
+#if defined(__AMDGCN__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+// the same row as signed integers (BPCEngine.cu:49: a float coefficient is truncated toward zero)
+template <bool FLOAT>
+__device__ __forceinline__ void load_row_raw(const BpcArgs &a, uint32_t off, int32_t &v0, int32_t &v1)
+{
+    const char *const p = reinterpret_cast<const char *>(a.coeffs_in) + (size_t)off;
+    if constexpr (FLOAT) {
+        float2 f = *reinterpret_cast<const float2 *>(p);
+        v0 = (int32_t)f.x; v1 = (int32_t)f.y;
+    } else {
+        int2 q = *reinterpret_cast<const int2 *>(p);
+        v0 = q.x; v1 = q.y;
+    }
+}
+
+// Four 8 x 8 bit matrices at once, one per byte lane of the eight words (row j of a lane's matrix = that byte of
+// x[j]), transposed in place by the three block-swap stages (1-, 2- and 4-bit blocks): afterwards bit j of byte b
+// of x[k] is what bit k of byte b of x[j] was.
+__device__ __forceinline__ void bit_swap_pair(uint32_t &lo, uint32_t &hi, uint32_t mask, uint32_t sh)
+{
+    const uint32_t a = lo, b = hi;
+    lo = bfi32(mask, a, b << sh);                           // (b & mask) << sh lands on the bits mask leaves out
+    hi = bfi32(mask, a >> sh, b);
+}
+__device__ __forceinline__ void bit_transpose_8x8x4(uint32_t (&x)[8])
+{
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) bit_swap_pair(x[j], x[j + 1], 0x55555555u, 1u);
+#pragma unroll
+    for (int j = 0; j < 8; j++) if ((j & 2) == 0) bit_swap_pair(x[j], x[j + 2], 0x33333333u, 2u);
+#pragma unroll
+    for (int j = 0; j < 4; j++) bit_swap_pair(x[j], x[j + 4], 0x0F0F0F0Fu, 4u);
+}
+
+// One pass over a lane's two columns: planes 8 pass .. 8 pass + 7 of all 64 rows as row masks, parked in the wave's
+// scratch as they come out ([plane][L rows 0-31, L rows 32-63, R rows 0-31, R rows 32-63][lane]: all eight planes of
+// the pass, whatever the codeblock's MSB turns out to be -- holding them back until it is known costs 32 registers
+// the kernel does not have); pass 0 also gathers the OR of the magnitudes and the sign masks.
+template <bool FLOAT>
+__device__ __forceinline__ void enc_transpose_pass(const BpcArgs &a, int pass, uint32_t cbyte, uint32_t rstride,
+                                                   uint32_t *pscr, uint32_t &ormag, U64 &sgL, U64 &sgR)
+{
+    // byte `pass` of a magnitude: the lower / upper pair of a word's four rows
+    const uint32_t sel_lo = pass == 0 ? 0x0c0c0400u : 0x0c0c0501u, sel_hi = pass == 0 ? 0x04000c0cu : 0x05010c0cu;
+#pragma unroll
+    for (int hw = 0; hw < 2; hw++) {
+        uint32_t B0[8], B1[8], sa0[4] = { 0u, 0u, 0u, 0u }, sa1[4] = { 0u, 0u, 0u, 0u };
+        uint32_t roff = cbyte + (uint32_t)(32 * hw + 7) * rstride;
+        opaque32(roff);       // (the rows' addresses are not to be computed ahead of the passes' loop: 64 pointers spill)
+#pragma unroll
+        for (int j = 7; j >= 0; j--) {                       // (descending: a row's sign is pushed in below the later rows')
+            uint32_t m0[4], m1[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                int32_t v0, v1;
+                load_row_raw<FLOAT>(a, roff + (uint32_t)(8 * b) * rstride, v0, v1);
+                m0[b] = (uint32_t)(v0 < 0 ? -v0 : v0); m1[b] = (uint32_t)(v1 < 0 ? -v1 : v1);
+                if (pass == 0) {
+                    ormag |= m0[b] | m1[b];
+                    // acc = (acc << 1) | sign: one funnel shift; rows 8 b + 7 .. 8 b in turn leave row 8 b + j at bit j
+                    sa0[b] = __builtin_amdgcn_alignbit(sa0[b], (uint32_t)v0, 31u);
+                    sa1[b] = __builtin_amdgcn_alignbit(sa1[b], (uint32_t)v1, 31u);
+                }
+            }
+            roff -= rstride;
+            B0[j] = __builtin_amdgcn_perm(m0[1], m0[0], sel_lo) | __builtin_amdgcn_perm(m0[3], m0[2], sel_hi);
+            B1[j] = __builtin_amdgcn_perm(m1[1], m1[0], sel_lo) | __builtin_amdgcn_perm(m1[3], m1[2], sel_hi);
+            // eight rows (16 registers) in flight, not all 32: the loop is unrolled for its constant word indices,
+            // and the scheduler would otherwise hoist every load to the top and spill
+            if ((j & 1) == 0) sched_fence();
+        }
+        if (pass == 0) {
+            const uint32_t s0 = sa0[0] | (sa0[1] << 8) | (sa0[2] << 16) | (sa0[3] << 24);
+            const uint32_t s1 = sa1[0] | (sa1[1] << 8) | (sa1[2] << 16) | (sa1[3] << 24);
+            if (hw == 0) { sgL.lo = s0; sgR.lo = s1; } else { sgL.hi = s0; sgR.hi = s1; }
+        }
+        bit_transpose_8x8x4(B0);
+        bit_transpose_8x8x4(B1);
+        uint32_t *q = pscr + (size_t)(pass * kEncPassPlanes) * kEncPlaneDwords + hw * 64;
+#pragma unroll
+        for (int k = 0; k < kEncPassPlanes; k++) { q[k * kEncPlaneDwords] = B0[k]; q[k * kEncPlaneDwords + 128] = B1[k]; }
+    }
+}
+
 // BULK = the -k > 0 instantiation (bulk scan after the ordinary planes, table s of the bit-plane
 // LUT files, LDS copy of that table); the k = 0 instantiation compiles to the plain coder.
 template <bool BULK>
@@ -877,32 +977,16 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     bool coded = false;
 #pragma unroll 1
     for (int pass = 0; pass < kMaxPlanes / kEncPassPlanes; pass++) {
-        uint32_t T[kEncPassPlanes][4];
-#pragma unroll
-        for (int k = 0; k < kEncPassPlanes; k++) { T[k][0] = T[k][1] = T[k][2] = T[k][3] = 0u; }
+        // The transposition, per column and half (32 rows x the pass's 8 planes), as a bit-matrix transpose
+        // instead of a bit at a time (2 instructions per bit, 16 per coefficient and pass): the rows' plane bytes
+        // are packed four to a word, row 8 b + j into byte b of word j -- two byte permutes and an OR per word --
+        // and the eight words go through the three block-swap stages of an 8 x 8 bit transpose, all four byte
+        // lanes at once (two shifts and two bit-field inserts per pair of words); word k then holds bit k of row
+        // 8 b + j at bit 8 b + j: the plane's row mask.  2.3 instructions per coefficient and pass.
         if (valid) {
-            const uint32_t dn = (uint32_t)(pass * kEncPassPlanes);
-            uint32_t roff = cbyte;
-#pragma unroll
-            for (int hw = 0; hw < 2; hw++) {
-#pragma unroll 8
-                for (int ii = 0; ii < 32; ii++) {
-                    uint32_t m0, m1, n0, n1;
-                    load_row(a, roff, m0, m1, n0, n1);
-                    roff += rstride;
-                    if (pass == 0) {
-                        ormag |= m0 | m1;
-                        if (hw == 0) { sgL.lo |= n0 << ii; sgR.lo |= n1 << ii; }
-                        else         { sgL.hi |= n0 << ii; sgR.hi |= n1 << ii; }
-                    }
-                    m0 >>= dn; m1 >>= dn;
-#pragma unroll
-                    for (int k = 0; k < kEncPassPlanes; k++) {
-                        T[k][hw] |= ((m0 >> k) & 1u) << ii;
-                        T[k][2 + hw] |= ((m1 >> k) & 1u) << ii;
-                    }
-                }
-            }
+            // (the coefficient type is wave-uniform: one branch around the whole pass, not one per row)
+            if (a.is_float) enc_transpose_pass<true>(a, pass, cbyte, rstride, pscr, ormag, sgL, sgR);
+            else enc_transpose_pass<false>(a, pass, cbyte, rstride, pscr, ormag, sgL, sgR);
         }
         if (pass == 0) {
             ormag = half_or_dpp(ormag, upper_mask);
@@ -912,14 +996,6 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
             int mm = coded ? msb : -1;
             { int o = __shfl_xor(mm, 32); mm = mm > o ? mm : o; }
             msbmax = (int)__builtin_amdgcn_readfirstlane((uint32_t)mm);
-        }
-#pragma unroll
-        for (int k = 0; k < kEncPassPlanes; k++) {
-            const int pk = pass * kEncPassPlanes + k;
-            if (pk <= msbmax) {
-                pscr[(pk * 4 + 0) * 64] = T[k][0]; pscr[(pk * 4 + 1) * 64] = T[k][1];
-                pscr[(pk * 4 + 2) * 64] = T[k][2]; pscr[(pk * 4 + 3) * 64] = T[k][3];
-            }
         }
         if (msbmax < (pass + 1) * kEncPassPlanes) break;
     }
