@@ -1339,31 +1339,48 @@ __device__ __forceinline__ uint64_t dec_spp_coeff(Coder &c, bool idle, uint64_t 
 }
 
 // 32 rows of the decoder's output: bit ii of plane register k is bit k of row row0 + ii's magnitude
+// The decoded planes of one column half (row masks PL / PR, plane k in word k) back to coefficients: the same 8 x 8
+// bit-matrix transpose as the encoder's prologue (bit_transpose_8x8x4 is its own inverse) turns eight plane words into
+// eight words of row bytes -- the magnitude byte of row 8 b + j is byte b of word j -- instead of a bit at a time.
 template <int NP, int NA>
 __device__ __forceinline__ void write_rows(const uint32_t (&PL)[NA], const uint32_t (&PR)[NA],
                                            uint32_t sgL, uint32_t sgR, int row0, bool valid, int32_t sz,
                                            const int32_t *stage, uint32_t t, int32_t *out, int AW)
 {
     if (!valid) return;
+    if (sz == 4096) {                                       // raw codeblock (expansionFix): words, not planes
 #pragma unroll 1
-    for (int ii = 0; ii < 32; ii++) {
-        const int i = row0 + ii;
-        int32_t v0, v1;
-        if (sz == 4096) {
+        for (int ii = 0; ii < 32; ii++) {
+            const int i = row0 + ii;
             int2 w = *reinterpret_cast<const int2 *>(stage + t * 128u + 2u * (uint32_t)i);
-            v0 = (int32_t)(((uint32_t)w.x & 0xFFFFFFu) >> 1); if (w.x & 1) v0 = -v0;
-            v1 = (int32_t)(((uint32_t)w.y & 0xFFFFFFu) >> 1); if (w.y & 1) v1 = -v1;
-        } else {
-            uint32_t m0 = 0u, m1 = 0u;
-#pragma unroll
-            for (int k = 0; k < NP; k++) {
-                m0 |= ((PL[k] >> ii) & 1u) << k;
-                m1 |= ((PR[k] >> ii) & 1u) << k;
-            }
-            v0 = ((sgL >> ii) & 1u) ? -(int32_t)m0 : (int32_t)m0;
-            v1 = ((sgR >> ii) & 1u) ? -(int32_t)m1 : (int32_t)m1;
+            int32_t v0 = (int32_t)(((uint32_t)w.x & 0xFFFFFFu) >> 1); if (w.x & 1) v0 = -v0;
+            int32_t v1 = (int32_t)(((uint32_t)w.y & 0xFFFFFFu) >> 1); if (w.y & 1) v1 = -v1;
+            *reinterpret_cast<int2 *>(out + (size_t)i * (size_t)AW) = make_int2(v0, v1);
         }
-        *reinterpret_cast<int2 *>(out + (size_t)i * (size_t)AW) = make_int2(v0, v1);
+        return;
+    }
+    static_assert(NP == 8 || NP == 16, "planes in groups of eight");
+    uint32_t X0[8], X1[8], Y0[8], Y1[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        X0[k] = PL[k]; X1[k] = PR[k];
+        Y0[k] = NP > 8 ? PL[(NP > 8 ? 8 : 0) + k] : 0u; Y1[k] = NP > 8 ? PR[(NP > 8 ? 8 : 0) + k] : 0u;
+    }
+    bit_transpose_8x8x4(X0);
+    bit_transpose_8x8x4(X1);
+    if (NP > 8) { bit_transpose_8x8x4(Y0); bit_transpose_8x8x4(Y1); }
+    int32_t *o = out + (size_t)row0 * (size_t)AW;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int ii = 8 * b + j;
+            uint32_t m0 = (X0[j] >> (8 * b)) & 0xFFu, m1 = (X1[j] >> (8 * b)) & 0xFFu;
+            if (NP > 8) { m0 |= ((Y0[j] >> (8 * b)) & 0xFFu) << 8; m1 |= ((Y1[j] >> (8 * b)) & 0xFFu) << 8; }
+            const int32_t v0 = ((sgL >> ii) & 1u) ? -(int32_t)m0 : (int32_t)m0;
+            const int32_t v1 = ((sgR >> ii) & 1u) ? -(int32_t)m1 : (int32_t)m1;
+            *reinterpret_cast<int2 *>(o + (size_t)ii * (size_t)AW) = make_int2(v0, v1);
+        }
     }
 }
 
