@@ -370,11 +370,42 @@ __device__ __forceinline__ RawRow<U8IN> load_raw(const DwtFwdArgs &a, int y, int
     return r;
 }
 
+// a wave-uniform float held in a vector register the optimiser cannot turn back into its scalar source
+__device__ __forceinline__ float in_vgpr(float x)
+{
+#if defined(__AMDGCN__)
+    float v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
+    return v;
+#else
+    return x;
+#endif
+}
+// byte N of a dword as a float: one conversion (v_cvt_f32_ubyteN) and, for the level shift, one full-rate
+// v_add_f32 -- left to itself the compiler subtracts in the integer domain first (v_add_u32_sdwa +
+// v_cvt_f32_i32: two half-rate instructions per sample)
+template <int N>
+__device__ __forceinline__ float byte_to_float(uint32_t w)
+{
+#if defined(__AMDGCN__)
+    float f;
+    if constexpr (N == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(w));
+    else if constexpr (N == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(w));
+    else if constexpr (N == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(w));
+    else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(w));
+    return f;
+#else
+    return (float)(int)((w >> (8 * N)) & 0xFFu);
+#endif
+}
 template <typename T, bool U8IN>
 __device__ __forceinline__ void unpack_row(const RawRow<U8IN> &r, T v[4])
 {
-    if constexpr (U8IN) {
+    if constexpr (U8IN && std::is_same<T, float>::value) {
         // offsetImage Engines/CodingEngine.cu:581-588 fused: (T)u8 - 128
+        v[0] = byte_to_float<0>(r.w) - 128.0f; v[1] = byte_to_float<1>(r.w) - 128.0f;
+        v[2] = byte_to_float<2>(r.w) - 128.0f; v[3] = byte_to_float<3>(r.w) - 128.0f;
+    } else if constexpr (U8IN) {
         v[0] = (T)(int)(r.w & 0xFFu) - (T)128; v[1] = (T)(int)((r.w >> 8) & 0xFFu) - (T)128;
         v[2] = (T)(int)((r.w >> 16) & 0xFFu) - (T)128; v[3] = (T)(int)(r.w >> 24) - (T)128;
     } else {
@@ -785,6 +816,9 @@ __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdA
     const uint32_t aw4 = (uint32_t)a.AW * 4u, ll4 = (uint32_t)a1.ll_stride * 4u;
     // level-1 LL: quantised on the transform's last level only; x * 1.0f * 1.0f is x
     const float qll = LOSSY && a1.last ? a1.q[0] : 1.0f, qsll = LOSSY && a1.last ? a1.qs : 1.0f;
+    // level 0's steps and qs as vector registers: a multiply with a scalar-register operand issues at half rate
+    // (tools/valu_probe), and there are 24 of them per iteration
+    const float vq1 = in_vgpr(a.q[1]), vq2 = in_vgpr(a.q[2]), vq3 = in_vgpr(a.q[3]), vqs = in_vgpr(a.qs);
 
     T xe[4], st0[3][4], xe1[2], st1[3][2], hist[kHist][2];
 #pragma unroll
@@ -828,9 +862,9 @@ __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdA
                 hfwd(Hr, le, re);
                 T hl0 = Lr[1], hl1 = Lr[3], lh0 = Hr[0], lh1 = Hr[2], hh0 = Hr[1], hh1 = Hr[3];
                 if (LOSSY) {
-                    hl0 = (T)(((float)hl0 * a.q[1]) * a.qs); hl1 = (T)(((float)hl1 * a.q[1]) * a.qs);
-                    lh0 = (T)(((float)lh0 * a.q[2]) * a.qs); lh1 = (T)(((float)lh1 * a.q[2]) * a.qs);
-                    hh0 = (T)(((float)hh0 * a.q[3]) * a.qs); hh1 = (T)(((float)hh1 * a.q[3]) * a.qs);
+                    hl0 = (T)(((float)hl0 * vq1) * vqs); hl1 = (T)(((float)hl1 * vq1) * vqs);
+                    lh0 = (T)(((float)lh0 * vq2) * vqs); lh1 = (T)(((float)lh1 * vq2) * vqs);
+                    hh0 = (T)(((float)hh0 * vq3) * vqs); hh1 = (T)(((float)hh1 * vq3) * vqs);
                 }
                 const uint32_t row0 = (uint32_t)(2 * n0 + r) * aw4, row1 = (uint32_t)(2 * n0 + r + hH) * aw4;
                 rb_store64(mal, vhl, row0, as_u32(hl0), as_u32(hl1));
@@ -853,9 +887,9 @@ __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdA
             T ll = L1[0], hl = L1[1], lh = H1[0], hh = H1[1];
             if (LOSSY) {
                 ll = (T)(((float)ll * qll) * qsll);
-                hl = (T)(((float)hl * a1.q[1]) * a1.qs);
-                lh = (T)(((float)lh * a1.q[2]) * a1.qs);
-                hh = (T)(((float)hh * a1.q[3]) * a1.qs);
+                hl = (T)(((float)hl * a1.q[1]) * vqs);      // (a1.qs == a.qs: one transform, one qs)
+                lh = (T)(((float)lh * a1.q[2]) * vqs);
+                hh = (T)(((float)hh * a1.q[3]) * vqs);
             }
             const uint32_t n = (uint32_t)(n0 + i - kLag1);
             rb_store32(ll2, vlh1, n * ll4, as_u32(ll));

@@ -8,8 +8,8 @@ ARGS="--streams 2" run s2 A=1
 ARGS="--streams 3" run s3 A=1
 ARGS="--streams 4" run s4 A=1
 ARGS="--streams 6" run s6 A=1
-ARGS="--streams 3" run s3_fused PICSONG_DWT_FUSE01=1
-ARGS="--streams 4" run s4_fused PICSONG_DWT_FUSE01=1
+ARGS="--streams 3" run s3_twolaunch PICSONG_DWT_NOFUSE01=1
+ARGS="--streams 5" run s5 A=1
 ARGS="--streams 3 --batch 2" run s3_b2 A=1
 ARGS="--streams 2 --batch 2" run s2_b2 A=1
 ARGS="--streams 3 --workload 4k_lossless --batch 4" run 4k_s3_b4 A=1
