@@ -10,7 +10,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 python3 bench.py > $out/bench.json 2> $out/bench.err
 echo "bench done"
-S="--steps 2 --warmup 1 --frames-per-step 12 --no-cpu-baseline"
+S="--steps 2 --warmup 1 --frames-per-step 12 --no-cpu-baseline --no-b3"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_default -- python3 bench.py $S > $out/bench_prof_default.json 2> $out/prof_default.err
 echo "prof default done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_single -- python3 bench.py $S --streams 1 > $out/bench_prof_single.json 2> $out/prof_single.err
@@ -19,7 +19,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/p
 echo "prof lossy done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_4k -- python3 bench.py $S --workload 4k_lossless > $out/bench_prof_4k.json 2> $out/prof_4k.err
 echo "prof 4k done"
-P="--steps 1 --warmup 1 --frames-per-step 4 --pool 4 --streams 1 --batch 1 --no-cpu-baseline"
+P="--steps 1 --warmup 1 --frames-per-step 4 --pool 4 --streams 1 --batch 1 --no-cpu-baseline --no-b3"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py $P > $out/pmc_fetch.json 2> $out/pmc_fetch.err
 echo "pmc fetch done"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py $P > $out/pmc_write.json 2> $out/pmc_write.err
@@ -30,3 +30,13 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INST_CYC
 echo "pmc sq2 done"
 timeout -k 10 240 tools/valu_probe $out/valu_probe.json > $out/valu_probe.txt 2>&1 || echo "probe failed"
 echo "probe done"
+# the other workloads' bench lines, the three-frames-per-call shape, the decoder
+python3 bench.py --no-cpu-baseline --workload 4k_lossless > $out/bench_4k.json 2> $out/bench_4k.err
+python3 bench.py --no-cpu-baseline --workload 8k_lossy > $out/bench_8k_lossy.json 2> $out/bench_8k_lossy.err
+python3 bench.py --no-cpu-baseline --streams 1 --batch 3 --steps 20 > $out/bench_8k_b3.json 2> $out/bench_8k_b3.err
+python3 bench.py --no-cpu-baseline --streams 1 --batch 3 --steps 20 --workload 8k_lossy > $out/bench_8k_lossy_b3.json 2> $out/bench_8k_lossy_b3.err
+echo "other benches done"
+{ python3 tools/decode_bench.py --streams=3; python3 tools/decode_bench.py lossy --streams=3; } > $out/decode.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_decode -- python3 tools/decode_bench.py > $out/prof_decode.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_decode_lossy -- python3 tools/decode_bench.py lossy > $out/prof_decode_lossy.log 2>&1
+echo "decode done"

@@ -8,6 +8,8 @@ cp $(ks prof_default) $dst/${tag}_kernel_stats.csv
 cp $(ks prof_single) $dst/${tag}_kernel_stats_single_stream.csv
 cp $(ks prof_lossy) $dst/${tag}_kernel_stats_8k_lossy.csv
 cp $(ks prof_4k) $dst/${tag}_kernel_stats_4k.csv
+[ -d $src/prof_decode ] && cp $(ks prof_decode) $dst/${tag}_kernel_stats_decode.csv
+[ -d $src/prof_decode_lossy ] && cp $(ks prof_decode_lossy) $dst/${tag}_kernel_stats_decode_8k_lossy.csv
 python3 tools/summarize_pmc.py $src/pmc_fetch/*/*counter_collection.csv $src/pmc_write/*/*counter_collection.csv > $dst/${tag}_pmc_hbm.csv
 python3 tools/summarize_pmc.py $src/pmc_sq/*/*counter_collection.csv $src/pmc_sq2/*/*counter_collection.csv > $dst/${tag}_pmc_sq.csv
 # keep the library's own kernels only (the bench also runs torch fills and copies)
