@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
                 // the carries of the bit-reversed column masks -- 4 half-rate instructions a row where the
                 // row-bit tests take 4 ands, 4 compares and the row bit's move
                 uint32_t xml = bitrev32(ml), xbl = bitrev32(bl), xmr = bitrev32(mr), xbr = bitrev32(br);
-#pragma unroll 2
+#pragma unroll 1
                 for (int ii = 0; ii < last; ii++) {
                     const uint64_t mL = shl_carry(xml), oL = shl_carry(xbl);
                     if (mL != 0ull) enc_site2(c, mL, oL, pl.ref, prec, upper_mask);
@@ -1384,7 +1384,6 @@ __device__ __forceinline__ uint64_t dec_spp_coeff(Coder &c, bool idle, uint64_t 
     return onem;
 }
 
-// 32 rows of the decoder's output: bit ii of plane register k is bit k of row row0 + ii's magnitude
 // The decoded planes of one column half (row masks PL / PR, plane k in word k) back to coefficients: the same 8 x 8
 // bit-matrix transpose as the encoder's prologue (bit_transpose_8x8x4 is its own inverse) turns eight plane words into
 // eight words of row bytes -- the magnitude byte of row 8 b + j is byte b of word j -- instead of a bit at a time.

@@ -427,10 +427,10 @@ __device__ __forceinline__ void store2(T *p, T x, T y, bool two)
 
 // writeSubbands DWTGenerator.cu:403-433 + placement :719-723.  Lrow/Hrow: vertically low / high
 // rows after horizontal analysis (s0,d0,s1,d1): s -> LL / LH, d -> HL / HH.
-template <typename T, bool LOSSY, bool VEC, bool NOLL = false>
+template <typename T, bool LOSSY, bool VEC>
 __device__ __forceinline__ void emit_pair(const DwtFwdArgs &a, int m, int pc, bool wr, bool le, bool re,
                                           T Lr[4], T Hr[4])
-{   // NOLL: the LL samples (left in Lr[0], Lr[2]) stay in registers for the next level (dwt_fwd2_kernel)
+{
     hfwd(Lr, le, re);
     hfwd(Hr, le, re);
     if (!wr || m < 0 || m >= (a.H >> 1)) return;
@@ -450,7 +450,7 @@ __device__ __forceinline__ void emit_pair(const DwtFwdArgs &a, int m, int pc, bo
         const uint32_t vo = (uint32_t)pc;
         T *rl = (T *)a.ll + (size_t)m * (size_t)a.ll_stride;
         T *r0 = mal + (size_t)m * (size_t)a.AW, *r1 = mal + (size_t)(m + hH) * (size_t)a.AW;
-        if constexpr (!NOLL) store2<T, true>(rl + vo, ll0, ll1, true);
+        store2<T, true>(rl + vo, ll0, ll1, true);
         store2<T, true>(r0 + hW + vo, hl0, hl1, true);
         store2<T, true>(r1 + vo, lh0, lh1, true);
         store2<T, true>(r1 + hW + vo, hh0, hh1, true);
@@ -605,13 +605,6 @@ constexpr int kF2Useful = kStripCols - 8 * kF2Edge;          // 232 columns writ
 #ifndef PICSONG_DWT_F2_WAVES
 #define PICSONG_DWT_F2_WAVES 5      // 96 VGPRs: the 9/7 instantiation needs 98 without the cap (43.3 -> 41.3 us)
 #endif
-#ifndef PICSONG_DWT_F2_GROUP
-#define PICSONG_DWT_F2_GROUP 0
-#endif
-// unrolled iterations per trip of the counted loop = rows fetched ahead / 4; 0 = the whole band, all its
-// rows fetched before the first store like dwt_fwd_kernel (8K 5/3, 32-row bands: 31.5 us; 3 / 5 / 6
-// iterations ahead: 42.9 / 34.4 / 37.4; 64-row bands 34.3, 16-row bands 33.9)
-constexpr int kF2GroupSet = PICSONG_DWT_F2_GROUP;
 // level-1 row pairs per band (8 = 32 input rows), by transform: the 9/7 band's run-in is 21 input rows, the 5/3 band's 9
 #ifndef PICSONG_DWT_F2_PAIRS
 #define PICSONG_DWT_F2_PAIRS 8
@@ -684,101 +677,6 @@ __device__ __forceinline__ void ll_row_or_mirror(T (&row)[2], T (&hist)[NH][2], 
 #pragma unroll
     for (int k = NH - 1; k > 0; k--) { hist[k][0] = hist[k - 1][0]; hist[k][1] = hist[k - 1][1]; }
     hist[0][0] = row[0]; hist[0][1] = row[1];
-}
-
-// level-1 subband samples of one lane (one pair per row pair): 4-byte stores, a 256-byte row per wave
-template <typename T, bool LOSSY>
-__device__ __forceinline__ void emit_pair1(const DwtFwdArgs &a, int n, int pc, bool wr, bool le, bool re,
-                                           T (&Lr)[2], T (&Hr)[2])
-{
-    hfwd2(Lr, le, re);
-    hfwd2(Hr, le, re);
-    if (!wr || n < 0 || n >= (a.H >> 1)) return;
-    T ll = Lr[0], hl = Lr[1], lh = Hr[0], hh = Hr[1];
-    if (LOSSY) {
-        if (a.last) ll = (T)(((float)ll * a.q[0]) * a.qs);
-        hl = (T)(((float)hl * a.q[1]) * a.qs);
-        lh = (T)(((float)lh * a.q[2]) * a.qs);
-        hh = (T)(((float)hh * a.q[3]) * a.qs);
-    }
-    const int hW = a.W >> 1, hH = a.H >> 1;
-    T *mal = (T *)a.mallat;
-    const uint32_t vo = (uint32_t)pc;
-    ((T *)a.ll + (size_t)n * (size_t)a.ll_stride)[vo] = ll;
-    (mal + (size_t)n * (size_t)a.AW + hW)[vo] = hl;
-    (mal + (size_t)(n + hH) * (size_t)a.AW)[vo] = lh;
-    (mal + (size_t)(n + hH) * (size_t)a.AW + hW)[vo] = hh;
-}
-
-// One wave's band.  EDGE: some lane of the wave owns the first or the last columns of the image and
-// substitutes its own mirror sample for a neighbour's; the other waves (all but the outermost strips)
-// run the instantiation without those per-use selects (15 % of the 9/7 kernel's vector instructions).
-template <typename T, bool LOSSY, bool U8IN, int NB, bool EDGE>
-__device__ __forceinline__ void dwt_fwd2_band_v1(const DwtFwdArgs &a, const DwtFwdArgs &a1, int strip, int lane)
-{
-    constexpr int kIters0 = NB + (LOSSY ? 5 : 2);
-    constexpr int kF2Group = kF2GroupSet > 0 && kF2GroupSet < kIters0 ? kF2GroupSet : kIters0;
-    constexpr int kIters = (kIters0 + kF2Group - 1) / kF2Group * kF2Group;   // padded: the extra ones store nothing
-    const int c0 = strip * kF2Useful - 4 * kF2Edge + 4 * lane;
-    const int n0 = blockIdx.y * NB;
-    int n1 = n0 + NB;
-    if (n1 > (a1.H >> 1)) n1 = a1.H >> 1;
-    const bool wr = lane >= kF2Edge && lane <= 63 - kF2Edge && c0 >= 0 && c0 < a.W;
-    const bool le = EDGE && c0 == 0, re = EDGE && c0 + 4 == a.W;
-    const int cl = c0 < 0 ? 0 : (c0 > a.W - 4 ? a.W - 4 : c0);
-    const int pc = cl >> 1, pc1 = cl >> 2;
-    const int S0 = 2 * n0 - (LOSSY ? 6 : 3);                 // first level-0 step
-
-    constexpr int kHist = LOSSY ? 6 : 2;                     // LL rows kept for level 1's bottom mirror
-    T xe[4], st0[3][4], xe1[2], st1[3][2], hist[kHist][2];
-#pragma unroll
-    for (int k = 0; k < kHist; k++) { hist[k][0] = hist[k][1] = (T)0; }
-#pragma unroll
-    for (int k = 0; k < 4; k++) { st0[0][k] = st0[1][k] = st0[2][k] = (T)0; }
-#pragma unroll
-    for (int k = 0; k < 2; k++) { xe1[k] = st1[0][k] = st1[1][k] = st1[2][k] = (T)0; }
-    RawRow<U8IN> raw[kF2Group][4];
-    __builtin_amdgcn_s_setprio(3);
-    const RawRow<U8IN> r0 = load_raw<T, U8IN, true>(a, 2 * S0, cl);
-#pragma unroll
-    for (int p = 0; p < kF2Group; p++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) raw[p][q] = load_raw<T, U8IN, true>(a, 2 * S0 + 1 + 4 * p + q, cl);
-    __builtin_amdgcn_s_setprio(0);
-    unpack_row<T, U8IN>(r0, xe);
-
-#pragma unroll 1
-    for (int g = 0; g < kIters / kF2Group; g++) {
-#pragma unroll
-        for (int r = 0; r < kF2Group; r++) {
-            const int i = g * kF2Group + r;
-            T x[4][4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) unpack_row<T, U8IN>(raw[r][q], x[q]);
-            if (g + 1 < kIters / kF2Group) {
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    raw[r][q] = load_raw<T, U8IN, true>(a, 2 * S0 + 1 + 4 * (i + kF2Group) + q, cl);
-            }
-            const int mA = S0 + 2 * i - (LOSSY ? 1 : 0);     // the pair level-0 step sA delivers
-            T LA[4], HA[4], LB[4], HB[4];
-            vstep<T, LOSSY, 4>(xe, st0, x[0], x[1], LA, HA);
-            emit_pair<T, LOSSY, true, true>(a, mA, pc, wr && mA >= 2 * n0 && mA < 2 * n1, le, re, LA, HA);
-            vstep<T, LOSSY, 4>(xe, st0, x[2], x[3], LB, HB);
-            emit_pair<T, LOSSY, true, true>(a, mA + 1, pc, wr && mA + 1 >= 2 * n0 && mA + 1 < 2 * n1, le, re, LB, HB);
-            // level 1: LL rows mA (odd row of its pair) and mA + 1 (the even row after it).  Past the
-            // bottom of the image they are level 1's OWN mirror, LL[N + k] = LL[N - 2 - k]: mirrored input
-            // rows do not give that (the input's mirror centre H - 1 is an odd row, so the even-row
-            // subsequence comes out half-sample symmetric) -- taken from the rows kept in `hist`.
-            T la[2] = { LA[0], LA[2] }, lb[2] = { LB[0], LB[2] };
-            ll_row_or_mirror<T, kHist>(la, hist, mA - a1.H);
-            ll_row_or_mirror<T, kHist>(lb, hist, mA + 1 - a1.H);
-            T L1[2], H1[2];
-            vstep<T, LOSSY, 2>(xe1, st1, la, lb, L1, H1);
-            const int n = LOSSY ? n0 - 5 + i : n0 - 2 + i;   // the pair that level-1 step delivers
-            emit_pair1<T, LOSSY>(a1, n, pc1, wr && n >= n0 && n < n1, le, re, L1, H1);
-        }
-    }
 }
 
 template <bool LOSSY, int NB> constexpr int f2_iters() { return NB + (LOSSY ? 5 : 2); }
@@ -915,18 +813,11 @@ __global__ __launch_bounds__(256, (LOSSY ? PICSONG_DWT_F2_WAVES_LOSSY : PICSONG_
     // the wave's 256 columns start at strip * kF2Useful - 4 * kF2Edge: does it hold column 0 or W - 4?
     const int first = strip * kF2Useful - 4 * kF2Edge;
     // (only the 9/7 kernel, which is bound by vector instructions, gets the second instantiation)
-#ifdef PICSONG_DWT_F2_V1
-    if (strip * kF2Useful >= a2.l0.W) return;
-    if (!LOSSY || first <= 0 || first + kStripCols >= a2.l0.W)
-        dwt_fwd2_band_v1<T, LOSSY, U8IN, NB, true>(a2.l0, a2.l1, strip, lane);
-    else dwt_fwd2_band_v1<T, LOSSY, U8IN, NB, LOSSY ? false : true>(a2.l0, a2.l1, strip, lane);
-#else
     static_assert(U8IN, "the fused head ingests u8 frames");
     if (strip * kF2Useful >= a2.l0.W) return;               // whole wave idle (no cross-lane use)
     if (!LOSSY || first <= 0 || first + kStripCols >= a2.l0.W)
         dwt_fwd2_band<T, LOSSY, NB, true>(a2.l0, a2.l1, strip, lane);
     else dwt_fwd2_band<T, LOSSY, NB, LOSSY ? false : true>(a2.l0, a2.l1, strip, lane);
-#endif
 }
 
 // ---- the small levels of the forward transform ---------------------------------------------------------
