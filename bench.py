@@ -155,6 +155,8 @@ def main():
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams (each with its own context) consecutive calls alternate on (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the N > 1 exchange path (per-step bucketed gather) at N = 1 too: exercises the code on a one-GPU box")
     ap.add_argument("--no-b3", action="store_true",
                     help="skip the three-frames-per-call measurement of the transform (traced runs: keeps every kernel's "
                          "average a single-frame launch's)")
@@ -176,12 +178,28 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the picsong HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    exch = world > 1 or args.force_exchange          # codestreams gathered at rank 0 (the frame-sharded path's exchange)
+    if exch:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         # RCCL's send / receive kernels share the GPU with the coder, which keeps every SIMD's wave slots
         # full: put them on a high-priority stream so that they are dispatched as slots free up
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints its version banner on STDOUT when the communicator comes up: this program's stdout is ONE JSON
+        # line, so file descriptor 1 points at stderr until the first collective has run
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     import picsong_amd as pa
     import picsong_dist as pdist
@@ -211,14 +229,25 @@ def main():
     frame = pool[0]
     outs = [torch.empty((batch, codec.max_stream_shorts()), dtype=torch.int16, device="cuda") for _ in range(nstreams)]
     out = outs[0][0]
-    gather_bufs = None
-    if world > 1 and rank == 0:
-        gather_bufs = [torch.empty(batch * codec.max_stream_shorts(), dtype=torch.int16, device="cuda")
-                       for _ in range(world - 1)]
     dev = torch.device("cuda", local_rank)
-
-    dx = pdist.DeferredExchange() if world > 1 else None
     calls_per_step = fps // batch
+    # ---- N > 1: the only exchange of the frame-sharded path, bucketed per STEP (picsong_dist.gather_step, covered by
+    # the gloo tests): a step's codestreams land in per-step slots, their lengths stay on the device
+    # (picsong_copy_last_totals), and ONE all-gather of the lengths + ONE grouped batch of sends to rank 0 move
+    # the whole step over RCCL -- run one step late (DeferredExchange), on a stream of its own, while the next step
+    # is being coded.  (Per call -- three host waits and two collectives every 0.2 ms -- the exchange was bound by
+    # launch latency, not by xGMI.)  Every step's exchange is inside the timed region (flush).
+    dx = pdist.DeferredExchange() if exch else None
+    if exch:
+        mss = codec.max_stream_shorts()
+        slots = [torch.empty((fps, mss), dtype=torch.int16, device="cuda") for _ in range(2)]
+        totals_dev = [torch.zeros(fps, dtype=torch.int32, device="cuda") for _ in range(2)]
+        gather_bufs = [torch.empty(fps * mss, dtype=torch.int16, device="cuda") for _ in range(world - 1)] if rank == 0 else None
+        xstream = torch.cuda.Stream(device=local_rank)
+        step_done = [[torch.cuda.Event() for _ in range(nstreams)] for _ in range(2)]
+        slots_free = [None, None]                       # recorded on xstream when a parity's slots have been sent
+        nstep = [0]
+        last_lens = [None]
     ncall = [0]
     last_call = {}
 
@@ -226,36 +255,51 @@ def main():
         # consecutive calls alternate over the streams: call i's coder tail overlaps call i+1's DWT / coder
         # head (each stream has its own context = its own workspace); `first`: this step holds frame 0 of the
         # video (the populated header)
+        par = 0
+        if exch:
+            par = nstep[0] & 1
+            nstep[0] += 1
+            if slots_free[par] is not None:             # the step before last has left these slots
+                for st in streams:
+                    st.wait_event(slots_free[par])
         for j in range(calls_per_step):
             i = ncall[0]
             ncall[0] += 1
             k = i % nstreams
             f0 = (i * batch) % pool_n
+            dst = slots[par][j * batch:(j + 1) * batch] if exch else outs[k]
             with torch.cuda.stream(streams[k]):
                 if batch == 1:
-                    codecs[k].encode_frame_async(pool[f0], outs[k][0], 0 if (first and j == 0) else 1)
+                    codecs[k].encode_frame_async(pool[f0], dst[0], 0 if (first and j == 0) else 1)
                 else:
-                    codecs[k].encode_frames_async(pool[f0:f0 + batch], outs[k], 0 if (first and j == 0) else 1)
-            last_call[k] = f0
-            if world > 1:
-                # the only exchange of the frame-sharded path (picsong_dist.gather_round, covered by the gloo
-                # tests): lengths all-gathered, then payload gatherv to rank 0 over RCCL.  It needs the
-                # lengths on the host, so it runs one call late (DeferredExchange): the host waits for call i
-                # only after call i+1 is queued, and the payload crosses xGMI while call i+1 is being coded.
-                # Every call's exchange is inside the timed region (flush).
-                def exchange(k=k):
-                    with torch.cuda.stream(streams[k]):
-                        if batch == 1:
-                            totals = [codecs[k].last_total()]
-                        else:
-                            totals = codecs[k].last_totals(batch)
-                        payload = torch.cat([outs[k][b, :t] for b, t in enumerate(totals)]) if batch > 1 else outs[k][0, :totals[0]]
-                        return pdist.gather_round(payload, rank, world, dev, recv_bufs=gather_bufs)
-                dx.submit(exchange)
+                    codecs[k].encode_frames_async(pool[f0:f0 + batch], dst, 0 if (first and j == 0) else 1)
+                if exch:
+                    codecs[k].copy_last_totals(batch, totals_dev[par][j * batch:(j + 1) * batch])
+            last_call[k] = (f0, dst)
+        if exch:
+            for k in range(nstreams):
+                step_done[par][k].record(streams[k])
+
+            def exchange(par=par):
+                for e in step_done[par]:
+                    e.synchronize()                     # this step is done; the next one keeps the GPU busy
+                lens = totals_dev[par].tolist()
+                last_lens[0] = lens
+                with torch.cuda.stream(xstream):
+                    # every frame's stream goes out from its slot (no packing copy); the slots are free again
+                    # when the sends have been handed to RCCL's stream and completed (q.wait() orders xstream)
+                    res = pdist.gather_step([slots[par][f, :lens[f]] for f in range(fps)], rank, world, dev,
+                                            recv_bufs=gather_bufs)
+                    ev = torch.cuda.Event()
+                    ev.record(xstream)
+                    slots_free[par] = ev
+                    return res
+            dx.submit(exchange)
 
     def sync_all():
-        if world > 1:
+        if exch:
             dx.flush()
+            xstream.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -280,12 +324,14 @@ def main():
 
     # ---- the timed loop's own last outputs (every stream's last call) against a fresh single-frame encode
     loop_ok = True
-    for k, f0 in last_call.items():
+    for k, (f0, dst) in last_call.items():
         with torch.cuda.stream(streams[k]):
             totals = [codecs[k].last_total()] if batch == 1 else codecs[k].last_totals(batch)
             for b, tl in enumerate(totals):
                 ref1 = codec.encode_frame(pool[f0 + b], 1)
-                loop_ok = loop_ok and tl == ref1.numel() and bool(torch.equal(outs[k][b, :tl], ref1))
+                loop_ok = loop_ok and tl == ref1.numel() and bool(torch.equal(dst[b, :tl], ref1))
+    if exch and last_lens[0] is not None:               # the lengths the last exchange moved are the streams' own
+        loop_ok = loop_ok and all(9 + 2 * nCB + 1 < ln <= codec.max_stream_shorts() for ln in last_lens[0])
     torch.cuda.synchronize()
 
     total_shorts = codec.last_total()
@@ -361,7 +407,7 @@ def main():
         roundtrip_ok = bool(torch.equal(dec, frame.view(AH, AW)))
 
     if rank != 0:
-        if world > 1:
+        if exch:
             dist.destroy_process_group()
         return
 
@@ -498,7 +544,7 @@ def main():
     if psnr is not None:
         line["psnr_db"] = round(psnr, 3)
     print(json.dumps(line))
-    if world > 1:
+    if exch:
         dist.destroy_process_group()
 
 

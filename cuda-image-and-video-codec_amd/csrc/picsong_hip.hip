@@ -874,6 +874,7 @@ int picsong_encode_frame(picsong_ctx *c, const uint8_t *d_frame, int iter, uint1
     if (iter == 0) picsong_header_pack(&c->p, hdr);
     rc = picsong_bitstream_pack(c, c->d_staging, c->d_sizes, iter == 0 ? hdr : nullptr, d_stream, nullptr, stream);
     if (ev) HIP_TRY(hipEventRecord(ev[3], s));
+    c->last_batch = 0;                                      // the most recent call's total is d_total
     return rc;
 }
 
@@ -1041,6 +1042,17 @@ int picsong_last_totals(picsong_ctx *c, void *stream, int n, int *h_totals)
     HIP_TRY(hipMemcpyAsync(c->h_totals, c->b_total, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     for (int i = 0; i < n; i++) h_totals[i] = c->h_totals[i];
+    return PICSONG_OK;
+}
+
+int picsong_copy_last_totals(picsong_ctx *c, void *stream, int n, int32_t *d_totals)
+{
+    if (!c || !d_totals) return fail(PICSONG_ERR_ARG, "copy_last_totals: null argument");
+    const bool single = n == 1 && c->last_batch == 0;       // the most recent call was picsong_encode_frame
+    if (!single && (n < 1 || n > c->last_batch))
+        return fail(PICSONG_ERR_ARG, "copy_last_totals: %d frames, the last batch had %d", n, c->last_batch);
+    HIP_TRY(hipMemcpyAsync(d_totals, single ? c->d_total : c->b_total, (size_t)n * sizeof(int32_t),
+                           hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return PICSONG_OK;
 }
 

@@ -43,6 +43,7 @@ EXPORTS = [
     "picsong_ctx_set_lut_device", "picsong_bpc_encode_component", "picsong_bpc_decode_component",
     "picsong_encode_frames", "picsong_last_totals", "picsong_selftest_lds_order",
     "picsong_dwt_forward_band", "picsong_dwt_forward_tail", "picsong_encode_stripe_coded", "picsong_lut_load_cp",
+    "picsong_copy_last_totals",
 ]
 
 _lib = None
@@ -107,6 +108,8 @@ def load():
         L.picsong_ctx_set_lut_device.argtypes = [vp, i, C.POINTER(LutInfo), vp]
         L.picsong_bpc_encode_component.argtypes = [vp, i, vp, vp, vp, vp]
         L.picsong_bpc_decode_component.argtypes = [vp, i, vp, vp, vp, vp]
+    if hasattr(L, "picsong_copy_last_totals"):
+        L.picsong_copy_last_totals.argtypes = [vp, vp, i, vp]
     if hasattr(L, "picsong_lut_load_cp"):
         L.picsong_lut_load_cp.argtypes = [C.c_char_p, i, i, i, i, C.POINTER(LutInfo), vp, C.c_size_t]
     if hasattr(L, "picsong_dwt_forward_band"):
@@ -351,6 +354,12 @@ class Codec:
         t = (C.c_int * n)()
         _check(self.L.picsong_last_totals(self.h, self._stream(), n, t))
         return list(t)
+
+    def copy_last_totals(self, n, d_totals):
+        """The lengths of the most recent encode_frame (n = 1) / encode_frames call into an int32 device tensor, on
+        this context's stream, without a wait."""
+        assert d_totals.dtype == self.torch.int32 and d_totals.numel() >= n
+        _check(self.L.picsong_copy_last_totals(self.h, self._stream(), n, self._p(d_totals)))
 
     def encode_frames(self, frames_u8_padded, first_iter=0):
         n = frames_u8_padded.shape[0]

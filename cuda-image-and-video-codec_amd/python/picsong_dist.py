@@ -59,6 +59,44 @@ def gather_round(local_stream, rank, world, device, recv_bufs=None, group=None):
     return out
 
 
+def gather_step(streams, rank, world, device, recv_bufs=None, group=None):
+    """One exchange for a whole STEP of frames (a bucket of rounds): `streams` = this rank's codestreams of the step
+    (list of 1-D int16 tensors on `device`, frame order, every rank the same count; an empty tensor = no payload).
+    The lengths travel as ONE all-gather of a [world, n] tensor, the payloads as ONE grouped point-to-point batch:
+    every frame's stream goes out from where the encoder put it (no packing copy) and lands back to back in the
+    root's buffer for its rank, every peer on its own xGMI link at the same time.  Against gather_round per call
+    this is one host wait and two collectives per step instead of three waits and two collectives per frame -- at
+    5000 frames per second and GPU the per-call form is bound by launch latency, not by the links.  Returns on rank
+    0 a list of `world` lists of per-frame views, elsewhere None."""
+    n = len(streams)
+    mine = torch.tensor([int(t.numel()) for t in streams], dtype=torch.int32, device=device)
+    lens = torch.zeros(world * n, dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(lens, mine, group=group)
+    lens = lens.view(world, n).tolist()
+    ops, out = [], None
+    if rank == 0:
+        out = [list(streams)]
+        for r in range(1, world):
+            tot = sum(lens[r])
+            buf = recv_bufs[r - 1][:tot] if recv_bufs is not None else torch.empty(tot, dtype=torch.int16, device=device)
+            views, o = [], 0
+            for ln in lens[r]:
+                v = buf[o:o + ln]
+                o += ln
+                views.append(v)
+                if ln:
+                    ops.append(dist.P2POp(dist.irecv, v, r, group))
+            out.append(views)
+    else:
+        for t in streams:
+            if t.numel():
+                ops.append(dist.P2POp(dist.isend, t, 0, group))
+    if ops:
+        for q in dist.batch_isend_irecv(ops):
+            q.wait()
+    return out
+
+
 class DeferredExchange:
     """Software-pipelines the per-round exchange by one frame.
 

@@ -196,6 +196,11 @@ int picsong_decode_frame(picsong_ctx *ctx, const uint16_t *d_stream, uint8_t *d_
 int picsong_encode_frames(picsong_ctx *ctx, int n, const uint8_t *d_frames, size_t frame_stride, int first_iter,
                           uint16_t *d_streams, size_t stream_stride, void *stream);
 int picsong_last_totals(picsong_ctx *ctx, void *stream, int n, int *h_totals);
+/* The same lengths without a wait: copies the totals of the most recent picsong_encode_frame (n = 1) or
+ * picsong_encode_frames (n = its frame count) into d_totals (device, int32[n]) on `stream`.  A caller that keeps
+ * many calls in flight (the frame-sharded multi-GPU exchange, bench.py --gpus N) collects them per bucket of
+ * calls and reads them back once, instead of synchronising after every call. */
+int picsong_copy_last_totals(picsong_ctx *ctx, void *stream, int n, int32_t *d_totals);
 
 /* ---- RGB path: RGBTransformLossless / RGBTransformLossy with the level shift
  *      fused (Engines/CodingEngine.cu:357-403,408-449; Engines/DecodingEngine.cu:599-701), then each

@@ -90,6 +90,48 @@ def test_frame_sharding_gather_matches_single_process(oracle, tmp_path, world, p
         assert np.array_equal(oracle.decode_frame(ref[f], W, H, WL, False, 1.0, lut), oracle.gen_frame(W, H, f))
 
 
+def _step_worker(rank, world, port, outdir):
+    """One bucketed exchange (picsong_dist.gather_step): every rank's step of streams, ragged lengths and an empty one."""
+    sys.path.insert(0, os.path.join(ROOT, "cuda-image-and-video-codec_amd", "python"))
+    import picsong_dist as pd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    rng = np.random.default_rng(100 + rank)
+    lens = [int(x) for x in rng.integers(0, 4000, 6)]
+    lens[rank % 6] = 0                                       # a frame without payload
+    streams = [torch.from_numpy(rng.integers(-32768, 32767, n).astype(np.int16)) for n in lens]
+    payload = torch.cat(streams) if sum(lens) else torch.empty(0, dtype=torch.int16)
+    for use_bufs in (False, True):
+        bufs = [torch.empty(6 * 4000, dtype=torch.int16) for _ in range(world - 1)] if (use_bufs and rank == 0) else None
+        got = pd.gather_step(streams, rank, world, dev, recv_bufs=bufs)
+        if rank == 0:
+            assert len(got) == world and all(len(g) == 6 for g in got)
+            np.save(os.path.join(outdir, f"got_{int(use_bufs)}.npy"),
+                    np.concatenate([v.numpy() for g in got for v in g]), allow_pickle=False)
+            np.save(os.path.join(outdir, f"lens_{int(use_bufs)}.npy"), np.array([[v.numel() for v in g] for g in got]))
+        else:
+            assert got is None
+    np.save(os.path.join(outdir, f"sent_{rank}.npy"), payload.numpy())
+    np.save(os.path.join(outdir, f"sentlens_{rank}.npy"), np.array(lens))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_step_moves_a_whole_step_in_one_exchange(tmp_path, world):
+    """gather_step: one all-gather of [world, n] lengths + one grouped batch of per-frame messages; rank 0 gets every
+    rank's per-frame views in rank and frame order (with and without preallocated receive buffers)."""
+    port = _free_port()
+    mp.spawn(_step_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    sent = np.concatenate([np.load(tmp_path / f"sent_{r}.npy") for r in range(world)])
+    lens = np.stack([np.load(tmp_path / f"sentlens_{r}.npy") for r in range(world)])
+    for u in (0, 1):
+        assert np.array_equal(np.load(tmp_path / f"got_{u}.npy"), sent)
+        assert np.array_equal(np.load(tmp_path / f"lens_{u}.npy"), lens)
+
+
 def test_deferred_exchange_order():
     sys.path.insert(0, os.path.join(ROOT, "cuda-image-and-video-codec_amd", "python"))
     import picsong_dist as pd
