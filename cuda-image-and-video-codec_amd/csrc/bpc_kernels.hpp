@@ -652,6 +652,17 @@ __device__ __forceinline__ uint64_t shl_carry(uint32_t &x)
     return m;
 #endif
 }
+// x = (x << 1) | (the lane's bit of m): v_addc_co_u32 x, -, x, x, m -- the decoder's dense half-passes collect a
+// column's decoded bits this way (row 0 first, so the word comes out bit-reversed)
+__device__ __forceinline__ void shl_in(uint32_t &x, uint64_t m)
+{
+#if defined(__AMDGCN__)
+    uint64_t co;
+    asm volatile("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(x), "=s"(co) : "s"(m));
+#else
+    x = (x << 1) | (__builtin_amdgcn_inverse_ballot_w64(m) ? 1u : 0u);
+#endif
+}
 __device__ __forceinline__ uint32_t bitrev32(uint32_t x)
 {
 #if defined(__AMDGCN__)
@@ -1566,6 +1577,28 @@ void bpc_decode_kernel(BpcArgs a)
             uint32_t curL = hw ? PLhi[0] : PLlo[0], curR = hw ? PRhi[0] : PRlo[0];
             const uint32_t rL = act ? (hw ? refL.hi : refL.lo) : 0u, rR = act ? (hw ? refR.hi : refR.lo) : 0u;
             uint32_t rows = wave_or32(rL | rR);
+            const int last = rows ? 32 - __builtin_clz(rows) : 0;           // rows [0, last) hold every row with work
+            if (5 * __builtin_popcount(rows) >= 3 * last && last > 0) {
+                // dense half-pass (the lower planes): every row in order, the lanes that refine a row off the carry
+                // of the bit-reversed mask (shl_carry, as in the encoder), the decoded bits shifted into a word per
+                // column (shl_in) instead of a select and an OR each
+                uint32_t xL = bitrev32(rL), xR = bitrev32(rR), accL = 0u, accR = 0u;
+#pragma unroll 1
+                for (int ii = 0; ii < last; ii++) {
+                    bool one;
+                    const uint64_t mL = shl_carry(xL);
+                    uint64_t dL = 0ull, dR = 0ull;
+                    if (mL != 0ull) dL = dec_site_m(c, __builtin_amdgcn_inverse_ballot_w64(mL), mL, pl.ref, prec, upper_mask, cw, one);
+                    shl_in(accL, dL);
+                    const uint64_t mR = shl_carry(xR);
+                    if (mR != 0ull) dR = dec_site_m(c, __builtin_amdgcn_inverse_ballot_w64(mR), mR, pl.ref, prec, upper_mask, cw, one);
+                    shl_in(accR, dR);
+                }
+                // row 0 sits at bit last - 1 of the accumulators
+                curL |= bitrev32(accL << (32 - last));
+                curR |= bitrev32(accR << (32 - last));
+                rows = 0u;
+            }
             while (rows) {
                 const uint32_t ii = (uint32_t)__builtin_ctz(rows);
                 rows &= rows - 1u;
