@@ -1077,9 +1077,24 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     U64 BLn, BRn;
     load_plane(0, BLn, BRn);
 
+    bool live = coded;                                     // false once the codeblock is bound for the raw fallback
     for (int p = 0; p < np; p++) {
         const int bp = msb - p;
-        const bool act = coded && bp >= cbp;
+        if (!BULK && p > 0) {
+            // A codeblock that has used up its 4095 codeword slots ends as raw words whatever else is coded
+            // (size = 4096, expansionFix): its half sits the remaining planes out, and a wave with nothing left
+            // stops.  (The wl = 6 tables' zero-probability groups send the deepest level's blocks this way after a
+            // plane or two of a dozen; their waves were the tail of the whole launch.)
+#if PS_ENC_LDS
+            wave_lds_done();
+            const uint32_t used = *c.ldscnt;
+#else
+            const uint32_t used = half ? c.cnt_hi : c.cnt_lo;
+#endif
+            live = live && used < 4095u;
+            if (__builtin_amdgcn_ballot_w64(live) == 0ull) break;
+        }
+        const bool act = live && bp >= cbp;
 
         PlaneLut pl = { 0u, 0u, 0u, 0u, 0u, 0u };
         if (act) pl = plane_lut(lv, a.g, grp, bp);
