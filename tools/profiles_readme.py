@@ -72,7 +72,7 @@ rows = [
      % (ss[enc][1], ss[head_i][1], find(ss, "dwt_fwd_kernel<int")[1], find(ss, "pack_kernel")[1], find(ss, "scan_sizes")[1])),
     ("`%s_kernel_stats.csv`" % tag, "the default command shape (3 streams; kernels of three calls share the GPU: coder %.0f us, fused DWT head %.1f us while sharing)"
      % (sd[enc][1], sd[head_i][1])),
-    ("`%s_kernel_stats_8k_lossy.csv`" % tag, "`--workload 8k_lossy --streams 1`: coder %.0f us (the wl = 6 LUT holes send the level-5 blocks through the raw fallback: a few long waves), `dwt_fwd2_kernel<float>` **%.1f us** + 4 x %.1f us"
+    ("`%s_kernel_stats_8k_lossy.csv`" % tag, "`--workload 8k_lossy --streams 1`: coder %.0f us (the wl = 6 LUT holes send the level-5 blocks through the raw fallback; their halves stop once their 4095 slots are used), `dwt_fwd2_kernel<float>` **%.1f us** + 4 x %.1f us"
      % (sl[enc][1], sl[head_f][1], find(sl, "dwt_fwd_kernel<float")[1])),
     ("`%s_kernel_stats_4k.csv`" % tag, "`--workload 4k_lossless` (4 frames per launch): coder %.0f us per 4-frame launch, fused DWT head %.1f us per 4 frames"
      % (s4[enc][1], s4[head_i][1])),
