@@ -153,6 +153,13 @@ def test_invalid_parameters_are_rejected_without_exit():
     assert L.picsong_ctx_create(C.byref(p), 0, C.byref(h)) == -1        # too small for 6 levels (2x2 at the last)
 
 
+def test_copy_last_totals_rejects_null_arguments():
+    import ctypes as C
+    L = C.CDLL(os.path.join(ROOT, "cuda-image-and-video-codec_amd", "csrc", "libpicsong_hip.so"))
+    L.picsong_copy_last_totals.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    assert L.picsong_copy_last_totals(None, None, 1, None) != 0
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     import torch
     if torch.cuda.is_available():

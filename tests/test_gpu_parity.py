@@ -268,6 +268,28 @@ def test_lds_atomic_reservation_order(pa, torch):
     assert bad.value == 0
 
 
+def test_copy_last_totals_matches_the_waited_for_lengths(oracle, pa, torch):
+    """picsong_copy_last_totals: the lengths of the most recent single-frame / batched call, copied on the device
+    without a wait, are the ones picsong_last_total(s) returns after one; the count is checked against the call."""
+    W, H, wl = 640, 448, 3
+    c = pa.Codec(W, H, wl=wl, lut_folder=_lutdir(oracle, False))
+    frames = _dev(torch, np.stack([oracle.pad_frame(oracle.gen_frame(W, H, 30 + i)).reshape(-1) for i in range(3)]))
+    out = torch.empty((3, c.max_stream_shorts()), dtype=torch.int16, device="cuda")
+    d = torch.zeros(4, dtype=torch.int32, device="cuda")
+    c.encode_frame_async(frames[0], out[0], 0)
+    c.copy_last_totals(1, d[3:4])
+    assert c.last_total() == int(d[3].item())
+    c.encode_frames_async(frames, out, 1)
+    c.copy_last_totals(3, d)
+    assert c.last_totals(3) == d[:3].tolist() and int(d[3].item()) != 0
+    with pytest.raises(pa.PicsongError):
+        c.copy_last_totals(4, torch.zeros(4, dtype=torch.int32, device="cuda"))     # the batch had three
+    c.encode_frame_async(frames[1], out[1], 1)                                       # a single frame again
+    c.copy_last_totals(1, d[0:1])
+    assert c.last_total() == int(d[0].item())
+    c.close()
+
+
 def test_batched_frames_argument_checks(oracle, pa, torch):
     c = pa.Codec(256, 256, wl=2, lut_folder=_lutdir(oracle, False))
     frames = torch.zeros((2, c.P), dtype=torch.uint8, device="cuda")
