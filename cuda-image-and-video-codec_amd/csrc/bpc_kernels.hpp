@@ -27,6 +27,15 @@
 
 namespace picsong {
 
+// time-resolved trace of the encoder's waves (variant builds only: -DPICSONG_DWT_TRACE, tools/bpc_trace.py): start,
+// planes parked, plane loop done (s_memrealtime, 100 MHz) and the wave's plane count, into the buffer of
+// picsong_debug_set_bpc_trace
+#ifdef PICSONG_DWT_TRACE
+__device__ unsigned long long *g_bpc_trace = nullptr;
+#define PS_BPC_TRACE(slot, val) do { if (g_bpc_trace && (threadIdx.x & 63) == 0) g_bpc_trace[(size_t)gwave * 4 + (slot)] = (val); } while (0)
+#else
+#define PS_BPC_TRACE(slot, val) do { } while (0)
+#endif
 constexpr int kMaxPlanes = 16;     // bit-planes a codeblock may have: supports MSB <= 15
 // The encoder holds ONE bit-plane of its two columns in registers (4 VGPRs): the one being coded.  All
 // planes are built in a single pass over the coefficients (8 at a time, in registers that are free
@@ -1017,6 +1026,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     uint32_t ormag = 0u;
     int msb = 32, msbmax = -1;
     bool coded = false;
+    PS_BPC_TRACE(0, __builtin_amdgcn_s_memrealtime());
 #pragma unroll 1
     for (int pass = 0; pass < kMaxPlanes / kEncPassPlanes; pass++) {
         // The transposition, per column and half (32 rows x the pass's 8 planes), as a bit-matrix transpose
@@ -1078,6 +1088,8 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     load_plane(0, BLn, BRn);
 
     bool live = coded;                                     // false once the codeblock is bound for the raw fallback
+    PS_BPC_TRACE(1, __builtin_amdgcn_s_memrealtime());
+    PS_BPC_TRACE(3, (unsigned long long)np);
     for (int p = 0; p < np; p++) {
         const int bp = msb - p;
         if (!BULK && p > 0) {
@@ -1178,6 +1190,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
         AL = AL2; AR = AR2;
     }
 
+    PS_BPC_TRACE(2, __builtin_amdgcn_s_memrealtime());
     // ---- bulk scan of the planes below cbp (encodeBulkMode :1640-1648): the rows are read again
     // from the coefficient array (L2-resident), three at a time in flight
     if constexpr (BULK) {

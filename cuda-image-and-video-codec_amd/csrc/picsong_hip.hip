@@ -1136,4 +1136,9 @@ extern "C" int picsong_debug_set_trace(void *d_buf)
     unsigned long long *p = (unsigned long long *)d_buf;
     return hipMemcpyToSymbol(HIP_SYMBOL(picsong::g_dwt_trace), &p, sizeof p) == hipSuccess ? 0 : -1;
 }
+extern "C" int picsong_debug_set_bpc_trace(void *d_buf)
+{
+    unsigned long long *p = (unsigned long long *)d_buf;
+    return hipMemcpyToSymbol(HIP_SYMBOL(picsong::g_bpc_trace), &p, sizeof p) == hipSuccess ? 0 : -1;
+}
 #endif
