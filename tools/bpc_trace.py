@@ -25,14 +25,23 @@ c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=lut)
 frame = torch.from_numpy(orc.pad_frame(orc.gen_frame(W, H, 0))).cuda()
 for _ in range(3):
     c.encode_frame(frame)
-nw = (c.ncb + 1) // 2
+import time
+torch.cuda.synchronize()
+t_0 = time.perf_counter()
+for _ in range(50):
+    s_ = c.encode_frame(frame)
+torch.cuda.synchronize()
+print(f"lone-frame encode (incl. the host's wait for the length): {(time.perf_counter() - t_0) / 50 * 1e3:.3f} ms;  round trip {bool(torch.equal(c.decode_frame(s_), frame.view(c.ah, c.aw))) if not lossy else None}")
+nw = c.ncb                                      # (a variant with one codeblock per wave has that many)
 buf = torch.zeros(4 * (nw + 8), dtype=torch.int64, device="cuda")
 c.L.picsong_debug_set_bpc_trace.argtypes = [C.c_void_p]
 assert c.L.picsong_debug_set_bpc_trace(C.c_void_p(buf.data_ptr())) == 0
 c.encode_frame(frame)
 torch.cuda.synchronize()
 assert c.L.picsong_debug_set_bpc_trace(C.c_void_p(0)) == 0
-t = buf.cpu().numpy().reshape(-1, 4)[:nw].astype(np.float64)
+t = buf.cpu().numpy().reshape(-1, 4)[:nw]
+t = t[t[:, 0] != 0].astype(np.float64)
+nw = len(t)
 t0 = t[:, 0].min()
 start, parked, done, npl = (t[:, 0] - t0) / 100, (t[:, 1] - t0) / 100, (t[:, 2] - t0) / 100, t[:, 3]
 dur = done - start
