@@ -1493,7 +1493,18 @@ void bpc_decode_kernel(BpcArgs a)
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
     if (t == 0u) lds_cnt[(threadIdx.x >> 6) * 2u + half] = 0u;        // (barrier: below, with the table copy)
     sign_table_fill(sign_tab, lane);                        // (the LUT copy below ends with the barrier)
-    const int wave = BULK ? (int)blockIdx.x : (int)blockIdx.x * kBpcDecWgWaves + (int)(threadIdx.x >> 6);
+    const int gwave = BULK ? (int)blockIdx.x : (int)blockIdx.x * kBpcDecWgWaves + (int)(threadIdx.x >> 6);
+    int wave = gwave;                                       // wave within its frame
+    if (a.frames > 1) {                                     // batched launch (picsong_decode_frames), as in the encoder
+        const int f = gwave / a.waves_per_frame;            // wave-uniform
+        wave = gwave - f * a.waves_per_frame;
+        if (f >= a.frames) { wave = a.waves_per_frame; }    // padding wave of the last workgroup: decodes nothing
+        else {
+            a.coeffs_out = (int32_t *)((char *)a.coeffs_out + (unsigned long long)f * a.coef_z);
+            a.staging += (size_t)f * (size_t)a.AW * (size_t)a.AH;
+            a.sizes += (size_t)f * (size_t)(a.nCB - a.cb_base);
+        }
+    }
     const int cb = a.cb_base + 2 * wave + (int)half;
     const bool valid = cb < a.nCB;
     const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;

@@ -104,7 +104,20 @@ struct DwtInvArgs {
     float rqs, rq[4];       // correctly rounded reciprocals 1.0f / qs, 1.0f / q[k] (FAST kernels)
     uint8_t *dst_u8;        // U8OUT kernels (finest level of the frame path): pixels, row stride W
     int off;                // level shift to add back (128 for 8-bit)
+    // batched launches (grid.z = frames of one picsong_decode_frames call): frame z reads mallat + z * mallat_z and
+    // ll + z * ll_z, writes dst + z * dst_z and dst_u8 + z * u8_z (bytes); 0 for a single frame
+    unsigned long long mallat_z, ll_z, dst_z, u8_z;
 };
+
+// frame blockIdx.z of a batched launch
+__device__ __forceinline__ void dwt_inv_select_frame(DwtInvArgs &a)
+{
+    const unsigned long long z = blockIdx.z;
+    a.mallat = (const int32_t *)((const char *)a.mallat + z * a.mallat_z);
+    a.ll = (const char *)a.ll + z * a.ll_z;
+    a.dst = (char *)a.dst + z * a.dst_z;
+    if (a.dst_u8) a.dst_u8 += z * a.u8_z;
+}
 
 __device__ __forceinline__ int reflect(int i, int n)
 {
@@ -941,6 +954,7 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int strip = blockIdx.x * 4 + wave;
     if (strip * kStripUseful >= a.W) return;
+    dwt_inv_select_frame(a);
     const int c0 = strip * kStripUseful - 4 * kEdgeLanes + 4 * lane;
     const int pc = c0 >> 1;                                  // arithmetic shift: -4 -> -2
     const int hW = a.W >> 1, hH = a.H >> 1;

@@ -171,6 +171,7 @@ inline std::vector<InvLaunch> plan_dwt_inverse(const int32_t *d_in, void *d_out,
         a.W = W; a.H = H;
         a.dst = (char *)d_out + write_off * 4;
         a.dst_u8 = nullptr; a.off = 0;
+        a.mallat_z = a.ll_z = a.dst_z = a.u8_z = 0;
         a.qs = qs;
         a.rqs = 1.0f / qs;
         for (int k = 0; k < 4; k++) { a.q[k] = kQSteps[l][k]; a.rq[k] = 1.0f / a.q[k]; }

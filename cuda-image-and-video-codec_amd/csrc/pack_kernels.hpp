@@ -82,8 +82,11 @@ __global__ __launch_bounds__(256) void pack_kernel(const int32_t *staging, const
 // retrieveSizeArray BitStreamBuilder.cpp:119-129 on the device.  A length outside 1..4096 cannot
 // come from the encoder; it is clamped (and flagged) so that a damaged stream can neither write
 // outside a codeblock's staging nor read past 9 + 2n + 4095n + 1 shorts of the stream buffer.
-__global__ __launch_bounds__(256) void read_sizes_kernel(const uint16_t *stream, int n, int32_t *sizes, int *flag)
+// (blockIdx.y = frame of a batched launch: the stream advances by stream_stride shorts, sizes by n)
+__global__ __launch_bounds__(256) void read_sizes_kernel(const uint16_t *stream, int n, int32_t *sizes, int *flag,
+                                                         size_t stream_stride = 0)
 {
+    stream += (size_t)blockIdx.y * stream_stride; sizes += (size_t)blockIdx.y * (size_t)n;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         int v = stream[10 + 2 * i];
@@ -93,9 +96,15 @@ __global__ __launch_bounds__(256) void read_sizes_kernel(const uint16_t *stream,
 }
 
 // buildCodeStreamLUTBS BitStreamBuilder.cu:142-171 layout
+// (blockIdx.y = frame of a batched launch: stream += stream_stride shorts, sizes / offsets += n, staging += frame_words)
 __global__ __launch_bounds__(256) void unpack_kernel(const uint16_t *stream, const int32_t *sizes,
-                                                     const int32_t *offsets, int n, int32_t *staging)
+                                                     const int32_t *offsets, int n, int32_t *staging,
+                                                     size_t stream_stride = 0, size_t frame_words = 0)
 {
+    {
+        const size_t f = blockIdx.y;
+        stream += f * stream_stride; sizes += f * (size_t)n; offsets += f * (size_t)n; staging += f * frame_words;
+    }
     const int cb = blockIdx.x, tid = threadIdx.x;
     int32_t *st = staging + (size_t)cb * 4096u;
     const int len = sizes[cb];

@@ -70,6 +70,8 @@ struct picsong_ctx {
     // batched frame path (picsong_encode_frames): workspaces for batch_cap frames, laid frame after frame
     int batch_cap;
     void *b_coef; int32_t *b_staging, *b_sizes, *b_offsets, *b_total;
+    int32_t *b_coef_i;    // decoded coefficients of a batch (picsong_decode_frames; lazy)
+    int b_coef_i_cap;
     uint32_t *b_plane_scratch;
     int32_t *h_totals;    // pinned, batch_cap
     int last_batch;       // frames of the most recent picsong_encode_frames
@@ -79,9 +81,9 @@ struct picsong_ctx {
 };
 
 template <int BAND>
-static void launch_inv(const picsong_ctx *c, const InvLaunch &f, hipStream_t s)
+static void launch_inv(const picsong_ctx *c, const InvLaunch &f, hipStream_t s, unsigned frames = 1)
 {
-    dim3 grid(f.gx, f.gy);
+    dim3 grid(f.gx, f.gy, frames);
     // f.fast: the 9/7 divisions in their reciprocal form (verified for this context's qs at creation)
     if (f.vec && f.a.dst_u8) {          // finest level of the frame path: pixels out, clamp fused
         if (c->p.lossy && f.fast) dwt_inv_kernel<float, true, BAND, true, true, true><<<grid, 256, 0, s>>>(f.a);
@@ -409,6 +411,8 @@ void picsong_ctx_destroy(picsong_ctx *c)
     if (c->b_offsets) (void)hipFree(c->b_offsets);
     if (c->b_total) (void)hipFree(c->b_total);
     if (c->b_plane_scratch) (void)hipFree(c->b_plane_scratch);
+    if (c->b_coef_i) (void)hipFree(c->b_coef_i);
+    c->b_coef_i = nullptr; c->b_coef_i_cap = 0;
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     if (c->prof_ev) {
         for (hipEvent_t e : *c->prof_ev) (void)hipEventDestroy(e);
@@ -584,22 +588,33 @@ int picsong_dwt_forward_tail(picsong_ctx *c, void *d_out, void *stream)
 
 // d_pixels != nullptr: the finest level writes clamped u8 pixels there (level shift + clamp fused,
 // when its vector kernel applies) instead of T samples into d_out; returns 1 in *fused then.
+// frames > 1 (picsong_decode_frames): grid.z = frame; frame z's coded coefficients at d_in + z * P, its work buffer at
+// d_out + z * (P + extra) elements, its pixels at d_pixels + z * pix_stride bytes
 static int dwt_inverse_impl(picsong_ctx *c, const int32_t *d_in, void *d_out, uint8_t *d_pixels, bool *fused,
-                            hipStream_t s)
+                            hipStream_t s, unsigned frames = 1, size_t pix_stride = 0)
 {
     if (fused) *fused = false;
     std::vector<InvLaunch> plan = plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs, c->fast_div);
-    if (d_pixels && !plan.empty() && plan.back().vec && (((uintptr_t)d_pixels) & 3u) == 0) {
+    if (d_pixels && !plan.empty() && plan.back().vec && (((uintptr_t)d_pixels) & 3u) == 0 && (pix_stride & 3u) == 0) {
         plan.back().a.dst_u8 = d_pixels;
         plan.back().a.off = 1 << (c->p.bit_depth - 1);
         if (fused) *fused = true;
     }
+    if (frames > 1) {
+        const unsigned long long in_z = (unsigned long long)c->P * 4ull, wrk_z = (unsigned long long)(c->P + c->extra) * 4ull;
+        for (InvLaunch &f : plan) {
+            f.a.mallat_z = in_z;
+            f.a.ll_z = f.a.first ? in_z : wrk_z;            // the coarsest level's LL comes from the coded array
+            f.a.dst_z = wrk_z;
+            f.a.u8_z = (unsigned long long)pix_stride;
+        }
+    }
     for (const InvLaunch &f : plan) {
         switch (f.band) {
-        case 32: launch_inv<32>(c, f, s); break;
-        case 16: launch_inv<16>(c, f, s); break;
-        case 8: launch_inv<8>(c, f, s); break;
-        default: launch_inv<4>(c, f, s); break;
+        case 32: launch_inv<32>(c, f, s, frames); break;
+        case 16: launch_inv<16>(c, f, s, frames); break;
+        case 8: launch_inv<8>(c, f, s, frames); break;
+        default: launch_inv<4>(c, f, s, frames); break;
         }
         HIP_TRY(hipGetLastError());
     }
@@ -946,6 +961,8 @@ static void free_batch(picsong_ctx *c)
     if (c->b_offsets) (void)hipFree(c->b_offsets);
     if (c->b_total) (void)hipFree(c->b_total);
     if (c->b_plane_scratch) (void)hipFree(c->b_plane_scratch);
+    if (c->b_coef_i) (void)hipFree(c->b_coef_i);
+    c->b_coef_i = nullptr; c->b_coef_i_cap = 0;
     if (c->h_totals) (void)hipHostFree(c->h_totals);
     c->b_coef = nullptr; c->b_staging = c->b_sizes = c->b_offsets = c->b_total = nullptr;
     c->b_plane_scratch = nullptr; c->h_totals = nullptr; c->batch_cap = 0;
@@ -1042,6 +1059,64 @@ int picsong_last_totals(picsong_ctx *c, void *stream, int n, int *h_totals)
     HIP_TRY(hipMemcpyAsync(c->h_totals, c->b_total, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     for (int i = 0; i < n; i++) h_totals[i] = c->h_totals[i];
+    return PICSONG_OK;
+}
+
+// n frames decoded through ONE launch per stage: the mirror of picsong_encode_frames (unpack with blockIdx.y =
+// frame, one decoder grid over n x nCB codeblocks, grid.z = frame for the inverse transform's levels)
+int picsong_decode_frames(picsong_ctx *c, int n, const uint16_t *d_streams, size_t stream_stride, uint8_t *d_frames_out,
+                          size_t frame_stride, void *stream)
+{
+    if (!c || !d_streams || !d_frames_out) return fail(PICSONG_ERR_ARG, "decode_frames: null argument");
+    if (n < 1 || n > 64) return fail(PICSONG_ERR_ARG, "decode_frames: n = %d outside 1..64", n);
+    if (c->p.k > 0.0f || c->p.cp == 3 || c->p.is_rgb)
+        return fail(PICSONG_ERR_ARG, "decode_frames: grey -cp 2 contexts with k = 0 only (decode those frame by frame)");
+    if (n > 1 && (stream_stride < picsong_max_stream_shorts(c->aw, c->ah) || frame_stride < c->P))
+        return fail(PICSONG_ERR_ARG, "decode_frames: strides %zu shorts / %zu bytes too small", stream_stride, frame_stride);
+    if (n == 1) return picsong_decode_frame(c, d_streams, d_frames_out, stream);
+    int rc = ensure_batch(c, n);
+    if (rc) return rc;
+    if (c->b_coef_i_cap < n) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (c->b_coef_i) (void)hipFree(c->b_coef_i);
+        c->b_coef_i = nullptr; c->b_coef_i_cap = 0;
+        HIP_TRY(hipMalloc(&c->b_coef_i, (size_t)n * c->P * sizeof(int32_t)));
+        c->b_coef_i_cap = n;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    // ---- unpack: lengths, offsets, codewords of the n streams
+    read_sizes_kernel<<<dim3((unsigned)((c->ncb + 255) / 256), (unsigned)n), 256, 0, s>>>(d_streams, c->ncb, c->b_sizes, c->d_flag,
+                                                                                      stream_stride);
+    HIP_TRY(hipGetLastError());
+    scan_sizes_kernel<<<(unsigned)n, 1024, 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
+    HIP_TRY(hipGetLastError());
+    unpack_kernel<<<dim3((unsigned)c->ncb, (unsigned)n), 256, 0, s>>>(d_streams, c->b_sizes, c->b_offsets, c->ncb, c->b_staging,
+                                                                     stream_stride, c->P);
+    HIP_TRY(hipGetLastError());
+    // ---- decoder: one grid over the n frames' codeblock pairs, both plane-count classes
+    BpcArgs a;
+    if ((rc = bpc_args(c, a, 0))) return rc;
+    const int wpf = (c->ncb + 1) / 2;
+    a.cb_base = 0; a.nCB = c->ncb;
+    a.coeffs_out = c->b_coef_i; a.staging = c->b_staging; a.sizes = c->b_sizes;
+    a.frames = n; a.waves_per_frame = wpf; a.coef_z = (unsigned long long)c->P * 4ull;
+    const unsigned wgs = (unsigned)(((size_t)n * (size_t)wpf + kBpcDecWgWaves - 1) / kBpcDecWgWaves);
+    bpc_decode_kernel<false, kDecSmallPlanes><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
+    bpc_decode_kernel<false, kMaxPlanes><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
+    HIP_TRY(hipGetLastError());
+    // ---- inverse transform, pixels out of the finest level where its vector kernel applies
+    bool fused = false;
+    if ((rc = dwt_inverse_impl(c, c->b_coef_i, c->b_coef, d_frames_out, &fused, s, (unsigned)n, frame_stride))) return rc;
+    if (fused) return PICSONG_OK;
+    const size_t n4 = c->P / 4;
+    const int off = 1 << (c->p.bit_depth - 1);
+    const int grid = (int)((n4 + 255) / 256 > 8192 ? 8192 : (n4 + 255) / 256);
+    for (int f = 0; f < n; f++) {
+        const void *img = (const char *)c->b_coef + ((size_t)f * (c->P + c->extra) + c->extra) * 4;
+        if (c->p.lossy) clamp_to_u8_f32_kernel<<<grid, 256, 0, s>>>((const float *)img, d_frames_out + (size_t)f * frame_stride, n4, (float)off);
+        else clamp_to_u8_i32_kernel<<<grid, 256, 0, s>>>((const int32_t *)img, d_frames_out + (size_t)f * frame_stride, n4, off);
+    }
+    HIP_TRY(hipGetLastError());
     return PICSONG_OK;
 }
 

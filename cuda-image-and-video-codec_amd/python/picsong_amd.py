@@ -43,7 +43,7 @@ EXPORTS = [
     "picsong_ctx_set_lut_device", "picsong_bpc_encode_component", "picsong_bpc_decode_component",
     "picsong_encode_frames", "picsong_last_totals", "picsong_selftest_lds_order",
     "picsong_dwt_forward_band", "picsong_dwt_forward_tail", "picsong_encode_stripe_coded", "picsong_lut_load_cp",
-    "picsong_copy_last_totals",
+    "picsong_copy_last_totals", "picsong_decode_frames",
 ]
 
 _lib = None
@@ -110,6 +110,8 @@ def load():
         L.picsong_bpc_decode_component.argtypes = [vp, i, vp, vp, vp, vp]
     if hasattr(L, "picsong_copy_last_totals"):
         L.picsong_copy_last_totals.argtypes = [vp, vp, i, vp]
+    if hasattr(L, "picsong_decode_frames"):
+        L.picsong_decode_frames.argtypes = [vp, i, vp, C.c_size_t, vp, C.c_size_t, vp]
     if hasattr(L, "picsong_lut_load_cp"):
         L.picsong_lut_load_cp.argtypes = [C.c_char_p, i, i, i, i, C.POINTER(LutInfo), vp, C.c_size_t]
     if hasattr(L, "picsong_dwt_forward_band"):
@@ -354,6 +356,16 @@ class Codec:
         t = (C.c_int * n)()
         _check(self.L.picsong_last_totals(self.h, self._stream(), n, t))
         return list(t)
+
+    def decode_frames(self, streams, out=None):
+        """streams: int16 [n, >= max_stream_shorts()] (codestream f in row f); returns uint8 [n, AH, AW]."""
+        n = streams.shape[0]
+        assert streams.stride(-1) == 1
+        if out is None:
+            out = self.torch.empty((n, self.ah, self.aw), dtype=self.torch.uint8, device=self.dev)
+        _check(self.L.picsong_decode_frames(self.h, n, self._p(streams), streams.stride(0), self._p(out), out.stride(0),
+                                            self._stream()))
+        return out
 
     def copy_last_totals(self, n, d_totals):
         """The lengths of the most recent encode_frame (n = 1) / encode_frames call into an int32 device tensor, on

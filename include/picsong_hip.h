@@ -196,6 +196,12 @@ int picsong_decode_frame(picsong_ctx *ctx, const uint16_t *d_stream, uint8_t *d_
 int picsong_encode_frames(picsong_ctx *ctx, int n, const uint8_t *d_frames, size_t frame_stride, int first_iter,
                           uint16_t *d_streams, size_t stream_stride, void *stream);
 int picsong_last_totals(picsong_ctx *ctx, void *stream, int n, int *h_totals);
+/* The mirror for decoding: n codestreams (stream f at d_streams + f * stream_stride shorts) to n padded u8 frames (frame f
+ * at d_frames_out + f * frame_stride bytes, 4-byte aligned strides) through one launch per stage -- DecodingEngine's
+ * video loop (Engines/DecodingEngine.cu:734-1141) for n consecutive frames.  Byte-identical to n calls of
+ * picsong_decode_frame; grey -cp 2 contexts with k = 0. */
+int picsong_decode_frames(picsong_ctx *ctx, int n, const uint16_t *d_streams, size_t stream_stride, uint8_t *d_frames_out,
+                          size_t frame_stride, void *stream);
 /* The same lengths without a wait: copies the totals of the most recent picsong_encode_frame (n = 1) or
  * picsong_encode_frames (n = its frame count) into d_totals (device, int32[n]) on `stream`.  A caller that keeps
  * many calls in flight (the frame-sharded multi-GPU exchange, bench.py --gpus N) collects them per bucket of

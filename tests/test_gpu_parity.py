@@ -268,6 +268,45 @@ def test_lds_atomic_reservation_order(pa, torch):
     assert bad.value == 0
 
 
+@pytest.mark.parametrize("W,H,wl,lossy,qs,n", [
+    (640, 448, 3, False, 1.0, 5),
+    (576, 320, 3, False, 1.0, 4),        # 45 codeblocks: the last wave of a frame is half empty
+    (512, 512, 4, True, 0.5, 2),
+    (3840, 2160, 5, False, 1.0, 4),      # BASELINE configs[3]'s frames, four to a launch
+    (1000, 300, 4, True, 0.7, 3),        # padded width not a multiple of 4 levels' vector widths at every level
+])
+def test_batched_decode_equals_frame_by_frame_and_oracle(oracle, pa, torch, W, H, wl, lossy, qs, n):
+    """picsong_decode_frames: n codestreams through one launch per stage give the frames of n picsong_decode_frame
+    calls -- and, lossless, the original frames; 9/7: the oracle's decode of the same streams."""
+    oracle.set_threads(oracle.usable_threads())
+    try:
+        lut = oracle.lut_for(lossy, wl)
+        imgs = [oracle.gen_frame(W, H, 40 + i) for i in range(n)]
+        c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=_lutdir(oracle, lossy))
+        frames = _dev(torch, np.stack([oracle.pad_frame(im).reshape(-1) for im in imgs]))
+        streams = torch.full((n, c.max_stream_shorts()), -1, dtype=torch.int16, device="cuda")
+        c.encode_frames_async(frames, streams, 0)
+        totals = c.last_totals(n)
+        got = c.decode_frames(streams)
+        assert c.range_flag() == 0
+        for i in range(n):
+            one = c.decode_frame(streams[i, :totals[i]].clone())
+            assert torch.equal(got[i], one), f"frame {i}: batched decode differs from the single-frame decode"
+            if lossy:
+                ref = oracle.decode_frame(streams[i, :totals[i]].cpu().numpy().view(np.uint16), W, H, wl, lossy, qs, lut)
+                assert np.array_equal(got[i].cpu().numpy()[:H, :W], ref)
+            else:
+                assert np.array_equal(got[i].cpu().numpy()[:H, :W], imgs[i])
+        # a smaller batch on the same context afterwards
+        two = c.decode_frames(streams[:2])
+        assert torch.equal(two[1], got[1])
+        with pytest.raises(pa.PicsongError):
+            c.decode_frames(torch.zeros((2, 100), dtype=torch.int16, device="cuda"))     # too short a stride
+        c.close()
+    finally:
+        oracle.set_threads(1)
+
+
 def test_copy_last_totals_matches_the_waited_for_lengths(oracle, pa, torch):
     """picsong_copy_last_totals: the lengths of the most recent single-frame / batched call, copied on the device
     without a wait, are the ones picsong_last_total(s) returns after one; the count is checked against the call."""

@@ -19,6 +19,8 @@ for a in sys.argv[1:]:
     if a.startswith("--streams="):
         nstreams = int(a.split("=")[1])
 W, H, wl, qs = (7680, 4320, 6, 0.5) if lossy else (7680, 4320, 5, 1.0)
+if "4k" in sys.argv[1:]:
+    W, H = 3840, 2160
 lut = os.path.join(orc.LUT_DIR, "n1_lossy" if lossy else "n1_lossless")
 c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=lut)
 frame = torch.from_numpy(orc.pad_frame(orc.gen_frame(W, H, 0))).cuda()
@@ -51,3 +53,24 @@ if nstreams > 1:
         dt = (time.perf_counter() - t0) / n
     okp = all(bool(torch.equal(o, frame.view(c.ah, c.aw))) for o in outs) if not lossy else None
     print(f"decode pipelined over {nstreams} streams: {dt * 1e3:.3f} ms/frame = {W * H / dt / 1e6:.0f} Mpixel/s, roundtrip_ok={okp}")
+
+for a in sys.argv[1:]:
+    if a.startswith("--batch="):
+        # n frames per picsong_decode_frames call (one launch per stage), the calls alternating over the streams
+        nb = int(a.split("=")[1])
+        sb = torch.stack([torch.nn.functional.pad(s, (0, c.max_stream_shorts() - s.numel())) for _ in range(nb)])
+        cs = [pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=lut) for _ in range(max(nstreams, 1))]
+        sts = [torch.cuda.Stream() for _ in cs]
+        outs = [torch.empty((nb, c.ah, c.aw), dtype=torch.uint8, device="cuda") for _ in cs]
+        for rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ncalls = max(6, 60 // nb)
+            for i in range(ncalls):
+                k = i % len(cs)
+                with torch.cuda.stream(sts[k]):
+                    cs[k].decode_frames(sb, outs[k])
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / (ncalls * nb)
+        okb = all(bool(torch.equal(o[j], frame.view(c.ah, c.aw))) for o in outs for j in range(nb)) if not lossy else None
+        print(f"decode {nb} frames per call over {len(cs)} streams: {dt * 1e3:.3f} ms/frame = {W * H / dt / 1e6:.0f} Mpixel/s, roundtrip_ok={okb}")
