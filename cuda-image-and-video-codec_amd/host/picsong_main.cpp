@@ -97,7 +97,7 @@ void help()
         " -gpus N             video coding: groups of frames sharded round-robin over devices D .. D+N-1 of this node\n"
         "                     (--devices a,b,c names them explicitly); every device copies its codestreams to the\n"
         "                     writer's pinned ring over its own host link, the output file is the 1-GPU file\n"
-        " -framesPerLaunch B  frames coded per launch (default: 4 up to 4K frames, 1 above)\n"
+        " -framesPerLaunch B  frames coded / decoded per launch (default: 4 up to 4K frames, 1 above)\n"
         " --lut-fill V        value of LUT entries the loader never writes (default 0)\n";
 }
 
@@ -628,6 +628,13 @@ int run_decode_video(const Options &o, const picsong_params &p, const std::vecto
     const size_t P = (size_t)aw * ah, max_shorts = picsong_max_stream_shorts(aw, ah);
     const size_t frame_bytes = (size_t)p.width * p.height;
     const int nslots = (o.streams < 3 ? 3 : o.streams) + 3;
+    // groups of B consecutive frames per launch (picsong_decode_frames), as the encoder's video engine codes them:
+    // a 4K frame alone is one decoder wave per SIMD
+    int B = o.frames_per_launch > 0 ? o.frames_per_launch : (P <= (size_t)3840 * 2176 ? 4 : 1);
+    if (p.k > 0.0f || p.cp == 3) B = 1;
+    if (B > 16) B = 16;
+    if ((long)B > nframes) B = (int)nframes;
+    const long ngroups = (nframes + B - 1) / B;
     struct Slot {
         picsong_ctx *ctx = nullptr; hipStream_t stream = nullptr;
         uint16_t *h_in = nullptr, *d_in = nullptr; uint8_t *h_pix = nullptr, *d_pix = nullptr;
@@ -641,10 +648,10 @@ int run_decode_video(const Options &o, const picsong_params &p, const std::vecto
         CK(picsong_ctx_create(&p, o.device, &k.ctx));
         load_lut(k.ctx, o, p.wl, 1, p.k, p.cp);
         HIPCK(hipStreamCreate(&k.stream));
-        HIPCK(hipHostMalloc(&k.h_in, max_shorts * 2));
-        HIPCK(hipMalloc(&k.d_in, max_shorts * 2));
-        HIPCK(hipHostMalloc(&k.h_pix, P));
-        HIPCK(hipMalloc(&k.d_pix, P));
+        HIPCK(hipHostMalloc(&k.h_in, max_shorts * 2 * B));
+        HIPCK(hipMalloc(&k.d_in, max_shorts * 2 * B));
+        HIPCK(hipHostMalloc(&k.h_pix, P * B));
+        HIPCK(hipMalloc(&k.d_pix, P * B));
         if (aw != p.width) k.crop.resize(frame_bytes);
         k.expect = i;
     }
@@ -664,52 +671,59 @@ int run_decode_video(const Options &o, const picsong_params &p, const std::vecto
     auto t0 = std::chrono::steady_clock::now();
 
     auto reader = [&](int r, int nreaders) {
-        for (long f = r; f < nframes; f += nreaders) {
-            Slot &k = sl[(size_t)(f % nslots)];
+        for (long g = r; g < ngroups; g += nreaders) {
+            Slot &k = sl[(size_t)(g % nslots)];
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !failure.empty() || (k.state == FREE && k.expect == f); });
+                cv.wait(lk, [&] { return !failure.empty() || (k.state == FREE && k.expect == g); });
                 if (!failure.empty()) return;
             }
-            const size_t bytes = (size_t)frame_shorts[(size_t)f] * 2;
-            size_t got = 0;
-            while (got < bytes) {
-                ssize_t n = pread(ifd, reinterpret_cast<char *>(k.h_in) + got, bytes - got, (off_t)(in_off[(size_t)f] * 2 + got));
-                if (n <= 0) break;
-                got += (size_t)n;
+            bool short_file = false;
+            for (long f = g * B; f < nframes && f < (g + 1) * B; f++) {
+                const size_t bytes = (size_t)frame_shorts[(size_t)f] * 2;
+                char *dst = reinterpret_cast<char *>(k.h_in + (size_t)(f - g * B) * max_shorts);
+                size_t got = 0;
+                while (got < bytes) {
+                    ssize_t n = pread(ifd, dst + got, bytes - got, (off_t)(in_off[(size_t)f] * 2 + got));
+                    if (n <= 0) break;
+                    got += (size_t)n;
+                }
+                short_file = short_file || got != bytes;
             }
             std::lock_guard<std::mutex> lk(mu);
-            if (got != bytes && failure.empty()) failure = "Input file is shorter than its _SIZE sidecar says.";
+            if (short_file && failure.empty()) failure = "Input file is shorter than its _SIZE sidecar says.";
             k.state = FILLED;
             cv.notify_all();
         }
     };
     auto writer = [&](int r, int nwriters) {
         (void)hipSetDevice(o.device);
-        for (long f = r; f < nframes; f += nwriters) {
-            Slot &k = sl[(size_t)(f % nslots)];
+        for (long g = r; g < ngroups; g += nwriters) {
+            Slot &k = sl[(size_t)(g % nslots)];
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return !failure.empty() || (k.state == LAUNCHED && k.expect == f); });
+                cv.wait(lk, [&] { return !failure.empty() || (k.state == LAUNCHED && k.expect == g); });
                 if (!failure.empty()) return;
             }
             std::string err;
             if (hipStreamSynchronize(k.stream) != hipSuccess) err = "HIP error while decoding a frame";
-            const uint8_t *src = k.h_pix;
-            if (err.empty() && aw != p.width) {
-                for (int y = 0; y < p.height; y++) memcpy(&k.crop[(size_t)y * p.width], k.h_pix + (size_t)y * aw, (size_t)p.width);
-                src = k.crop.data();
-            }
-            size_t left = err.empty() ? frame_bytes : 0, done = 0;
-            while (left) {
-                ssize_t n = pwrite(ofd, src + done, left, out_base + (off_t)((size_t)f * frame_bytes + done));
-                if (n <= 0) { err = "Cannot write the output file " + o.output; break; }
-                done += (size_t)n; left -= (size_t)n;
+            for (long f = g * B; err.empty() && f < nframes && f < (g + 1) * B; f++) {
+                const uint8_t *pix = k.h_pix + (size_t)(f - g * B) * P, *src = pix;
+                if (aw != p.width) {
+                    for (int y = 0; y < p.height; y++) memcpy(&k.crop[(size_t)y * p.width], pix + (size_t)y * aw, (size_t)p.width);
+                    src = k.crop.data();
+                }
+                size_t left = frame_bytes, done = 0;
+                while (left) {
+                    ssize_t n = pwrite(ofd, src + done, left, out_base + (off_t)((size_t)f * frame_bytes + done));
+                    if (n <= 0) { err = "Cannot write the output file " + o.output; break; }
+                    done += (size_t)n; left -= (size_t)n;
+                }
             }
             std::lock_guard<std::mutex> lk(mu);
             if (!err.empty() && failure.empty()) failure = err;
             k.state = FREE;
-            k.expect = f + nslots;
+            k.expect = g + nslots;
             cv.notify_all();
         }
     };
@@ -717,18 +731,22 @@ int run_decode_video(const Options &o, const picsong_params &p, const std::vecto
     std::vector<std::thread> threads;
     for (int r = 0; r < nreaders; r++) threads.emplace_back(reader, r, nreaders);
     for (int r = 0; r < nwriters; r++) threads.emplace_back(writer, r, nwriters);
-    for (long f = 0; f < nframes; f++) {
-        Slot &k = sl[(size_t)(f % nslots)];
+    for (long g = 0; g < ngroups; g++) {
+        Slot &k = sl[(size_t)(g % nslots)];
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return !failure.empty() || (k.state == FILLED && k.expect == f); });
+            cv.wait(lk, [&] { return !failure.empty() || (k.state == FILLED && k.expect == g); });
             if (!failure.empty()) break;
         }
+        const int n = (int)std::min<long>(B, nframes - g * B);
         std::string err;
-        if (hipMemcpyAsync(k.d_in, k.h_in, (size_t)frame_shorts[(size_t)f] * 2, hipMemcpyHostToDevice, k.stream) != hipSuccess)
-            err = "HIP error in the codestream upload";
-        else if (picsong_decode_frame(k.ctx, k.d_in, k.d_pix, k.stream) != PICSONG_OK) err = picsong_last_error();
-        else if (hipMemcpyAsync(k.h_pix, k.d_pix, P, hipMemcpyDeviceToHost, k.stream) != hipSuccess)
+        for (int b = 0; err.empty() && b < n; b++)
+            if (hipMemcpyAsync(k.d_in + (size_t)b * max_shorts, k.h_in + (size_t)b * max_shorts,
+                               (size_t)frame_shorts[(size_t)(g * B + b)] * 2, hipMemcpyHostToDevice, k.stream) != hipSuccess)
+                err = "HIP error in the codestream upload";
+        if (!err.empty()) { }
+        else if (picsong_decode_frames(k.ctx, n, k.d_in, max_shorts, k.d_pix, P, k.stream) != PICSONG_OK) err = picsong_last_error();
+        else if (hipMemcpyAsync(k.h_pix, k.d_pix, P * (size_t)n, hipMemcpyDeviceToHost, k.stream) != hipSuccess)
             err = "HIP error in the frame download";
         std::lock_guard<std::mutex> lk(mu);
         if (!err.empty() && failure.empty()) failure = err;

@@ -111,6 +111,12 @@ def test_video_sharded_and_batched_equals_oracle(oracle, tmp_path, extra):
     r = _run("-cd", 1, "-i", enc, "-o", dec, "-video", 1, "-LUTFolder", lutdir)
     assert r.returncode == 0, r.stdout + r.stderr
     assert np.array_equal(np.fromfile(dec, np.uint8), np.fromfile(raw, np.uint8))
+    # the decoder's video engine takes groups of frames per launch too (default 4: 4 + 4 + 3 above)
+    for b in (1, 3):
+        d2 = tmp_path / f"v{b}.dec"
+        r = _run("-cd", 1, "-i", enc, "-o", d2, "-video", 1, "-LUTFolder", lutdir, "-framesPerLaunch", b)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert np.array_equal(np.fromfile(d2, np.uint8), np.fromfile(raw, np.uint8))
 
 
 @pytest.mark.gpu
