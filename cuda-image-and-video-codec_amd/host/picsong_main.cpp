@@ -727,7 +727,11 @@ int run_decode_video(const Options &o, const picsong_params &p, const std::vecto
             cv.notify_all();
         }
     };
-    const int nreaders = 2, nwriters = 2;
+    int nreaders = 2, nwriters = 2;
+    if (const char *e = getenv("PICSONG_READERS")) { int v = atoi(e); if (v >= 1 && v <= 16) nreaders = v; }
+    if (const char *e = getenv("PICSONG_WRITERS")) { int v = atoi(e); if (v >= 1 && v <= 16) nwriters = v; }
+    if (nreaders > nslots - 1) nreaders = nslots - 1;
+    if (nwriters > nslots - 1) nwriters = nslots - 1;
     std::vector<std::thread> threads;
     for (int r = 0; r < nreaders; r++) threads.emplace_back(reader, r, nreaders);
     for (int r = 0; r < nwriters; r++) threads.emplace_back(writer, r, nwriters);
