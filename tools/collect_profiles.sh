@@ -36,7 +36,7 @@ python3 bench.py --no-cpu-baseline --workload 8k_lossy > $out/bench_8k_lossy.jso
 python3 bench.py --no-cpu-baseline --streams 1 --batch 3 --steps 20 > $out/bench_8k_b3.json 2> $out/bench_8k_b3.err
 python3 bench.py --no-cpu-baseline --streams 1 --batch 3 --steps 20 --workload 8k_lossy > $out/bench_8k_lossy_b3.json 2> $out/bench_8k_lossy_b3.err
 echo "other benches done"
-{ python3 tools/decode_bench.py --streams=3; python3 tools/decode_bench.py lossy --streams=3; } > $out/decode.txt 2>&1
+{ python3 tools/decode_bench.py --streams=3; python3 tools/decode_bench.py lossy --streams=3; python3 tools/decode_bench.py 4k --streams=3 --batch=4; } > $out/decode.txt 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_decode -- python3 tools/decode_bench.py > $out/prof_decode.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_decode_lossy -- python3 tools/decode_bench.py lossy > $out/prof_decode_lossy.log 2>&1
 echo "decode done"

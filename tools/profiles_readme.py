@@ -91,8 +91,8 @@ rows = [
         sq[(head_i, "SQ_INSTS_VALU")] / 1e6, sq[(head_i, "SQ_INSTS_SALU")] / 1e6)),
     ("`%s_valu_probe.txt` / `.json`" % tag,
      "`tools/valu_probe`: issue rates per instruction class, 1..8 waves per SIMD (DESIGN.md 4.0): and/or/xor/add/sub/mov on VGPR or literal operands, `v_add/mul/fmac_f32` 0.38-0.43 per cycle per SIMD; shifts, min, compares, every VOP3 form (`v_fma_f32` too), packed fp32, 24-bit multiplies, DPP, SDWA, conversions, any SGPR operand 0.22-0.27; `v_cndmask_e32` on a scalar-written VCC 0.044; scalar ALU 0.23 per SIMD"),
-    ("`%s_decode.txt`" % tag, "`tools/decode_bench.py --streams=3` (lossless) and `lossy`: lone frame %.1f Gpixel/s, pipelined **%.1f Gpixel/s**; 9/7 wl 6: %.1f, pipelined **%.1f**; round trip checked"
-     % tuple(int(x) / 1e3 for x in decn[:4])),
+    ("`%s_decode.txt`" % tag, "`tools/decode_bench.py --streams=3` (lossless) and `lossy`: lone frame %.1f Gpixel/s, pipelined **%.1f Gpixel/s**; 9/7 wl 6: %.1f, pipelined **%.1f**; 4K frames: %.1f alone, %.1f over three streams, **%.1f** four to a `picsong_decode_frames` call; round trip checked"
+     % tuple(int(x) / 1e3 for x in (decn + ["0"] * 7)[:7])),
 ]
 insts = sq[(enc, "SQ_INSTS_VALU")] / 1e6
 table = "| file | what |\n|---|---|\n" + "\n".join("| %s | %s |" % r for r in rows) + "\n"
