@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cmath>
 #include <type_traits>
 
 namespace picsong {
@@ -53,6 +54,9 @@ constexpr int kStripUseful = kStripCols - 8 * kEdgeLanes;   // lanes kEdgeLanes 
 #define PICSONG_DWT_INV_GROUP 3       // 9/7 inverse kernels: unrolled iterations per trip of the counted loop (at most)
 #endif
 constexpr int inv_group(int iters, int most) { return iters % most == 0 ? most : inv_group(iters, most - 1); }
+#ifndef PICSONG_DWT_INV97_GROUP
+#define PICSONG_DWT_INV97_GROUP 3     // dwt_inv97_kernel: likewise
+#endif
 #ifndef PICSONG_DWT_INV_AHEAD
 #define PICSONG_DWT_INV_AHEAD 6       // inverse kernels: row pairs whose loads are in flight ahead of the math
 #endif
@@ -107,6 +111,10 @@ struct DwtInvArgs {
     // batched launches (grid.z = frames of one picsong_decode_frames call): frame z reads mallat + z * mallat_z and
     // ll + z * ll_z, writes dst + z * dst_z and dst_u8 + z * u8_z (bytes); 0 for a single frame
     unsigned long long mallat_z, ll_z, dst_z, u8_z;
+    // dwt_inv97_kernel: qs is a power of two (the two de-quantising divisions are one: x / (q * qs) is exact scaling);
+    // the coefficients come from this library's decoder (at most 16 bit-planes: inside the domain the reciprocal
+    // form was verified on, no range check)
+    int one_div, trusted;
 };
 
 // frame blockIdx.z of a batched launch
@@ -204,6 +212,30 @@ __device__ __forceinline__ uint4 rb_load128(const RowBuf &b, uint32_t lane_off, 
     uint4 r = { 0u, 0u, 0u, 0u };
     if (lane_off < kRbDrop) memcpy(&r, b.base + row_off + lane_off, 16);
     return r;
+#endif
+}
+__device__ __forceinline__ uint2 rb_load64(const RowBuf &b, uint32_t lane_off, uint32_t row_off)
+{
+#if defined(__AMDGCN__)
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(b.rs, lane_off, row_off, 0);
+    uint2 r; r.x = w.x; r.y = w.y;
+    return r;
+#else
+    uint2 r = { 0u, 0u };
+    if (lane_off < kRbDrop) memcpy(&r, b.base + row_off + lane_off, 8);
+    return r;
+#endif
+}
+__device__ __forceinline__ void rb_store128(const RowBuf &b, uint32_t lane_off, uint32_t row_off, uint32_t x, uint32_t y,
+                                            uint32_t z, uint32_t w)
+{
+#if defined(__AMDGCN__)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v; v.x = x; v.y = y; v.z = z; v.w = w;
+    __builtin_amdgcn_raw_buffer_store_b128(v, b.rs, lane_off, row_off, 0);
+#else
+    if (lane_off < kRbDrop) { const uint32_t v[4] = { x, y, z, w }; memcpy(b.base + row_off + lane_off, v, 16); }
 #endif
 }
 __device__ __forceinline__ void rb_store32(const RowBuf &b, uint32_t lane_off, uint32_t row_off, uint32_t x)
@@ -1072,6 +1104,230 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
         }
         }
     }
+}
+
+// ---- 9/7 synthesis of one level, lean (round 2) ---------------------------------------------------
+// The vector launches of a context whose reciprocal divisions verified (InvLaunch::fast).  Same strips, bands and
+// streamed vertical synthesis as dwt_inv_kernel, same arithmetic value for value; what is gone is everything that
+// is not arithmetic (the kernel is bound by vector-instruction issue: profiles/r02_kernel_stats_decode_8k_lossy.csv,
+// 54 us for level 0 of an 8K frame against 33 us for the 5/3 kernel over the same bytes):
+//  * de-quantisation without control flow.  (|v| + 0.5) * sgn(v) is (2 v + sgn v) / 2 exactly, sgn by v_med3_i32, and
+//    the halving folds into the divisor (2 q: the same quotient, scaled operands); 0 stays 0.  When qs is a power of
+//    two the second division is exact scaling and folds in too (one_div).  The per-value branches (zero test,
+//    domain test) of dequant() were two exec-mask regions per coefficient;
+//  * the range the reciprocal form was verified on (|v| < 65536) is not tested where the coefficients come from this
+//    library's decoder (trusted: 16 bit-planes at most); otherwise once per row for the wave, the row falling back;
+//  * the step constants live in vector registers (a VOP3 fma with a scalar operand issues at half rate), the lifting
+//    constants are literals of v_fmamk / v_mul;
+//  * the too-small-for-the-residual test of the lifting divisions is one v_frexp_exp per value and only where a value
+//    can be small: not for freshly de-quantised samples (0 or >= 0.75 / (q qs), qs <= 2^20);
+//  * rows addressed by scalar offsets into buffer resources, never-written lanes parked on the dropped offset,
+//    waves that hold no image-edge column without the mirror selects (EDGE).
+struct DivK { float rc, nc; };                  // a divisor's correctly rounded reciprocal and its negative, in VGPRs
+__device__ __forceinline__ float div_rcv(float x, const DivK &k)
+{   // div_rc(x, c, rc): fma(q, -c, x) is fma(-q, c, x)
+    const float q = x * k.rc;
+    const float r = fmaf(q, k.nc, x);
+    return fmaf(r, k.rc, q);
+}
+__device__ __forceinline__ float dequant2(uint32_t raw, const DivK &k2)
+{   // k2: the step doubled; |v| < 2^16
+    const int v = (int)raw;
+    const int t = v > 1 ? 1 : (v < -1 ? -1 : v);
+    return div_rcv((float)(2 * v + t), k2);
+}
+// binary exponent e of x = m 2^e, 0.5 <= |m| < 1; 0 for zero (and infinities / NaN)
+__device__ __forceinline__ int frexp_exp(float x)
+{
+#if defined(__AMDGCN__)
+    return __builtin_amdgcn_frexp_expf(x);
+#else
+    if (x == 0.0f || !std::isfinite(x)) return 0;
+    int e;
+    (void)std::frexp(x, &e);
+    return e;
+#endif
+}
+constexpr int kTinyExp = -96;                   // |x| < 2^-96 (tiny_key's bound): e <= -96
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+
+// hinv<true>(float) with the divisions' fallback decided by the caller's exponent
+template <bool EDGE>
+__device__ __forceinline__ void hinv97(float v[4], bool le, bool re, int tiny_e)
+{   // DWTGenerator.cu:326-339, lifting :110-122
+    if (__builtin_amdgcn_ballot_w64(tiny_e <= kTinyExp) == 0ull) {
+        v[1] = fmaf(fmaf(v[1] * PS_RN1, -PS_N1, v[1]), PS_RN1, v[1] * PS_RN1);
+        v[3] = fmaf(fmaf(v[3] * PS_RN1, -PS_N1, v[3]), PS_RN1, v[3] * PS_RN1);
+        v[0] = fmaf(fmaf(v[0] * PS_RN2, -PS_N2, v[0]), PS_RN2, v[0] * PS_RN2);
+        v[2] = fmaf(fmaf(v[2] * PS_RN2, -PS_N2, v[2]), PS_RN2, v[2] * PS_RN2);
+    } else {
+        keep_in_branch(v[0]); keep_in_branch(v[1]); keep_in_branch(v[2]); keep_in_branch(v[3]);
+        v[1] = v[1] / PS_N1; v[3] = v[3] / PS_N1;
+        v[0] = v[0] / PS_N2; v[2] = v[2] / PS_N2;
+    }
+    const bool l = EDGE && le, r = EDGE && re;
+    float dp = prv<float>(v[3], v[1], l);
+    v[0] = fmaf(-(v[1] + dp), PS_A4, v[0]);
+    v[2] = fmaf(-(v[3] + v[1]), PS_A4, v[2]);
+    float sn = nxt<float>(v[0], v[2], r);
+    v[1] = fmaf(-(v[0] + v[2]), PS_A3, v[1]);
+    v[3] = fmaf(-(v[2] + sn), PS_A3, v[3]);
+    dp = prv<float>(v[3], v[1], l);
+    v[0] = fmaf(-(v[1] + dp), PS_A2, v[0]);
+    v[2] = fmaf(-(v[3] + v[1]), PS_A2, v[2]);
+    sn = nxt<float>(v[0], v[2], r);
+    v[1] = fmaf(-(v[0] + v[2]), PS_A1, v[1]);
+    v[3] = fmaf(-(v[2] + sn), PS_A1, v[3]);
+}
+
+struct Inv97Steps { DivK ll, hl, lh, hh, qs; };
+
+// one subband row pair-segment to samples (s0, d0, s1, d1); `high`: LH / HH row, else LL / HL
+template <bool HIGH>
+__device__ __forceinline__ void convert97(const DwtInvArgs &a, const Inv97Steps &k, const SubRaw &r, float v[4])
+{
+    const bool deq_s = HIGH || a.first;
+    if (!a.trusted) {
+        // |v| < 65536, the domain dequant_fast_ok verified: once per row for the wave
+        uint32_t m = r.d0 + 65535u > r.d1 + 65535u ? r.d0 + 65535u : r.d1 + 65535u;
+        if (deq_s) {
+            const uint32_t n = r.s0 + 65535u > r.s1 + 65535u ? r.s0 + 65535u : r.s1 + 65535u;
+            m = m > n ? m : n;
+        }
+        if (__builtin_amdgcn_ballot_w64(m > 131070u) != 0ull) {
+            convert_sub<float, true, true>(a, r, HIGH, v);
+            keep_in_branch(v[0]);
+            return;
+        }
+    }
+    const DivK &kd = HIGH ? k.hh : k.hl, &ks = HIGH ? k.lh : k.ll;
+    v[1] = dequant2(r.d0, kd); v[3] = dequant2(r.d1, kd);
+    if (deq_s) { v[0] = dequant2(r.s0, ks); v[2] = dequant2(r.s1, ks); }
+    else { v[0] = __uint_as_float(r.s0); v[2] = __uint_as_float(r.s1); }
+    if (!a.one_div) {
+        keep_in_branch(v[1]);
+        v[1] = div_rcv(v[1], k.qs); v[3] = div_rcv(v[3], k.qs);
+        if (deq_s) { v[0] = div_rcv(v[0], k.qs); v[2] = div_rcv(v[2], k.qs); }
+    }
+}
+
+template <int BAND, bool U8OUT, bool EDGE>
+__device__ __forceinline__ void dwt_inv97_band(const DwtInvArgs &a, int strip, int lane)
+{
+    const int c0 = strip * kStripUseful - 4 * kEdgeLanes + 4 * lane;
+    const int pc = c0 >> 1;                                  // arithmetic shift: -4 -> -2
+    const int hW = a.W >> 1, hH = a.H >> 1;
+    const int m0 = blockIdx.y * (BAND / 2);
+    const int m1 = m0 + BAND / 2 > hH ? hH : m0 + BAND / 2;
+    const bool wr = lane >= kEdgeLanes && lane <= 63 - kEdgeLanes && c0 >= 0 && c0 < a.W;
+    const bool le = EDGE && c0 == 0, re = EDGE && c0 + 4 == a.W;
+    const int pl = pc < 0 ? 0 : (pc > hW - 2 ? hW - 2 : pc);
+
+    const RowBuf mal = rowbuf(a.mallat), lls = rowbuf(a.first ? (const void *)a.mallat : a.ll);
+    const RowBuf out = rowbuf(U8OUT ? (const void *)a.dst_u8 : (const void *)a.dst);
+    const uint32_t vd = (uint32_t)(hW + pl) * 4u, vs = (uint32_t)pl * 4u;
+    const uint32_t vo = wr ? (U8OUT ? (uint32_t)c0 : (uint32_t)c0 * 4u) : kRbDrop;
+    const uint32_t aw4 = (uint32_t)a.AW * 4u, ll4 = a.first ? aw4 : (uint32_t)a.ll_stride * 4u;
+    const uint32_t ow = U8OUT ? (uint32_t)a.W : (uint32_t)a.W * 4u;
+
+    // the doubled steps (times qs when that is exact scaling) as reciprocal / negative pairs in vector registers
+    Inv97Steps k;
+    {
+        const float sc = a.one_div ? a.qs : 1.0f, rsc = a.one_div ? a.rqs : 1.0f;
+        const float vsc = in_vgpr(2.0f * sc), vrsc = in_vgpr(0.5f * rsc);
+        k.ll.rc = in_vgpr(a.rq[0]) * vrsc; k.ll.nc = -(in_vgpr(a.q[0]) * vsc);
+        k.hl.rc = in_vgpr(a.rq[1]) * vrsc; k.hl.nc = -(in_vgpr(a.q[1]) * vsc);
+        k.lh.rc = in_vgpr(a.rq[2]) * vrsc; k.lh.nc = -(in_vgpr(a.q[2]) * vsc);
+        k.hh.rc = in_vgpr(a.rq[3]) * vrsc; k.hh.nc = -(in_vgpr(a.q[3]) * vsc);
+        k.qs.rc = in_vgpr(a.rqs); k.qs.nc = in_vgpr(-a.qs);
+    }
+
+    constexpr int kIters = BAND / 2 + 4;                     // two pairs of run-in either side
+    constexpr int kGroup = inv_group(kIters, PICSONG_DWT_INV97_GROUP);
+    const int j0 = m0 - 2;
+    SubRaw rawL[kGroup], rawH[kGroup];
+    auto load_pair = [&](int j, SubRaw &L, SubRaw &H) {
+        const uint32_t rl = (uint32_t)reflect_s(j, hH), rh = (uint32_t)(reflect_d(j, hH) + hH);
+        const uint2 ld = rb_load64(mal, vd, rl * aw4), ls = rb_load64(lls, vs, rl * ll4);
+        const uint2 hd = rb_load64(mal, vd, rh * aw4), hs = rb_load64(mal, vs, rh * aw4);
+        L.d0 = ld.x; L.d1 = ld.y; L.s0 = ls.x; L.s1 = ls.y;
+        H.d0 = hd.x; H.d1 = hd.y; H.s0 = hs.x; H.s1 = hs.y;
+    };
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int p = 0; p < kGroup; p++) load_pair(j0 + p, rawL[p], rawH[p]);
+    __builtin_amdgcn_s_setprio(0);
+
+    // vertical 9/7 synthesis, DWTGenerator.cu:230-272, streamed: at step j pair j-2 completes
+    float ddp[4], s1p[4], d1p[4], s0p[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { ddp[i] = s1p[i] = d1p[i] = s0p[i] = 0.0f; }
+#pragma unroll 1
+    for (int g = 0; g < kIters / kGroup; g++) {
+#pragma unroll
+        for (int r = 0; r < kGroup; r++) {
+            const int it = g * kGroup + r;
+            const int j = j0 + it;
+            float ln[4], hn[4];
+            convert97<false>(a, k, rawL[r], ln);
+            convert97<true>(a, k, rawH[r], hn);
+            if (g + 1 < kIters / kGroup) load_pair(j + kGroup, rawL[r], rawH[r]);
+            // the previous level's LL samples are the only ones that can be tiny at this point
+            hinv97<EDGE>(ln, le, re, a.first ? 0 : imin(frexp_exp(ln[0]), frexp_exp(ln[2])));
+            hinv97<EDGE>(hn, le, re, 0);
+            int te = imin(imin(frexp_exp(hn[0]), frexp_exp(hn[1])), imin(frexp_exp(hn[2]), frexp_exp(hn[3])));
+            te = imin(te, imin(imin(frexp_exp(ln[0]), frexp_exp(ln[1])), imin(frexp_exp(ln[2]), frexp_exp(ln[3]))));
+            if (__builtin_amdgcn_ballot_w64(te <= kTinyExp) == 0ull) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    hn[i] = fmaf(fmaf(hn[i] * PS_RN1, -PS_N1, hn[i]), PS_RN1, hn[i] * PS_RN1);
+                    ln[i] = fmaf(fmaf(ln[i] * PS_RN2, -PS_N2, ln[i]), PS_RN2, ln[i] * PS_RN2);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    keep_in_branch(hn[i]); keep_in_branch(ln[i]);
+                    hn[i] = hn[i] / PS_N1; ln[i] = ln[i] / PS_N2;
+                }
+            }
+            float ev[4], od[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float dd = hn[i];
+                const float s1 = fmaf(-(ddp[i] + dd), PS_A4, ln[i]);
+                const float d1 = fmaf(-(s1p[i] + s1), PS_A3, ddp[i]);       // d1[j-1]
+                const float s0 = fmaf(-(d1p[i] + d1), PS_A2, s1p[i]);       // s0[j-1]
+                const float xo = fmaf(-(s0p[i] + s0), PS_A1, d1p[i]);       // x[2(j-2)+1]
+                ev[i] = s0p[i];
+                od[i] = xo;
+                ddp[i] = dd; s1p[i] = s1; d1p[i] = d1; s0p[i] = s0;
+            }
+            if (it >= 4 && j - 2 < m1) {
+                const uint32_t y = (uint32_t)(2 * (j - 2));
+                if constexpr (U8OUT) {
+                    rb_store32(out, vo, y * ow, to_pixel(ev[0], a.off) | (to_pixel(ev[1], a.off) << 8) |
+                                                   (to_pixel(ev[2], a.off) << 16) | (to_pixel(ev[3], a.off) << 24));
+                    rb_store32(out, vo, (y + 1u) * ow, to_pixel(od[0], a.off) | (to_pixel(od[1], a.off) << 8) |
+                                                         (to_pixel(od[2], a.off) << 16) | (to_pixel(od[3], a.off) << 24));
+                } else {
+                    rb_store128(out, vo, y * ow, as_u32(ev[0]), as_u32(ev[1]), as_u32(ev[2]), as_u32(ev[3]));
+                    rb_store128(out, vo, (y + 1u) * ow, as_u32(od[0]), as_u32(od[1]), as_u32(od[2]), as_u32(od[3]));
+                }
+            }
+        }
+    }
+}
+
+template <int BAND, bool U8OUT>
+__global__ __launch_bounds__(256) void dwt_inv97_kernel(DwtInvArgs a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int strip = blockIdx.x * 4 + wave;
+    if (strip * kStripUseful >= a.W) return;                 // whole wave idle (no cross-lane use)
+    dwt_inv_select_frame(a);
+    const int first = strip * kStripUseful - 4 * kEdgeLanes;
+    if (first <= 0 || first + kStripCols >= a.W) dwt_inv97_band<BAND, U8OUT, true>(a, strip, lane);
+    else dwt_inv97_band<BAND, U8OUT, false>(a, strip, lane);
 }
 
 // ---- level shift kernels (used when the stages are called one by one) -------------------------

@@ -6,6 +6,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <cmath>
 #include <vector>
 
 #include "dwt_kernels.hpp"
@@ -172,6 +173,11 @@ inline std::vector<InvLaunch> plan_dwt_inverse(const int32_t *d_in, void *d_out,
         a.dst = (char *)d_out + write_off * 4;
         a.dst_u8 = nullptr; a.off = 0;
         a.mallat_z = a.ll_z = a.dst_z = a.u8_z = 0;
+        {   // qs = 2^k: dividing by it is exact scaling, dwt_inv97_kernel folds it into the step
+            int e = 0;
+            a.one_div = std::frexp(qs, &e) == 0.5f ? 1 : 0;
+            a.trusted = 0;
+        }
         a.qs = qs;
         a.rqs = 1.0f / qs;
         for (int k = 0; k < 4; k++) { a.q[k] = kQSteps[l][k]; a.rq[k] = 1.0f / a.q[k]; }

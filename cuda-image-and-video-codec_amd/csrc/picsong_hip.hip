@@ -84,13 +84,17 @@ template <int BAND>
 static void launch_inv(const picsong_ctx *c, const InvLaunch &f, hipStream_t s, unsigned frames = 1)
 {
     dim3 grid(f.gx, f.gy, frames);
-    // f.fast: the 9/7 divisions in their reciprocal form (verified for this context's qs at creation)
+    // f.fast: the 9/7 divisions in their reciprocal form (verified for this context's qs at creation); the vector
+    // launches of such a context are the lean kernel's (PICSONG_DWT_INV97=0: dwt_inv_kernel's FAST instantiations)
+    static const bool lean97 = !(getenv("PICSONG_DWT_INV97") && atoi(getenv("PICSONG_DWT_INV97")) == 0);
     if (f.vec && f.a.dst_u8) {          // finest level of the frame path: pixels out, clamp fused
-        if (c->p.lossy && f.fast) dwt_inv_kernel<float, true, BAND, true, true, true><<<grid, 256, 0, s>>>(f.a);
+        if (c->p.lossy && f.fast && lean97) dwt_inv97_kernel<BAND, true><<<grid, 256, 0, s>>>(f.a);
+        else if (c->p.lossy && f.fast) dwt_inv_kernel<float, true, BAND, true, true, true><<<grid, 256, 0, s>>>(f.a);
         else if (c->p.lossy) dwt_inv_kernel<float, true, BAND, true, true><<<grid, 256, 0, s>>>(f.a);
         else dwt_inv_kernel<int, false, BAND, true, true><<<grid, 256, 0, s>>>(f.a);
     } else if (f.vec) {
-        if (c->p.lossy && f.fast) dwt_inv_kernel<float, true, BAND, true, false, true><<<grid, 256, 0, s>>>(f.a);
+        if (c->p.lossy && f.fast && lean97) dwt_inv97_kernel<BAND, false><<<grid, 256, 0, s>>>(f.a);
+        else if (c->p.lossy && f.fast) dwt_inv_kernel<float, true, BAND, true, false, true><<<grid, 256, 0, s>>>(f.a);
         else if (c->p.lossy) dwt_inv_kernel<float, true, BAND, true><<<grid, 256, 0, s>>>(f.a);
         else dwt_inv_kernel<int, false, BAND, true><<<grid, 256, 0, s>>>(f.a);
     } else {
@@ -600,6 +604,7 @@ static int dwt_inverse_impl(picsong_ctx *c, const int32_t *d_in, void *d_out, ui
         plan.back().a.off = 1 << (c->p.bit_depth - 1);
         if (fused) *fused = true;
     }
+    for (InvLaunch &f : plan) f.a.trusted = 1;               // the coefficients are bpc_decode_kernel's: 16 bit-planes at most
     if (frames > 1) {
         const unsigned long long in_z = (unsigned long long)c->P * 4ull, wrk_z = (unsigned long long)(c->P + c->extra) * 4ull;
         for (InvLaunch &f : plan) {

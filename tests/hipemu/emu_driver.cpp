@@ -43,10 +43,15 @@ template <int BAND, bool VEC> static void emu_inv_v(const InvLaunch &f, int loss
     else if (lossy) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<float, true, BAND, VEC>(a); });
     else emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<int, false, BAND, VEC>(a); });
 }
+// mirrors launch_inv (picsong_hip.hip): the lean 9/7 kernel for the vector launches of a verified context
+static bool emu_lean97() { const char *e = getenv("PICSONG_DWT_INV97"); return !(e && atoi(e) == 0); }
 template <int BAND> static void emu_inv(const InvLaunch &f, int lossy)
 {
     DwtInvArgs a = f.a;
-    if (f.vec && a.dst_u8) {            // finest level of the frame path: pixels out, clamp fused
+    if (f.vec && lossy && f.fast && emu_lean97()) {
+        if (a.dst_u8) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv97_kernel<BAND, true>(a); });
+        else emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv97_kernel<BAND, false>(a); });
+    } else if (f.vec && a.dst_u8) {     // finest level of the frame path: pixels out, clamp fused
         if (lossy && f.fast) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<float, true, BAND, true, true, true>(a); });
         else if (lossy) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<float, true, BAND, true, true>(a); });
         else emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<int, false, BAND, true, true>(a); });
@@ -151,6 +156,7 @@ int emu_dwt_inverse_u8(const int32_t *in, void *scratch, uint8_t *pixels, int aw
     std::vector<InvLaunch> plan = plan_dwt_inverse(in, scratch, aw, ah, wl, qs, emu_fast_div(lossy, qs, wl));
     const bool fused = !plan.empty() && plan.back().vec && (((uintptr_t)pixels) & 3u) == 0;
     if (fused) { plan.back().a.dst_u8 = pixels; plan.back().a.off = 128; }
+    for (InvLaunch &f : plan) f.a.trusted = 1;
     for (const InvLaunch &f : plan) {
         switch (f.band) {
         case 32: emu_inv<32>(f, lossy); break;
