@@ -115,6 +115,7 @@ struct DwtInvArgs {
     // the coefficients come from this library's decoder (at most 16 bit-planes: inside the domain the reciprocal
     // form was verified on, no range check)
     int one_div, trusted;
+    int exact_replay;       // debug: every wave of dwt_inv97_kernel runs its band a second time with true divisions
 };
 
 // frame blockIdx.z of a batched launch
@@ -234,6 +235,16 @@ __device__ __forceinline__ void rb_store128(const RowBuf &b, uint32_t lane_off, 
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 v; v.x = x; v.y = y; v.z = z; v.w = w;
     __builtin_amdgcn_raw_buffer_store_b128(v, b.rs, lane_off, row_off, 0);
+    // A buffer store of more than 64 bits reads its data registers for a few cycles after issue, and a vector
+    // instruction that overwrites them in the next two wait states wins in the last lanes read (lanes 12-15 of each
+    // row of 16 got the NEXT value: seen as frexp exponents in place of samples, tools/inv97_debug2.py).  The
+    // compiler's hazard recognizer inserts the wait states for flat / global stores and for buffer stores WITHOUT a
+    // scalar offset only (GCNHazardRecognizer::createsVALUHazard: "this hazard only exists if the instruction is not
+    // using a register in the soffset field") -- on gfx950 it exists with one too.  So the two wait states are here,
+    // fenced so that nothing is scheduled between the store and them.
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1");
+    __builtin_amdgcn_sched_barrier(0);
 #else
     if (lane_off < kRbDrop) { const uint32_t v[4] = { x, y, z, w }; memcpy(b.base + row_off + lane_off, v, 16); }
 #endif
@@ -971,6 +982,28 @@ __device__ __forceinline__ uint32_t to_pixel(float v, int off)
     r = r < 0.0f ? 0.0f : r;
     return (uint32_t)(int)r;
 }
+// four float samples to one dword of pixels, to_pixel's arithmetic: the two roundings of v + off and + 0.01, round
+// to nearest even, then v_cvt_pk_u8_f32 -- the conversion saturates to 0..255 (NaN: 0) and drops the byte into
+// place, where the compare / select clamp, the integer conversion and the shift-or cost five instructions more
+// per pixel.  (tests/test_gpu_parity.py::test_lossy_pixels_clamp_like_the_oracle holds the hardware to that.)
+__device__ __forceinline__ uint32_t pack_pixels(const float v[4], float foff)
+{
+#if defined(__AMDGCN__)
+    uint32_t w = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) w = __builtin_amdgcn_cvt_pk_u8_f32(rintf((v[i] + foff) + 0.01f), (uint32_t)i, w);
+    return w;
+#else
+    uint32_t w = 0u;
+    for (int i = 0; i < 4; i++) {
+        float r = rintf((v[i] + foff) + 0.01f);
+        r = r > 255.0f ? 255.0f : r;
+        r = r < 0.0f ? 0.0f : r;                 // (NaN stays NaN through both and converts to 0 on the GPU)
+        w |= (r == r ? (uint32_t)(int)r : 0u) << (8 * i);
+    }
+    return w;
+#endif
+}
 template <typename T>
 __device__ __forceinline__ void store_row4_u8(const DwtInvArgs &a, int y, int c0, const T v[4])
 {
@@ -1107,22 +1140,24 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
 }
 
 // ---- 9/7 synthesis of one level, lean (round 2) ---------------------------------------------------
-// The vector launches of a context whose reciprocal divisions verified (InvLaunch::fast).  Same strips, bands and
+// The frame path's vector launches of a context whose reciprocal divisions verified (InvLaunch::fast; coefficients
+// from this library's decoder: 16 bit-planes at most, the domain dequant_fast_ok checked).  Same strips, bands and
 // streamed vertical synthesis as dwt_inv_kernel, same arithmetic value for value; what is gone is everything that
-// is not arithmetic (the kernel is bound by vector-instruction issue: profiles/r02_kernel_stats_decode_8k_lossy.csv,
-// 54 us for level 0 of an 8K frame against 33 us for the 5/3 kernel over the same bytes):
-//  * de-quantisation without control flow.  (|v| + 0.5) * sgn(v) is (2 v + sgn v) / 2 exactly, sgn by v_med3_i32, and
-//    the halving folds into the divisor (2 q: the same quotient, scaled operands); 0 stays 0.  When qs is a power of
-//    two the second division is exact scaling and folds in too (one_div).  The per-value branches (zero test,
-//    domain test) of dequant() were two exec-mask regions per coefficient;
-//  * the range the reciprocal form was verified on (|v| < 65536) is not tested where the coefficients come from this
-//    library's decoder (trusted: 16 bit-planes at most); otherwise once per row for the wave, the row falling back;
+// is not arithmetic (the kernel is bound by vector-instruction issue and by its waves' dependent chains: 54 us for
+// level 0 of an 8K frame in dwt_inv_kernel's FAST form against 33 us for the 5/3 kernel over the same bytes):
+//  * de-quantisation without control flow.  (|v| + 0.5) * sgn(v) is v + clamp(v, -0.5, 0.5) exactly (v_cvt, v_med3_f32,
+//    v_add), 0 stays 0.  When qs is a power of two the second division is exact scaling and folds into the step
+//    (ONE_DIV).  dequant()'s zero and domain tests were two exec-mask regions per coefficient;
+//  * no branch in the band's loop but the (wave-uniform) one around an iteration's stores.  The reciprocal form of the lifting divisions is wrong for a nonzero value below
+//    2^-96 (never seen on image data): instead of testing before each division, the wave keeps the smallest
+//    exponent it divided (one v_frexp_exp per value that can be small -- not the freshly de-quantised ones, 0 or
+//    >= 0.75 / (q qs) -- and a running minimum) and looks at it ONCE, after the band: a wave that met such a value
+//    runs its band again with true divisions (EXACT) and overwrites what it stored.  So an iteration is one basic
+//    block up to its stores and the scheduler overlaps its chains;
 //  * the step constants live in vector registers (a VOP3 fma with a scalar operand issues at half rate), the lifting
-//    constants are literals of v_fmamk / v_mul;
-//  * the too-small-for-the-residual test of the lifting divisions is one v_frexp_exp per value and only where a value
-//    can be small: not for freshly de-quantised samples (0 or >= 0.75 / (q qs), qs <= 2^20);
-//  * rows addressed by scalar offsets into buffer resources, never-written lanes parked on the dropped offset,
-//    waves that hold no image-edge column without the mirror selects (EDGE).
+//    constants are literals of v_fmamk / v_mul; rows addressed by scalar offsets into buffer resources; waves that
+//    hold no image-edge column without the mirror selects (EDGE); the coarsest level's LL de-quantisation is an
+//    instantiation (FIRST), not a test per row.
 struct DivK { float rc, nc; };                  // a divisor's correctly rounded reciprocal and its negative, in VGPRs
 __device__ __forceinline__ float div_rcv(float x, const DivK &k)
 {   // div_rc(x, c, rc): fma(q, -c, x) is fma(-q, c, x)
@@ -1130,11 +1165,18 @@ __device__ __forceinline__ float div_rcv(float x, const DivK &k)
     const float r = fmaf(q, k.nc, x);
     return fmaf(r, k.rc, q);
 }
-__device__ __forceinline__ float dequant2(uint32_t raw, const DivK &k2)
-{   // k2: the step doubled; |v| < 2^16
-    const int v = (int)raw;
-    const int t = v > 1 ? 1 : (v < -1 ? -1 : v);
-    return div_rcv((float)(2 * v + t), k2);
+__device__ __forceinline__ float fmed3(float x, float lo, float hi)
+{
+#if defined(__AMDGCN__)
+    return __builtin_amdgcn_fmed3f(x, lo, hi);
+#else
+    return x < lo ? lo : (x > hi ? hi : x);
+#endif
+}
+__device__ __forceinline__ float dequant1(uint32_t raw, const DivK &k)
+{   // (|v| + 0.5) sgn v = v + clamp(v, -0.5, 0.5), exact for |v| < 2^23; 0 stays 0
+    const float y = (float)(int)raw;
+    return div_rcv(y + fmed3(y, -0.5f, 0.5f), k);
 }
 // binary exponent e of x = m 2^e, 0.5 <= |m| < 1; 0 for zero (and infinities / NaN)
 __device__ __forceinline__ int frexp_exp(float x)
@@ -1150,21 +1192,25 @@ __device__ __forceinline__ int frexp_exp(float x)
 }
 constexpr int kTinyExp = -96;                   // |x| < 2^-96 (tiny_key's bound): e <= -96
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+template <bool EXACT> __device__ __forceinline__ float div_n1(float x)
+{
+    if constexpr (EXACT) return x / PS_N1;
+    const float q = x * PS_RN1;
+    return fmaf(fmaf(q, -PS_N1, x), PS_RN1, q);
+}
+template <bool EXACT> __device__ __forceinline__ float div_n2(float x)
+{
+    if constexpr (EXACT) return x / PS_N2;
+    const float q = x * PS_RN2;
+    return fmaf(fmaf(q, -PS_N2, x), PS_RN2, q);
+}
 
-// hinv<true>(float) with the divisions' fallback decided by the caller's exponent
-template <bool EDGE>
-__device__ __forceinline__ void hinv97(float v[4], bool le, bool re, int tiny_e)
+// hinv(float) without its test
+template <bool EDGE, bool EXACT>
+__device__ __forceinline__ void hinv97(float v[4], bool le, bool re)
 {   // DWTGenerator.cu:326-339, lifting :110-122
-    if (__builtin_amdgcn_ballot_w64(tiny_e <= kTinyExp) == 0ull) {
-        v[1] = fmaf(fmaf(v[1] * PS_RN1, -PS_N1, v[1]), PS_RN1, v[1] * PS_RN1);
-        v[3] = fmaf(fmaf(v[3] * PS_RN1, -PS_N1, v[3]), PS_RN1, v[3] * PS_RN1);
-        v[0] = fmaf(fmaf(v[0] * PS_RN2, -PS_N2, v[0]), PS_RN2, v[0] * PS_RN2);
-        v[2] = fmaf(fmaf(v[2] * PS_RN2, -PS_N2, v[2]), PS_RN2, v[2] * PS_RN2);
-    } else {
-        keep_in_branch(v[0]); keep_in_branch(v[1]); keep_in_branch(v[2]); keep_in_branch(v[3]);
-        v[1] = v[1] / PS_N1; v[3] = v[3] / PS_N1;
-        v[0] = v[0] / PS_N2; v[2] = v[2] / PS_N2;
-    }
+    v[1] = div_n1<EXACT>(v[1]); v[3] = div_n1<EXACT>(v[3]);
+    v[0] = div_n2<EXACT>(v[0]); v[2] = div_n2<EXACT>(v[2]);
     const bool l = EDGE && le, r = EDGE && re;
     float dp = prv<float>(v[3], v[1], l);
     v[0] = fmaf(-(v[1] + dp), PS_A4, v[0]);
@@ -1182,37 +1228,32 @@ __device__ __forceinline__ void hinv97(float v[4], bool le, bool re, int tiny_e)
 
 struct Inv97Steps { DivK ll, hl, lh, hh, qs; };
 
-// one subband row pair-segment to samples (s0, d0, s1, d1); `high`: LH / HH row, else LL / HL
-template <bool HIGH>
+// one subband row pair-segment to samples (s0, d0, s1, d1); HIGH: LH / HH row, else LL / HL (LL de-quantised on
+// the coarsest level only: DEQ_S)
+template <bool HIGH, bool DEQ_S, bool ONE_DIV, bool EXACT>
 __device__ __forceinline__ void convert97(const DwtInvArgs &a, const Inv97Steps &k, const SubRaw &r, float v[4])
 {
-    const bool deq_s = HIGH || a.first;
-    if (!a.trusted) {
-        // |v| < 65536, the domain dequant_fast_ok verified: once per row for the wave
-        uint32_t m = r.d0 + 65535u > r.d1 + 65535u ? r.d0 + 65535u : r.d1 + 65535u;
-        if (deq_s) {
-            const uint32_t n = r.s0 + 65535u > r.s1 + 65535u ? r.s0 + 65535u : r.s1 + 65535u;
-            m = m > n ? m : n;
-        }
-        if (__builtin_amdgcn_ballot_w64(m > 131070u) != 0ull) {
-            convert_sub<float, true, true>(a, r, HIGH, v);
-            keep_in_branch(v[0]);
-            return;
-        }
+    if constexpr (EXACT) {
+        const float qd = HIGH ? a.q[3] : a.q[1], qsb = HIGH ? a.q[2] : a.q[0];
+        v[1] = dequant<false>((int32_t)r.d0, qd, 0.0f, a.qs, 0.0f); v[3] = dequant<false>((int32_t)r.d1, qd, 0.0f, a.qs, 0.0f);
+        if (DEQ_S) { v[0] = dequant<false>((int32_t)r.s0, qsb, 0.0f, a.qs, 0.0f); v[2] = dequant<false>((int32_t)r.s1, qsb, 0.0f, a.qs, 0.0f); }
+        else { v[0] = __uint_as_float(r.s0); v[2] = __uint_as_float(r.s1); }
+        return;
     }
     const DivK &kd = HIGH ? k.hh : k.hl, &ks = HIGH ? k.lh : k.ll;
-    v[1] = dequant2(r.d0, kd); v[3] = dequant2(r.d1, kd);
-    if (deq_s) { v[0] = dequant2(r.s0, ks); v[2] = dequant2(r.s1, ks); }
+    v[1] = dequant1(r.d0, kd); v[3] = dequant1(r.d1, kd);
+    if (DEQ_S) { v[0] = dequant1(r.s0, ks); v[2] = dequant1(r.s1, ks); }
     else { v[0] = __uint_as_float(r.s0); v[2] = __uint_as_float(r.s1); }
-    if (!a.one_div) {
-        keep_in_branch(v[1]);
+    if (!ONE_DIV) {
         v[1] = div_rcv(v[1], k.qs); v[3] = div_rcv(v[3], k.qs);
-        if (deq_s) { v[0] = div_rcv(v[0], k.qs); v[2] = div_rcv(v[2], k.qs); }
+        if (DEQ_S) { v[0] = div_rcv(v[0], k.qs); v[2] = div_rcv(v[2], k.qs); }
     }
 }
 
-template <int BAND, bool U8OUT, bool EDGE>
-__device__ __forceinline__ void dwt_inv97_band(const DwtInvArgs &a, int strip, int lane)
+// returns (wave-uniform) whether some lane divided a value too small for the reciprocal form: the band must be
+// run again with EXACT
+template <int BAND, bool U8OUT, bool FIRST, bool ONE_DIV, bool EDGE, bool EXACT>
+__device__ __forceinline__ bool dwt_inv97_band(const DwtInvArgs &a, int strip, int lane)
 {
     const int c0 = strip * kStripUseful - 4 * kEdgeLanes + 4 * lane;
     const int pc = c0 >> 1;                                  // arithmetic shift: -4 -> -2
@@ -1223,24 +1264,25 @@ __device__ __forceinline__ void dwt_inv97_band(const DwtInvArgs &a, int strip, i
     const bool le = EDGE && c0 == 0, re = EDGE && c0 + 4 == a.W;
     const int pl = pc < 0 ? 0 : (pc > hW - 2 ? hW - 2 : pc);
 
-    const RowBuf mal = rowbuf(a.mallat), lls = rowbuf(a.first ? (const void *)a.mallat : a.ll);
+    const RowBuf mal = rowbuf(a.mallat), lls = rowbuf(FIRST ? (const void *)a.mallat : a.ll);
     const RowBuf out = rowbuf(U8OUT ? (const void *)a.dst_u8 : (const void *)a.dst);
     const uint32_t vd = (uint32_t)(hW + pl) * 4u, vs = (uint32_t)pl * 4u;
     const uint32_t vo = wr ? (U8OUT ? (uint32_t)c0 : (uint32_t)c0 * 4u) : kRbDrop;
-    const uint32_t aw4 = (uint32_t)a.AW * 4u, ll4 = a.first ? aw4 : (uint32_t)a.ll_stride * 4u;
+    const uint32_t aw4 = (uint32_t)a.AW * 4u, ll4 = FIRST ? aw4 : (uint32_t)a.ll_stride * 4u;
     const uint32_t ow = U8OUT ? (uint32_t)a.W : (uint32_t)a.W * 4u;
 
-    // the doubled steps (times qs when that is exact scaling) as reciprocal / negative pairs in vector registers
+    // the steps (times qs when that is exact scaling) as reciprocal / negative pairs in vector registers
     Inv97Steps k;
-    {
-        const float sc = a.one_div ? a.qs : 1.0f, rsc = a.one_div ? a.rqs : 1.0f;
-        const float vsc = in_vgpr(2.0f * sc), vrsc = in_vgpr(0.5f * rsc);
+    if constexpr (!EXACT) {
+        const float vsc = in_vgpr(ONE_DIV ? a.qs : 1.0f), vrsc = in_vgpr(ONE_DIV ? a.rqs : 1.0f);
         k.ll.rc = in_vgpr(a.rq[0]) * vrsc; k.ll.nc = -(in_vgpr(a.q[0]) * vsc);
         k.hl.rc = in_vgpr(a.rq[1]) * vrsc; k.hl.nc = -(in_vgpr(a.q[1]) * vsc);
         k.lh.rc = in_vgpr(a.rq[2]) * vrsc; k.lh.nc = -(in_vgpr(a.q[2]) * vsc);
         k.hh.rc = in_vgpr(a.rq[3]) * vrsc; k.hh.nc = -(in_vgpr(a.q[3]) * vsc);
         k.qs.rc = in_vgpr(a.rqs); k.qs.nc = in_vgpr(-a.qs);
     }
+
+    const float foff = U8OUT ? in_vgpr((float)a.off) : 0.0f;
 
     constexpr int kIters = BAND / 2 + 4;                     // two pairs of run-in either side
     constexpr int kGroup = inv_group(kIters, PICSONG_DWT_INV97_GROUP);
@@ -1262,6 +1304,7 @@ __device__ __forceinline__ void dwt_inv97_band(const DwtInvArgs &a, int strip, i
     float ddp[4], s1p[4], d1p[4], s0p[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) { ddp[i] = s1p[i] = d1p[i] = s0p[i] = 0.0f; }
+    int emin = 0;                                            // smallest exponent a lifting division has seen
 #pragma unroll 1
     for (int g = 0; g < kIters / kGroup; g++) {
 #pragma unroll
@@ -1269,32 +1312,31 @@ __device__ __forceinline__ void dwt_inv97_band(const DwtInvArgs &a, int strip, i
             const int it = g * kGroup + r;
             const int j = j0 + it;
             float ln[4], hn[4];
-            convert97<false>(a, k, rawL[r], ln);
-            convert97<true>(a, k, rawH[r], hn);
-            if (g + 1 < kIters / kGroup) load_pair(j + kGroup, rawL[r], rawH[r]);
+            convert97<false, FIRST, ONE_DIV, EXACT>(a, k, rawL[r], ln);
+            convert97<true, true, ONE_DIV, EXACT>(a, k, rawH[r], hn);
+            // (also in the last trip, whose rows nobody uses: an `if` here makes the compiler merge loaded and kept
+            // registers with copies behind a full s_waitcnt, which serialises the prefetch; reflect_* keep every
+            // row inside the subband).  Fenced: left to itself the scheduler sinks the loads to the end of the trip.
+#if defined(__AMDGCN__)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            load_pair(j + kGroup, rawL[r], rawH[r]);
+#if defined(__AMDGCN__)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             // the previous level's LL samples are the only ones that can be tiny at this point
-            hinv97<EDGE>(ln, le, re, a.first ? 0 : imin(frexp_exp(ln[0]), frexp_exp(ln[2])));
-            hinv97<EDGE>(hn, le, re, 0);
-            int te = imin(imin(frexp_exp(hn[0]), frexp_exp(hn[1])), imin(frexp_exp(hn[2]), frexp_exp(hn[3])));
-            te = imin(te, imin(imin(frexp_exp(ln[0]), frexp_exp(ln[1])), imin(frexp_exp(ln[2]), frexp_exp(ln[3]))));
-            if (__builtin_amdgcn_ballot_w64(te <= kTinyExp) == 0ull) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    hn[i] = fmaf(fmaf(hn[i] * PS_RN1, -PS_N1, hn[i]), PS_RN1, hn[i] * PS_RN1);
-                    ln[i] = fmaf(fmaf(ln[i] * PS_RN2, -PS_N2, ln[i]), PS_RN2, ln[i] * PS_RN2);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    keep_in_branch(hn[i]); keep_in_branch(ln[i]);
-                    hn[i] = hn[i] / PS_N1; ln[i] = ln[i] / PS_N2;
-                }
+            if (!EXACT && !FIRST) emin = imin(emin, imin(frexp_exp(ln[0]), frexp_exp(ln[2])));
+            hinv97<EDGE, EXACT>(ln, le, re);
+            hinv97<EDGE, EXACT>(hn, le, re);
+            if (!EXACT) {
+                emin = imin(emin, imin(imin(frexp_exp(hn[0]), frexp_exp(hn[1])), imin(frexp_exp(hn[2]), frexp_exp(hn[3]))));
+                emin = imin(emin, imin(imin(frexp_exp(ln[0]), frexp_exp(ln[1])), imin(frexp_exp(ln[2]), frexp_exp(ln[3]))));
             }
             float ev[4], od[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const float dd = hn[i];
-                const float s1 = fmaf(-(ddp[i] + dd), PS_A4, ln[i]);
+                const float dd = div_n1<EXACT>(hn[i]);
+                const float s1 = fmaf(-(ddp[i] + dd), PS_A4, div_n2<EXACT>(ln[i]));
                 const float d1 = fmaf(-(s1p[i] + s1), PS_A3, ddp[i]);       // d1[j-1]
                 const float s0 = fmaf(-(d1p[i] + d1), PS_A2, s1p[i]);       // s0[j-1]
                 const float xo = fmaf(-(s0p[i] + s0), PS_A1, d1p[i]);       // x[2(j-2)+1]
@@ -1302,13 +1344,12 @@ __device__ __forceinline__ void dwt_inv97_band(const DwtInvArgs &a, int strip, i
                 od[i] = xo;
                 ddp[i] = dd; s1p[i] = s1; d1p[i] = d1; s0p[i] = s0;
             }
+            // pair j - 2: stored when it is one of the band's (not a run-in pair, not past the image's last pair)
             if (it >= 4 && j - 2 < m1) {
                 const uint32_t y = (uint32_t)(2 * (j - 2));
                 if constexpr (U8OUT) {
-                    rb_store32(out, vo, y * ow, to_pixel(ev[0], a.off) | (to_pixel(ev[1], a.off) << 8) |
-                                                   (to_pixel(ev[2], a.off) << 16) | (to_pixel(ev[3], a.off) << 24));
-                    rb_store32(out, vo, (y + 1u) * ow, to_pixel(od[0], a.off) | (to_pixel(od[1], a.off) << 8) |
-                                                         (to_pixel(od[2], a.off) << 16) | (to_pixel(od[3], a.off) << 24));
+                    rb_store32(out, vo, y * ow, pack_pixels(ev, foff));
+                    rb_store32(out, vo, (y + 1u) * ow, pack_pixels(od, foff));
                 } else {
                     rb_store128(out, vo, y * ow, as_u32(ev[0]), as_u32(ev[1]), as_u32(ev[2]), as_u32(ev[3]));
                     rb_store128(out, vo, (y + 1u) * ow, as_u32(od[0]), as_u32(od[1]), as_u32(od[2]), as_u32(od[3]));
@@ -1316,18 +1357,25 @@ __device__ __forceinline__ void dwt_inv97_band(const DwtInvArgs &a, int strip, i
             }
         }
     }
+    return !EXACT && __builtin_amdgcn_ballot_w64(emin <= kTinyExp) != 0ull;
 }
 
-template <int BAND, bool U8OUT>
-__global__ __launch_bounds__(256) void dwt_inv97_kernel(DwtInvArgs a)
+#ifndef PICSONG_DWT_INV97_WAVES
+#define PICSONG_DWT_INV97_WAVES 5     // dwt_inv97_kernel: resident waves per SIMD the register budget is set for
+#endif
+template <int BAND, bool U8OUT, bool FIRST, bool ONE_DIV>
+__global__ __launch_bounds__(256, PICSONG_DWT_INV97_WAVES) void dwt_inv97_kernel(DwtInvArgs a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int strip = blockIdx.x * 4 + wave;
     if (strip * kStripUseful >= a.W) return;                 // whole wave idle (no cross-lane use)
     dwt_inv_select_frame(a);
     const int first = strip * kStripUseful - 4 * kEdgeLanes;
-    if (first <= 0 || first + kStripCols >= a.W) dwt_inv97_band<BAND, U8OUT, true>(a, strip, lane);
-    else dwt_inv97_band<BAND, U8OUT, false>(a, strip, lane);
+    bool again;
+    if (first <= 0 || first + kStripCols >= a.W) again = dwt_inv97_band<BAND, U8OUT, FIRST, ONE_DIV, true, false>(a, strip, lane);
+    else again = dwt_inv97_band<BAND, U8OUT, FIRST, ONE_DIV, false, false>(a, strip, lane);
+    // (a.exact_replay: PICSONG_DWT_EXACT_REPLAY=1, the tests' way into the second pass)
+    if (__builtin_expect(again || a.exact_replay, 0)) dwt_inv97_band<BAND, U8OUT, FIRST, ONE_DIV, true, true>(a, strip, lane);
 }
 
 // ---- level shift kernels (used when the stages are called one by one) -------------------------

@@ -41,7 +41,7 @@ inline bool dwt_vec_ok(int W, int aw, const void *p0, const void *p1)
 // Band height per level: big levels want taller bands (less vertical halo re-read), small levels
 // want many short waves (a level with a handful of tall waves is bound by one wave's serial
 // instruction time, not by memory); PICSONG_DWT_BANDS="16,8,4,..." overrides per level.
-inline int fwd_band_rows(int level, int strips, int H)
+inline int band_rows_override(int level)
 {
     if (const char *e = getenv("PICSONG_DWT_BANDS")) {
         int l = 0;
@@ -52,9 +52,23 @@ inline int fwd_band_rows(int level, int strips, int H)
             if (*p == ',') p++;
         }
     }
+    return 0;
+}
+inline int fwd_band_rows(int level, int strips, int H)
+{
+    if (const int v = band_rows_override(level)) return v;
     // measured on MI355X (8K: 16,8,4,4,4 best; 4K: 8,8,4,4,4): by level size in samples
     const long n = (long)H * (long)strips * kStripUseful;
     return n >= (16L << 20) ? 16 : (n >= (4L << 20) ? 8 : 4);
+}
+// The 9/7 synthesis of a context whose reciprocal divisions verified (dwt_inv97_kernel) is bound by its vector
+// instructions, a third of which a 16-row band spends on run-in rows (12 iterations for 8 row pairs; 32 rows: 20
+// for 16): 8K level 0 40.9 us with 32-row bands, 48.6 with 16 (one round of 4352 waves against 1.7 of 8704).
+inline int inv97_band_rows(int level, int strips, int H)
+{
+    if (const int v = band_rows_override(level)) return v;
+    const long n = (long)H * (long)strips * kStripUseful;
+    return n >= (16L << 20) ? 32 : (n >= (4L << 20) ? 8 : 4);
 }
 
 inline std::vector<FwdLaunch> plan_dwt_forward(const void *d_in, bool u8in, void *d_out, int aw, int ah,
@@ -177,13 +191,15 @@ inline std::vector<InvLaunch> plan_dwt_inverse(const int32_t *d_in, void *d_out,
             int e = 0;
             a.one_div = std::frexp(qs, &e) == 0.5f ? 1 : 0;
             a.trusted = 0;
+            const char *x = getenv("PICSONG_DWT_EXACT_REPLAY");
+            a.exact_replay = x && atoi(x) != 0 ? 1 : 0;
         }
         a.qs = qs;
         a.rqs = 1.0f / qs;
         for (int k = 0; k < 4; k++) { a.q[k] = kQSteps[l][k]; a.rq[k] = 1.0f / a.q[k]; }
         f.fast = fast;
         const int strips = (W + kStripUseful - 1) / kStripUseful;
-        f.band = fwd_band_rows(l, strips, H);
+        f.band = fast ? inv97_band_rows(l, strips, H) : fwd_band_rows(l, strips, H);
         f.gx = (unsigned)((strips + 3) / 4);
         f.gy = (unsigned)(((H >> 1) + f.band / 2 - 1) / (f.band / 2));
         f.vec = dwt_vec_ok(W, aw, d_in, d_out);

@@ -87,14 +87,26 @@ static void launch_inv(const picsong_ctx *c, const InvLaunch &f, hipStream_t s, 
     // f.fast: the 9/7 divisions in their reciprocal form (verified for this context's qs at creation); the vector
     // launches of such a context are the lean kernel's (PICSONG_DWT_INV97=0: dwt_inv_kernel's FAST instantiations)
     static const bool lean97 = !(getenv("PICSONG_DWT_INV97") && atoi(getenv("PICSONG_DWT_INV97")) == 0);
-    if (f.vec && f.a.dst_u8) {          // finest level of the frame path: pixels out, clamp fused
-        if (c->p.lossy && f.fast && lean97) dwt_inv97_kernel<BAND, true><<<grid, 256, 0, s>>>(f.a);
-        else if (c->p.lossy && f.fast) dwt_inv_kernel<float, true, BAND, true, true, true><<<grid, 256, 0, s>>>(f.a);
+    // (its instantiations: the frame path's coefficients, i.e. trusted; a coarsest level that also writes pixels,
+    // wl = 1, stays with dwt_inv_kernel)
+    const bool l97 = c->p.lossy && f.fast && lean97 && f.vec && f.a.trusted && !(f.a.first && f.a.dst_u8);
+    if (l97) {
+        if (f.a.dst_u8) {
+            if (f.a.one_div) dwt_inv97_kernel<BAND, true, false, true><<<grid, 256, 0, s>>>(f.a);
+            else dwt_inv97_kernel<BAND, true, false, false><<<grid, 256, 0, s>>>(f.a);
+        } else if (f.a.first) {
+            if (f.a.one_div) dwt_inv97_kernel<BAND, false, true, true><<<grid, 256, 0, s>>>(f.a);
+            else dwt_inv97_kernel<BAND, false, true, false><<<grid, 256, 0, s>>>(f.a);
+        } else {
+            if (f.a.one_div) dwt_inv97_kernel<BAND, false, false, true><<<grid, 256, 0, s>>>(f.a);
+            else dwt_inv97_kernel<BAND, false, false, false><<<grid, 256, 0, s>>>(f.a);
+        }
+    } else if (f.vec && f.a.dst_u8) {   // finest level of the frame path: pixels out, clamp fused
+        if (c->p.lossy && f.fast) dwt_inv_kernel<float, true, BAND, true, true, true><<<grid, 256, 0, s>>>(f.a);
         else if (c->p.lossy) dwt_inv_kernel<float, true, BAND, true, true><<<grid, 256, 0, s>>>(f.a);
         else dwt_inv_kernel<int, false, BAND, true, true><<<grid, 256, 0, s>>>(f.a);
     } else if (f.vec) {
-        if (c->p.lossy && f.fast && lean97) dwt_inv97_kernel<BAND, false><<<grid, 256, 0, s>>>(f.a);
-        else if (c->p.lossy && f.fast) dwt_inv_kernel<float, true, BAND, true, false, true><<<grid, 256, 0, s>>>(f.a);
+        if (c->p.lossy && f.fast) dwt_inv_kernel<float, true, BAND, true, false, true><<<grid, 256, 0, s>>>(f.a);
         else if (c->p.lossy) dwt_inv_kernel<float, true, BAND, true><<<grid, 256, 0, s>>>(f.a);
         else dwt_inv_kernel<int, false, BAND, true><<<grid, 256, 0, s>>>(f.a);
     } else {
@@ -630,7 +642,12 @@ int picsong_dwt_inverse(picsong_ctx *c, const int32_t *d_in, void *d_out, void *
 {
     if (!c || !d_in || !d_out) return fail(PICSONG_ERR_ARG, "dwt_inverse: null argument");
     hipStream_t s = (hipStream_t)stream;
-    for (const InvLaunch &f : plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs, c->fast_div)) {
+    // PICSONG_DWT_TRUST_STAGE=1 (tests, tools): the stage call promises coefficients of at most 16 bit-planes like the
+    // frame path does, and so runs the frame path's kernels with samples out
+    const char *te = getenv("PICSONG_DWT_TRUST_STAGE");
+    const int trusted = te && atoi(te) != 0 ? 1 : 0;
+    for (InvLaunch &f : plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs, c->fast_div)) {
+        f.a.trusted = trusted;
         switch (f.band) {
         case 32: launch_inv<32>(c, f, s); break;
         case 16: launch_inv<16>(c, f, s); break;

@@ -48,9 +48,18 @@ static bool emu_lean97() { const char *e = getenv("PICSONG_DWT_INV97"); return !
 template <int BAND> static void emu_inv(const InvLaunch &f, int lossy)
 {
     DwtInvArgs a = f.a;
-    if (f.vec && lossy && f.fast && emu_lean97()) {
-        if (a.dst_u8) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv97_kernel<BAND, true>(a); });
-        else emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv97_kernel<BAND, false>(a); });
+    if (f.vec && lossy && f.fast && emu_lean97() && a.trusted && !(a.first && a.dst_u8)) {
+        const dim3 grid(f.gx, f.gy);
+        if (a.dst_u8) {
+            if (a.one_div) emu::launch(grid, dim3(256), [&] { dwt_inv97_kernel<BAND, true, false, true>(a); });
+            else emu::launch(grid, dim3(256), [&] { dwt_inv97_kernel<BAND, true, false, false>(a); });
+        } else if (a.first) {
+            if (a.one_div) emu::launch(grid, dim3(256), [&] { dwt_inv97_kernel<BAND, false, true, true>(a); });
+            else emu::launch(grid, dim3(256), [&] { dwt_inv97_kernel<BAND, false, true, false>(a); });
+        } else {
+            if (a.one_div) emu::launch(grid, dim3(256), [&] { dwt_inv97_kernel<BAND, false, false, true>(a); });
+            else emu::launch(grid, dim3(256), [&] { dwt_inv97_kernel<BAND, false, false, false>(a); });
+        }
     } else if (f.vec && a.dst_u8) {     // finest level of the frame path: pixels out, clamp fused
         if (lossy && f.fast) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<float, true, BAND, true, true, true>(a); });
         else if (lossy) emu::launch(dim3(f.gx, f.gy), dim3(256), [&] { dwt_inv_kernel<float, true, BAND, true, true>(a); });
@@ -140,6 +149,21 @@ void emu_dwt_forward_tail(void *out, int aw, int ah, int wl, int lossy, float qs
 void emu_dwt_inverse(const int32_t *in, void *out, int aw, int ah, int wl, int lossy, float qs)
 {
     for (const InvLaunch &f : plan_dwt_inverse(in, out, aw, ah, wl, qs, emu_fast_div(lossy, qs, wl))) {
+        switch (f.band) {
+        case 32: emu_inv<32>(f, lossy); break;
+        case 16: emu_inv<16>(f, lossy); break;
+        case 8: emu_inv<8>(f, lossy); break;
+        default: emu_inv<4>(f, lossy); break;
+        }
+    }
+}
+
+// the stage call with the frame path's promise (coefficients of at most 16 bit-planes): the lean 9/7 kernel's
+// instantiations with samples out
+void emu_dwt_inverse_trusted(const int32_t *in, void *out, int aw, int ah, int wl, int lossy, float qs)
+{
+    for (InvLaunch &f : plan_dwt_inverse(in, out, aw, ah, wl, qs, emu_fast_div(lossy, qs, wl))) {
+        f.a.trusted = 1;
         switch (f.band) {
         case 32: emu_inv<32>(f, lossy); break;
         case 16: emu_inv<16>(f, lossy); break;

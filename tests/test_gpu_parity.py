@@ -125,6 +125,27 @@ def test_edge_inputs_roundtrip_and_oracle_parity(oracle, pa, torch, name):
     c.close()
 
 
+@pytest.mark.parametrize("qs", [0.5, 0.3, 0.05])
+def test_lossy_pixels_clamp_like_the_oracle(oracle, pa, torch, qs):
+    """9/7 reconstruction of a frame of 0 / 255 pixels overshoots the pixel range on both sides all over the
+    frame: the fused pixel store of the finest inverse level (v_cvt_pk_u8_f32's saturation) must clamp like
+    removeOffsetAndApplyMaxMinLossy + the u8 conversion do (oracle), pixel for pixel; qs = 0.5 is the
+    one-division form of the lean 9/7 kernel, 0.3 the two-division form, 0.05 coarse enough for big overshoots."""
+    W, H, wl = 512, 320, 3
+    rng = np.random.default_rng(31)
+    img = (rng.integers(0, 2, (H, W), dtype=np.uint8) * 255).astype(np.uint8)
+    img[:, :W // 2] = np.where(np.arange(W // 2)[None, :] // 7 % 2 == 0, 0, 255)     # hard vertical edges too
+    lut = oracle.lut_for(True, wl)
+    c = pa.Codec(W, H, wl=wl, lossy=True, qs=qs, lut_folder=_lutdir(oracle, True))
+    s = c.encode_frame(_dev(torch, oracle.pad_frame(img))).cpu().numpy().view(np.uint16)
+    assert np.array_equal(s, oracle.encode_frame(img, wl, True, qs, lut))
+    want = oracle.decode_frame(s, W, H, wl, True, qs, lut)
+    got = c.decode_frame(_dev(torch, s.view(np.int16))).cpu().numpy()
+    assert np.array_equal(got[:H, :W], np.asarray(want)[:H, :W])
+    assert (got == 0).mean() > 0.05 and (got == 255).mean() > 0.05
+    c.close()
+
+
 def test_raw_fallback_and_mixed_blocks(oracle, pa, torch):
     rng = np.random.default_rng(4)
     coef = np.zeros((64, 256), np.int32)

@@ -408,6 +408,40 @@ def test_dwt97_inverse_fast_and_dividing_kernels_agree(oracle, E, monkeypatch, W
     assert np.array_equal(fast[extra:].view(np.uint32), ref[ex:].view(np.uint32))
 
 
+@pytest.mark.parametrize("W,H,wl,qs", [(320, 192, 3, 0.5), (64, 128, 5, 0.3), (512, 320, 6, 0.5), (1024, 64, 2, 2.0),
+                                       (328, 192, 3, 0.7), (256, 64, 1, 0.5), (1864, 128, 2, 0.25)])
+@pytest.mark.parametrize("replay", [False, True])
+def test_dwt97_inverse_lean_kernel(oracle, E, monkeypatch, W, H, wl, qs, replay):
+    """The frame path's 9/7 synthesis (dwt_inv97_kernel: branch-free de-quantisation, one division when qs is a
+    power of two, the coarsest level's instantiation, bands past the bottom edge, edge and interior waves) against
+    the oracle, samples and fused pixels; `replay`: every wave runs its band a second time with true divisions
+    (the pass a too-small lifting operand asks for) and must leave the same words."""
+    monkeypatch.delenv("PICSONG_DWT_EXACTDIV", raising=False)
+    monkeypatch.delenv("PICSONG_DWT_INV97", raising=False)
+    if replay:
+        monkeypatch.setenv("PICSONG_DWT_EXACT_REPLAY", "1")
+    else:
+        monkeypatch.delenv("PICSONG_DWT_EXACT_REPLAY", raising=False)
+    rng = np.random.default_rng(W + wl)
+    coef = rng.integers(-300, 301, (H, W)).astype(np.int32)
+    coef[rng.random((H, W)) < 0.6] = 0
+    coef[3, 5] = 65535
+    coef[H // 2 + 1, W // 2 + 2] = -65535
+    coef[H - 1, W - 1] = 4000
+    coef[0, :8] = rng.integers(-20000, 20000, 8)
+    extra = oracle.dwt_extra(W, H, wl)
+    ref, ex = oracle.dwt_inverse(coef, wl, True, qs)
+    got = E.dwt_inverse(coef, wl, True, qs, extra=extra, trusted=True)
+    assert np.array_equal(got[extra:].view(np.uint32), ref[ex:].view(np.uint32))
+    want = oracle.level_shift_inv(ref[ex:]).reshape(H, W).astype(np.uint8)
+    pix, fused = E.dwt_inverse_u8(coef, wl, True, qs, extra=extra)
+    assert fused and np.array_equal(pix, want)
+    # and the same launches through dwt_inv_kernel's FAST instantiations
+    monkeypatch.setenv("PICSONG_DWT_INV97", "0")
+    old = E.dwt_inverse(coef, wl, True, qs, extra=extra, trusted=True)
+    assert np.array_equal(old[extra:].view(np.uint32), ref[ex:].view(np.uint32))
+
+
 # ---- levels 0 + 1 of the forward transform in one launch (dwt_fwd2_kernel) ---------------------------
 @pytest.mark.parametrize("W,H,wl,lossy,qs", [(320, 192, 3, False, 1.0), (64, 64, 5, False, 1.0), (256, 64, 2, False, 1.0),
                                              (1024, 320, 4, False, 1.0), (768, 128, 2, True, 0.5),
