@@ -63,12 +63,14 @@ inline int fwd_band_rows(int level, int strips, int H)
 }
 // The 9/7 synthesis of a context whose reciprocal divisions verified (dwt_inv97_kernel) is bound by its vector
 // instructions, a third of which a 16-row band spends on run-in rows (12 iterations for 8 row pairs; 32 rows: 20
-// for 16): 8K level 0 40.9 us with 32-row bands, 48.6 with 16 (one round of 4352 waves against 1.7 of 8704).
+// for 16): taller bands than the other kernels want.  Measured on an 8K frame, wl = 6 (tools/inv97_variants.sh):
+// 32,16,8,4,4,4 rows for levels 0..5 81.1 us; 32,8,4,4,4,4 83.9; 16,8,4,4,4,4 95.2; 32-row bands on level 1
+// double level 0's time (38.7 -> 76.5 us; same words out).
 inline int inv97_band_rows(int level, int strips, int H)
 {
     if (const int v = band_rows_override(level)) return v;
     const long n = (long)H * (long)strips * kStripUseful;
-    return n >= (16L << 20) ? 32 : (n >= (4L << 20) ? 8 : 4);
+    return n >= (16L << 20) ? 32 : (n >= (4L << 20) ? 16 : (n >= (1L << 20) ? 8 : 4));
 }
 
 inline std::vector<FwdLaunch> plan_dwt_forward(const void *d_in, bool u8in, void *d_out, int aw, int ah,
