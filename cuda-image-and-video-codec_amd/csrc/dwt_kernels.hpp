@@ -55,7 +55,7 @@ constexpr int kStripUseful = kStripCols - 8 * kEdgeLanes;   // lanes kEdgeLanes 
 #endif
 constexpr int inv_group(int iters, int most) { return iters % most == 0 ? most : inv_group(iters, most - 1); }
 #ifndef PICSONG_DWT_INV97_GROUP
-#define PICSONG_DWT_INV97_GROUP 3     // dwt_inv97_kernel: likewise
+#define PICSONG_DWT_INV97_GROUP 2     // dwt_inv97_kernel: likewise (3 spills at its 96 registers)
 #endif
 #ifndef PICSONG_DWT_INV_AHEAD
 #define PICSONG_DWT_INV_AHEAD 6       // inverse kernels: row pairs whose loads are in flight ahead of the math
@@ -111,10 +111,8 @@ struct DwtInvArgs {
     // batched launches (grid.z = frames of one picsong_decode_frames call): frame z reads mallat + z * mallat_z and
     // ll + z * ll_z, writes dst + z * dst_z and dst_u8 + z * u8_z (bytes); 0 for a single frame
     unsigned long long mallat_z, ll_z, dst_z, u8_z;
-    // dwt_inv97_kernel: qs is a power of two (the two de-quantising divisions are one: x / (q * qs) is exact scaling);
-    // the coefficients come from this library's decoder (at most 16 bit-planes: inside the domain the reciprocal
-    // form was verified on, no range check)
-    int one_div, trusted;
+    // dwt_inv97_kernel: qs is a power of two (the two de-quantising divisions are one: x / (q * qs) is exact scaling)
+    int one_div;
     int exact_replay;       // debug: every wave of dwt_inv97_kernel runs its band a second time with true divisions
 };
 
@@ -1140,8 +1138,7 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
 }
 
 // ---- 9/7 synthesis of one level, lean (round 2) ---------------------------------------------------
-// The frame path's vector launches of a context whose reciprocal divisions verified (InvLaunch::fast; coefficients
-// from this library's decoder: 16 bit-planes at most, the domain dequant_fast_ok checked).  Same strips, bands and
+// The vector launches of a context whose reciprocal divisions verified (InvLaunch::fast).  Same strips, bands and
 // streamed vertical synthesis as dwt_inv_kernel, same arithmetic value for value; what is gone is everything that
 // is not arithmetic (the kernel is bound by vector-instruction issue and by its waves' dependent chains: 54 us for
 // level 0 of an 8K frame in dwt_inv_kernel's FAST form against 33 us for the 5/3 kernel over the same bytes):
@@ -1152,8 +1149,11 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
 //    2^-96 (never seen on image data): instead of testing before each division, the wave keeps the smallest
 //    exponent it divided (one v_frexp_exp per value that can be small -- not the freshly de-quantised ones, 0 or
 //    >= 0.75 / (q qs) -- and a running minimum) and looks at it ONCE, after the band: a wave that met such a value
-//    runs its band again with true divisions (EXACT) and overwrites what it stored.  So an iteration is one basic
-//    block up to its stores and the scheduler overlaps its chains;
+//    runs its band again with true divisions (EXACT) and overwrites what it stored.  The same second pass takes a
+//    wave that de-quantised a coefficient outside the 16 bit-planes the reciprocal form of the step divisions was
+//    verified for (a running v_max3_f32 of magnitudes: coded planes never get there, the 23-bit words of a
+//    raw-fallback codeblock or a caller's own array can).  So an iteration is one basic block up to its stores and
+//    the scheduler overlaps its chains;
 //  * the step constants live in vector registers (a VOP3 fma with a scalar operand issues at half rate), the lifting
 //    constants are literals of v_fmamk / v_mul; rows addressed by scalar offsets into buffer resources; waves that
 //    hold no image-edge column without the mirror selects (EDGE); the coarsest level's LL de-quantisation is an
@@ -1173,10 +1173,17 @@ __device__ __forceinline__ float fmed3(float x, float lo, float hi)
     return x < lo ? lo : (x > hi ? hi : x);
 #endif
 }
-__device__ __forceinline__ float dequant1(uint32_t raw, const DivK &k)
+__device__ __forceinline__ float fmax3abs(float m, float a, float b)
+{   // max(m, |a|, |b|): one v_max3_f32 with source modifiers
+    return __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(a)), __builtin_fabsf(b));
+}
+// two coefficients of one subband; vmax: the largest magnitude the wave's lanes have de-quantised
+__device__ __forceinline__ void dequant1x2(uint32_t raw0, uint32_t raw1, const DivK &k, float &x0, float &x1, float &vmax)
 {   // (|v| + 0.5) sgn v = v + clamp(v, -0.5, 0.5), exact for |v| < 2^23; 0 stays 0
-    const float y = (float)(int)raw;
-    return div_rcv(y + fmed3(y, -0.5f, 0.5f), k);
+    const float y0 = (float)(int)raw0, y1 = (float)(int)raw1;
+    vmax = fmax3abs(vmax, y0, y1);
+    x0 = div_rcv(y0 + fmed3(y0, -0.5f, 0.5f), k);
+    x1 = div_rcv(y1 + fmed3(y1, -0.5f, 0.5f), k);
 }
 // binary exponent e of x = m 2^e, 0.5 <= |m| < 1; 0 for zero (and infinities / NaN)
 __device__ __forceinline__ int frexp_exp(float x)
@@ -1231,7 +1238,7 @@ struct Inv97Steps { DivK ll, hl, lh, hh, qs; };
 // one subband row pair-segment to samples (s0, d0, s1, d1); HIGH: LH / HH row, else LL / HL (LL de-quantised on
 // the coarsest level only: DEQ_S)
 template <bool HIGH, bool DEQ_S, bool ONE_DIV, bool EXACT>
-__device__ __forceinline__ void convert97(const DwtInvArgs &a, const Inv97Steps &k, const SubRaw &r, float v[4])
+__device__ __forceinline__ void convert97(const DwtInvArgs &a, const Inv97Steps &k, const SubRaw &r, float v[4], float &vmax)
 {
     if constexpr (EXACT) {
         const float qd = HIGH ? a.q[3] : a.q[1], qsb = HIGH ? a.q[2] : a.q[0];
@@ -1241,8 +1248,8 @@ __device__ __forceinline__ void convert97(const DwtInvArgs &a, const Inv97Steps 
         return;
     }
     const DivK &kd = HIGH ? k.hh : k.hl, &ks = HIGH ? k.lh : k.ll;
-    v[1] = dequant1(r.d0, kd); v[3] = dequant1(r.d1, kd);
-    if (DEQ_S) { v[0] = dequant1(r.s0, ks); v[2] = dequant1(r.s1, ks); }
+    dequant1x2(r.d0, r.d1, kd, v[1], v[3], vmax);
+    if (DEQ_S) dequant1x2(r.s0, r.s1, ks, v[0], v[2], vmax);
     else { v[0] = __uint_as_float(r.s0); v[2] = __uint_as_float(r.s1); }
     if (!ONE_DIV) {
         v[1] = div_rcv(v[1], k.qs); v[3] = div_rcv(v[3], k.qs);
@@ -1305,6 +1312,7 @@ __device__ __forceinline__ bool dwt_inv97_band(const DwtInvArgs &a, int strip, i
 #pragma unroll
     for (int i = 0; i < 4; i++) { ddp[i] = s1p[i] = d1p[i] = s0p[i] = 0.0f; }
     int emin = 0;                                            // smallest exponent a lifting division has seen
+    float vmax = 0.0f;                                       // largest coefficient magnitude de-quantised
 #pragma unroll 1
     for (int g = 0; g < kIters / kGroup; g++) {
 #pragma unroll
@@ -1312,8 +1320,8 @@ __device__ __forceinline__ bool dwt_inv97_band(const DwtInvArgs &a, int strip, i
             const int it = g * kGroup + r;
             const int j = j0 + it;
             float ln[4], hn[4];
-            convert97<false, FIRST, ONE_DIV, EXACT>(a, k, rawL[r], ln);
-            convert97<true, true, ONE_DIV, EXACT>(a, k, rawH[r], hn);
+            convert97<false, FIRST, ONE_DIV, EXACT>(a, k, rawL[r], ln, vmax);
+            convert97<true, true, ONE_DIV, EXACT>(a, k, rawH[r], hn, vmax);
             // (also in the last trip, whose rows nobody uses: an `if` here makes the compiler merge loaded and kept
             // registers with copies behind a full s_waitcnt, which serialises the prefetch; reflect_* keep every
             // row inside the subband).  Fenced: left to itself the scheduler sinks the loads to the end of the trip.
@@ -1357,7 +1365,8 @@ __device__ __forceinline__ bool dwt_inv97_band(const DwtInvArgs &a, int strip, i
             }
         }
     }
-    return !EXACT && __builtin_amdgcn_ballot_w64(emin <= kTinyExp) != 0ull;
+    // (65536: the reciprocal form of the de-quantisation is verified for 16 bit-planes, dequant_fast_ok)
+    return !EXACT && __builtin_amdgcn_ballot_w64(emin <= kTinyExp || !(vmax < 65536.0f)) != 0ull;
 }
 
 #ifndef PICSONG_DWT_INV97_WAVES

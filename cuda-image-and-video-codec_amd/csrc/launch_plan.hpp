@@ -192,7 +192,6 @@ inline std::vector<InvLaunch> plan_dwt_inverse(const int32_t *d_in, void *d_out,
         {   // qs = 2^k: dividing by it is exact scaling, dwt_inv97_kernel folds it into the step
             int e = 0;
             a.one_div = std::frexp(qs, &e) == 0.5f ? 1 : 0;
-            a.trusted = 0;
             const char *x = getenv("PICSONG_DWT_EXACT_REPLAY");
             a.exact_replay = x && atoi(x) != 0 ? 1 : 0;
         }

@@ -87,9 +87,8 @@ static void launch_inv(const picsong_ctx *c, const InvLaunch &f, hipStream_t s, 
     // f.fast: the 9/7 divisions in their reciprocal form (verified for this context's qs at creation); the vector
     // launches of such a context are the lean kernel's (PICSONG_DWT_INV97=0: dwt_inv_kernel's FAST instantiations)
     static const bool lean97 = !(getenv("PICSONG_DWT_INV97") && atoi(getenv("PICSONG_DWT_INV97")) == 0);
-    // (its instantiations: the frame path's coefficients, i.e. trusted; a coarsest level that also writes pixels,
-    // wl = 1, stays with dwt_inv_kernel)
-    const bool l97 = c->p.lossy && f.fast && lean97 && f.vec && f.a.trusted && !(f.a.first && f.a.dst_u8);
+    // (a coarsest level that also writes pixels, wl = 1, stays with dwt_inv_kernel)
+    const bool l97 = c->p.lossy && f.fast && lean97 && f.vec && !(f.a.first && f.a.dst_u8);
     if (l97) {
         if (f.a.dst_u8) {
             if (f.a.one_div) dwt_inv97_kernel<BAND, true, false, true><<<grid, 256, 0, s>>>(f.a);
@@ -616,7 +615,6 @@ static int dwt_inverse_impl(picsong_ctx *c, const int32_t *d_in, void *d_out, ui
         plan.back().a.off = 1 << (c->p.bit_depth - 1);
         if (fused) *fused = true;
     }
-    for (InvLaunch &f : plan) f.a.trusted = 1;               // the coefficients are bpc_decode_kernel's: 16 bit-planes at most
     if (frames > 1) {
         const unsigned long long in_z = (unsigned long long)c->P * 4ull, wrk_z = (unsigned long long)(c->P + c->extra) * 4ull;
         for (InvLaunch &f : plan) {
@@ -642,12 +640,7 @@ int picsong_dwt_inverse(picsong_ctx *c, const int32_t *d_in, void *d_out, void *
 {
     if (!c || !d_in || !d_out) return fail(PICSONG_ERR_ARG, "dwt_inverse: null argument");
     hipStream_t s = (hipStream_t)stream;
-    // PICSONG_DWT_TRUST_STAGE=1 (tests, tools): the stage call promises coefficients of at most 16 bit-planes like the
-    // frame path does, and so runs the frame path's kernels with samples out
-    const char *te = getenv("PICSONG_DWT_TRUST_STAGE");
-    const int trusted = te && atoi(te) != 0 ? 1 : 0;
-    for (InvLaunch &f : plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs, c->fast_div)) {
-        f.a.trusted = trusted;
+    for (const InvLaunch &f : plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs, c->fast_div)) {
         switch (f.band) {
         case 32: launch_inv<32>(c, f, s); break;
         case 16: launch_inv<16>(c, f, s); break;

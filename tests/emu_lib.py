@@ -93,13 +93,11 @@ def bpc_encode_range(coef, wl, lut, cb_begin, cb_count):
     return staging, sizes, int(flag[0])
 
 
-def dwt_inverse(coef, wl, lossy, qs=1.0, extra=0, trusted=False):
-    """trusted: the launches the frame path makes (coefficients of at most 16 bit-planes promised)."""
+def dwt_inverse(coef, wl, lossy, qs=1.0, extra=0):
     AH, AW = coef.shape
     coef = aligned_copy(np.ascontiguousarray(coef, np.int32))
     out = aligned_zeros(AW * AH + extra, np.float32 if lossy else np.int32)
-    fn = lib().emu_dwt_inverse_trusted if trusted else lib().emu_dwt_inverse
-    fn(_p(coef), _p(out), AW, AH, wl, int(lossy), C.c_float(qs))
+    lib().emu_dwt_inverse(_p(coef), _p(out), AW, AH, wl, int(lossy), C.c_float(qs))
     return out
 
 

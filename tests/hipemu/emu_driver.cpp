@@ -48,7 +48,7 @@ static bool emu_lean97() { const char *e = getenv("PICSONG_DWT_INV97"); return !
 template <int BAND> static void emu_inv(const InvLaunch &f, int lossy)
 {
     DwtInvArgs a = f.a;
-    if (f.vec && lossy && f.fast && emu_lean97() && a.trusted && !(a.first && a.dst_u8)) {
+    if (f.vec && lossy && f.fast && emu_lean97() && !(a.first && a.dst_u8)) {
         const dim3 grid(f.gx, f.gy);
         if (a.dst_u8) {
             if (a.one_div) emu::launch(grid, dim3(256), [&] { dwt_inv97_kernel<BAND, true, false, true>(a); });
@@ -158,21 +158,6 @@ void emu_dwt_inverse(const int32_t *in, void *out, int aw, int ah, int wl, int l
     }
 }
 
-// the stage call with the frame path's promise (coefficients of at most 16 bit-planes): the lean 9/7 kernel's
-// instantiations with samples out
-void emu_dwt_inverse_trusted(const int32_t *in, void *out, int aw, int ah, int wl, int lossy, float qs)
-{
-    for (InvLaunch &f : plan_dwt_inverse(in, out, aw, ah, wl, qs, emu_fast_div(lossy, qs, wl))) {
-        f.a.trusted = 1;
-        switch (f.band) {
-        case 32: emu_inv<32>(f, lossy); break;
-        case 16: emu_inv<16>(f, lossy); break;
-        case 8: emu_inv<8>(f, lossy); break;
-        default: emu_inv<4>(f, lossy); break;
-        }
-    }
-}
-
 // the frame path's inverse: the finest level writes clamped pixels (mirrors dwt_inverse_impl);
 // returns 1 when that fused kernel applied
 int emu_dwt_inverse_u8(const int32_t *in, void *scratch, uint8_t *pixels, int aw, int ah, int wl, int lossy, float qs)
@@ -180,7 +165,6 @@ int emu_dwt_inverse_u8(const int32_t *in, void *scratch, uint8_t *pixels, int aw
     std::vector<InvLaunch> plan = plan_dwt_inverse(in, scratch, aw, ah, wl, qs, emu_fast_div(lossy, qs, wl));
     const bool fused = !plan.empty() && plan.back().vec && (((uintptr_t)pixels) & 3u) == 0;
     if (fused) { plan.back().a.dst_u8 = pixels; plan.back().a.off = 128; }
-    for (InvLaunch &f : plan) f.a.trusted = 1;
     for (const InvLaunch &f : plan) {
         switch (f.band) {
         case 32: emu_inv<32>(f, lossy); break;

@@ -412,10 +412,11 @@ def test_dwt97_inverse_fast_and_dividing_kernels_agree(oracle, E, monkeypatch, W
                                        (328, 192, 3, 0.7), (256, 64, 1, 0.5), (1864, 128, 2, 0.25)])
 @pytest.mark.parametrize("replay", [False, True])
 def test_dwt97_inverse_lean_kernel(oracle, E, monkeypatch, W, H, wl, qs, replay):
-    """The frame path's 9/7 synthesis (dwt_inv97_kernel: branch-free de-quantisation, one division when qs is a
-    power of two, the coarsest level's instantiation, bands past the bottom edge, edge and interior waves) against
-    the oracle, samples and fused pixels; `replay`: every wave runs its band a second time with true divisions
-    (the pass a too-small lifting operand asks for) and must leave the same words."""
+    """The lean 9/7 synthesis (dwt_inv97_kernel: branch-free de-quantisation, one division when qs is a power of
+    two, the coarsest level's instantiation, bands past the bottom edge, edge and interior waves, coefficients
+    beyond the verified 16 bit-planes) against the oracle, samples and fused pixels; `replay`: every wave runs its
+    band a second time with true divisions (the pass a too-small lifting operand or a too-big coefficient asks
+    for) and must leave the same words."""
     monkeypatch.delenv("PICSONG_DWT_EXACTDIV", raising=False)
     monkeypatch.delenv("PICSONG_DWT_INV97", raising=False)
     if replay:
@@ -428,17 +429,20 @@ def test_dwt97_inverse_lean_kernel(oracle, E, monkeypatch, W, H, wl, qs, replay)
     coef[3, 5] = 65535
     coef[H // 2 + 1, W // 2 + 2] = -65535
     coef[H - 1, W - 1] = 4000
+    if W >= 512:                                         # beyond 16 bit-planes: those waves take the second pass
+        coef[7, 300] = 65536
+        coef[H // 2 + 3, 40] = -(1 << 23) + 1
     coef[0, :8] = rng.integers(-20000, 20000, 8)
     extra = oracle.dwt_extra(W, H, wl)
     ref, ex = oracle.dwt_inverse(coef, wl, True, qs)
-    got = E.dwt_inverse(coef, wl, True, qs, extra=extra, trusted=True)
+    got = E.dwt_inverse(coef, wl, True, qs, extra=extra)
     assert np.array_equal(got[extra:].view(np.uint32), ref[ex:].view(np.uint32))
     want = oracle.level_shift_inv(ref[ex:]).reshape(H, W).astype(np.uint8)
     pix, fused = E.dwt_inverse_u8(coef, wl, True, qs, extra=extra)
     assert fused and np.array_equal(pix, want)
     # and the same launches through dwt_inv_kernel's FAST instantiations
     monkeypatch.setenv("PICSONG_DWT_INV97", "0")
-    old = E.dwt_inverse(coef, wl, True, qs, extra=extra, trusted=True)
+    old = E.dwt_inverse(coef, wl, True, qs, extra=extra)
     assert np.array_equal(old[extra:].view(np.uint32), ref[ex:].view(np.uint32))
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Level-by-level comparison of the 9/7 synthesis work buffer: PICSONG_DWT_TRUST_STAGE=1 runs of picsong_dwt_inverse
-against a reference buffer (save with `save`, compare with `cmp N`)."""
+"""Level-by-level comparison of the 9/7 synthesis work buffer: runs of picsong_dwt_inverse against a reference
+buffer (`save` under PICSONG_DWT_INV97=0, i.e. the other kernel family, then `cmp N`)."""
 import os, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, os.path.join(ROOT, "cuda-image-and-video-codec_amd", "python")); sys.path.insert(0, os.path.join(ROOT, "tests"))
