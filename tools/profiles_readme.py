@@ -51,6 +51,12 @@ dec = open(P("decode.txt")).read()
 decn = re.findall(r"= (\d+) Mpixel/s", dec)
 rd, r3 = b["roofline_dwt"], b["roofline_dwt"]["three_frames_per_call"]
 rl, rl3 = bl["roofline_dwt"], bl["roofline_dwt"]["three_frames_per_call"]
+# the lean 9/7 synthesis kernel's launches of one decoded frame, finest level first (band height 32, 16, 8, 4 ...)
+_inv97 = sorted(((k, v) for k, v in sdecl.items() if "dwt_inv97_kernel<" in k),
+                key=lambda kv: (-int(kv[0].split("dwt_inv97_kernel<")[1].split(",")[0]), "false, true, " in kv[0]))
+_per_frame = min(v[0] for _, v in _inv97) if _inv97 else 1
+inv97_txt = " + ".join(("%d x %.1f" % (v[0] // _per_frame, v[1])) if v[0] // _per_frame > 1 else "%.1f" % v[1] for _, v in _inv97)
+inv97_sum = sum(v[0] // _per_frame * v[1] for _, v in _inv97)
 rows = [
     ("`%s_bench.json`" % tag,
      "the default bench line: 8K lossless, 3 streams x 1 frame per call, %d steps x %d frames (%.2f s timed): **%.1f Gpixel/s, %.4f ms/frame**; "
@@ -77,10 +83,10 @@ rows = [
     ("`%s_kernel_stats_4k.csv`" % tag, "`--workload 4k_lossless` (4 frames per launch): coder %.0f us per 4-frame launch, fused DWT head %.1f us per 4 frames"
      % (s4[enc][1], s4[head_i][1])),
     ("`%s_kernel_stats_decode.csv`, `..._decode_8k_lossy.csv`" % tag,
-     "`rocprofv3 --kernel-trace --stats -- python3 tools/decode_bench.py [lossy]`: decoder `<false, 8>` %.0f / %.0f us, inverse DWT %.1f + %.1f + 3 x %.1f us (5/3), %.1f + %.1f + 4 x %.1f us (9/7), unpack %.1f / %.1f us"
+     "`rocprofv3 --kernel-trace --stats -- python3 tools/decode_bench.py [lossy]`: decoder `<false, 8>` %.0f / %.0f us, inverse DWT %.1f + %.1f + 3 x %.1f us (5/3), %s = **%.0f us** (9/7, `dwt_inv97_kernel`, levels 0 .. 5; before it: 54.5 + 22.8 + 4 x 10.2 = 118), unpack %.1f / %.1f us"
      % (find(sdec, "bpc_decode_kernel<false, 8>")[1], find(sdecl, "bpc_decode_kernel<false, 8>")[1],
         find(sdec, "dwt_inv_kernel<int, false, 16")[1], find(sdec, "dwt_inv_kernel<int, false, 8")[1], find(sdec, "dwt_inv_kernel<int, false, 4")[1],
-        find(sdecl, "dwt_inv_kernel<float, true, 16")[1], find(sdecl, "dwt_inv_kernel<float, true, 8")[1], find(sdecl, "dwt_inv_kernel<float, true, 4")[1],
+        inv97_txt, inv97_sum,
         find(sdec, "unpack_kernel")[1], find(sdecl, "unpack_kernel")[1])),
     ("`%s_pmc_hbm.csv`" % tag,
      "FETCH_SIZE / WRITE_SIZE passes: coder FETCH x2 = %.1f MB (coefficients once + the plane scratch read back) + WRITE %.1f MB = **%.0f MB = %.2f x the %.1f MB algorithmic** (round 1: 344 MB, 2.24 x); fused DWT head FETCH x2 = %.1f MB, WRITE %.1f MB"
