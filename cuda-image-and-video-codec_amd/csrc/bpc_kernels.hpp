@@ -193,10 +193,15 @@ __device__ __forceinline__ void wave_lds_done()
 // (arithmeticDecoder BPCEngine.cu:420-428), so a load from the staging array puts an L2 / HBM round trip
 // (500-900 cycles) into the dependent chain of every call site that starts a codeword -- about 1100 times
 // per wave.  Codewords are consumed in slot order, so the wave keeps a window of its two codeblocks'
-// streams in LDS: 128 entries per codeblock, of which [cnt, cnt + 64) are always there; whenever a counter
-// passes a multiple of 64 the lanes of that half fetch the next 64 (two coalesced loads), which will not be
-// needed for at least 32 more reservations.  A reservation then reads its codeword with LDS latency.
-constexpr int kDecRing = 128;
+// streams in LDS: 256 entries per codeblock, filled 64 at a time (two coalesced loads by the lanes of that
+// half) up to an edge F (next_lo / next_hi) that dec_ring_keep holds at least 192 ahead of the codeblock's
+// counter.  A reservation then reads its codeword with LDS latency.  The plane loops look after the window
+// once per ROW (a row's call sites reserve at most 4 x 32 slots of a codeblock: two columns, bit and sign),
+// not per call site: seven scalar instructions and a branch fewer at every site that starts a codeword, which
+// nearly every site does for some lane.  (-k's row scan, with up to 34 sites a row, and -cp 3 keep the check
+// in the call site.)
+constexpr int kDecRing = 256;
+constexpr uint32_t kDecRingAhead = 192u;
 __device__ __forceinline__ void dec_ring_fill(const int32_t *cwarr, uint32_t *ring, uint32_t first, uint32_t t)
 {   // entries first .. first + 63 of the lane's codeblock (cwarr[k] = codeword k; k <= 4094 exists)
     const uint32_t e0 = first + t, e1 = first + 32u + t;
@@ -204,17 +209,26 @@ __device__ __forceinline__ void dec_ring_fill(const int32_t *cwarr, uint32_t *ri
     ring[e0 & (kDecRing - 1)] = (uint32_t)v0;
     ring[e1 & (kDecRing - 1)] = (uint32_t)v1;
 }
-// after a reservation: refill the half whose counter passed its window edge
-__device__ __forceinline__ void dec_ring_advance(Coder &c, const int32_t *cwarr, uint32_t upper_mask)
+// codewords 0 .. 255 of both codeblocks (reads stay inside the codeblock's 4096 staging words whatever its
+// length; what lies beyond the length is never used)
+__device__ __forceinline__ void dec_ring_init(Coder &c, const int32_t *cwarr)
 {
-    const bool lo = c.cnt_lo >= c.next_lo, hi = c.cnt_hi >= c.next_hi;        // wave-uniform
-    if (lo || hi) {
-        wave_lds_done();                                   // every lane has read this site's codeword
+#pragma unroll
+    for (uint32_t f = 0; f < (uint32_t)kDecRing; f += 64u) dec_ring_fill(cwarr, c.ring, f, c.t);
+    c.next_lo = c.next_hi = (uint32_t)kDecRing;
+}
+// the window of both codeblocks at least kDecRingAhead codewords ahead of their counters
+__device__ __forceinline__ void dec_ring_keep(Coder &c, const int32_t *cwarr, uint32_t upper_mask)
+{
+    bool lo = c.next_lo - c.cnt_lo < kDecRingAhead, hi = c.next_hi - c.cnt_hi < kDecRingAhead;     // wave-uniform
+    while (lo || hi) {
+        wave_lds_done();                                   // every lane has read the codewords of its earlier sites
         const uint32_t edge = upper_mask ? c.next_hi : c.next_lo;
-        if (upper_mask ? hi : lo) dec_ring_fill(cwarr, c.ring, edge + 64u, c.t);
+        if (upper_mask ? hi : lo) dec_ring_fill(cwarr, c.ring, edge, c.t);
         wave_lds_done();                                   // (a later reservation of another lane reads them)
         if (lo) c.next_lo = __builtin_amdgcn_readfirstlane(c.next_lo + 64u);
         if (hi) c.next_hi = __builtin_amdgcn_readfirstlane(c.next_hi + 64u);
+        lo = c.next_lo - c.cnt_lo < kDecRingAhead; hi = c.next_hi - c.cnt_hi < kDecRingAhead;
     }
 }
 
@@ -1300,6 +1314,8 @@ __global__ __launch_bounds__(256) void lds_order_selftest_kernel(int iters, uint
 // sets `one` in them.  The interval split and the compare run in every lane (the result of a lane
 // that is off is never used) so that the ballot is the compare's own mask: a bool that leaves an
 // exec-masked region costs a select and a second compare to get back into a mask.
+// KEEP: look after the codeword window here (callers without a per-row dec_ring_keep)
+template <bool KEEP = true>
 __device__ __forceinline__ uint64_t dec_site_m(Coder &c, bool on, uint64_t onm, uint32_t p, uint32_t prec,
                                                uint32_t upper_mask, const int32_t *stage, bool &one)
 {
@@ -1320,7 +1336,7 @@ __device__ __forceinline__ uint64_t dec_site_m(Coder &c, bool on, uint64_t onm, 
         reserve_enc(c, on && empty, m, upper_mask);
         if (on && empty) c.cw = c.ring[c.slot & (kDecRing - 1)];
 #endif
-        dec_ring_advance(c, stage, upper_mask);            // stage = the codeword array (staging + 1)
+        if constexpr (KEEP) dec_ring_keep(c, stage, upper_mask);       // stage = the codeword array (staging + 1)
     }
 #if defined(__AMDGCN__)
     // a = ((S * p) >> prec) + 1;  cw >= L + a decodes a 1: S' = S - a, L' = L + a;  else S' = a - 1
@@ -1360,11 +1376,12 @@ __device__ __forceinline__ uint64_t dec_site_m(Coder &c, bool on, uint64_t onm, 
     return gem & onm;
 #endif
 }
+template <bool KEEP = true>
 __device__ __forceinline__ bool dec_site_on(Coder &c, bool on, uint64_t onm, uint32_t p, uint32_t prec,
                                             uint32_t upper_mask, const int32_t *stage)
 {
     bool one;
-    (void)dec_site_m(c, on, onm, p, prec, upper_mask, stage, one);
+    (void)dec_site_m<KEEP>(c, on, onm, p, prec, upper_mask, stage, one);
     return one;
 }
 __device__ __forceinline__ uint32_t dec_site(Coder &c, uint32_t inact, uint32_t p, uint32_t prec,
@@ -1389,7 +1406,7 @@ __device__ __forceinline__ void sign_table_fill(uint8_t *tab, uint32_t lane)
 }
 
 // One coefficient of the decoder's significance propagation pass; returns the ballot of the lanes
-// whose coefficient became significant.  wo/wl/wr: W-form significance of the own / left / right
+// whose coefficient became significant.  (The caller looks after the codeword window: dec_ring_keep once a row.)  wo/wl/wr: W-form significance of the own / left / right
 // column, so/sl/sr: W-form signs; cur: the plane's 32 rows being decoded (X-form dword).
 __device__ __forceinline__ uint64_t dec_spp_coeff(Coder &c, bool idle, uint64_t actm, uint32_t ii, M64 &wo, const M64 &wl,
                                                   const M64 &wr, M64 &so, const M64 &sl, const M64 &sr,
@@ -1405,7 +1422,7 @@ __device__ __forceinline__ uint64_t dec_spp_coeff(Coder &c, bool idle, uint64_t 
                          (uint32_t)__builtin_popcount(tr);
     const uint32_t p07 = __builtin_amdgcn_perm(pl.sig1, pl.sig0, ctx | 0x0C0C0C00u);
     bool one;
-    const uint64_t onem = dec_site_m(c, on, onm, ctx >= 8u ? pl.sig8 : p07, prec, upper_mask, stage, one);
+    const uint64_t onem = dec_site_m<false>(c, on, onm, ctx >= 8u ? pl.sig8 : p07, prec, upper_mask, stage, one);
     if (onem != 0ull) {
         const uint32_t xo = triple(so, ii), xl = triple(sl, ii), xr = triple(sr, ii);
         // index: up (to/xo bit 0) | down (bit 2) | left (tl/xl bit 1) | right (tr/xr bit 1)
@@ -1413,7 +1430,7 @@ __device__ __forceinline__ uint64_t dec_spp_coeff(Coder &c, bool idle, uint64_t 
         idx |= ((tl & 2u) << 3) | ((xl & 2u) << 4) | ((tr & 2u) << 5) | ((xr & 2u) << 6);
         const uint32_t tv = sgt[idx];
         const uint32_t p2 = (pl.sign >> (tv >> 3)) & 0xFFu;
-        const bool s2 = dec_site_on(c, one, onem, p2, prec, upper_mask, stage);
+        const bool s2 = dec_site_on<false>(c, one, onem, p2, prec, upper_mask, stage);
         if (one) {
             w_set(so, ii, (s2 ? 1u : 0u) ^ (tv & 1u));          // :587-589
             w_set(wo, ii, 1u);
@@ -1534,10 +1551,7 @@ void bpc_decode_kernel(BpcArgs a)
     Coder c = { 0u, 0u, 0u, 0u, 0u, 0u, ~0ull, 64u, 64u, nullptr, t, nullptr };
     c.ldscnt = &lds_cnt[(threadIdx.x >> 6) * 2u + half];
     c.ring = cw_ring + ((threadIdx.x >> 6) * 2u + half) * kDecRing;
-    // codewords 0 .. 127 of both codeblocks (reads stay inside the codeblock's 4096 staging words whatever
-    // its length; what lies beyond the length is never used)
-    dec_ring_fill(cw, c.ring, 0u, t);
-    dec_ring_fill(cw, c.ring, 64u, t);
+    dec_ring_init(c, cw);
     wave_lds_done();
     M64 sigL = { 0u, 0u }, sigR = { 0u, 0u }, refL = { 0u, 0u }, refR = { 0u, 0u };
 
@@ -1587,6 +1601,7 @@ void bpc_decode_kernel(BpcArgs a)
             while (rows) {
                 const uint32_t ii = (uint32_t)__builtin_ctz(rows);
                 rows &= rows - 1u;
+                dec_ring_keep(c, cw, upper_mask);
                 // all lanes: left column, neighbours = lane-1's right column | own right column
                 const uint64_t bL = dec_spp_coeff(c, idle != 0u, actm, ii, wL, wPR, wR, sL, sPR, sR, curL, pl, prec, upper_mask, cw, sign_tab);
                 // lane+1's left column as it is after this row's left phase (:791, shfl_down)
@@ -1625,12 +1640,13 @@ void bpc_decode_kernel(BpcArgs a)
 #pragma unroll 1
                 for (int ii = 0; ii < last; ii++) {
                     bool one;
+                    dec_ring_keep(c, cw, upper_mask);
                     const uint64_t mL = shl_carry(xL);
                     uint64_t dL = 0ull, dR = 0ull;
-                    if (mL != 0ull) dL = dec_site_m(c, __builtin_amdgcn_inverse_ballot_w64(mL), mL, pl.ref, prec, upper_mask, cw, one);
+                    if (mL != 0ull) dL = dec_site_m<false>(c, __builtin_amdgcn_inverse_ballot_w64(mL), mL, pl.ref, prec, upper_mask, cw, one);
                     shl_in(accL, dL);
                     const uint64_t mR = shl_carry(xR);
-                    if (mR != 0ull) dR = dec_site_m(c, __builtin_amdgcn_inverse_ballot_w64(mR), mR, pl.ref, prec, upper_mask, cw, one);
+                    if (mR != 0ull) dR = dec_site_m<false>(c, __builtin_amdgcn_inverse_ballot_w64(mR), mR, pl.ref, prec, upper_mask, cw, one);
                     shl_in(accR, dR);
                 }
                 // row 0 sits at bit last - 1 of the accumulators
@@ -1643,8 +1659,9 @@ void bpc_decode_kernel(BpcArgs a)
                 rows &= rows - 1u;
                 const bool oL = ((rL >> ii) & 1u) != 0u, oR = ((rR >> ii) & 1u) != 0u;
                 const uint64_t mL = __builtin_amdgcn_ballot_w64(oL), mR = __builtin_amdgcn_ballot_w64(oR);
-                if (mL != 0ull) curL |= dec_site_on(c, oL, mL, pl.ref, prec, upper_mask, cw) ? (1u << ii) : 0u;
-                if (mR != 0ull) curR |= dec_site_on(c, oR, mR, pl.ref, prec, upper_mask, cw) ? (1u << ii) : 0u;
+                dec_ring_keep(c, cw, upper_mask);
+                if (mL != 0ull) curL |= dec_site_on<false>(c, oL, mL, pl.ref, prec, upper_mask, cw) ? (1u << ii) : 0u;
+                if (mR != 0ull) curR |= dec_site_on<false>(c, oR, mR, pl.ref, prec, upper_mask, cw) ? (1u << ii) : 0u;
             }
             if (hw == 0) { PLlo[0] = curL; PRlo[0] = curR; } else { PLhi[0] = curL; PRhi[0] = curR; }
         }
@@ -1877,8 +1894,7 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
         c = Coder{ 0u, 0u, 0u, 0u, 0u, 0u, ~0ull, 64u, 64u, nullptr, t, nullptr };
         c.ldscnt = &lds_cnt[(threadIdx.x >> 6) * 2u + half];
         c.ring = cw_ring + ((threadIdx.x >> 6) * 2u + half) * kDecRing;
-        dec_ring_fill(cw, c.ring, 0u, t);
-        dec_ring_fill(cw, c.ring, 64u, t);
+        dec_ring_init(c, cw);
         wave_lds_done();
     } else {
         c.L = 0u; c.S = 0u; c.off = half * 16384u;
