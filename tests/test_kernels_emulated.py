@@ -408,7 +408,7 @@ def test_dwt97_inverse_fast_and_dividing_kernels_agree(oracle, E, monkeypatch, W
     assert np.array_equal(fast[extra:].view(np.uint32), ref[ex:].view(np.uint32))
 
 
-@pytest.mark.parametrize("W,H,wl,qs", [(320, 192, 3, 0.5), (64, 128, 5, 0.3), (512, 320, 6, 0.5), (1024, 64, 2, 2.0),
+@pytest.mark.parametrize("W,H,wl,qs", [(320, 192, 3, 0.5), (64, 128, 5, 0.3), (512, 320, 6, 0.5),
                                        (328, 192, 3, 0.7), (256, 64, 1, 0.5), (1864, 128, 2, 0.25)])
 @pytest.mark.parametrize("replay", [False, True])
 def test_dwt97_inverse_lean_kernel(oracle, E, monkeypatch, W, H, wl, qs, replay):
