@@ -9,9 +9,11 @@ A "step" = one batch of --frames-per-step 7680x4320 frames per rank (default 48:
 video), taken from a pool of --pool distinct device-resident frames (default 16 = 535 MB at 8K, past the
 256 MiB Infinity Cache, so that every frame's input comes from HBM) and coded --batch frames per call of
 picsong_encode_frames, the calls alternating over --streams HIP streams.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank codes its own frames ("weak"), and each call ends
-with the path's only exchange: codestream lengths all-gathered and payloads gathered to rank 0 over RCCL
-(SURVEY.md 8e); value = pixels all ranks encoded / max-over-ranks time.
+torch.distributed.run, one rank per GPU) every rank codes its own frames ("weak"), and each step ends
+with the path's only exchange: codestream lengths all-gathered and payloads gathered over RCCL --
+frame f of every rank's step to rank f mod N by default (--gather rotate: the writer role rotates, every xGMI
+link carries 1/N of a step), or all of them to rank 0 (--gather root0: 99 GB/s per peer at 8K lossless, more
+than one link direction carries); value = pixels all ranks encoded / max-over-ranks time.
 
 Prints ONE JSON line on rank 0.
 """
@@ -155,6 +157,10 @@ def main():
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams (each with its own context) consecutive calls alternate on (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", choices=["rotate", "root0"], default="rotate",
+                    help="N > 1: where a step's codestreams go -- 'rotate': frame f of every rank's step to rank f mod N "
+                         "(the writer role rotates: every xGMI link carries 1/N of a step), 'root0': everything to rank 0 "
+                         "(99 GB/s per peer at 8K against the ~77 GB/s of one link direction)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the N > 1 exchange path (per-step bucketed gather) at N = 1 too: exercises the code on a one-GPU box")
     ap.add_argument("--no-b3", action="store_true",
@@ -233,16 +239,21 @@ def main():
     calls_per_step = fps // batch
     # ---- N > 1: the only exchange of the frame-sharded path, bucketed per STEP (picsong_dist.gather_step, covered by
     # the gloo tests): a step's codestreams land in per-step slots, their lengths stay on the device
-    # (picsong_copy_last_totals), and ONE all-gather of the lengths + ONE grouped batch of sends to rank 0 move
-    # the whole step over RCCL -- run one step late (DeferredExchange), on a stream of its own, while the next step
-    # is being coded.  (Per call -- three host waits and two collectives every 0.2 ms -- the exchange was bound by
+    # (picsong_copy_last_totals), and ONE all-gather of the lengths + ONE grouped batch of sends / receives (to the
+    # frames' writers: rank f mod N, or rank 0 with --gather root0) move the whole step over RCCL -- run one step late
+    # (DeferredExchange), on a stream of its own, while the next step is being coded.  (Per call -- three host waits and two collectives every 0.2 ms -- the exchange was bound by
     # launch latency, not by xGMI.)  Every step's exchange is inside the timed region (flush).
     dx = pdist.DeferredExchange() if exch else None
     if exch:
         mss = codec.max_stream_shorts()
         slots = [torch.empty((fps, mss), dtype=torch.int16, device="cuda") for _ in range(2)]
         totals_dev = [torch.zeros(fps, dtype=torch.int32, device="cuda") for _ in range(2)]
-        gather_bufs = [torch.empty(fps * mss, dtype=torch.int16, device="cuda") for _ in range(world - 1)] if rank == 0 else None
+        rotate = args.gather == "rotate"
+        if rotate:      # every rank receives ceil(fps / world) frames from every peer
+            gather_bufs = [torch.empty((fps + world - 1) // world * mss, dtype=torch.int16, device="cuda") for _ in range(world - 1)]
+        else:
+            gather_bufs = [torch.empty(fps * mss, dtype=torch.int16, device="cuda") for _ in range(world - 1)] if rank == 0 else None
+        last_res = [None]
         xstream = torch.cuda.Stream(device=local_rank)
         step_done = [[torch.cuda.Event() for _ in range(nstreams)] for _ in range(2)]
         slots_free = [None, None]                       # recorded on xstream when a parity's slots have been sent
@@ -289,7 +300,8 @@ def main():
                     # every frame's stream goes out from its slot (no packing copy); the slots are free again
                     # when the sends have been handed to RCCL's stream and completed (q.wait() orders xstream)
                     res = pdist.gather_step([slots[par][f, :lens[f]] for f in range(fps)], rank, world, dev,
-                                            recv_bufs=gather_bufs)
+                                            recv_bufs=gather_bufs, rotate=rotate)
+                    last_res[0] = (par, lens, res)
                     ev = torch.cuda.Event()
                     ev.record(xstream)
                     slots_free[par] = ev
@@ -333,6 +345,30 @@ def main():
     if exch and last_lens[0] is not None:               # the lengths the last exchange moved are the streams' own
         loop_ok = loop_ok and all(9 + 2 * nCB + 1 < ln <= codec.max_stream_shorts() for ln in last_lens[0])
     torch.cuda.synchronize()
+    # ---- the last exchange's payloads, end to end: every sender's per-frame checksums (all-gathered, outside the
+    # timed region) against the checksums of what the receivers hold
+    exchange_ok = None
+    if exch and last_res[0] is not None:
+        par, lens, res = last_res[0]
+
+        def cksum(v):
+            v = v.to(torch.int64)
+            return (v * (torch.arange(v.numel(), device=v.device, dtype=torch.int64) % 251 + 1)).sum()
+        mine = torch.stack([cksum(slots[par][f, :lens[f]]) for f in range(fps)])
+        allck = torch.zeros(world * fps, dtype=torch.int64, device="cuda")
+        dist.all_gather_into_tensor(allck, mine)
+        allck = allck.view(world, fps)
+        ok = True
+        if res is not None:
+            for r in range(world):
+                for f in range(fps):
+                    v = res[r][f]
+                    if v is not None:
+                        ok = ok and int(cksum(v).item()) == int(allck[r, f].item())
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        exchange_ok = bool(okt.item())
+        loop_ok = loop_ok and exchange_ok
 
     total_shorts = codec.last_total()
     flag = codec.range_flag()
@@ -535,6 +571,10 @@ def main():
                    "bits_per_pixel": round(total_shorts * 16 / (W * H), 4)},
         "ms_per_frame": round(ms_per_frame, 5), "timed_seconds": round(dt, 3),
         "roundtrip_ok": roundtrip_ok, "timed_loop_outputs_ok": loop_ok, "range_flag": flag,
+        "exchange": None if not exch else {
+            "form": "frame f of a rank's step to rank f mod N, one grouped RCCL send / receive batch per step, one step late"
+                    if rotate else "every codestream to rank 0, one grouped RCCL send / receive batch per step, one step late",
+            "payloads_ok": exchange_ok},
         "stage_ms": {"dwt": round(dwt_ms, 4), "bpc": round(bpc_ms, 4), "pack": round(pack_ms, 4),
                      "note": "per frame, HIP events on the launch streams inside the timed region"},
         "stage_ms_single_stream": {"dwt": round(float(iso_ms[0]), 4), "bpc": round(float(iso_ms[1]), 4),

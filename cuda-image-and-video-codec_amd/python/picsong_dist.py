@@ -59,7 +59,7 @@ def gather_round(local_stream, rank, world, device, recv_bufs=None, group=None):
     return out
 
 
-def gather_step(streams, rank, world, device, recv_bufs=None, group=None):
+def gather_step(streams, rank, world, device, recv_bufs=None, group=None, rotate=False):
     """One exchange for a whole STEP of frames (a bucket of rounds): `streams` = this rank's codestreams of the step
     (list of 1-D int16 tensors on `device`, frame order, every rank the same count; an empty tensor = no payload).
     The lengths travel as ONE all-gather of a [world, n] tensor, the payloads as ONE grouped point-to-point batch:
@@ -67,14 +67,42 @@ def gather_step(streams, rank, world, device, recv_bufs=None, group=None):
     root's buffer for its rank, every peer on its own xGMI link at the same time.  Against gather_round per call
     this is one host wait and two collectives per step instead of three waits and two collectives per frame -- at
     5000 frames per second and GPU the per-call form is bound by launch latency, not by the links.  Returns on rank
-    0 a list of `world` lists of per-frame views, elsewhere None."""
+    0 a list of `world` lists of per-frame views, elsewhere None.
+
+    `rotate`: the writer role rotates frame by frame -- frame f of every rank's step goes to rank f mod world (and
+    stays where it is on that rank).  One destination cannot take the streams of eight encoders: an 8K lossless frame
+    is 20 MB every 0.2 ms, 99 GB/s per GPU, against the ~77 GB/s one direction of one xGMI link carries and the
+    7 x 77 GB/s a GPU can take in at all; rotated, a link carries 1/world of a step.  Returns on EVERY rank a list of
+    `world` lists of n entries: the view of frame f from rank r where f mod world == rank, None elsewhere;
+    `recv_bufs`: world - 1 buffers (peers in rank order, this rank left out), each big enough for the
+    ceil(n / world) frames a peer sends here."""
     n = len(streams)
     mine = torch.tensor([int(t.numel()) for t in streams], dtype=torch.int32, device=device)
     lens = torch.zeros(world * n, dtype=torch.int32, device=device)
     dist.all_gather_into_tensor(lens, mine, group=group)
     lens = lens.view(world, n).tolist()
     ops, out = [], None
-    if rank == 0:
+    if rotate:
+        out = [[None] * n for _ in range(world)]
+        for r in range(world):                               # what lands here: frames rank, rank + world, ... of every rank
+            if r == rank:
+                for f in range(rank, n, world):
+                    out[r][f] = streams[f]
+                continue
+            tot = sum(lens[r][f] for f in range(rank, n, world))
+            b = r if r < rank else r - 1
+            buf = recv_bufs[b][:tot] if recv_bufs is not None else torch.empty(tot, dtype=torch.int16, device=device)
+            o = 0
+            for f in range(rank, n, world):
+                v = buf[o:o + lens[r][f]]
+                o += lens[r][f]
+                out[r][f] = v
+                if lens[r][f]:
+                    ops.append(dist.P2POp(dist.irecv, v, r, group))
+        for f, t in enumerate(streams):                      # what leaves: in frame order per destination, as it is received
+            if f % world != rank and t.numel():
+                ops.append(dist.P2POp(dist.isend, t, f % world, group))
+    elif rank == 0:
         out = [list(streams)]
         for r in range(1, world):
             tot = sum(lens[r])

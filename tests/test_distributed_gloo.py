@@ -132,6 +132,49 @@ def test_gather_step_moves_a_whole_step_in_one_exchange(tmp_path, world):
         assert np.array_equal(np.load(tmp_path / f"lens_{u}.npy"), lens)
 
 
+def _rotate_worker(rank, world, port, outdir):
+    """picsong_dist.gather_step(rotate=True): frame f of every rank's step lands on rank f mod world."""
+    sys.path.insert(0, os.path.join(ROOT, "cuda-image-and-video-codec_amd", "python"))
+    import picsong_dist as pd
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    n = 7                                                    # not a multiple of the world size
+    rng = np.random.default_rng(200 + rank)
+    lens = [int(x) for x in rng.integers(1, 3000, n)]
+    lens[(rank + 2) % n] = 0                                 # a frame without payload
+    streams = [torch.from_numpy(rng.integers(-32768, 32767, k).astype(np.int16)) for k in lens]
+    for f, t in enumerate(streams):
+        np.save(os.path.join(outdir, f"sent_{rank}_{f}.npy"), t.numpy())
+    for use_bufs in (False, True):
+        per_peer = (n + world - 1) // world * 3000
+        bufs = [torch.empty(per_peer, dtype=torch.int16) for _ in range(world - 1)] if use_bufs else None
+        got = pd.gather_step(streams, rank, world, dev, recv_bufs=bufs, rotate=True)
+        assert len(got) == world and all(len(g) == n for g in got)
+        for r in range(world):
+            for f in range(n):
+                if f % world == rank:
+                    np.save(os.path.join(outdir, f"got{int(use_bufs)}_{rank}_{r}_{f}.npy"), got[r][f].numpy().copy())
+                else:
+                    assert got[r][f] is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_step_with_the_writer_role_rotating(tmp_path, world):
+    """Every (rank, frame) stream arrives, whole, at rank frame mod world and nowhere else (both buffer forms)."""
+    port = _free_port()
+    mp.spawn(_rotate_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for u in (0, 1):
+        for r in range(world):
+            for f in range(7):
+                want = np.load(tmp_path / f"sent_{r}_{f}.npy")
+                got = np.load(tmp_path / f"got{u}_{f % world}_{r}_{f}.npy")
+                assert np.array_equal(got, want)
+
+
 def test_deferred_exchange_order():
     sys.path.insert(0, os.path.join(ROOT, "cuda-image-and-video-codec_amd", "python"))
     import picsong_dist as pd
