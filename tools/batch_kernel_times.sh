@@ -1,3 +1,5 @@
+#!/bin/bash
+# rocprofv3 kernel averages of the 9/7 encode for 1 .. 6 frames per call (how the level launches amortise; run through gpurun)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for b in 1 2 3 4 6; do
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/bz_$b -- python3 bench.py --steps 4 --warmup 1 --frames-per-step 12 --streams 1 --batch $b --workload 8k_lossy --no-cpu-baseline --no-b3 > gpurun_out/bz_$b.log 2>&1
