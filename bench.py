@@ -245,7 +245,7 @@ def main():
     # launch latency, not by xGMI.)  Every step's exchange is inside the timed region (flush).
     dx = pdist.DeferredExchange() if exch else None
     if exch:
-        mss = codec.max_stream_shorts()
+        mss = (codec.max_stream_shorts() + 7) & ~7      # (slot rows and received streams on 16-byte boundaries)
         slots = [torch.empty((fps, mss), dtype=torch.int16, device="cuda") for _ in range(2)]
         totals_dev = [torch.zeros(fps, dtype=torch.int32, device="cuda") for _ in range(2)]
         rotate = args.gather == "rotate"

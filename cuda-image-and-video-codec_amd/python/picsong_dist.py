@@ -75,7 +75,7 @@ def gather_step(streams, rank, world, device, recv_bufs=None, group=None, rotate
     7 x 77 GB/s a GPU can take in at all; rotated, a link carries 1/world of a step.  Returns on EVERY rank a list of
     `world` lists of n entries: the view of frame f from rank r where f mod world == rank, None elsewhere;
     `recv_bufs`: world - 1 buffers (peers in rank order, this rank left out), each big enough for the
-    ceil(n / world) frames a peer sends here."""
+    ceil(n / world) frames a peer sends here, every length rounded up to a multiple of 8 shorts."""
     n = len(streams)
     mine = torch.tensor([int(t.numel()) for t in streams], dtype=torch.int32, device=device)
     lens = torch.zeros(world * n, dtype=torch.int32, device=device)
@@ -89,13 +89,14 @@ def gather_step(streams, rank, world, device, recv_bufs=None, group=None, rotate
                 for f in range(rank, n, world):
                     out[r][f] = streams[f]
                 continue
-            tot = sum(lens[r][f] for f in range(rank, n, world))
+            # (every received stream starts on a 16-byte boundary of its buffer: RCCL's copies vectorise)
+            tot = sum((lens[r][f] + 7) & ~7 for f in range(rank, n, world))
             b = r if r < rank else r - 1
             buf = recv_bufs[b][:tot] if recv_bufs is not None else torch.empty(tot, dtype=torch.int16, device=device)
             o = 0
             for f in range(rank, n, world):
                 v = buf[o:o + lens[r][f]]
-                o += lens[r][f]
+                o += (lens[r][f] + 7) & ~7
                 out[r][f] = v
                 if lens[r][f]:
                     ops.append(dist.P2POp(dist.irecv, v, r, group))

@@ -148,7 +148,7 @@ def _rotate_worker(rank, world, port, outdir):
     for f, t in enumerate(streams):
         np.save(os.path.join(outdir, f"sent_{rank}_{f}.npy"), t.numpy())
     for use_bufs in (False, True):
-        per_peer = (n + world - 1) // world * 3000
+        per_peer = (n + world - 1) // world * 3008
         bufs = [torch.empty(per_peer, dtype=torch.int16) for _ in range(world - 1)] if use_bufs else None
         got = pd.gather_step(streams, rank, world, dev, recv_bufs=bufs, rotate=True)
         assert len(got) == world and all(len(g) == n for g in got)
