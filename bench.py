@@ -146,8 +146,9 @@ def dwt_bytes(P, wl, s0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # a step = --frames-per-step frames; the default timed region is > 1 s (80 x 48 8K frames at ~0.3 ms)
-    ap.add_argument("--steps", type=int, default=80)
+    # a step = --frames-per-step frames; the default timed region is > 1 s (120 x 48 8K frames at ~0.2 ms)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default 120 at 8K, 480 at 4K: about 1.2 s of coding)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames-per-step", type=int, default=48)
     ap.add_argument("--batch", type=int, default=0,
@@ -169,6 +170,8 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=0,
                     help="rows of the frame the CPU baseline encodes (0 = whole frame)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 480 if args.workload.startswith("4k") else 120
 
     import torch
     import torch.distributed as dist
