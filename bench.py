@@ -5,8 +5,8 @@ Metric (BASELINE.json): Mpixels/s, encode (level shift + DWT + BPC + pack), 8K g
 -type 0 (5/3 lossless), device-resident u8 frame in -> device-resident uint16 codestream out;
 decode must round-trip bit-exactly (checked outside the timed region, reported as roundtrip_ok).
 
-A "step" = one batch of --frames-per-step 7680x4320 frames per rank (default 48: a second of a 48 fps
-video), taken from a pool of --pool distinct device-resident frames (default 16 = 535 MB at 8K, past the
+A "step" = one batch of --frames-per-step 7680x4320 frames per rank (default 256, about 50 ms of coding: the
+driver's `--steps 20` times about a second), taken from a pool of --pool distinct device-resident frames (default 16 = 535 MB at 8K, past the
 256 MiB Infinity Cache, so that every frame's input comes from HBM) and coded --batch frames per call of
 picsong_encode_frames, the calls alternating over --streams HIP streams.  With N > 1 (launched by
 torch.distributed.run, one rank per GPU) every rank codes its own frames ("weak"), and each step ends
@@ -15,7 +15,9 @@ frame f of every rank's step to rank f mod N by default (--gather rotate: the wr
 link carries 1/N of a step), or all of them to rank 0 (--gather root0: 99 GB/s per peer at 8K lossless, more
 than one link direction carries); value = pixels all ranks encoded / max-over-ranks time.
 
-Prints ONE JSON line on rank 0.
+`python bench.py --gpus N` with N > 1 and no torch.distributed environment starts the N ranks itself (a child
+`python -m torch.distributed.run`, before this process touches the GPU) and relays rank 0's line; fewer than N GPUs
+on the node is an error.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -51,7 +53,35 @@ def host_cores():
     return n
 
 
-PROFILE_TAG = "r02"          # profiles/<tag>_pmc_hbm.csv, <tag>_pmc_sq.csv, <tag>_valu_probe.json (tools/collect_profiles.sh)
+def _profile_tag():
+    """Newest round whose counter summaries are committed: profiles/<tag>_pmc_hbm.csv, <tag>_pmc_sq.csv,
+    <tag>_valu_probe.json, <tag>_library.sha256 (tools/collect_profiles.sh + tools/publish_profiles.sh)."""
+    for tag in ("r03", "r02"):
+        if os.path.exists(os.path.join(ROOT, "profiles", tag + "_pmc_sq.csv")):
+            return tag
+    return "r03"
+
+
+PROFILE_TAG = _profile_tag()
+
+
+def library_hashes():
+    """sha256 (first 16 hex digits) of the library this run loads and of the one the committed counter passes were
+    taken from (profiles/<tag>_library.sha256): the OFFLINE figures of the line (`traffic`, `valu_issue`) describe the
+    latter."""
+    import hashlib
+    so = os.environ.get("PICSONG_SO") or os.path.join(ROOT, "cuda-image-and-video-codec_amd", "csrc", "libpicsong_hip.so")
+    try:
+        mine = hashlib.sha256(open(so, "rb").read()).hexdigest()[:16]
+    except OSError:
+        mine = None
+    try:
+        prof = open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_library.sha256")).read().split()[0][:16]
+    except (OSError, IndexError):
+        prof = None
+    return {"library_sha256_16": mine, "profiles_tag": PROFILE_TAG, "profiles_library_sha256_16": prof,
+            "profiles_match_library": (mine == prof) if (mine and prof) else None}
+
 
 
 def pmc_traffic(workload, batch=1):
@@ -143,14 +173,108 @@ def dwt_bytes(P, wl, s0):
     return P * (s0 + 4) + 8 * P * sum(4.0 ** -l for l in range(1, wl))
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no torch.distributed environment: start the N ranks ourselves, as a CHILD
+    process (python -m torch.distributed.run, one rank per GPU) -- before this process has made any HIP call: a
+    process that has touched the GPU must never be replaced or forked -- relay the ranks' output and exit with the
+    child's code.  A node with fewer than N GPUs is an error, not a quiet world = 1 run."""
+    import subprocess
+    if not args.dry:
+        import torch                                    # (device_count() does not initialise the GPU)
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but this node has {have} GPU(s)", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in child.stdout:
+        if out.lstrip().startswith("{"):
+            line = out.strip()                          # rank 0's JSON line (printed once, below)
+        else:
+            sys.stderr.write(out)
+    rc = child.wait()
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        rc = 1
+    if line is not None:
+        print(line, flush=True)
+    return rc
+
+
+def dry_main(args, rank, world):
+    """--dry: the N-rank protocol of this benchmark without a GPU and without the codec (CPU tests of the launcher):
+    rendezvous, per-step exchange of stand-in codestreams over picsong_dist.gather_step, barrier-bracketed timing,
+    MAX over ranks, one JSON line on rank 0."""
+    import torch
+    import torch.distributed as dist
+    import picsong_dist as pdist
+    if world > 1:
+        dist.init_process_group(args.backend)
+    dev = torch.device("cpu")
+    fps = max(1, min(args.frames_per_step, 8))
+    def streams_of(r):                                  # every rank can rebuild what a peer sends
+        g = torch.Generator().manual_seed(1234 + r)
+        return [torch.randint(-32768, 32767, (64 + 8 * ((r + f) % 5),), dtype=torch.int16, generator=g) for f in range(fps)]
+    streams = streams_of(rank)
+    expect = [streams_of(r) for r in range(world)]
+    ok = True
+
+    def step():
+        nonlocal ok
+        if world == 1:
+            return
+        res = pdist.gather_step(streams, rank, world, dev, rotate=args.gather == "rotate")
+        if res is not None:
+            for r in range(world):
+                for f, v in enumerate(res[r]):
+                    if v is not None:
+                        ok = ok and bool(torch.equal(v, expect[r][f]))
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item())
+    if rank == 0:
+        print(json.dumps({"metric": "dry run of the N-rank protocol (no GPU, no codec)", "value": None, "unit": "Mpixels/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 4), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dry": True, "backend": args.backend,
+                          "exchange": {"payloads_ok": ok}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # a step = --frames-per-step frames; the default timed region is > 1 s (120 x 48 8K frames at ~0.2 ms)
+    # a step = --frames-per-step frames; the default timed region is > 1 s (24 x 256 8K frames at ~0.2 ms)
     ap.add_argument("--steps", type=int, default=None,
-                    help="timed steps (default 120 at 8K, 480 at 4K: about 1.2 s of coding)")
+                    help="timed steps (default 24 at 8K, 90 at 4K: about 1.2 s of coding)")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames-per-step", type=int, default=48)
+    # 256 frames: the driver's `--steps 20` then times about a second (5120 8K frames at ~0.2 ms)
+    ap.add_argument("--frames-per-step", type=int, default=256)
     ap.add_argument("--batch", type=int, default=0,
                     help="frames per picsong_encode_frames call (0 = the workload's default)")
     ap.add_argument("--pool", type=int, default=16, help="distinct device-resident input frames the steps rotate over")
@@ -169,21 +293,31 @@ def main():
                          "average a single-frame launch's)")
     ap.add_argument("--cpu-sample-rows", type=int, default=0,
                     help="rows of the frame the CPU baseline encodes (0 = whole frame)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the ranks (gloo: only with --dry)")
+    ap.add_argument("--dry", action="store_true",
+                    help="the N-rank protocol only (launcher, rendezvous, per-step exchange, timing) on CPU tensors: no GPU, "
+                         "no codec, no throughput -- what the CPU tests of the launcher run")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 480 if args.workload.startswith("4k") else 120
+        args.steps = 90 if args.workload.startswith("4k") else 24
+    if args.backend == "gloo" and not args.dry:
+        raise SystemExit("bench.py: --backend gloo only with --dry (the codec has no CPU path)")
 
-    import torch
-    import torch.distributed as dist
-
+    in_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not in_dist:
+        sys.exit(launch_ranks(args))                    # (nothing above has touched the GPU)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with "
-                  f"python -m torch.distributed.run --nproc-per-node {args.gpus} ...", file=sys.stderr)
-        args.gpus = world
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry:
+        sys.exit(dry_main(args, rank, world))
+
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the picsong HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -475,10 +609,15 @@ def main():
                 "single_stream": {"avg_launch_ms": round(float(iso_ms[1]) * batch, 4),
                                   "codeblocks_per_s": round(nCB / (float(iso_ms[1]) * 1e-3), 1)},
                 "valu_issue": valu_issue(pmc_valu(args.workload), ms_per_frame * 1e-3, float(iso_ms[1]) * 1e-3),
+                "source": library_hashes(),
                 "note": "BPC is bound by vector-instruction issue, not HBM (SURVEY 8d): codeblocks/s and "
                         "valu_issue are the figures of merit, the HBM fraction is reported for completeness. "
                         "`traffic` is the PMC figure of the committed counter passes (profiles/): the coefficients "
-                        "are read once, the transposed bit-planes go through a 16 KB-per-wave scratch"}
+                        "are read once, the transposed bit-planes go through a 16 KB-per-wave scratch.  "
+                        "frames_per_step x the isolated launch time exceeds ms_per_step: legal because the coder "
+                        "kernels of the calls in flight on the %d streams CO-RESIDE (a frame's launch fills 4 of a "
+                        "SIMD's 5 wave slots; the next call's waves take slots as they free up), so `avg_launch_ms` "
+                        "(HIP events around a launch that shares the GPU) is longer than a frame's share of the step" % nstreams}
     roofline_dwt = {"kernel": "dwt_fwd_kernel / dwt_fwd2_kernel (all levels, u8 ingest fused)", "bound": "hbm",
                     "achieved": round(dwt_b / (dwt_launch_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(dwt_b / (dwt_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),

@@ -566,21 +566,6 @@ __device__ __forceinline__ void enc_update(EncCoder &c, uint64_t onm, uint64_t o
 #undef PS_ENC_UPDATE
 #undef PS_ENC_UPDATE_TAIL
     c.emptym = em;
-#if 0
-    asm volatile(
-        "v_mul_u32_u24 %[a], %[S], %[p]\n\t"
-        "v_lshrrev_b32 %[a], %[pr], %[a]\n\t"          // a0
-        "s_mov_b64 exec, %[one]\n\t"
-        "v_add_u32 %[a], 1, %[a]\n\t"                   // lanes coding a 1: a = a0 + 1
-        "v_add_u32 %[L], %[L], %[a]\n\t"                //   L += a
-        "v_sub_u32 %[a], %[S], %[a]\n\t"                //   a = S - a  (their new S)
-        "s_mov_b64 exec, %[on]\n\t"
-        "v_mov_b32 %[S], %[a]\n\t"                      // lanes coding a 0 still hold a0 in a
-        "s_mov_b64 exec, -1\n\t"
-        "v_cmp_eq_u32_e64 %[em], 0, %[S]"
-        : [S] "+v"(c.S), [L] "+v"(c.L), [a] "=&v"(a), [em] "=s"(em)
-        : [on] "s"(onm), [one] "s"(onem), [p] "v"(p), [pr] "s"(prec));
-#endif
 #else
     if (J >= 0) p = (p >> (8 * (J < 0 ? 0 : J))) & 0xFFu;
     const uint32_t pe = __builtin_amdgcn_inverse_ballot_w64(onm) ? p : c.pone;     // (S * pone) >> prec == S

@@ -484,8 +484,18 @@ int picsong_ctx_set_lut_device(picsong_ctx *c, int comp, const picsong_lut_info 
     if (li.n_ref <= 0) li.n_ref = li.n_subbands * li.n_bitplanes * li.ctx_ref * wl + li.n_bitplanes * li.ctx_ref;
     if (li.n_sig <= 0) li.n_sig = li.n_subbands * li.n_bitplanes * li.ctx_sig * wl + li.n_bitplanes * li.ctx_sig;
     if (li.n_sign <= 0) li.n_sign = li.n_subbands * li.n_bitplanes * li.ctx_sign * wl + li.n_bitplanes * li.ctx_sign;
-    if ((size_t)li.n_ref + li.n_sig + li.n_sign > (size_t)kLutLdsMax)
-        return fail(PICSONG_ERR_ARG, "LUT table exceeds the %d entries the coder kernels hold in LDS", kLutLdsMax);
+    // the borrowed table is laid out for the context's coding passes: [ref | sig | sign] for -cp 2, the five sections
+    // [ref | sig | sign | cp_sig | cp_sign] for -cp 3 (what bpc3_kernel copies to LDS); `info->cp` as the façade's
+    // geometry() leaves it (0) means "the context's"; a table declared for the other mode is refused
+    const bool cp3 = c->p.cp == 3;
+    if (info->cp != 0 && cp3 != (info->cp == 3))
+        return fail(PICSONG_ERR_ARG, "the context codes %d passes, the device table is laid out for %d", c->p.cp,
+                    info->cp == 3 ? 3 : 2);
+    li.cp = c->p.cp;
+    const size_t one = (size_t)li.n_ref + (cp3 ? 2 : 1) * ((size_t)li.n_sig + li.n_sign);
+    if (one > (size_t)(cp3 ? kLutLdsMax3 : kLutLdsMax))
+        return fail(PICSONG_ERR_ARG, "LUT table of %zu entries exceeds the %d the coder kernels hold in LDS", one,
+                    cp3 ? kLutLdsMax3 : kLutLdsMax);
     if (li.n_tables <= 0) li.n_tables = 1;
     if (c->d_lut[comp] && !c->lut_borrowed[comp]) (void)hipFree(c->d_lut[comp]);
     c->d_lut[comp] = const_cast<int32_t *>(d_table);
@@ -807,6 +817,7 @@ static int pack_range(picsong_ctx *c, const int32_t *d_staging, const int32_t *d
     HeaderArg h;
     memset(&h, 0, sizeof h);
     if (h_header) { memcpy(h.h, h_header, sizeof h.h); h.has = 1; }
+    c->last_batch = 0;                                      // the most recent total is d_total (picsong_copy_last_totals)
     scan_sizes_kernel<<<1, 1024, 0, s>>>(d_sizes, n, c->d_offsets, c->d_total);
     HIP_TRY(hipGetLastError());
     pack_kernel<<<(unsigned)n, 256, 0, s>>>(d_staging, d_sizes, c->d_offsets, c->d_total, n, h, d_stream);
@@ -1008,9 +1019,11 @@ int picsong_encode_frames(picsong_ctx *c, int n, const uint8_t *d_frames, size_t
     if (n < 1 || n > 64) return fail(PICSONG_ERR_ARG, "encode_frames: %d frames outside 1..64", n);
     if (n > 1 && (frame_stride < c->P || stream_stride < picsong_max_stream_shorts(c->aw, c->ah)))
         return fail(PICSONG_ERR_ARG, "encode_frames: strides smaller than a padded frame / a worst-case codestream");
-    if (c->p.k > 0.0f || c->p.cp == 3)
-        return fail(PICSONG_ERR_ARG, "encode_frames: -k > 0 and -cp 3 are coded frame by frame (picsong_encode_frame)");
+    if (c->p.k > 0.0f || c->p.cp == 3 || c->p.is_rgb)
+        return fail(PICSONG_ERR_ARG, "encode_frames: grey -cp 2 contexts with k = 0 only (-k > 0, -cp 3 and RGB components "
+                                     "are coded frame by frame: picsong_encode_frame / picsong_encode_plane)");
     if (((uintptr_t)d_frames | frame_stride) & 15u) return fail(PICSONG_ERR_ARG, "encode_frames: frames must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(c->device));                       // (a caller with several devices may be on another one)
     BpcArgs a;
     int rc = bpc_args(c, a, 0);
     if (rc) return rc;
@@ -1070,6 +1083,7 @@ int picsong_last_totals(picsong_ctx *c, void *stream, int n, int *h_totals)
 {
     if (!c || !h_totals) return fail(PICSONG_ERR_ARG, "last_totals: null argument");
     if (n < 1 || n > c->last_batch) return fail(PICSONG_ERR_ARG, "last_totals: %d frames, the last batch had %d", n, c->last_batch);
+    HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(c->h_totals, c->b_total, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1089,8 +1103,10 @@ int picsong_decode_frames(picsong_ctx *c, int n, const uint16_t *d_streams, size
     if (n > 1 && (stream_stride < picsong_max_stream_shorts(c->aw, c->ah) || frame_stride < c->P))
         return fail(PICSONG_ERR_ARG, "decode_frames: strides %zu shorts / %zu bytes too small", stream_stride, frame_stride);
     if (n == 1) return picsong_decode_frame(c, d_streams, d_frames_out, stream);
+    HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_batch(c, n);
     if (rc) return rc;
+    c->last_batch = -1;                                     // the batch buffers hold a decode now: no encode totals to hand out
     if (c->b_coef_i_cap < n) {
         HIP_TRY(hipDeviceSynchronize());
         if (c->b_coef_i) (void)hipFree(c->b_coef_i);
@@ -1138,9 +1154,12 @@ int picsong_decode_frames(picsong_ctx *c, int n, const uint16_t *d_streams, size
 int picsong_copy_last_totals(picsong_ctx *c, void *stream, int n, int32_t *d_totals)
 {
     if (!c || !d_totals) return fail(PICSONG_ERR_ARG, "copy_last_totals: null argument");
-    const bool single = n == 1 && c->last_batch == 0;       // the most recent call was picsong_encode_frame
+    // last_batch = 0: the most recent call that packed a stream was a single-frame one (picsong_encode_frame, a stripe,
+    // a plane, picsong_bitstream_pack: every writer of d_total resets it); -1: a batched decode has used the buffers
+    const bool single = n == 1 && c->last_batch == 0;
     if (!single && (n < 1 || n > c->last_batch))
         return fail(PICSONG_ERR_ARG, "copy_last_totals: %d frames, the last batch had %d", n, c->last_batch);
+    HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(d_totals, single ? c->d_total : c->b_total, (size_t)n * sizeof(int32_t),
                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return PICSONG_OK;

@@ -322,3 +322,42 @@ def test_band_plan():
     assert covered == list(range(65536))
     assert sum(q["ll1_count"] for q in p) == 8192 * 8192
     assert pd.band_plan(7680, 4352, 8) is None        # 4352 is not a multiple of 1024
+
+
+# ---- bench.py's own launcher: `python bench.py --gpus N` starts the N ranks itself ---------
+def _run_bench(*argv):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True,
+                          text=True, timeout=300)
+
+
+def test_bench_launches_its_own_ranks_dry_gloo():
+    """`python bench.py --gpus 2` without a torch.distributed environment spawns two ranks (a child
+    torch.distributed.run), they rendezvous over gloo, run the per-step exchange on stand-in codestreams and rank 0's
+    ONE JSON line comes back through the launcher with "n_gpus": 2."""
+    import json
+    r = _run_bench("--gpus", "2", "--backend", "gloo", "--dry", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["dry"] is True
+    assert d["exchange"]["payloads_ok"] is True and d["scaling"] == "weak"
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """No quiet world = 1 run: asking for more GPUs than the node has is an error (here: none visible, or one)."""
+    if torch.cuda.device_count() >= 64:
+        pytest.skip("a node with 64 GPUs")
+    r = _run_bench("--gpus", "64", "--steps", "1")
+    assert r.returncode != 0
+    assert "GPU(s)" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

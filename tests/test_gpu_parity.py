@@ -384,6 +384,58 @@ def test_batched_frames_argument_checks(oracle, pa, torch):
     with pytest.raises(pa.PicsongError):
         c.last_totals(3)
     c.close()
+    # an RGB context codes component by component (picsong_encode_plane): the batched grey path refuses it
+    c = pa.Codec(256, 256, wl=2, lut_folder=_lutdir(oracle, False), rgb=True)
+    out = torch.empty((2, c.max_stream_shorts()), dtype=torch.int16, device="cuda")
+    with pytest.raises(pa.PicsongError):
+        c.encode_frames_async(frames, out, 0)
+    c.close()
+
+
+def test_copy_last_totals_follows_every_call_that_packs_a_stream(oracle, pa, torch):
+    """After a batched encode, a stripe (or any other single-stream pack) makes ITS length the most recent total --
+    not the stale first length of the batch --, and a batched decode leaves no encode totals to hand out."""
+    W, H, wl = 512, 320, 3
+    c = pa.Codec(W, H, wl=wl, lut_folder=_lutdir(oracle, False))
+    frames = _dev(torch, np.stack([oracle.pad_frame(oracle.gen_frame(W, H, 40 + i)).reshape(-1) for i in range(2)]))
+    out = torch.empty((2, c.max_stream_shorts()), dtype=torch.int16, device="cuda")
+    d = torch.zeros(2, dtype=torch.int32, device="cuda")
+    c.encode_frames_async(frames, out, 1)
+    batch = c.last_totals(2)
+    mini = c.encode_frame_stripe(frames[1], 3, 5)
+    c.copy_last_totals(1, d[0:1])
+    assert int(d[0].item()) == mini.numel() != batch[0]
+    with pytest.raises(pa.PicsongError):
+        c.copy_last_totals(2, d)                                                      # the batch is no longer the last call
+    c.encode_frames_async(frames, out, 1)
+    streams = torch.stack([out[0], out[1]])
+    dec = c.decode_frames(streams)
+    assert torch.equal(dec[0].view(-1), frames[0]) and torch.equal(dec[1].view(-1), frames[1])
+    with pytest.raises(pa.PicsongError):
+        c.copy_last_totals(2, d)
+    c.close()
+
+
+def test_borrowed_device_table_follows_the_contexts_coding_passes(oracle, pa, torch):
+    """picsong_ctx_set_lut_device: a -cp 3 context takes a five-section device table (and codes with it like the host
+    path's copy); a table declared for the other mode is refused instead of being read out of bounds."""
+    import ctypes as C
+    W, H, wl = 256, 192, 2
+    img = oracle.gen_frame(W, H, 50)
+    frame = _dev(torch, oracle.pad_frame(img))
+    lut3 = os.path.join(oracle.LUT_CP3_DIR, "n1_lossless")
+    info3, table3 = pa.lut_load(lut3, wl, 1, 0, 1, 3)
+    c = pa.Codec(W, H, wl=wl, cp=3)
+    d_table = torch.from_numpy(np.ascontiguousarray(table3, np.int32)).cuda()
+    pa._check(c.L.picsong_ctx_set_lut_device(c.h, 0, C.byref(info3), C.c_void_p(d_table.data_ptr())))
+    got = c.encode_frame(frame, 0)
+    ref = pa.Codec(W, H, wl=wl, cp=3, lut_folder=lut3)
+    assert torch.equal(got, ref.encode_frame(frame, 0))
+    info2, table2 = pa.lut_load(_lutdir(oracle, False), wl, 1, 0, 1, 2)
+    d2 = torch.from_numpy(np.ascontiguousarray(table2, np.int32)).cuda()
+    with pytest.raises(pa.PicsongError):
+        pa._check(c.L.picsong_ctx_set_lut_device(c.h, 0, C.byref(info2), C.c_void_p(d2.data_ptr())))
+    c.close(); ref.close()
 
 
 @pytest.mark.parametrize("W,H,wl", [(3840, 2160, 5), (7680, 4320, 5)])
@@ -466,6 +518,14 @@ def test_config5_16k_single_frame_roundtrip(oracle, pa, torch):
     frame[5000:5064, 7000:7064] = torch.randint(0, 256, (64, 64), dtype=torch.uint8, device="cuda")
     s = c.encode_frame(frame)
     assert c.range_flag() == 0
+    # the WHOLE codestream against the oracle at full size (header, MSB / length table, payload): the oracle's
+    # OpenMP loops on all of the box's cores take a few seconds for the 268 Mpixel frame
+    oracle.set_threads(oracle.usable_threads())
+    ref = oracle.encode_frame(frame.cpu().numpy(), 5, False, 1.0, oracle.lut_for(False, 5))
+    oracle.set_threads(1)
+    assert ref.size == s.numel()
+    assert np.array_equal(s.cpu().numpy().view(np.uint16), ref)
+    del ref
     dec = c.decode_frame(s)
     assert torch.equal(dec, frame)
     # two stripes of the same frame splice to the same bytes
@@ -518,6 +578,11 @@ def test_banded_transform_sharding_equals_full_frame(oracle, pa, torch, W, H, wl
     counts = [p["stripes"][0][1] for p in plan] + [p["stripes"][1][1] for p in plan]
     spliced = pd.splice_stripes(hdr, minis[0] + minis[1], counts)
     assert torch.equal(spliced, full)
+    # ... and the oracle's stream for the same frame, not only HIP's own (config 5 at full size included)
+    oracle.set_threads(oracle.usable_threads())
+    ref = oracle.encode_frame(frame.view(AH, AW)[:H, :W].cpu().numpy(), wl, lossy, qs, oracle.lut_for(lossy, wl))
+    oracle.set_threads(1)
+    assert np.array_equal(spliced.cpu().numpy().view(np.uint16), ref)
     c.close()
 
 

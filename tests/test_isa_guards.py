@@ -16,32 +16,60 @@ CSRC = os.path.join(ROOT, "cuda-image-and-video-codec_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
-@pytest.fixture(scope="module")
-def device_asm(tmp_path_factory):
+FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "--offload-arch=gfx950"]
+# the flag sets the tools build besides the default (tools/*_variants.sh, dwt_trace / bpc_trace): the guard must hold
+# in each of them -- a regression there shows only as a few wrong samples in one decode of a dozen
+VARIANTS = {
+    "default": [],
+    "trace": ["-DPICSONG_DWT_TRACE"],
+    "inv97_group3_waves4": ["-DPICSONG_DWT_INV97_GROUP=3", "-DPICSONG_DWT_INV97_WAVES=4", "-DPICSONG_DWT_INV_GROUP=2"],
+}
+
+
+def _compile(tmp_path_factory, name, src, extra):
     if not os.path.exists(HIPCC) and shutil.which("hipcc") is None:
         pytest.skip("hipcc not installed")
-    out = tmp_path_factory.mktemp("isa") / "picsong.s"
-    flags = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "--offload-arch=gfx950"]
-    mk = open(os.path.join(CSRC, "Makefile")).read()
-    for f in flags[2:4]:
-        assert f in mk, f"the library is no longer built with {f}: update this test's flags"
-    r = subprocess.run([HIPCC if os.path.exists(HIPCC) else "hipcc", *flags, "--cuda-device-only", "-S", "-o", str(out),
-                        os.path.join(CSRC, "picsong_hip.hip")], capture_output=True, text=True, timeout=900)
+    out = tmp_path_factory.mktemp("isa") / (name + ".s")
+    r = subprocess.run([HIPCC if os.path.exists(HIPCC) else "hipcc", *FLAGS, *extra, "--cuda-device-only", "-S", "-o", str(out),
+                        src], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     return open(out).read().splitlines()
 
 
-def test_wide_buffer_stores_are_followed_by_two_wait_states(device_asm):
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    for f in FLAGS[2:4]:
+        assert f in mk, f"the library is no longer built with {f}: update this test's flags"
+    return _compile(tmp_path_factory, "picsong", os.path.join(CSRC, "picsong_hip.hip"), [])
+
+
+def _check_wide_stores(asm):
     wide = re.compile(r"^\s*buffer_store_dwordx[34]\b")
     n = 0
-    for i, line in enumerate(device_asm):
+    for i, line in enumerate(asm):
         if not wide.match(line):
             continue
         n += 1
-        nxt = next(x.strip() for x in device_asm[i + 1:] if x.strip() and not x.strip().startswith(";"))
+        nxt = next(x.strip() for x in asm[i + 1:] if x.strip() and not x.strip().startswith(";"))
         m = re.match(r"s_nop (\d+)", nxt)
         assert m and int(m.group(1)) >= 1, f"line {i + 1}: '{line.strip()}' is followed by '{nxt}'"
-    assert n > 0          # (rb_store128 is in use; if it goes, so can this test)
+    return n
+
+
+def test_wide_buffer_stores_are_followed_by_two_wait_states(device_asm):
+    assert _check_wide_stores(device_asm) > 0          # (rb_store128 is in use; if it goes, so can this test)
+
+
+@pytest.mark.parametrize("variant", [v for v in VARIANTS if v != "default"])
+def test_wide_buffer_stores_in_the_variant_builds(tmp_path_factory, variant):
+    asm = _compile(tmp_path_factory, variant, os.path.join(CSRC, "picsong_hip.hip"), VARIANTS[variant])
+    assert _check_wide_stores(asm) > 0
+
+
+def test_the_issue_rate_probe_has_no_unguarded_wide_store(tmp_path_factory):
+    asm = _compile(tmp_path_factory, "valu_probe", os.path.join(ROOT, "tools", "valu_probe.hip"), [])
+    _check_wide_stores(asm)
 
 
 def test_lean_synthesis_kernels_do_not_spill(device_asm):
