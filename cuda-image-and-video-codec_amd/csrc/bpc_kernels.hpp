@@ -218,7 +218,7 @@ __device__ __forceinline__ void dec_ring_init(Coder &c, const int32_t *cwarr)
     c.next_lo = c.next_hi = (uint32_t)kDecRing;
 }
 // the window of both codeblocks at least kDecRingAhead codewords ahead of their counters
-__device__ __forceinline__ void dec_ring_keep(Coder &c, const int32_t *cwarr, uint32_t upper_mask)
+__device__ __forceinline__ void dec_ring_refill(Coder &c, const int32_t *cwarr, uint32_t upper_mask)
 {
     bool lo = c.next_lo - c.cnt_lo < kDecRingAhead, hi = c.next_hi - c.cnt_hi < kDecRingAhead;     // wave-uniform
     while (lo || hi) {
@@ -230,6 +230,12 @@ __device__ __forceinline__ void dec_ring_keep(Coder &c, const int32_t *cwarr, ui
         if (hi) c.next_hi = __builtin_amdgcn_readfirstlane(c.next_hi + 64u);
         lo = c.next_lo - c.cnt_lo < kDecRingAhead; hi = c.next_hi - c.cnt_hi < kDecRingAhead;
     }
+}
+// (the check once a row: two subtractions, a minimum, a compare and a branch of the scalar unit)
+__device__ __forceinline__ void dec_ring_keep(Coder &c, const int32_t *cwarr, uint32_t upper_mask)
+{
+    const uint32_t a = c.next_lo - c.cnt_lo, b = c.next_hi - c.cnt_hi;
+    if ((a < b ? a : b) < kDecRingAhead) dec_ring_refill(c, cwarr, upper_mask);
 }
 
 // significance probabilities for contexts 0..8 packed as bytes: w0 = ctx 0-3, w1 = ctx 4-7, p8.
@@ -1390,39 +1396,143 @@ __device__ __forceinline__ void sign_table_fill(uint8_t *tab, uint32_t lane)
     }
 }
 
-// One coefficient of the decoder's significance propagation pass; returns the ballot of the lanes
-// whose coefficient became significant.  (The caller looks after the codeword window: dec_ring_keep once a row.)  wo/wl/wr: W-form significance of the own / left / right
-// column, so/sl/sr: W-form signs; cur: the plane's 32 rows being decoded (X-form dword).
-__device__ __forceinline__ uint64_t dec_spp_coeff(Coder &c, bool idle, uint64_t actm, uint32_t ii, M64 &wo, const M64 &wl,
-                                                  const M64 &wr, M64 &so, const M64 &sl, const M64 &sr,
-                                                  uint32_t &cur, const PlaneLut &pl, uint32_t prec,
-                                                  uint32_t upper_mask, const int32_t *stage, const uint8_t *sgt)
+// ---- decoder, significance propagation pass: interleaved column masks ("C-form") --------------------------------
+// What a visit needs of a neighbour column is (significant, sign) of three rows; kept as separate row masks (round 2)
+// that is six funnel shifts and a dozen shift-and-mask instructions to assemble the 8-bit index of the sign table.
+// Here a column is ONE mask of 2 bits per row -- row r: significant at bit 2 (r + 1), sign at bit 2 (r + 1) + 1, rows
+// -1 and 64 (always zero) included: 132 bits, five words -- so that ONE funnel shift of the pair (word k, word k + 1)
+// by 2 j puts rows 16 k + j - 1, + j, + j + 1 at bits 0..5: `x & 0x15` are the three significance bits of the context
+// count, `x & 0x33` / `x & 0xC` the fields of the sign index.  The pass runs in four blocks of 16 rows, each on the
+// static register pair of its rows; a newly significant coefficient ORs (1 | sign << 1) << (2 j + 2) into its pair.
+// The codeblock edge (lane 0 has no left neighbour, lane 31 no right one: correctCBBorders BPCEngine.cu:465-484) is
+// folded into the per-lane masks the neighbour fields are extracted with, so the DPP copies need no fix-up; a half
+// that codes nothing in this plane carries all-significant masks for the duration (never "on", no test per site).
+//
+// Sign table (LDS, 256 bytes), index = up | left << 2 | down << 4 | right << 6, each field (significant, sign):
+// bits 0-4 = bit offset 8 * (c >> 1) of the context's probability inside PlaneLut::sign (v_bfe_u32 takes exactly
+// these five bits of its offset operand), bit 6 = c & 1: the polarity (computeSignContext BPCEngine.cu:252-308), so
+// that entry >> 5 is the 0 / 2 that flips the sign bit of the value ORed into the column mask.
+__device__ __forceinline__ void sign_table2_fill(uint8_t *tab, uint32_t lane)
 {
-    const uint32_t to = triple(wo, ii), tl = triple(wl, ii), tr = triple(wr, ii);
-    const bool insig = (to & 2u) == 0u;
-    const bool on = !idle && insig;
-    const uint64_t onm = __builtin_amdgcn_ballot_w64(insig) & actm;     // actm = ballot(!idle)
-    // computeContext BPCEngine.cu:222-230 -- the coefficient's own bit is 0 whenever it is visited
-    const uint32_t ctx = (uint32_t)__builtin_popcount(to) + (uint32_t)__builtin_popcount(tl) +
-                         (uint32_t)__builtin_popcount(tr);
-    const uint32_t p07 = __builtin_amdgcn_perm(pl.sig1, pl.sig0, ctx | 0x0C0C0C00u);
+    for (uint32_t idx = lane; idx < 256u; idx += 64u) {
+        const int up = (int)(idx & 1u) - (int)(idx & 2u), lf = (int)((idx >> 2) & 1u) - (int)((idx >> 2) & 2u);
+        const int dn = (int)((idx >> 4) & 1u) - (int)((idx >> 4) & 2u), rt = (int)((idx >> 6) & 1u) - (int)((idx >> 6) & 2u);
+        const uint32_t sc = sign_ctx(lf + rt, up + dn);
+        tab[idx] = (uint8_t)((8u * (sc >> 1)) | ((sc & 1u) << 6));
+    }
+}
+
+// popcount(x) + acc: v_bcnt_u32_b32's own accumulator
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
+{
+#if defined(__AMDGCN__)
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+#else
+    return (uint32_t)__builtin_popcount(x) + acc;
+#endif
+}
+__device__ __forceinline__ uint32_t dpp_prev(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x138 /*wave_shr:1*/, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t dpp_next(uint32_t v) { return __builtin_amdgcn_update_dpp(0u, v, 0x130 /*wave_shl:1*/, 0xf, 0xf, true); }
+
+// per-lane constants of the pass: the masks neighbour fields are extracted with (zero at the codeblock's edge)
+struct DecEdge { uint32_t p15, pC, n15, nC; };
+
+// arithmeticDecoder (BPCEngine.cu:405-442) for the lanes in onm with probability p; returns the ballot of the
+// lanes that decoded a 1.  (The caller looks after the codeword window: dec_ring_keep once a row.)
+__device__ __forceinline__ uint64_t dec_site_lean(Coder &c, uint64_t onm, uint32_t p, uint32_t prec, uint32_t upper_mask,
+                                                  const int32_t *stage)
+{
     bool one;
-    const uint64_t onem = dec_site_m<false>(c, on, onm, ctx >= 8u ? pl.sig8 : p07, prec, upper_mask, stage, one);
-    if (onem != 0ull) {
-        const uint32_t xo = triple(so, ii), xl = triple(sl, ii), xr = triple(sr, ii);
-        // index: up (to/xo bit 0) | down (bit 2) | left (tl/xl bit 1) | right (tr/xr bit 1)
-        uint32_t idx = (to & 5u) | ((xo & 5u) << 1);
-        idx |= ((tl & 2u) << 3) | ((xl & 2u) << 4) | ((tr & 2u) << 5) | ((xr & 2u) << 6);
-        const uint32_t tv = sgt[idx];
-        const uint32_t p2 = (pl.sign >> (tv >> 3)) & 0xFFu;
-        const bool s2 = dec_site_on<false>(c, one, onem, p2, prec, upper_mask, stage);
-        if (one) {
-            w_set(so, ii, (s2 ? 1u : 0u) ^ (tv & 1u));          // :587-589
-            w_set(wo, ii, 1u);
-            cur |= 1u << ii;
+    return dec_site_m<false>(c, __builtin_amdgcn_inverse_ballot_w64(onm), onm, p, prec, upper_mask, stage, one);
+}
+
+// One block of 16 rows (rows 16 K .. 16 K + 15 of the codeblocks) of the significance propagation pass
+// (SPPDecoderLauncher BPCEngine.cu:770-843 order: row by row, all left columns, then all right columns).
+// (l0, l1) / (r0, r1): words K, K + 1 of the lane's left / right column masks; sxL / sxR: the X-form significance
+// word of these rows' 32-row half, `xb` = bit of the block's row 0 in it; rows: the block's rows in which some
+// lane of the wave has an insignificant coefficient.
+__device__ __forceinline__ void dec_spp_block(Coder &c, uint32_t rows, uint32_t &l0, uint32_t &l1, uint32_t &r0, uint32_t &r1,
+                                              uint32_t &sxL, uint32_t &sxR, uint32_t xb, const DecEdge &e,
+                                              const PlaneLut &pl, uint32_t prec, uint32_t upper_mask,
+                                              const int32_t *cw, const uint8_t *sgt)
+{
+    const uint32_t kSel = 0x0C0C0C00u;                     // byte 0 of the permute selector = the context; bytes 1..3 zero
+    // lane-1's right column, lane+1's left column (as they are now; refreshed after a phase that changed them)
+    uint32_t p0 = dpp_prev(r0), p1 = dpp_prev(r1), n0 = dpp_next(l0), n1 = dpp_next(l1);
+    while (rows) {
+        const uint32_t j = (uint32_t)__builtin_ctz(rows);
+        rows &= rows - 1u;
+        const uint32_t sh = 2u * j;
+        dec_ring_keep(c, cw, upper_mask);
+        // ---- all lanes: left column; neighbours = lane-1's right column | own right column
+        const uint32_t xo = __builtin_amdgcn_alignbit(l1, l0, sh), xp = __builtin_amdgcn_alignbit(p1, p0, sh);
+        const uint32_t xr = __builtin_amdgcn_alignbit(r1, r0, sh);
+        const uint32_t cR = bcnt_acc(xr & 0x15u, kSel);     // own right column: shared by both visits of the row
+        uint32_t xl = xo;                                   // the left column as the right column's visit sees it
+        {
+            const uint64_t onm = __builtin_amdgcn_ballot_w64((xo & 4u) == 0u);
+            const uint32_t sel = bcnt_acc(xo & 0x15u, bcnt_acc(xp & e.p15, cR));      // computeContext :222-230
+            const uint32_t p07 = __builtin_amdgcn_perm(pl.sig1, pl.sig0, sel);
+            const uint64_t onem = dec_site_lean(c, onm, sel > (kSel | 7u) ? pl.sig8 : p07, prec, upper_mask, cw);
+            if (onem != 0ull) {
+                // sign: index = up | left << 2 | down << 4 | right << 6 (each: significant, sign)
+                uint32_t idx = (xp & e.pC) | (xo & 0x33u);
+                idx |= (xr & 0xCu) << 4;
+                const uint32_t tv = sgt[idx];
+                const uint32_t p2 = __builtin_amdgcn_ubfe(pl.sign, tv, 8u);
+                const uint64_t s2m = dec_site_lean(c, onem, p2, prec, upper_mask, cw);
+                if (__builtin_amdgcn_inverse_ballot_w64(onem)) {
+                    const uint32_t val = (__builtin_amdgcn_inverse_ballot_w64(s2m) ? 3u : 1u) ^ (tv >> 5);   // :587-589
+                    const uint64_t sv = (uint64_t)val << (sh + 2u);
+                    l0 |= (uint32_t)sv; l1 |= (uint32_t)(sv >> 32);
+                    sxL |= 1u << (xb + j);
+                }
+                // lane+1's left column as it is after this row's left phase (:791, shfl_down)
+                n0 = dpp_next(l0); n1 = dpp_next(l1);
+                xl = __builtin_amdgcn_alignbit(l1, l0, sh);
+            }
+        }
+        // ---- all lanes: right column; neighbours = own left column | lane+1's left column
+        {
+            const uint32_t xn = __builtin_amdgcn_alignbit(n1, n0, sh);
+            const uint64_t onm = __builtin_amdgcn_ballot_w64((xr & 4u) == 0u);
+            const uint32_t sel = bcnt_acc(xl & 0x15u, bcnt_acc(xn & e.n15, cR));
+            const uint32_t p07 = __builtin_amdgcn_perm(pl.sig1, pl.sig0, sel);
+            const uint64_t onem = dec_site_lean(c, onm, sel > (kSel | 7u) ? pl.sig8 : p07, prec, upper_mask, cw);
+            if (onem != 0ull) {
+                uint32_t idx = (xl & 0xCu) | (xr & 0x33u);
+                idx |= (xn & e.nC) << 4;
+                const uint32_t tv = sgt[idx];
+                const uint32_t p2 = __builtin_amdgcn_ubfe(pl.sign, tv, 8u);
+                const uint64_t s2m = dec_site_lean(c, onem, p2, prec, upper_mask, cw);
+                if (__builtin_amdgcn_inverse_ballot_w64(onem)) {
+                    const uint32_t val = (__builtin_amdgcn_inverse_ballot_w64(s2m) ? 3u : 1u) ^ (tv >> 5);
+                    const uint64_t sv = (uint64_t)val << (sh + 2u);
+                    r0 |= (uint32_t)sv; r1 |= (uint32_t)(sv >> 32);
+                    sxR |= 1u << (xb + j);
+                }
+                // lane-1's right column as it is after this row's right phase (:804, shfl_up)
+                p0 = dpp_prev(r0); p1 = dpp_prev(r1);
+            }
         }
     }
-    return onem;
+}
+
+// the sign bits (odd positions) of 32 rows of a C-form column -- words a, b, c hold rows 32 h - 1 .. 32 h + 31 -- as an
+// X-form row mask
+__device__ __forceinline__ uint32_t cform_signs(uint32_t a, uint32_t b, uint32_t c2)
+{
+    auto odd16 = [](uint32_t y) -> uint32_t {              // bits 1, 3, .. 31 -> bits 0 .. 15
+        uint32_t x = (y >> 1) & 0x55555555u;
+        x = (x | (x >> 1)) & 0x33333333u;
+        x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+        x = (x | (x >> 4)) & 0x00FF00FFu;
+        return (x | (x >> 8)) & 0xFFFFu;
+    };
+    const uint32_t lo = __builtin_amdgcn_alignbit(b, a, 2u), hi = __builtin_amdgcn_alignbit(c2, b, 2u);
+    return odd16(lo) | (odd16(hi) << 16);
 }
 
 // The decoded planes of one column half (row masks PL / PR, plane k in word k) back to coefficients: the same 8 x 8
@@ -1474,17 +1584,21 @@ __device__ __forceinline__ void write_rows(const uint32_t (&PL)[NA], const uint3
 #ifndef PICSONG_BPC_DEC_WAVES
 #define PICSONG_BPC_DEC_WAVES 4
 #endif
+// The k = 0 decoder (one plane in registers, the finished ones parked in the scratch) fits 64 VGPRs in its plane
+// loop -- only the prologue and the epilogue spill a few dwords, once per wave -- so eight waves share a SIMD: the
+// decoder's call sites wait on LDS (codeword ring, sign table, slot reservation) where the encoder's do not, and
+// resident waves hide that.  Measured, 8K lossless, three streams: 5 / 6 / 7 / 8 waves 113 / 118 / 121 / 127 Gpixel/s.
 #ifndef PICSONG_BPC_DEC_WAVES8
-#define PICSONG_BPC_DEC_WAVES8 5
+#define PICSONG_BPC_DEC_WAVES8 8
 #endif
-// Two instantiations share a launch's waves: NP = 8 keeps 8 plane registers per column half (5
-// waves / SIMD) and takes the waves whose two codeblocks have at most 8 coded planes -- nearly all --,
+// -k > 0: two instantiations share a launch's waves: NP = 8 keeps 8 plane registers per column half
+// and takes the waves whose two codeblocks have at most 8 coded planes -- nearly all --,
 // NP = 16 (4 waves / SIMD) takes the rest; the host launches both, a wave of the other class returns
 // at once.
 constexpr int kDecSmallPlanes = 8;
 template <bool BULK, int NP>
 __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcDecWgWaves,
-                             (NP == kDecSmallPlanes && !BULK) ? PICSONG_BPC_DEC_WAVES8 : PICSONG_BPC_DEC_WAVES)
+                             !BULK ? PICSONG_BPC_DEC_WAVES8 : (NP == kDecSmallPlanes ? 5 : PICSONG_BPC_DEC_WAVES))
 void bpc_decode_kernel(BpcArgs a)
 {
     static_assert(NP == kDecSmallPlanes || NP == kMaxPlanes, "two classes");
@@ -1494,7 +1608,7 @@ void bpc_decode_kernel(BpcArgs a)
     __shared__ uint32_t lds_cnt[(BULK ? 1 : kBpcDecWgWaves) * 2];
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
     if (t == 0u) lds_cnt[(threadIdx.x >> 6) * 2u + half] = 0u;        // (barrier: below, with the table copy)
-    sign_table_fill(sign_tab, lane);                        // (the LUT copy below ends with the barrier)
+    sign_table2_fill(sign_tab, lane);                       // (the LUT copy below ends with the barrier)
     const int gwave = BULK ? (int)blockIdx.x : (int)blockIdx.x * kBpcDecWgWaves + (int)(threadIdx.x >> 6);
     int wave = gwave;                                       // wave within its frame
     if (a.frames > 1) {                                     // batched launch (picsong_decode_frames), as in the encoder
@@ -1516,10 +1630,21 @@ void bpc_decode_kernel(BpcArgs a)
     const uint32_t prec = (uint32_t)a.g.prec;
     const uint32_t upper_mask = opaque_mask(half ? 0xFFFFFFFFu : 0u);
 
-    uint32_t PLlo[NP], PLhi[NP], PRlo[NP], PRhi[NP];
+    // k = 0: ONE plane in registers, the one being decoded; a finished plane is parked in the wave's scratch (the
+    // encoder's layout: [plane][L rows 0-31, L rows 32-63, R rows 0-31, R rows 32-63][lane], every access a 256-byte
+    // row) and the epilogue reads the planes back eight at a time for the transposition -- 28 registers fewer than
+    // eight resident planes, none of the 28 moves a plane that rotated them upward, and one kernel for every plane
+    // count (round 2: two instantiations over the same grid, NP = 8 and NP = 16, a launch of nothing for most frames).
+    // -k > 0 keeps its planes in registers (the bulk scan reads them row by row).
+    constexpr int NPR = BULK ? NP : 1;
+    uint32_t PLlo[NPR], PLhi[NPR], PRlo[NPR], PRhi[NPR];
 #pragma unroll
-    for (int k = 0; k < NP; k++) { PLlo[k] = PLhi[k] = PRlo[k] = PRhi[k] = 0u; }
-    M64 sgnL = { 0u, 0u }, sgnR = { 0u, 0u };
+    for (int k = 0; k < NPR; k++) { PLlo[k] = PLhi[k] = PRlo[k] = PRhi[k] = 0u; }
+    uint32_t *const pscr = BULK ? nullptr : a.plane_scratch + (size_t)gwave * (size_t)kEncScratchDwordsPerWave + lane;
+    // significance + sign of the lane's two columns, interleaved (C-form, see dec_spp_block)
+    // (ten scalars, not two arrays: an array lives in a register tuple, and a masked update of one element copies it)
+    uint32_t CL0 = 0u, CL1 = 0u, CL2 = 0u, CL3 = 0u, CL4 = 0u, CR0 = 0u, CR1 = 0u, CR2 = 0u, CR3 = 0u, CR4 = 0u;
+    const DecEdge edge = { t == 0u ? 0u : 0x15u, t == 0u ? 0u : 0xCu, t == 31u ? 0u : 0x15u, t == 31u ? 0u : 0xCu };
     int msb = 32;
     int32_t sz = 0;
     if (valid) { msb = stage[0]; sz = a.sizes[cb]; }
@@ -1550,63 +1675,50 @@ void bpc_decode_kernel(BpcArgs a)
     int np = coded ? (msb + 1 - cbp > 0 ? msb + 1 - cbp : 0) : 0;
     { int o = __shfl_xor(np, 32); np = np > o ? np : o; }
     np = (int)__builtin_amdgcn_readfirstlane((uint32_t)np);
-    if ((NP == kDecSmallPlanes) != (np <= kDecSmallPlanes)) return;      // the other instantiation's wave
+    if (BULK && (NP == kDecSmallPlanes) != (np <= kDecSmallPlanes)) return;      // (-k > 0) the other instantiation's wave
 
     for (int p = 0; p < np; p++) {
         const int bp = msb - p;
         const bool act = coded && bp >= cbp;
-        const uint32_t idle = act ? 0u : 1u;
-        const uint64_t actm = __builtin_amdgcn_ballot_w64(act);
 
         // make room: plane registers move up so that after the last plane index k = plane k
-        if (act && p > 0) {
+        if constexpr (BULK) {
+            if (act && p > 0) {
 #pragma unroll
-            for (int k = NP - 1; k > 0; k--) {
-                PLlo[k] = PLlo[k - 1]; PLhi[k] = PLhi[k - 1];
-                PRlo[k] = PRlo[k - 1]; PRhi[k] = PRhi[k - 1];
+                for (int k = NPR - 1; k > 0; k--) {
+                    PLlo[k] = PLlo[k - 1]; PLhi[k] = PLhi[k - 1];
+                    PRlo[k] = PRlo[k - 1]; PRhi[k] = PRhi[k - 1];
+                }
+                PLlo[0] = PLhi[0] = PRlo[0] = PRhi[0] = 0u;
             }
+        } else {
             PLlo[0] = PLhi[0] = PRlo[0] = PRhi[0] = 0u;
         }
 
         PlaneLut pl = { 0u, 0u, 0u, 0u, 0u, 0u };
         if (act) pl = plane_lut(lv, a.g, grp, bp);
 
-        // ---- significance propagation pass (SPPDecoderLauncher), rows with an insignificant coeff
-#pragma unroll
-        for (int hw = 0; hw < 2; hw++) {
-            M64 wL = to_w(sigL, hw), wR = to_w(sigR, hw);
-            M64 sL = to_w(sgnL, hw), sR = to_w(sgnR, hw);
-            M64 wPR = { from_prev32(wR.lo, t), from_prev32(wR.hi, t) };    // lane-1's right column
-            M64 wNL = { from_next32(wL.lo, t), from_next32(wL.hi, t) };    // lane+1's left column
-            M64 sPR = { from_prev32(sR.lo, t), from_prev32(sR.hi, t) };
-            M64 sNL = { from_next32(sL.lo, t), from_next32(sL.hi, t) };
-            uint32_t curL = hw ? PLhi[0] : PLlo[0], curR = hw ? PRhi[0] : PRlo[0];
-            const uint32_t xl = hw ? sigL.hi : sigL.lo, xr = hw ? sigR.hi : sigR.lo;
-            uint32_t rows = wave_or32(act ? ~(xl & xr) : 0u);
-            while (rows) {
-                const uint32_t ii = (uint32_t)__builtin_ctz(rows);
-                rows &= rows - 1u;
-                dec_ring_keep(c, cw, upper_mask);
-                // all lanes: left column, neighbours = lane-1's right column | own right column
-                const uint64_t bL = dec_spp_coeff(c, idle != 0u, actm, ii, wL, wPR, wR, sL, sPR, sR, curL, pl, prec, upper_mask, cw, sign_tab);
-                // lane+1's left column as it is after this row's left phase (:791, shfl_down)
-                if (bL != 0ull) {
-                    wNL.lo = from_next32(wL.lo, t); wNL.hi = from_next32(wL.hi, t);
-                    sNL.lo = from_next32(sL.lo, t); sNL.hi = from_next32(sL.hi, t);
-                }
-                // all lanes: right column, neighbours = own left column | lane+1's left column
-                const uint64_t bR = dec_spp_coeff(c, idle != 0u, actm, ii, wR, wL, wNL, sR, sL, sNL, curR, pl, prec, upper_mask, cw, sign_tab);
-                // lane-1's right column as it is after this row's right phase (:804, shfl_up)
-                if (bR != 0ull) {
-                    wPR.lo = from_prev32(wR.lo, t); wPR.hi = from_prev32(wR.hi, t);
-                    sPR.lo = from_prev32(sR.lo, t); sPR.hi = from_prev32(sR.hi, t);
-                }
-            }
-            // fold the 32 rows of this half-pass back
-            if (hw == 0) { sigL.lo = w_rows(wL); sigR.lo = w_rows(wR); sgnL.lo = w_rows(sL); sgnR.lo = w_rows(sR);
-                           PLlo[0] = curL; PRlo[0] = curR; }
-            else         { sigL.hi = w_rows(wL); sigR.hi = w_rows(wR); sgnL.hi = w_rows(sL); sgnR.hi = w_rows(sR);
-                           PLhi[0] = curL; PRhi[0] = curR; }
+        // ---- significance propagation pass (SPPDecoderLauncher), rows with an insignificant coeff.  A half that
+        // codes nothing in this plane (its codeblock is done, all zero, raw or beyond the last one) shows every
+        // coefficient as significant to the pass: never "on", and its lanes are nobody's neighbours (DecEdge).
+        {
+            const uint32_t allsig = act ? 0u : 0x55555555u;
+            CL0 |= allsig; CL1 |= allsig; CL2 |= allsig; CL3 |= allsig; CL4 |= allsig;
+            CR0 |= allsig; CR1 |= allsig; CR2 |= allsig; CR3 |= allsig; CR4 |= allsig;
+        }
+        {
+            const uint32_t rows32 = wave_or32(act ? ~(sigL.lo & sigR.lo) : 0u);
+            if (rows32 & 0xFFFFu) dec_spp_block(c, rows32 & 0xFFFFu, CL0, CL1, CR0, CR1, sigL.lo, sigR.lo, 0u, edge, pl, prec, upper_mask, cw, sign_tab);
+            if (rows32 >> 16) dec_spp_block(c, rows32 >> 16, CL1, CL2, CR1, CR2, sigL.lo, sigR.lo, 16u, edge, pl, prec, upper_mask, cw, sign_tab);
+            // coefficients that became significant have a 1 in this plane (:577), the others a 0 so far
+            // (an idle half's register 0 holds its last plane: sig ^ ref is zero there)
+            PLlo[0] |= sigL.lo ^ refL.lo; PRlo[0] |= sigR.lo ^ refR.lo;
+        }
+        {
+            const uint32_t rows32 = wave_or32(act ? ~(sigL.hi & sigR.hi) : 0u);
+            if (rows32 & 0xFFFFu) dec_spp_block(c, rows32 & 0xFFFFu, CL2, CL3, CR2, CR3, sigL.hi, sigR.hi, 0u, edge, pl, prec, upper_mask, cw, sign_tab);
+            if (rows32 >> 16) dec_spp_block(c, rows32 >> 16, CL3, CL4, CR3, CR4, sigL.hi, sigR.hi, 16u, edge, pl, prec, upper_mask, cw, sign_tab);
+            PLhi[0] |= sigL.hi ^ refL.hi; PRhi[0] |= sigR.hi ^ refR.hi;
         }
 
         // ---- magnitude refinement pass (MRPDecoderLauncher): coefficients significant before this
@@ -1651,7 +1763,16 @@ void bpc_decode_kernel(BpcArgs a)
             if (hw == 0) { PLlo[0] = curL; PRlo[0] = curR; } else { PLhi[0] = curL; PRhi[0] = curR; }
         }
         refL = sigL; refR = sigR;
+        if constexpr (!BULK) {
+            if (act) {                                         // plane bp of this lane's codeblock is complete
+                uint32_t *q = pscr + (size_t)bp * kEncPlaneDwords;
+                q[0] = PLlo[0]; q[64] = PLhi[0]; q[128] = PRlo[0]; q[192] = PRhi[0];
+            }
+        }
     }
+    // the signs back as X-form row masks (the all-significant marks of an idle half sit on the even bits)
+    const M64 sgnL = { cform_signs(CL0, CL1, CL2), cform_signs(CL2, CL3, CL4) };
+    const M64 sgnR = { cform_signs(CR0, CR1, CR2), cform_signs(CR2, CR3, CR4) };
 
     if constexpr (BULK) {
         // ---- bulk scan (decodeBulkMode :1653-1662) fused with writeCoefficients: plane register k
@@ -1696,8 +1817,36 @@ void bpc_decode_kernel(BpcArgs a)
     } else {
         // writeCoefficients BPCEngine.cu:94-111 / copyEntireCodeblock :1915-1922.  Plane registers
         // NP.. do not exist in this instantiation (its waves have at most NP coded planes).
-        write_rows<NP>(PLlo, PRlo, sgnL.lo, sgnR.lo, 0, valid, sz, stage, t, a.coeffs_out + cbase, a.AW);
-        write_rows<NP>(PLhi, PRhi, sgnL.hi, sgnR.hi, 32, valid, sz, stage, t, a.coeffs_out + cbase, a.AW);
+        // The planes come back from the scratch, eight (sixteen for a wave with a codeblock of MSB >= 8) of one
+        // 32-row half at a time; planes above a codeblock's MSB were never written and read as zero.
+        const bool have = coded;
+        auto planes_of = [&](auto &A, auto &B, int hw, int n) {
+#pragma unroll
+            for (int k = 0; k < (int)(sizeof(A) / sizeof(A[0])); k++) {
+                A[k] = 0u; B[k] = 0u;
+                if (k < n && have && k <= msb) {
+                    const uint32_t *q = pscr + (size_t)k * kEncPlaneDwords + hw * 64;
+                    A[k] = q[0]; B[k] = q[128];
+                }
+            }
+        };
+        if (np > kDecSmallPlanes) {
+#pragma unroll 1
+            for (int hw = 0; hw < 2; hw++) {
+                uint32_t A[kMaxPlanes], B[kMaxPlanes];
+                planes_of(A, B, hw, kMaxPlanes);
+                write_rows<kMaxPlanes>(A, B, hw ? sgnL.hi : sgnL.lo, hw ? sgnR.hi : sgnR.lo, 32 * hw, valid, sz, stage, t,
+                                       a.coeffs_out + cbase, a.AW);
+            }
+        } else {
+#pragma unroll 1
+            for (int hw = 0; hw < 2; hw++) {
+                uint32_t A[kDecSmallPlanes], B[kDecSmallPlanes];
+                planes_of(A, B, hw, kDecSmallPlanes);
+                write_rows<kDecSmallPlanes>(A, B, hw ? sgnL.hi : sgnL.lo, hw ? sgnR.hi : sgnR.lo, 32 * hw, valid, sz, stage, t,
+                                            a.coeffs_out + cbase, a.AW);
+            }
+        }
     }
 }
 

@@ -681,6 +681,17 @@ static int bpc_args(picsong_ctx *c, BpcArgs &a, int comp = 0)
     return PICSONG_OK;
 }
 
+// the coders' bit-plane scratch: kEncScratchDwordsPerWave per wave of a frame's launch (whole workgroups), allocated
+// at the first use
+static int ensure_plane_scratch(picsong_ctx *c)
+{
+    static_assert(kBpcEncWgWaves == kBpcDecWgWaves, "one scratch serves the launches of both directions");
+    if (c->d_plane_scratch) return PICSONG_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMalloc(&c->d_plane_scratch, (size_t)(((c->ncb + 1) / 2 + kBpcEncWgWaves - 1) / kBpcEncWgWaves * kBpcEncWgWaves) * kEncScratchDwordsPerWave * sizeof(uint32_t)));
+    return PICSONG_OK;
+}
+
 static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_staging, int32_t *d_sizes,
                            bool memset_staging, hipStream_t s, int cb_begin = 0, int cb_count = -1, int comp = 0)
 {
@@ -692,10 +703,7 @@ static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_stag
     a.nCB = cb_begin + cb_count;
     a.coeffs_in = d_coeffs; a.is_float = c->p.lossy ? 1 : 0;
     a.staging = d_staging; a.sizes = d_sizes;
-    if (!c->d_plane_scratch) {
-        HIP_TRY(hipSetDevice(c->device));
-        HIP_TRY(hipMalloc(&c->d_plane_scratch, (size_t)(((c->ncb + 1) / 2 + kBpcEncWgWaves - 1) / kBpcEncWgWaves * kBpcEncWgWaves) * kEncScratchDwordsPerWave * sizeof(uint32_t)));
-    }
+    if (int rc2 = ensure_plane_scratch(c)) return rc2;
     a.plane_scratch = c->d_plane_scratch;
     // BPCEngine::deviceMemoryAllocator BPCEngine.cu:2429-2441.  Slots beyond a codeblock's length
     // are never read downstream, so the fused frame path skips this 4*AW*AH-byte fill.
@@ -727,7 +735,8 @@ static int bpc_decode_impl(picsong_ctx *c, const int32_t *d_staging, const int32
     a.coeffs_out = d_coeffs;
     a.staging = const_cast<int32_t *>(d_staging);
     a.sizes = const_cast<int32_t *>(d_sizes);
-    // both plane-count classes over the same grid: each wave is taken by exactly one of them
+    if (int rc2 = ensure_plane_scratch(c)) return rc2;      // the decoder parks its finished planes there too
+    a.plane_scratch = c->d_plane_scratch;
     const unsigned waves = (unsigned)((c->ncb + 1) / 2);
     if (c->p.cp == 3) {
         bpc3_kernel<true><<<(waves + kBpc3WgWaves - 1) / kBpc3WgWaves, 64 * kBpc3WgWaves, 0, s>>>(a);
@@ -735,12 +744,12 @@ static int bpc_decode_impl(picsong_ctx *c, const int32_t *d_staging, const int32
         return PICSONG_OK;
     }
     if (a.k > 0.0f) {
+        // -k > 0: both plane-count classes over the same grid, each wave is taken by exactly one of them
         bpc_decode_kernel<true, kDecSmallPlanes><<<waves, 64, 0, s>>>(a);
         bpc_decode_kernel<true, kMaxPlanes><<<waves, 64, 0, s>>>(a);
     } else {
         const unsigned wgs = (waves + kBpcDecWgWaves - 1) / kBpcDecWgWaves;
         bpc_decode_kernel<false, kDecSmallPlanes><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
-        bpc_decode_kernel<false, kMaxPlanes><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
     }
     HIP_TRY(hipGetLastError());
     return PICSONG_OK;
@@ -1129,11 +1138,10 @@ int picsong_decode_frames(picsong_ctx *c, int n, const uint16_t *d_streams, size
     if ((rc = bpc_args(c, a, 0))) return rc;
     const int wpf = (c->ncb + 1) / 2;
     a.cb_base = 0; a.nCB = c->ncb;
-    a.coeffs_out = c->b_coef_i; a.staging = c->b_staging; a.sizes = c->b_sizes;
+    a.coeffs_out = c->b_coef_i; a.staging = c->b_staging; a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch;
     a.frames = n; a.waves_per_frame = wpf; a.coef_z = (unsigned long long)c->P * 4ull;
     const unsigned wgs = (unsigned)(((size_t)n * (size_t)wpf + kBpcDecWgWaves - 1) / kBpcDecWgWaves);
     bpc_decode_kernel<false, kDecSmallPlanes><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
-    bpc_decode_kernel<false, kMaxPlanes><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
     HIP_TRY(hipGetLastError());
     // ---- inverse transform, pixels out of the finest level where its vector kernel applies
     bool fused = false;

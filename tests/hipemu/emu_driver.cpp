@@ -260,8 +260,10 @@ void emu_bpc_decode(const int32_t *staging, const int32_t *sizes, int aw, int ah
         emu::launch(grid, dim3(64), [&] { bpc_decode_kernel<true, kMaxPlanes>(a); });
     } else {
         const dim3 wgs((grid.x + kBpcDecWgWaves - 1) / kBpcDecWgWaves);
+        // (the decoder parks its finished planes in the scratch; poisoned: planes above a codeblock's MSB are never written)
+        std::vector<uint32_t> plane_scratch((size_t)wgs.x * kBpcDecWgWaves * kEncScratchDwordsPerWave, 0xDEADBEEFu);
+        a.plane_scratch = plane_scratch.data();
         emu::launch(wgs, dim3(64 * kBpcDecWgWaves), [&] { bpc_decode_kernel<false, kDecSmallPlanes>(a); });
-        emu::launch(wgs, dim3(64 * kBpcDecWgWaves), [&] { bpc_decode_kernel<false, kMaxPlanes>(a); });
     }
 }
 

@@ -123,6 +123,11 @@ static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsig
     uint64_t both = ((uint64_t)hi << 32) | lo;
     return (unsigned)(both >> (sh & 31u));
 }
+static inline unsigned __builtin_amdgcn_ubfe(unsigned v, unsigned off, unsigned w)
+{
+    off &= 31u; w &= 31u;
+    return w ? (v >> off) & ((1u << w) - 1u) : 0u;
+}
 template <typename T> static inline T __shfl_xor(T v, int mask)
 {
     uint64_t in = 0;
