@@ -70,6 +70,10 @@ struct BpcArgs {
     // 0 / 1 frames = a single frame (waves_per_frame unused)
     int frames, waves_per_frame;
     unsigned long long coef_z;
+    // the frames of a batched launch are the three COMPONENTS of one RGB frame (picsong_encode_rgb_frame): frame f
+    // codes with table lut_c[f] (same geometry); waves_per_frame is then a whole number of workgroups, a workgroup's
+    // LDS copy of the table being its frame's.  lut_c[0] = nullptr: every frame uses `lut`
+    const int32_t *lut_c[3];
 };
 
 // ---- cross-lane helpers ---------------------------------------------------------------------
@@ -163,18 +167,20 @@ __device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b)
 
 // Per-lane arithmetic coder state (arithmeticEncoder/Decoder BPCEngine.cu:371-442).
 struct Coder {
-    uint32_t L, S;      // interval lower bound / size
+    uint32_t L, S;      // interval lower bound / size; the DECODER keeps D = codeword - lower bound in L (dec_site_m)
     uint32_t slot;      // reserved codeword slot (staging index = 1 + slot)
-    uint32_t cw;        // decoder: current codeword
+    uint32_t cw;        // (unused)
     uint32_t cnt_lo, cnt_hi;   // codeword counters (codeStreamShared) of the codeblocks in lanes 0-31 /
                                // 32-63: wave-uniform, they live in SGPRs and are updated by SALU
     uint64_t emptym;           // encoder: ballot(S == 0) as of the end of the previous call site
     // decoder: the codeblocks' next codewords wait in an LDS ring (see dec_ring_*): window edges of the two
     // codeblocks (wave-uniform), the lane's ring (its codeblock's) and lane index inside its half
     uint32_t next_lo, next_hi;
-    uint32_t *ring;
+    uint16_t *ring;
     uint32_t t;
     uint32_t *ldscnt;          // LDS form of the reservation: the lane's codeblock's codeword counter
+    uint32_t ringaddr;         // LDS form: LDS byte address of the lane's ring (1 KB aligned)
+    uint32_t pend;             // LDS form: the codeblock's counter as read at the start of the previous row (dec_ring_row)
 };
 
 // LDS operations of the wave's other lanes have completed
@@ -185,6 +191,30 @@ __device__ __forceinline__ void wave_lds_done()
     __builtin_amdgcn_wave_barrier();
 #else
     (void)__builtin_amdgcn_ballot_w64(true);
+#endif
+}
+
+// LDS form of the codeword slot reservation (see enc_reserve below): the default on the GPU; the CPU wave emulator
+// of the tests builds the v_mbcnt form.
+#ifndef PICSONG_ENC_LDS_RESERVE
+#define PICSONG_ENC_LDS_RESERVE 1
+#endif
+// (the CPU wave emulator of the tests runs lanes as coroutines, not in lane order between two cross-lane
+// operations: it builds the v_mbcnt form, which states the order explicitly)
+#if PICSONG_ENC_LDS_RESERVE && defined(__AMDGCN__)
+#define PS_ENC_LDS 1
+#else
+#define PS_ENC_LDS 0
+#endif
+
+// the LDS byte address of a pointer into a __shared__ array
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p)
+{
+#if defined(__AMDGCN__)
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+#else
+    (void)p;
+    return 0u;
 #endif
 }
 
@@ -200,42 +230,85 @@ __device__ __forceinline__ void wave_lds_done()
 // not per call site: seven scalar instructions and a branch fewer at every site that starts a codeword, which
 // nearly every site does for some lane.  (-k's row scan, with up to 34 sites a row, and -cp 3 keep the check
 // in the call site.)
-constexpr int kDecRing = 256;
-constexpr uint32_t kDecRingAhead = 192u;
-__device__ __forceinline__ void dec_ring_fill(const int32_t *cwarr, uint32_t *ring, uint32_t first, uint32_t t)
+constexpr int kDecRing = 512;                 // 16-bit entries per codeblock: 1 KB
+constexpr uint32_t kDecRingAhead = 192u;      // per-site check (dec_site_m<true>): exact counters
+constexpr uint32_t kDecRingAheadRow = 256u;   // per-row check (dec_ring_row): counters one row old
+// LDS form of the reservation (GPU build): the codeblock's counter counts BYTES of its 16-bit ring (2 per codeword),
+// so that a lane's pre-add value masked to the ring's size IS its slot's offset in the ring; the window edges
+// next_lo / next_hi are kept in the same unit.
+#if PS_ENC_LDS
+constexpr uint32_t kDecCntUnit = 2u;
+#else
+constexpr uint32_t kDecCntUnit = 1u;
+#endif
+__device__ __forceinline__ void dec_ring_fill(const int32_t *cwarr, uint16_t *ring, uint32_t first, uint32_t t)
 {   // entries first .. first + 63 of the lane's codeblock (cwarr[k] = codeword k; k <= 4094 exists)
     const uint32_t e0 = first + t, e1 = first + 32u + t;
     const int32_t v0 = cwarr[e0 > 4094u ? 4094u : e0], v1 = cwarr[e1 > 4094u ? 4094u : e1];
-    ring[e0 & (kDecRing - 1)] = (uint32_t)v0;
-    ring[e1 & (kDecRing - 1)] = (uint32_t)v1;
+    ring[e0 & (kDecRing - 1)] = (uint16_t)v0;
+    ring[e1 & (kDecRing - 1)] = (uint16_t)v1;
 }
-// codewords 0 .. 255 of both codeblocks (reads stay inside the codeblock's 4096 staging words whatever its
+// codewords 0 .. 511 of both codeblocks (reads stay inside the codeblock's 4096 staging words whatever its
 // length; what lies beyond the length is never used)
 __device__ __forceinline__ void dec_ring_init(Coder &c, const int32_t *cwarr)
 {
-#pragma unroll
+#pragma unroll 1
     for (uint32_t f = 0; f < (uint32_t)kDecRing; f += 64u) dec_ring_fill(cwarr, c.ring, f, c.t);
-    c.next_lo = c.next_hi = (uint32_t)kDecRing;
+    c.next_lo = c.next_hi = (uint32_t)kDecRing * kDecCntUnit;
+    c.pend = 0u;
 }
-// the window of both codeblocks at least kDecRingAhead codewords ahead of their counters
-__device__ __forceinline__ void dec_ring_refill(Coder &c, const int32_t *cwarr, uint32_t upper_mask)
+// the window of both codeblocks at least `ahead` codewords ahead of the counters cnt_lo / cnt_hi (codewords; exact or
+// older values).  A fill overwrites entries next - 512 .. next - 449, all consumed: it happens only while
+// next - cnt < ahead <= 256.
+__device__ __forceinline__ void dec_ring_refill(Coder &c, const int32_t *cwarr, uint32_t upper_mask, uint32_t cnt_lo,
+                                                uint32_t cnt_hi, uint32_t ahead)
 {
-    bool lo = c.next_lo - c.cnt_lo < kDecRingAhead, hi = c.next_hi - c.cnt_hi < kDecRingAhead;     // wave-uniform
+    bool lo = c.next_lo - cnt_lo * kDecCntUnit < ahead * kDecCntUnit, hi = c.next_hi - cnt_hi * kDecCntUnit < ahead * kDecCntUnit;     // wave-uniform
     while (lo || hi) {
         wave_lds_done();                                   // every lane has read the codewords of its earlier sites
-        const uint32_t edge = upper_mask ? c.next_hi : c.next_lo;
+        const uint32_t edge = (upper_mask ? c.next_hi : c.next_lo) / kDecCntUnit;
         if (upper_mask ? hi : lo) dec_ring_fill(cwarr, c.ring, edge, c.t);
         wave_lds_done();                                   // (a later reservation of another lane reads them)
-        if (lo) c.next_lo = __builtin_amdgcn_readfirstlane(c.next_lo + 64u);
-        if (hi) c.next_hi = __builtin_amdgcn_readfirstlane(c.next_hi + 64u);
-        lo = c.next_lo - c.cnt_lo < kDecRingAhead; hi = c.next_hi - c.cnt_hi < kDecRingAhead;
+        if (lo) c.next_lo = __builtin_amdgcn_readfirstlane(c.next_lo + 64u * kDecCntUnit);
+        if (hi) c.next_hi = __builtin_amdgcn_readfirstlane(c.next_hi + 64u * kDecCntUnit);
+        lo = c.next_lo - cnt_lo * kDecCntUnit < ahead * kDecCntUnit; hi = c.next_hi - cnt_hi * kDecCntUnit < ahead * kDecCntUnit;
     }
 }
-// (the check once a row: two subtractions, a minimum, a compare and a branch of the scalar unit)
+// per call site (dec_site_m<true>: -k's row scan, -cp 3): the exact counters c.cnt_lo / c.cnt_hi
 __device__ __forceinline__ void dec_ring_keep(Coder &c, const int32_t *cwarr, uint32_t upper_mask)
 {
+    const uint32_t a = c.next_lo - c.cnt_lo * kDecCntUnit, b = c.next_hi - c.cnt_hi * kDecCntUnit;
+    if ((a < b ? a : b) < kDecRingAhead * kDecCntUnit) dec_ring_refill(c, cwarr, upper_mask, c.cnt_lo, c.cnt_hi, kDecRingAhead);
+}
+// Once per ROW of call sites of the plane loops (a row reserves at most 4 x 32 slots of a codeblock: two columns, bit
+// and sign).  LDS form: the call sites keep no scalar counters at all (two popcounts and two additions of the scalar
+// unit at every site that starts a codeword, which nearly every site does for some lane); the codeblocks' LDS
+// counters are read here instead, and used ONE ROW LATE -- the read of row r is consumed at row r + 1, so no wait
+// for the LDS sits in a row's path: with v the value read at the start of row r - 1, the counter at the end of row
+// r is at most v + 256, and the window is kept 256 codewords ahead of v.
+__device__ __forceinline__ void dec_ring_row(Coder &c, const int32_t *cwarr, uint32_t upper_mask)
+{
+#if PS_ENC_LDS
+    const uint32_t vlo = __builtin_amdgcn_readlane(c.pend, 0), vhi = __builtin_amdgcn_readlane(c.pend, 32);   // bytes
+    const uint32_t a = c.next_lo - vlo, b = c.next_hi - vhi;
+    if ((a < b ? a : b) < kDecRingAheadRow * kDecCntUnit) dec_ring_refill(c, cwarr, upper_mask, vlo / kDecCntUnit, vhi / kDecCntUnit, kDecRingAheadRow);
+    c.pend = __hip_atomic_load(c.ldscnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
     const uint32_t a = c.next_lo - c.cnt_lo, b = c.next_hi - c.cnt_hi;
-    if ((a < b ? a : b) < kDecRingAhead) dec_ring_refill(c, cwarr, upper_mask);
+    if ((a < b ? a : b) < kDecRingAheadRow) dec_ring_refill(c, cwarr, upper_mask, c.cnt_lo, c.cnt_hi, kDecRingAheadRow);
+#endif
+}
+// the exact counters for the per-site form that follows the plane loops (-k's row scan)
+__device__ __forceinline__ void dec_ring_sync(Coder &c)
+{
+#if PS_ENC_LDS
+    wave_lds_done();
+    const uint32_t v = __hip_atomic_load(c.ldscnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    c.cnt_lo = __builtin_amdgcn_readlane(v, 0) / kDecCntUnit;
+    c.cnt_hi = __builtin_amdgcn_readlane(v, 32) / kDecCntUnit;
+#else
+    (void)c;
+#endif
 }
 
 // significance probabilities for contexts 0..8 packed as bytes: w0 = ctx 0-3, w1 = ctx 4-7, p8.
@@ -251,22 +324,28 @@ struct LutView {
     const int32_t *glob;           // the whole table array, for indices outside the table (as lut_at)
     int total, glob_total, loff;   // entries of one table / of the array / offset of table s
 };
+// SINGLE: the array is ONE table and the LDS copy holds all of it (k = 0, -cp 3), so an index outside the table
+// clamps into the LDS copy exactly as lut_at clamps it into the array -- no branch and no global fallback (which cost
+// an exec-masked region with a 64-bit address per entry: 14 entries a plane, 140 vector and 110 scalar instructions)
+template <bool SINGLE = false>
 __device__ __forceinline__ uint32_t lut_get(const LutView &v, int idx)
 {
+    if constexpr (SINGLE) return v.lds[idx < 0 ? 0 : (idx >= v.total ? v.total - 1 : idx)];
     if (idx >= 0 && idx < v.total) return v.lds[idx];
     return lut_at(v.glob, v.loff + idx, v.glob_total);
 }
-__device__ __forceinline__ PlaneLut plane_lut(const LutView &v, const LutGeo &g, int grp, int bp)
+template <bool SINGLE = false>
+__device__ __forceinline__ PlaneLut plane_lut(const LutView &v, const LutGeo &g, int grp, int bp, int aux = 0)
 {
     PlaneLut pl;
     const int ri = (grp * g.nBp + bp) * g.cRef;
-    const int si = (grp * g.nBp + bp) * g.cSig + g.nRef;
-    const int gi = (grp * g.nBp + bp) * g.cSign + g.nRef + g.nSig;
-    pl.ref = lut_get(v, ri);
-    pl.sig0 = lut_get(v, si + 0) | (lut_get(v, si + 1) << 8) | (lut_get(v, si + 2) << 16) | (lut_get(v, si + 3) << 24);
-    pl.sig1 = lut_get(v, si + 4) | (lut_get(v, si + 5) << 8) | (lut_get(v, si + 6) << 16) | (lut_get(v, si + 7) << 24);
-    pl.sig8 = lut_get(v, si + 8);
-    pl.sign = lut_get(v, gi + 0) | (lut_get(v, gi + 1) << 8) | (lut_get(v, gi + 2) << 16) | (lut_get(v, gi + 3) << 24);
+    const int si = (grp * g.nBp + bp) * g.cSig + g.nRef + aux;
+    const int gi = (grp * g.nBp + bp) * g.cSign + g.nRef + g.nSig + aux;
+    pl.ref = lut_get<SINGLE>(v, ri);
+    pl.sig0 = lut_get<SINGLE>(v, si + 0) | (lut_get<SINGLE>(v, si + 1) << 8) | (lut_get<SINGLE>(v, si + 2) << 16) | (lut_get<SINGLE>(v, si + 3) << 24);
+    pl.sig1 = lut_get<SINGLE>(v, si + 4) | (lut_get<SINGLE>(v, si + 5) << 8) | (lut_get<SINGLE>(v, si + 6) << 16) | (lut_get<SINGLE>(v, si + 7) << 24);
+    pl.sig8 = lut_get<SINGLE>(v, si + 8);
+    pl.sign = lut_get<SINGLE>(v, gi + 0) | (lut_get<SINGLE>(v, gi + 1) << 8) | (lut_get<SINGLE>(v, gi + 2) << 16) | (lut_get<SINGLE>(v, gi + 3) << 24);
     pl.sig8x4 = pl.sig8 * 0x01010101u;
     return pl;
 }
@@ -469,16 +548,7 @@ __device__ __forceinline__ void reserve_enc(Coder &c, bool need, uint64_t m, uin
 // comparison with the oracle, and PICSONG_ENC_LDS_RESERVE=0 builds the v_mbcnt form.  The returned value is
 // not needed until the lane's NEXT reservation (it only addresses the deferred store), so no wait for the
 // LDS sits in the call site's dependent chain.
-#ifndef PICSONG_ENC_LDS_RESERVE
-#define PICSONG_ENC_LDS_RESERVE 1
-#endif
-// (the CPU wave emulator of the tests runs lanes as coroutines, not in lane order between two cross-lane
-// operations: it builds the v_mbcnt form, which states the order explicitly)
-#if PICSONG_ENC_LDS_RESERVE && defined(__AMDGCN__)
-#define PS_ENC_LDS 1
-#else
-#define PS_ENC_LDS 0
-#endif
+// (PICSONG_ENC_LDS_RESERVE / PS_ENC_LDS: defined at the top of this header)
 
 struct EncCoder {
     uint32_t L, S, off;
@@ -1010,6 +1080,8 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
             a.coeffs_in = (const char *)a.coeffs_in + (unsigned long long)f * a.coef_z;
             a.staging += (size_t)f * (size_t)a.AW * (size_t)a.AH;
             a.sizes += (size_t)f * (size_t)(a.nCB - a.cb_base);
+            // (scalar selects: indexing the argument struct with f would move all of it to scratch memory)
+            if (a.lut_c[0]) a.lut = f == 0 ? a.lut_c[0] : (f == 1 ? a.lut_c[1] : a.lut_c[2]);
         }
     }
     const int cb = a.cb_base + 2 * wave + (int)half;
@@ -1114,7 +1186,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
         const bool act = live && bp >= cbp;
 
         PlaneLut pl = { 0u, 0u, 0u, 0u, 0u, 0u };
-        if (act) pl = plane_lut(lv, a.g, grp, bp);
+        if (act) pl = plane_lut<!BULK>(lv, a.g, grp, bp);
 
         const U64 BL = BLn, BR = BRn;
         const U64 AL2 = u_or(AL, BL), AR2 = u_or(AR, BR);            // state after this plane's SPP
@@ -1310,58 +1382,63 @@ template <bool KEEP = true>
 __device__ __forceinline__ uint64_t dec_site_m(Coder &c, bool on, uint64_t onm, uint32_t p, uint32_t prec,
                                                uint32_t upper_mask, const int32_t *stage, bool &one)
 {
+    // The decoder keeps D = cw - L in place of (cw, L) (Coder::L holds D): arithmeticDecoder's test cw >= L + a with
+    // a = a0 + 1 is D > a0, and L += a is D -= a.  cw >= L holds at every step of ANY stream -- L starts at 0 and
+    // only moves to an L + a that the test has just found <= cw -- so D never wraps and the form is the reference's
+    // for damaged streams too.  One register, one instruction per call site and one per reservation fewer.
     const bool empty = c.S == 0u;
     const uint64_t m = __builtin_amdgcn_ballot_w64(empty) & onm;
     if (m != 0ull) {
 #if PS_ENC_LDS
-        // the slot by one LDS atomic add per requesting lane (see the encoder's enc_reserve); the scalar
-        // counters only steer the codeword ring
+        // the slot by one LDS atomic add per requesting lane (see the encoder's enc_reserve)
         if (__builtin_amdgcn_inverse_ballot_w64(m)) {
-            const uint32_t slot = __hip_atomic_fetch_add(c.ldscnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            c.cw = c.ring[slot & (kDecRing - 1)];
-            c.L = 0u; c.S = 0xFFFFu;
+            // (the counter counts bytes of the 16-bit ring: pre-add value & 0x3FE = the slot's offset in the 1 KB
+            // aligned ring, one v_and_or away from its LDS address)
+            const uint32_t off = __hip_atomic_fetch_add(c.ldscnt, kDecCntUnit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            c.L = *(const __attribute__((address_space(3))) uint16_t *)(uintptr_t)(c.ringaddr | (off & (uint32_t)(kDecRing * 2 - 2)));
+            c.S = 0xFFFFu;
         }
-        c.cnt_lo = __builtin_amdgcn_readfirstlane(c.cnt_lo + (uint32_t)__builtin_popcount((uint32_t)m));
-        c.cnt_hi = __builtin_amdgcn_readfirstlane(c.cnt_hi + (uint32_t)__builtin_popcount((uint32_t)(m >> 32)));
+        if constexpr (KEEP) {                              // (the plane loops read the LDS counters once a row instead)
+            c.cnt_lo = __builtin_amdgcn_readfirstlane(c.cnt_lo + (uint32_t)__builtin_popcount((uint32_t)m));
+            c.cnt_hi = __builtin_amdgcn_readfirstlane(c.cnt_hi + (uint32_t)__builtin_popcount((uint32_t)(m >> 32)));
+        }
 #else
         reserve_enc(c, on && empty, m, upper_mask);
-        if (on && empty) c.cw = c.ring[c.slot & (kDecRing - 1)];
+        if (on && empty) c.L = c.ring[c.slot & (kDecRing - 1)];          // D = cw - 0
 #endif
         if constexpr (KEEP) dec_ring_keep(c, stage, upper_mask);       // stage = the codeword array (staging + 1)
     }
 #if defined(__AMDGCN__)
-    // a = ((S * p) >> prec) + 1;  cw >= L + a decodes a 1: S' = S - a, L' = L + a;  else S' = a - 1
+    // a0 = (S * p) >> prec;  D > a0 decodes a 1: S' = S - a0 - 1, D' = D - a0 - 1;  else S' = a0
     // (arithmeticDecoder BPCEngine.cu:405-442).  As the encoder's update: the instructions themselves over
     // exec masks (exec is all ones on entry), full-rate moves and adds where the compiler's form selects.
-    uint32_t a, t2;
-    uint64_t gem, onem;
+    // (v_cmpx on this target writes the lane mask to its scalar destination AND to exec: with exec = the coding lanes
+    // the compare delivers "lanes decoding a 1" in both -- no scalar and)
+    uint32_t a;
+    uint64_t onem;
     asm volatile(
         "v_mul_u32_u24 %[a], %[S], %[p]\n\t"
-        "v_lshrrev_b32 %[a], %[pr], %[a]\n\t"          // a0 = a - 1
-        "v_add3_u32 %[t2], %[L], %[a], 1\n\t"           // L + a
-        "v_cmp_ge_u32_e64 %[gem], %[cw], %[t2]\n\t"
-        "s_and_b64 %[onem], %[gem], %[on]\n\t"
-        "s_mov_b64 exec, %[onem]\n\t"                   // lanes decoding a 1
-        "v_add_u32 %[a], 1, %[a]\n\t"
-        "v_mov_b32 %[L], %[t2]\n\t"
-        "v_sub_u32 %[a], %[S], %[a]\n\t"                //   a = S - a (their new S)
+        "v_lshrrev_b32 %[a], %[pr], %[a]\n\t"          // a0
         "s_mov_b64 exec, %[on]\n\t"
-        "v_mov_b32 %[S], %[a]\n\t"                      // lanes decoding a 0 still hold a0 = a - 1
+        "v_cmpx_gt_u32_e64 %[onem], %[D], %[a]\n\t"    // exec = onem = lanes decoding a 1
+        "v_not_b32 %[a], %[a]\n\t"                      //   -(a0 + 1)
+        "v_add_u32 %[D], %[D], %[a]\n\t"
+        "v_add_u32 %[a], %[S], %[a]\n\t"                //   a = S - a0 - 1 (their new S)
+        "s_mov_b64 exec, %[on]\n\t"
+        "v_mov_b32 %[S], %[a]\n\t"                      // lanes decoding a 0 still hold a0
         "s_mov_b64 exec, -1"
-        : [S] "+v"(c.S), [L] "+v"(c.L), [a] "=&v"(a), [t2] "=&v"(t2), [gem] "=&s"(gem), [onem] "=&s"(onem)
-        : [on] "s"(onm), [p] "v"(p), [pr] "s"(prec), [cw] "v"(c.cw)
-        : "scc");
+        : [S] "+v"(c.S), [D] "+v"(c.L), [a] "=&v"(a), [onem] "=&s"(onem)
+        : [on] "s"(onm), [p] "v"(p), [pr] "s"(prec));
     (void)on;
     one = __builtin_amdgcn_inverse_ballot_w64(onem);
     return onem;
 #else
-    const uint32_t a = (mul_u24(c.S, p) >> prec) + 1u;
-    const uint32_t a2 = c.L + a;
-    const bool ge = c.cw >= a2;
+    const uint32_t a0 = mul_u24(c.S, p) >> prec;
+    const bool ge = c.L > a0;
     const uint64_t gem = __builtin_amdgcn_ballot_w64(ge);
     if (on) {
-        c.S = ge ? c.S - a : a - 1u;
-        c.L = ge ? a2 : c.L;
+        c.S = ge ? c.S + ~a0 : a0;
+        c.L = ge ? c.L + ~a0 : c.L;
     }
     one = ge && on;
     return gem & onm;
@@ -1465,7 +1542,7 @@ __device__ __forceinline__ void dec_spp_block(Coder &c, uint32_t rows, uint32_t 
         const uint32_t j = (uint32_t)__builtin_ctz(rows);
         rows &= rows - 1u;
         const uint32_t sh = 2u * j;
-        dec_ring_keep(c, cw, upper_mask);
+        dec_ring_row(c, cw, upper_mask);
         // ---- all lanes: left column; neighbours = lane-1's right column | own right column
         const uint32_t xo = __builtin_amdgcn_alignbit(l1, l0, sh), xp = __builtin_amdgcn_alignbit(p1, p0, sh);
         const uint32_t xr = __builtin_amdgcn_alignbit(r1, r0, sh);
@@ -1480,7 +1557,8 @@ __device__ __forceinline__ void dec_spp_block(Coder &c, uint32_t rows, uint32_t 
                 // sign: index = up | left << 2 | down << 4 | right << 6 (each: significant, sign)
                 uint32_t idx = (xp & e.pC) | (xo & 0x33u);
                 idx |= (xr & 0xCu) << 4;
-                const uint32_t tv = sgt[idx];
+                uint32_t tv = sgt[idx];
+                opaque32(tv);             // (the zero extension belongs to the load: used from another block it costs an and)
                 const uint32_t p2 = __builtin_amdgcn_ubfe(pl.sign, tv, 8u);
                 const uint64_t s2m = dec_site_lean(c, onem, p2, prec, upper_mask, cw);
                 if (__builtin_amdgcn_inverse_ballot_w64(onem)) {
@@ -1504,7 +1582,8 @@ __device__ __forceinline__ void dec_spp_block(Coder &c, uint32_t rows, uint32_t 
             if (onem != 0ull) {
                 uint32_t idx = (xl & 0xCu) | (xr & 0x33u);
                 idx |= (xn & e.nC) << 4;
-                const uint32_t tv = sgt[idx];
+                uint32_t tv = sgt[idx];
+                opaque32(tv);
                 const uint32_t p2 = __builtin_amdgcn_ubfe(pl.sign, tv, 8u);
                 const uint64_t s2m = dec_site_lean(c, onem, p2, prec, upper_mask, cw);
                 if (__builtin_amdgcn_inverse_ballot_w64(onem)) {
@@ -1604,7 +1683,7 @@ void bpc_decode_kernel(BpcArgs a)
     static_assert(NP == kDecSmallPlanes || NP == kMaxPlanes, "two classes");
     __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
     __shared__ uint8_t sign_tab[256];
-    __shared__ uint32_t cw_ring[(BULK ? 1 : kBpcDecWgWaves) * 2 * kDecRing];
+    __shared__ __attribute__((aligned(1024))) uint16_t cw_ring[(BULK ? 1 : kBpcDecWgWaves) * 2 * kDecRing];
     __shared__ uint32_t lds_cnt[(BULK ? 1 : kBpcDecWgWaves) * 2];
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
     if (t == 0u) lds_cnt[(threadIdx.x >> 6) * 2u + half] = 0u;        // (barrier: below, with the table copy)
@@ -1619,6 +1698,8 @@ void bpc_decode_kernel(BpcArgs a)
             a.coeffs_out = (int32_t *)((char *)a.coeffs_out + (unsigned long long)f * a.coef_z);
             a.staging += (size_t)f * (size_t)a.AW * (size_t)a.AH;
             a.sizes += (size_t)f * (size_t)(a.nCB - a.cb_base);
+            // (scalar selects: indexing the argument struct with f would move all of it to scratch memory)
+            if (a.lut_c[0]) a.lut = f == 0 ? a.lut_c[0] : (f == 1 ? a.lut_c[1] : a.lut_c[2]);
         }
     }
     const int cb = a.cb_base + 2 * wave + (int)half;
@@ -1658,9 +1739,10 @@ void bpc_decode_kernel(BpcArgs a)
     find_subband(cbx * 64 + 2 * (int)t, cby * 64, a.AW, a.AH, a.wl, level, sb);
     const int grp = level * a.g.nSub + sb;
 
-    Coder c = { 0u, 0u, 0u, 0u, 0u, 0u, ~0ull, 64u, 64u, nullptr, t, nullptr };
+    Coder c = { 0u, 0u, 0u, 0u, 0u, 0u, ~0ull, 64u, 64u, nullptr, t, nullptr, 0u, 0u };
     c.ldscnt = &lds_cnt[(threadIdx.x >> 6) * 2u + half];
     c.ring = cw_ring + ((threadIdx.x >> 6) * 2u + half) * kDecRing;
+    c.ringaddr = lds_addr_of(c.ring);
     dec_ring_init(c, cw);
     wave_lds_done();
     M64 sigL = { 0u, 0u }, sigR = { 0u, 0u }, refL = { 0u, 0u }, refR = { 0u, 0u };
@@ -1696,7 +1778,7 @@ void bpc_decode_kernel(BpcArgs a)
         }
 
         PlaneLut pl = { 0u, 0u, 0u, 0u, 0u, 0u };
-        if (act) pl = plane_lut(lv, a.g, grp, bp);
+        if (act) pl = plane_lut<!BULK>(lv, a.g, grp, bp);
 
         // ---- significance propagation pass (SPPDecoderLauncher), rows with an insignificant coeff.  A half that
         // codes nothing in this plane (its codeblock is done, all zero, raw or beyond the last one) shows every
@@ -1737,7 +1819,7 @@ void bpc_decode_kernel(BpcArgs a)
 #pragma unroll 1
                 for (int ii = 0; ii < last; ii++) {
                     bool one;
-                    dec_ring_keep(c, cw, upper_mask);
+                    dec_ring_row(c, cw, upper_mask);
                     const uint64_t mL = shl_carry(xL);
                     uint64_t dL = 0ull, dR = 0ull;
                     if (mL != 0ull) dL = dec_site_m<false>(c, __builtin_amdgcn_inverse_ballot_w64(mL), mL, pl.ref, prec, upper_mask, cw, one);
@@ -1756,7 +1838,7 @@ void bpc_decode_kernel(BpcArgs a)
                 rows &= rows - 1u;
                 const bool oL = ((rL >> ii) & 1u) != 0u, oR = ((rR >> ii) & 1u) != 0u;
                 const uint64_t mL = __builtin_amdgcn_ballot_w64(oL), mR = __builtin_amdgcn_ballot_w64(oR);
-                dec_ring_keep(c, cw, upper_mask);
+                dec_ring_row(c, cw, upper_mask);
                 if (mL != 0ull) curL |= dec_site_on<false>(c, oL, mL, pl.ref, prec, upper_mask, cw) ? (1u << ii) : 0u;
                 if (mR != 0ull) curR |= dec_site_on<false>(c, oR, mR, pl.ref, prec, upper_mask, cw) ? (1u << ii) : 0u;
             }
@@ -1777,6 +1859,7 @@ void bpc_decode_kernel(BpcArgs a)
     if constexpr (BULK) {
         // ---- bulk scan (decodeBulkMode :1653-1662) fused with writeCoefficients: plane register k
         // holds plane Bh+1+k here, the scan delivers the Bh+1 low bits and the missing signs row by row
+        dec_ring_sync(c);                                  // (the scan's call sites keep exact counters themselves)
         int Bmax = bl.Bh;
         { int o = __shfl_xor(Bmax, 32); Bmax = Bmax > o ? Bmax : o; }
         Bmax = (int)__builtin_amdgcn_readfirstlane((uint32_t)Bmax);
@@ -1869,21 +1952,6 @@ void bpc_decode_kernel(BpcArgs a)
 // =============================================================================================
 constexpr int kLutLdsMax3 = 2 * kLutLdsMax;        // bytes of one 5-section table
 
-__device__ __forceinline__ PlaneLut plane_lut_aux(const LutView &v, const LutGeo &g, int grp, int bp, int aux)
-{
-    PlaneLut pl;
-    const int ri = (grp * g.nBp + bp) * g.cRef;
-    const int si = (grp * g.nBp + bp) * g.cSig + g.nRef + aux;
-    const int gi = (grp * g.nBp + bp) * g.cSign + g.nRef + g.nSig + aux;
-    pl.ref = lut_get(v, ri);
-    pl.sig0 = lut_get(v, si + 0) | (lut_get(v, si + 1) << 8) | (lut_get(v, si + 2) << 16) | (lut_get(v, si + 3) << 24);
-    pl.sig1 = lut_get(v, si + 4) | (lut_get(v, si + 5) << 8) | (lut_get(v, si + 6) << 16) | (lut_get(v, si + 7) << 24);
-    pl.sig8 = lut_get(v, si + 8);
-    pl.sign = lut_get(v, gi + 0) | (lut_get(v, gi + 1) << 8) | (lut_get(v, gi + 2) << 16) | (lut_get(v, gi + 3) << 24);
-    pl.sig8x4 = pl.sig8 * 0x01010101u;
-    return pl;
-}
-
 // One coefficient of the significance pass (CLEANUP = false) or of the cleanup pass (true), encoder
 // (DEC = false: `cur` holds the plane's bits, `so` every coefficient's sign) or decoder (`cur` and `so`
 // receive them).  wo/wl/wr: W-form significance of the own / left / right column, so/sl/sr: signs.  flag:
@@ -1956,7 +2024,7 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
     constexpr int NP = kMaxPlanes;
     __shared__ uint8_t lds_lut[kLutLdsMax3];
     __shared__ uint8_t sign_tab[256];
-    __shared__ uint32_t cw_ring[kBpc3WgWaves * 2 * kDecRing];
+    __shared__ __attribute__((aligned(1024))) uint16_t cw_ring[kBpc3WgWaves * 2 * kDecRing];
     __shared__ uint32_t lds_cnt[kBpc3WgWaves * 2];
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
     sign_table_fill(sign_tab, lane);
@@ -2025,9 +2093,10 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
 
     CT c;
     if constexpr (DEC) {
-        c = Coder{ 0u, 0u, 0u, 0u, 0u, 0u, ~0ull, 64u, 64u, nullptr, t, nullptr };
+        c = Coder{ 0u, 0u, 0u, 0u, 0u, 0u, ~0ull, 64u, 64u, nullptr, t, nullptr, 0u, 0u };
         c.ldscnt = &lds_cnt[(threadIdx.x >> 6) * 2u + half];
         c.ring = cw_ring + ((threadIdx.x >> 6) * 2u + half) * kDecRing;
+        c.ringaddr = lds_addr_of(c.ring);
         dec_ring_init(c, cw);
         wave_lds_done();
     } else {
@@ -2058,7 +2127,7 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
             }
         }
         PlaneLut pl = { 0u, 0u, 0u, 0u, 0u, 0u }, plc = pl;
-        if (act) { pl = plane_lut_aux(lv, a.g, grp, bp, 0); plc = plane_lut_aux(lv, a.g, grp, bp, aux); }
+        if (act) { pl = plane_lut<true>(lv, a.g, grp, bp, 0); plc = plane_lut<true>(lv, a.g, grp, bp, aux); }
 
         // ---- significance pass, then refinement pass (not on a codeblock's top plane, Encode3CP :1744-1751)
         const bool top = act && p == 0 && bp == msb;       // this lane's codeblock is at its MSB plane

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(1024) void scan_sizes_kernel(const int32_t *sizes, 
 
 // one workgroup per codeblock (buildBitStreamLUTBS BitStreamBuilder.cu:106-137 layout); blockIdx.y = frame
 // of a batched launch (staging advances by frame_words, sizes / offsets by n, total by 1, out by
-// out_stride shorts; only the frame hdr.has - 1 == blockIdx.y carries the populated header -- has = 0: none)
+// out_stride shorts; only the frame hdr.has - 1 == blockIdx.y carries the populated header -- has = 0: none;
+// has < 0: -has is a bit mask of the frames that carry it (the components of an RGB frame))
 __global__ __launch_bounds__(256) void pack_kernel(const int32_t *staging, const int32_t *sizes,
                                                    const int32_t *offsets, const int32_t *total, int n,
                                                    HeaderArg hdr, uint16_t *out, size_t frame_words = 0,
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const int32_t *staging, const
     {
         const size_t f = blockIdx.y;
         staging += f * frame_words; sizes += f * (size_t)n; offsets += f * (size_t)n; total += f; out += f * out_stride;
-        hdr.has = (hdr.has != 0 && (size_t)(hdr.has - 1) == f) ? 1 : 0;
+        hdr.has = hdr.has < 0 ? (int)(((unsigned)(-hdr.has) >> f) & 1u) : ((hdr.has != 0 && (size_t)(hdr.has - 1) == f) ? 1 : 0);
     }
     const int32_t *st = staging + (size_t)cb * 4096u;
     const int len = sizes[cb];

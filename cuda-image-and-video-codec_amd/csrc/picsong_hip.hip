@@ -1009,7 +1009,8 @@ static int ensure_batch(picsong_ctx *c, int n)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipDeviceSynchronize());                 // a smaller batch may still be running on the old buffers
     free_batch(c);
-    const size_t waves = ((size_t)n * (size_t)((c->ncb + 1) / 2) + kBpcEncWgWaves - 1) / kBpcEncWgWaves * kBpcEncWgWaves;
+    // (scratch for whole workgroups per frame: the RGB form pads every component's waves to workgroups)
+    const size_t waves = (size_t)n * (size_t)(((c->ncb + 1) / 2 + kBpcEncWgWaves - 1) / kBpcEncWgWaves * kBpcEncWgWaves);
     HIP_TRY(hipMalloc(&c->b_coef, (size_t)n * (c->P + c->extra) * 4));
     HIP_TRY(hipMalloc(&c->b_staging, (size_t)n * c->P * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&c->b_sizes, (size_t)n * (size_t)c->ncb * sizeof(int32_t)));
@@ -1018,6 +1019,18 @@ static int ensure_batch(picsong_ctx *c, int n)
     HIP_TRY(hipMalloc(&c->b_plane_scratch, waves * kEncScratchDwordsPerWave * sizeof(uint32_t)));
     HIP_TRY(hipHostMalloc(&c->h_totals, (size_t)n * sizeof(int32_t)));
     c->batch_cap = n;
+    return PICSONG_OK;
+}
+
+// n planes of P 32-bit words: the decoded coefficients of a batch / the colour-transformed components of an RGB frame
+static int ensure_coef_i(picsong_ctx *c, int n)
+{
+    if (c->b_coef_i_cap >= n) return PICSONG_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    if (c->b_coef_i) (void)hipFree(c->b_coef_i);
+    c->b_coef_i = nullptr; c->b_coef_i_cap = 0;
+    HIP_TRY(hipMalloc(&c->b_coef_i, (size_t)n * c->P * sizeof(int32_t)));
+    c->b_coef_i_cap = n;
     return PICSONG_OK;
 }
 
@@ -1116,13 +1129,7 @@ int picsong_decode_frames(picsong_ctx *c, int n, const uint16_t *d_streams, size
     int rc = ensure_batch(c, n);
     if (rc) return rc;
     c->last_batch = -1;                                     // the batch buffers hold a decode now: no encode totals to hand out
-    if (c->b_coef_i_cap < n) {
-        HIP_TRY(hipDeviceSynchronize());
-        if (c->b_coef_i) (void)hipFree(c->b_coef_i);
-        c->b_coef_i = nullptr; c->b_coef_i_cap = 0;
-        HIP_TRY(hipMalloc(&c->b_coef_i, (size_t)n * c->P * sizeof(int32_t)));
-        c->b_coef_i_cap = n;
-    }
+    if ((rc = ensure_coef_i(c, n))) return rc;
     hipStream_t s = (hipStream_t)stream;
     // ---- unpack: lengths, offsets, codewords of the n streams
     read_sizes_kernel<<<dim3((unsigned)((c->ncb + 255) / 256), (unsigned)n), 256, 0, s>>>(d_streams, c->ncb, c->b_sizes, c->d_flag,
@@ -1226,6 +1233,105 @@ int picsong_decode_plane(picsong_ctx *c, const uint16_t *d_stream, int comp, voi
     if ((rc = unpack_impl(c, d_stream, c->d_staging, c->d_sizes, false, s))) return rc;
     if ((rc = bpc_decode_impl(c, c->d_staging, c->d_sizes, c->d_coef_i, s, comp))) return rc;
     return picsong_dwt_inverse(c, c->d_coef_i, d_plane_out, stream);
+}
+
+
+// The three component tables of an RGB context for ONE coder grid: same geometry, every frame f of the batched
+// launch coding with table f; waves_per_frame = whole workgroups.
+static int bpc_args_rgb(picsong_ctx *c, BpcArgs &a)
+{
+    int rc = bpc_args(c, a, 0);
+    if (rc) return rc;
+    for (int k = 1; k < 3; k++) {
+        if (!c->has_lut[k]) return fail(PICSONG_ERR_ARG, "no LUT loaded for component %d", k);
+        const picsong_lut_info &x = c->li[0], &y = c->li[k];
+        if (x.n_bitplanes != y.n_bitplanes || x.n_subbands != y.n_subbands || x.precision != y.precision ||
+            x.n_ref != y.n_ref || x.n_sig != y.n_sig || x.n_sign != y.n_sign)
+            return fail(PICSONG_ERR_ARG, "the components' tables differ in geometry: code the planes one by one (picsong_encode_plane)");
+    }
+    for (int k = 0; k < 3; k++) a.lut_c[k] = c->d_lut[k];
+    const int wpf = (c->ncb + 1) / 2;
+    a.cb_base = 0; a.nCB = c->ncb;
+    a.frames = 3; a.waves_per_frame = (wpf + kBpcEncWgWaves - 1) / kBpcEncWgWaves * kBpcEncWgWaves;
+    return PICSONG_OK;
+}
+
+int picsong_encode_rgb_frame(picsong_ctx *c, const uint8_t *d_r, const uint8_t *d_g, const uint8_t *d_b, int header_mask,
+                             uint16_t *d_streams, size_t stream_stride, void *stream)
+{
+    if (!c || !d_r || !d_g || !d_b || !d_streams) return fail(PICSONG_ERR_ARG, "encode_rgb_frame: null argument");
+    if (!c->p.is_rgb) return fail(PICSONG_ERR_ARG, "encode_rgb_frame: the context is not an RGB one");
+    if (c->p.k > 0.0f || c->p.cp == 3) return fail(PICSONG_ERR_ARG, "encode_rgb_frame: -k > 0 and -cp 3 code their planes one by one");
+    if (stream_stride < picsong_max_stream_shorts(c->aw, c->ah)) return fail(PICSONG_ERR_ARG, "encode_rgb_frame: stream stride smaller than a worst-case codestream");
+    HIP_TRY(hipSetDevice(c->device));
+    BpcArgs a;
+    int rc = bpc_args_rgb(c, a);
+    if (rc) return rc;
+    if ((rc = ensure_batch(c, 3))) return rc;
+    if ((rc = ensure_coef_i(c, 3))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t coef_z = (c->P + c->extra) * 4;
+    char *planes = (char *)c->b_coef_i;
+    // ---- colour transform (level shift fused) into three planes, then the transform of all three per launch
+    if ((rc = picsong_rgb_forward(c, d_r, d_g, d_b, planes, planes + c->P * 4, planes + 2 * c->P * 4, stream))) return rc;
+    std::vector<FwdLaunch> plan = plan_dwt_forward(planes, false, c->b_coef, c->aw, c->ah, c->p.wl, c->p.qs);
+    for (size_t l = 0; l < plan.size(); l++) {
+        plan[l].a.src_z = l == 0 ? (unsigned long long)c->P * 4ull : (unsigned long long)coef_z;
+        plan[l].a.dst_z = (unsigned long long)coef_z;
+    }
+    if ((rc = launch_fwd_levels(c, plan, 0, s, 3u))) return rc;
+    // ---- coder: one grid over the three components' codeblock pairs, component f with table f
+    a.coeffs_in = c->b_coef; a.is_float = c->p.lossy ? 1 : 0;
+    a.staging = c->b_staging; a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch; a.coef_z = coef_z;
+    bpc_encode_kernel<false><<<(unsigned)(3 * a.waves_per_frame / kBpcEncWgWaves), 64 * kBpcEncWgWaves, 0, s>>>(a);
+    HIP_TRY(hipGetLastError());
+    // ---- pack: the populated header on the components of header_mask
+    HeaderArg h;
+    memset(&h, 0, sizeof h);
+    if (header_mask & 7) {
+        uint16_t hdr[PICSONG_HDR_SHORTS];
+        picsong_header_pack(&c->p, hdr);
+        memcpy(h.h, hdr, sizeof h.h);
+        h.has = -(header_mask & 7);
+    }
+    scan_sizes_kernel<<<3, 1024, 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
+    HIP_TRY(hipGetLastError());
+    pack_kernel<<<dim3((unsigned)c->ncb, 3u), 256, 0, s>>>(c->b_staging, c->b_sizes, c->b_offsets, c->b_total, c->ncb, h,
+                                                          d_streams, c->P, stream_stride);
+    HIP_TRY(hipGetLastError());
+    c->last_batch = 3;
+    return PICSONG_OK;
+}
+
+int picsong_decode_rgb_frame(picsong_ctx *c, const uint16_t *d_streams, size_t stream_stride, uint8_t *d_r, uint8_t *d_g,
+                             uint8_t *d_b, void *stream)
+{
+    if (!c || !d_streams || !d_r || !d_g || !d_b) return fail(PICSONG_ERR_ARG, "decode_rgb_frame: null argument");
+    if (!c->p.is_rgb) return fail(PICSONG_ERR_ARG, "decode_rgb_frame: the context is not an RGB one");
+    if (c->p.k > 0.0f || c->p.cp == 3) return fail(PICSONG_ERR_ARG, "decode_rgb_frame: -k > 0 and -cp 3 decode their planes one by one");
+    if (stream_stride < picsong_max_stream_shorts(c->aw, c->ah)) return fail(PICSONG_ERR_ARG, "decode_rgb_frame: stream stride smaller than a worst-case codestream");
+    HIP_TRY(hipSetDevice(c->device));
+    BpcArgs a;
+    int rc = bpc_args_rgb(c, a);
+    if (rc) return rc;
+    if ((rc = ensure_batch(c, 3))) return rc;
+    if ((rc = ensure_coef_i(c, 3))) return rc;
+    c->last_batch = -1;
+    hipStream_t s = (hipStream_t)stream;
+    read_sizes_kernel<<<dim3((unsigned)((c->ncb + 255) / 256), 3u), 256, 0, s>>>(d_streams, c->ncb, c->b_sizes, c->d_flag, stream_stride);
+    HIP_TRY(hipGetLastError());
+    scan_sizes_kernel<<<3, 1024, 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
+    HIP_TRY(hipGetLastError());
+    unpack_kernel<<<dim3((unsigned)c->ncb, 3u), 256, 0, s>>>(d_streams, c->b_sizes, c->b_offsets, c->ncb, c->b_staging, stream_stride, c->P);
+    HIP_TRY(hipGetLastError());
+    a.coeffs_out = c->b_coef_i; a.staging = c->b_staging; a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch;
+    a.coef_z = (unsigned long long)c->P * 4ull;
+    bpc_decode_kernel<false, kDecSmallPlanes><<<(unsigned)(3 * a.waves_per_frame / kBpcDecWgWaves), 64 * kBpcDecWgWaves, 0, s>>>(a);
+    HIP_TRY(hipGetLastError());
+    if ((rc = dwt_inverse_impl(c, c->b_coef_i, c->b_coef, nullptr, nullptr, s, 3u, 0))) return rc;
+    const char *img = (const char *)c->b_coef + c->extra * 4;
+    const size_t z = (c->P + c->extra) * 4;
+    return picsong_rgb_inverse(c, img, img + z, img + 2 * z, d_r, d_g, d_b, stream);
 }
 
 int picsong_pad_frame_host(const uint8_t *in, int w, int h, uint8_t *out, int aw, int ah)

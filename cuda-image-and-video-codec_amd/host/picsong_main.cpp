@@ -234,8 +234,11 @@ int run_encode_rgb(const Options &o, size_t file_base, long nframes)
     uint16_t *h_out, *d_out;
     HIPCK(hipHostMalloc(&h_in, P));
     for (int c = 0; c < 3; c++) { HIPCK(hipMalloc(&d_in[c], P)); HIPCK(hipMalloc(&d_c[c], P * 4)); }
+    // the three components of a frame through ONE launch per stage (picsong_encode_rgb_frame) wherever the library
+    // offers it: -cp 2, k = 0; otherwise plane by plane
+    const bool batched = o.k <= 0.0f && o.cp != 3;
     HIPCK(hipHostMalloc(&h_out, max_shorts * 2));
-    HIPCK(hipMalloc(&d_out, max_shorts * 2));
+    HIPCK(hipMalloc(&d_out, max_shorts * 2 * (batched ? 3 : 1)));
     std::vector<uint8_t> raw((size_t)o.x * o.y);
     std::ifstream in(o.input, std::ios::binary);
     if (!in) die("Cannot open input file " + o.input);
@@ -250,13 +253,21 @@ int run_encode_rgb(const Options &o, size_t file_base, long nframes)
             HIPCK(hipMemcpyAsync(d_in[c], h_in, P, hipMemcpyHostToDevice, s));
             HIPCK(hipStreamSynchronize(s));          // h_in is reused for the next plane
         }
-        CK(picsong_rgb_forward(ctx, d_in[0], d_in[1], d_in[2], d_c[0], d_c[1], d_c[2], s));
+        int totals[3] = { 0, 0, 0 };
+        if (batched) {
+            CK(picsong_encode_rgb_frame(ctx, d_in[0], d_in[1], d_in[2], o.video ? (f == 0 ? 7 : 0) : 1, d_out, max_shorts, s));
+            CK(picsong_last_totals(ctx, s, 3, totals));
+        } else {
+            CK(picsong_rgb_forward(ctx, d_in[0], d_in[1], d_in[2], d_c[0], d_c[1], d_c[2], s));
+        }
         for (int c = 0; c < 3; c++) {
-            const int with_header = o.video ? (f == 0) : (c == 0);
-            CK(picsong_encode_plane(ctx, d_c[c], c, with_header, d_out, s));
-            int total = 0;
-            CK(picsong_last_total(ctx, s, &total));
-            HIPCK(hipMemcpyAsync(h_out, d_out, (size_t)total * 2, hipMemcpyDeviceToHost, s));
+            int total = totals[c];
+            if (!batched) {
+                const int with_header = o.video ? (f == 0) : (c == 0);
+                CK(picsong_encode_plane(ctx, d_c[c], c, with_header, d_out, s));
+                CK(picsong_last_total(ctx, s, &total));
+            }
+            HIPCK(hipMemcpyAsync(h_out, d_out + (batched ? (size_t)c * max_shorts : 0), (size_t)total * 2, hipMemcpyDeviceToHost, s));
             HIPCK(hipStreamSynchronize(s));
             out.write(reinterpret_cast<const char *>(h_out), (std::streamsize)total * 2);
             if (f == 0 && c == 0) sizes << total; else sizes << "," << total;
@@ -576,8 +587,9 @@ int run_decode_rgb(const Options &o, const picsong_params &p, picsong_ctx *ctx, 
     uint16_t *h_in, *d_in;
     uint8_t *h_pix, *d_pix[3];
     char *d_plane[3];
+    const bool batched = p.k <= 0.0f && p.cp != 3;      // (picsong_decode_rgb_frame: one launch per stage for the three components)
     HIPCK(hipHostMalloc(&h_in, max_shorts * 2));
-    HIPCK(hipMalloc(&d_in, max_shorts * 2));
+    HIPCK(hipMalloc(&d_in, max_shorts * 2 * (batched ? 3 : 1)));
     HIPCK(hipHostMalloc(&h_pix, P));
     for (int c = 0; c < 3; c++) { HIPCK(hipMalloc(&d_pix[c], P)); HIPCK(hipMalloc(&d_plane[c], (P + extra) * 4)); }
     std::vector<uint8_t> crop((size_t)p.width * p.height);
@@ -593,12 +605,15 @@ int run_decode_rgb(const Options &o, const picsong_params &p, picsong_ctx *ctx, 
             in.read(reinterpret_cast<char *>(h_in), (std::streamsize)(n * 2));
             if ((size_t)in.gcount() != n * 2) die("Input file is shorter than its _SIZE sidecar says.");
             pos += n;
-            HIPCK(hipMemcpyAsync(d_in, h_in, n * 2, hipMemcpyHostToDevice, s));
-            CK(picsong_decode_plane(ctx, d_in, c, d_plane[c], s));
-            HIPCK(hipStreamSynchronize(s));          // h_in / d_in are reused for the next component
+            HIPCK(hipMemcpyAsync(d_in + (batched ? (size_t)c * max_shorts : 0), h_in, n * 2, hipMemcpyHostToDevice, s));
+            if (!batched) CK(picsong_decode_plane(ctx, d_in, c, d_plane[c], s));
+            HIPCK(hipStreamSynchronize(s));          // h_in (and, plane by plane, d_in) are reused for the next component
         }
-        CK(picsong_rgb_inverse(ctx, d_plane[0] + extra * 4, d_plane[1] + extra * 4, d_plane[2] + extra * 4, d_pix[0],
-                               d_pix[1], d_pix[2], s));
+        if (batched)
+            CK(picsong_decode_rgb_frame(ctx, d_in, max_shorts, d_pix[0], d_pix[1], d_pix[2], s));
+        else
+            CK(picsong_rgb_inverse(ctx, d_plane[0] + extra * 4, d_plane[1] + extra * 4, d_plane[2] + extra * 4, d_pix[0],
+                                   d_pix[1], d_pix[2], s));
         std::ofstream out(o.output, std::ios::binary | std::ios::app);
         for (int c = 0; c < 3; c++) {
             HIPCK(hipMemcpyAsync(h_pix, d_pix[c], P, hipMemcpyDeviceToHost, s));

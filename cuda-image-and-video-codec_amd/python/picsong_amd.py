@@ -112,6 +112,9 @@ def load():
         L.picsong_copy_last_totals.argtypes = [vp, vp, i, vp]
     if hasattr(L, "picsong_decode_frames"):
         L.picsong_decode_frames.argtypes = [vp, i, vp, C.c_size_t, vp, C.c_size_t, vp]
+    if hasattr(L, "picsong_encode_rgb_frame"):
+        L.picsong_encode_rgb_frame.argtypes = [vp, vp, vp, vp, i, vp, C.c_size_t, vp]
+        L.picsong_decode_rgb_frame.argtypes = [vp, vp, C.c_size_t, vp, vp, vp, vp]
     if hasattr(L, "picsong_lut_load_cp"):
         L.picsong_lut_load_cp.argtypes = [C.c_char_p, i, i, i, i, C.POINTER(LutInfo), vp, C.c_size_t]
     if hasattr(L, "picsong_dwt_forward_band"):
@@ -251,6 +254,21 @@ class Codec:
         _check(self.L.picsong_encode_plane(self.h, self._p(plane), component, int(with_header), self._p(out),
                                            self._stream()))
         return out[:self.last_total()]
+
+    def encode_rgb_frame(self, r, g, b, header_mask=1):
+        """One RGB frame (padded u8 planes) through one launch per stage; returns the three codestreams."""
+        out = self.torch.empty((3, self.max_stream_shorts()), dtype=self.torch.int16, device=self.dev)
+        _check(self.L.picsong_encode_rgb_frame(self.h, self._p(r), self._p(g), self._p(b), header_mask, self._p(out),
+                                               out.stride(0), self._stream()))
+        totals = self.last_totals(3)
+        return [out[k, :totals[k]] for k in range(3)]
+
+    def decode_rgb_frame(self, streams):
+        """streams: int16 [3, >= max_stream_shorts()]; returns the three padded u8 planes."""
+        outs = [self.torch.empty((self.ah, self.aw), dtype=self.torch.uint8, device=self.dev) for _ in range(3)]
+        _check(self.L.picsong_decode_rgb_frame(self.h, self._p(streams), streams.stride(0), self._p(outs[0]),
+                                               self._p(outs[1]), self._p(outs[2]), self._stream()))
+        return outs
 
     def decode_plane(self, stream, component):
         out = self.torch.empty(self.P + self.extra, dtype=self.dtype, device=self.dev)

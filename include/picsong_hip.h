@@ -223,6 +223,19 @@ int picsong_encode_plane(picsong_ctx *ctx, const void *d_plane, int component, i
                          uint16_t *d_stream, void *stream);
 int picsong_decode_plane(picsong_ctx *ctx, const uint16_t *d_stream, int component, void *d_plane_out,
                          void *stream);
+/* One RGB frame through ONE launch per stage -- the colour transform, then its three components as the three frames
+ * of the batched grid: grid.z = 3 for the transform's levels, one coder grid in which component c codes with table c,
+ * one scan + pack -- in place of picsong_rgb_forward + 3 x picsong_encode_plane (the reference codes the components
+ * one after the other, Engines/CodingEngine.cu:598-633).  d_r / d_g / d_b: padded u8[AW*AH] planes; component c's
+ * codestream lands at d_streams + c * stream_stride (shorts, >= picsong_max_stream_shorts); header_mask bit c = that
+ * component carries the populated header (image: 1 -- component 0 only, iter = component; video frame 0: 7; else 0).
+ * Lengths: picsong_last_totals(ctx, stream, 3, ..) / picsong_copy_last_totals.  Byte-identical to the plane-by-plane
+ * calls; -cp 2, k = 0 RGB contexts whose three tables share one geometry.  The decoder's mirror takes the three
+ * codestreams (same stride) to the three padded u8 planes (Engines/DecodingEngine.cu:599-701, 736-769). */
+int picsong_encode_rgb_frame(picsong_ctx *ctx, const uint8_t *d_r, const uint8_t *d_g, const uint8_t *d_b, int header_mask,
+                             uint16_t *d_streams, size_t stream_stride, void *stream);
+int picsong_decode_rgb_frame(picsong_ctx *ctx, const uint16_t *d_streams, size_t stream_stride, uint8_t *d_r, uint8_t *d_g,
+                             uint8_t *d_b, void *stream);
 
 /* ---- intra-frame sharding (BASELINE config 5): codeblocks are independent
  *      (correctCBBorders zeroes outside neighbours, BPC/BPCEngine.cu:465-484), so a rank can code

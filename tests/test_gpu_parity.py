@@ -620,6 +620,42 @@ def test_rgb_components_parity(oracle, pa, torch, lossy, qs):
     c.close()
 
 
+@pytest.mark.parametrize("W,H,wl,lossy,qs,mask", [(320, 192, 3, False, 1.0, 1), (704, 448, 4, True, 0.5, 7), (1000, 300, 3, False, 1.0, 0)])
+def test_rgb_frame_through_the_batched_grid_equals_oracle(oracle, pa, torch, W, H, wl, lossy, qs, mask):
+    """picsong_encode_rgb_frame / picsong_decode_rgb_frame: the three components of an RGB frame as the three frames
+    of ONE launch per stage (component c with table c) -- every component's codestream equals the oracle's and the
+    plane-by-plane calls', the header lands on the components of the mask, and the decode returns the planes."""
+    planes = [oracle.pad_frame(oracle.gen_frame(W, H, 60 + c)) for c in range(3)]
+    AH, AW = planes[0].shape
+    c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=_lutdir(oracle, lossy), rgb=True)
+    d = [_dev(torch, p) for p in planes]
+    hdr = pa.header_pack(c.params)
+    got = [g.clone() for g in c.encode_rgb_frame(*d, header_mask=mask)]
+    ref_comps = oracle.rgb_forward(*planes, lossy)
+    comps = c.rgb_forward(*d)
+    for k in range(3):
+        with_hdr = (mask >> k) & 1
+        ref = oracle.encode_plane(ref_comps[k], wl, lossy, qs, oracle.lut_for_component(lossy, wl, k), hdr if with_hdr else None)
+        assert np.array_equal(got[k].cpu().numpy().view(np.uint16), ref), f"component {k}"
+        assert torch.equal(got[k], c.encode_plane(comps[k], k, bool(with_hdr)))
+    streams = torch.zeros((3, c.max_stream_shorts()), dtype=torch.int16, device="cuda")
+    for k in range(3):
+        streams[k, :got[k].numel()] = got[k]
+    back = c.decode_rgb_frame(streams)
+    dec = [c.decode_plane(got[k].clone(), k).clone() for k in range(3)]
+    ref_back = c.rgb_inverse(*dec)
+    for k in range(3):
+        assert torch.equal(back[k].view(-1), ref_back[k].view(-1))
+        if not lossy:
+            assert np.array_equal(back[k].cpu().numpy(), planes[k])
+    # a grey context refuses the call
+    g = pa.Codec(W, H, wl=wl, lut_folder=_lutdir(oracle, False))
+    with pytest.raises(pa.PicsongError):
+        g.encode_rgb_frame(*d)
+    g.close()
+    c.close()
+
+
 # ---- complexity-scalable mode -k > 0 (SURVEY 8f row 3) -------------------------------------------
 @pytest.mark.parametrize("W,H,wl,lossy,qs,k", [(512, 512, 3, False, 1.0, 0.3), (700, 500, 4, False, 1.0, 1.5),
                                                (512, 384, 3, False, 1.0, 65.0), (640, 384, 3, True, 0.5, 0.7)])

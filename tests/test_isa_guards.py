@@ -84,3 +84,22 @@ def test_lean_synthesis_kernels_do_not_spill(device_asm):
             seen += 1
             assert int(m.group(1)) == 0, f"{name} uses {m.group(1)} bytes of scratch"
     assert seen >= 12
+
+
+def test_coder_kernels_keep_their_argument_struct_in_registers(device_asm):
+    """The coders' per-wave scratch is a few spilled dwords of the prologue / epilogue.  Indexing the by-value argument
+    struct with a run-time value (round 3: `a.lut_c[f]`) moves the whole struct to scratch memory and every use of an
+    argument in the plane loops becomes a scratch load -- 15 % of the encoder's rate, with every test still green."""
+    name, sizes = None, {}
+    for line in device_asm:
+        m = re.match(r"^\s*\.amdhsa_kernel (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.match(r"^\s*\.amdhsa_private_segment_fixed_size (\d+)", line)
+        if m and name:
+            sizes[name] = int(m.group(1))
+    enc = [v for k, v in sizes.items() if "bpc_encode_kernelILb0E" in k]
+    dec = [v for k, v in sizes.items() if "bpc_decode_kernelILb0ELi8" in k]
+    assert enc and dec
+    assert enc[0] <= 128, f"bpc_encode_kernel<false> uses {enc[0]} bytes of scratch"
+    assert dec[0] <= 192, f"bpc_decode_kernel<false, 8> uses {dec[0]} bytes of scratch"
