@@ -96,7 +96,7 @@ def pmc_traffic(workload, batch=1):
         return None, None
     bpc = dwt = 0.0
     frames = None
-    rows = list(csv.DictReader(open(path)))
+    rows = list(csv.DictReader(ln for ln in open(path) if not ln.startswith("#")))
     for r in rows:
         if "bpc_encode_kernel" in r["Kernel_Name"]:
             frames = int(r["Dispatches"])
@@ -117,10 +117,39 @@ def pmc_valu(workload):
     path = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_sq.csv")
     if workload != "8k_lossless" or not os.path.exists(path):
         return None
-    for r in csv.DictReader(open(path)):
+    for r in csv.DictReader(ln for ln in open(path) if not ln.startswith("#")):
         if "bpc_encode_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "SQ_INSTS_VALU":
             return float(r["MeanValue"])
     return None
+
+
+def pmc_pipelined(workload):
+    """Counter-derived occupancy of the vector ALUs by the coder while frames of three calls share the GPU
+    (profiles/*_pmc_sq_pipelined.csv: a rocprofv3 --pmc pass over the DEFAULT three-stream shape): per dispatch of
+    bpc_encode_kernel, the share of its waves' cycles spent issuing (SQ_ACTIVE_INST_ANY), issuing vector instructions
+    (SQ_INST_CYCLES_VALU / SQ_ACTIVE_INST_VALU), waiting on s_waitcnt (SQ_WAIT_ANY) or for an issue slot
+    (SQ_WAIT_INST_ANY).  OFFLINE, like `traffic`."""
+    import csv
+    path = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_sq_pipelined.csv")
+    if workload != "8k_lossless" or not os.path.exists(path):
+        return None
+    c = {}
+    for r in csv.DictReader(ln for ln in open(path) if not ln.startswith("#")):
+        if "bpc_encode_kernel" in r["Kernel_Name"]:
+            c[r["Counter_Name"]] = float(r["MeanValue"])
+    if "SQ_WAVE_CYCLES" not in c:
+        return None
+    wc = c["SQ_WAVE_CYCLES"]
+    out = {"source": "profiles/%s_pmc_sq_pipelined.csv" % PROFILE_TAG, "counters_per_dispatch": {k: int(v) for k, v in c.items()}}
+    for name, key in (("wave_cycles_issuing_any", "SQ_ACTIVE_INST_ANY"), ("wave_cycles_issuing_valu", "SQ_INST_CYCLES_VALU"),
+                      ("wave_cycles_waiting_waitcnt", "SQ_WAIT_ANY"), ("wave_cycles_waiting_issue", "SQ_WAIT_INST_ANY")):
+        if key in c and wc:
+            out[name] = round(c[key] / wc, 4)
+    # the SIMDs' view: vector-instruction issue cycles of ALL resident waves per cycle the CUs were busy -- one SIMD
+    # issues one vector instruction at a time, a CU has four
+    if "SQ_INST_CYCLES_VALU" in c and c.get("SQ_BUSY_CU_CYCLES"):
+        out["valu_busy_fraction_per_simd"] = round(c["SQ_INST_CYCLES_VALU"] / (4.0 * c["SQ_BUSY_CU_CYCLES"]), 4)
+    return out
 
 
 def probe_rates():
@@ -531,6 +560,17 @@ def main():
     torch.cuda.synchronize()
     iso_ms = iso.profile_read(iso_n).mean(axis=0) / batch              # per frame
     iso.profile_begin(0)
+    # ---- a LONE frame (an image encoder cannot batch): single-frame calls on one stream, nothing else on the GPU
+    lone_ms = iso_ms
+    if batch != 1:
+        for i in range(2 + iso_n):
+            if i == 2:
+                torch.cuda.synchronize()
+                iso.profile_begin(iso_n)
+            iso.encode_frame_async(pool[i % pool_n], outs[0][0], 1)
+        torch.cuda.synchronize()
+        lone_ms = iso.profile_read(iso_n).mean(axis=0)
+        iso.profile_begin(0)
     # ---- and as a video engine hands them over: three frames per call (picsong_encode_frames: every launch of
     # the transform's levels serves three frames), still one stream with nothing else on the GPU
     b3_ms = None
@@ -609,6 +649,7 @@ def main():
                 "single_stream": {"avg_launch_ms": round(float(iso_ms[1]) * batch, 4),
                                   "codeblocks_per_s": round(nCB / (float(iso_ms[1]) * 1e-3), 1)},
                 "valu_issue": valu_issue(pmc_valu(args.workload), ms_per_frame * 1e-3, float(iso_ms[1]) * 1e-3),
+                "valu_busy_pipelined": pmc_pipelined(args.workload),
                 "source": library_hashes(),
                 "note": "BPC is bound by vector-instruction issue, not HBM (SURVEY 8d): codeblocks/s and "
                         "valu_issue are the figures of merit, the HBM fraction is reported for completeness. "
@@ -721,6 +762,10 @@ def main():
                      "note": "per frame, HIP events on the launch streams inside the timed region"},
         "stage_ms_single_stream": {"dwt": round(float(iso_ms[0]), 4), "bpc": round(float(iso_ms[1]), 4),
                                    "pack": round(float(iso_ms[2]), 4)},
+        "lone_frame": {"ms": round(float(sum(lone_ms)), 4), "mpixels_per_s": round(W * H / (float(sum(lone_ms)) * 1e-3) / 1e6, 1),
+                       "stage_ms": {"dwt": round(float(lone_ms[0]), 4), "bpc": round(float(lone_ms[1]), 4), "pack": round(float(lone_ms[2]), 4)},
+                       "note": "one frame per call on one stream with nothing else on the GPU (HIP events around the stages): "
+                               "what a single image costs"},
         "roofline": roofline, "roofline_dwt": roofline_dwt, "cpu_baseline": cpu,
     }
     if psnr is not None:

@@ -55,6 +55,7 @@ struct BpcArgs {
     const void *coeffs_in;         // encoder: Mallat T[AW*AH]
     int32_t *coeffs_out;           // decoder: Mallat int32[AW*AH]
     int is_float;                  // encoder input is float (truncated toward zero on load)
+    int c16;                       // frame paths: the Mallat array (coeffs_in / coeffs_out) is int16, row stride AW
     int AW, AH, wl, nCB, ncx;
     int cb_base;                   // first codeblock of this launch (intra-frame striping), nCB = end
     const int32_t *lut;
@@ -949,7 +950,10 @@ __device__ __forceinline__ void load_row(const BpcArgs &a, uint32_t off, uint32_
 {
     int32_t v0, v1;
     const char *const p = reinterpret_cast<const char *>(a.coeffs_in) + (size_t)off;
-    if (a.is_float) {
+    if (a.c16) {                                            // (int16 array: `off` counts its bytes)
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(p);
+        v0 = (int32_t)(int16_t)(w & 0xFFFFu); v1 = (int32_t)w >> 16;
+    } else if (a.is_float) {
         float2 f = *reinterpret_cast<const float2 *>(p);
         v0 = (int32_t)f.x; v1 = (int32_t)f.y;               // BPCEngine.cu:49: truncation toward zero
     } else {
@@ -978,11 +982,15 @@ __device__ __forceinline__ void sched_fence()
 }
 
 // the same row as signed integers (BPCEngine.cu:49: a float coefficient is truncated toward zero)
-template <bool FLOAT>
+// MODE: 0 = int32, 1 = float, 2 = the frame paths' int16 array
+template <int MODE>
 __device__ __forceinline__ void load_row_raw(const BpcArgs &a, uint32_t off, int32_t &v0, int32_t &v1)
 {
     const char *const p = reinterpret_cast<const char *>(a.coeffs_in) + (size_t)off;
-    if constexpr (FLOAT) {
+    if constexpr (MODE == 2) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(p);
+        v0 = (int32_t)(int16_t)(w & 0xFFFFu); v1 = (int32_t)w >> 16;
+    } else if constexpr (MODE == 1) {
         float2 f = *reinterpret_cast<const float2 *>(p);
         v0 = (int32_t)f.x; v1 = (int32_t)f.y;
     } else {
@@ -1014,7 +1022,7 @@ __device__ __forceinline__ void bit_transpose_8x8x4(uint32_t (&x)[8])
 // scratch as they come out ([plane][L rows 0-31, L rows 32-63, R rows 0-31, R rows 32-63][lane]: all eight planes of
 // the pass, whatever the codeblock's MSB turns out to be -- holding them back until it is known costs 32 registers
 // the kernel does not have); pass 0 also gathers the OR of the magnitudes and the sign masks.
-template <bool FLOAT>
+template <int MODE>
 __device__ __forceinline__ void enc_transpose_pass(const BpcArgs &a, int pass, uint32_t cbyte, uint32_t rstride,
                                                    uint32_t *pscr, uint32_t &ormag, U64 &sgL, U64 &sgR)
 {
@@ -1031,7 +1039,7 @@ __device__ __forceinline__ void enc_transpose_pass(const BpcArgs &a, int pass, u
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 int32_t v0, v1;
-                load_row_raw<FLOAT>(a, roff + (uint32_t)(8 * b) * rstride, v0, v1);
+                load_row_raw<MODE>(a, roff + (uint32_t)(8 * b) * rstride, v0, v1);
                 m0[b] = (uint32_t)(v0 < 0 ? -v0 : v0); m1[b] = (uint32_t)(v1 < 0 ? -v1 : v1);
                 if (pass == 0) {
                     ormag |= m0[b] | m1[b];
@@ -1088,7 +1096,8 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     const bool valid = cb < a.nCB;
     const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
     const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
-    const uint32_t cbyte = (uint32_t)cbase * 4u, rstride = (uint32_t)a.AW * 4u;  // byte offset of row 0 / of a row step
+    const uint32_t esz = a.c16 ? 2u : 4u;                    // bytes of a coefficient
+    const uint32_t cbyte = (uint32_t)cbase * esz, rstride = (uint32_t)a.AW * esz;  // byte offset of row 0 / of a row step
     int32_t *const stw = a.staging + (size_t)(a.cb_base + 2 * wave) * 4096u;     // wave-uniform: the pair's first codeblock
     int32_t *const st = stw + (size_t)half * 4096u;                             // (an invalid upper half never touches it)
     const uint32_t prec = (uint32_t)a.g.prec;
@@ -1114,8 +1123,9 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
         // 8 b + j at bit 8 b + j: the plane's row mask.  2.3 instructions per coefficient and pass.
         if (valid) {
             // (the coefficient type is wave-uniform: one branch around the whole pass, not one per row)
-            if (a.is_float) enc_transpose_pass<true>(a, pass, cbyte, rstride, pscr, ormag, sgL, sgR);
-            else enc_transpose_pass<false>(a, pass, cbyte, rstride, pscr, ormag, sgL, sgR);
+            if (!BULK && a.c16) enc_transpose_pass<2>(a, pass, cbyte, rstride, pscr, ormag, sgL, sgR);
+            else if (a.is_float) enc_transpose_pass<1>(a, pass, cbyte, rstride, pscr, ormag, sgL, sgR);
+            else enc_transpose_pass<0>(a, pass, cbyte, rstride, pscr, ormag, sgL, sgR);
         }
         if (pass == 0) {
             ormag = half_or_dpp(ormag, upper_mask);
@@ -1617,10 +1627,17 @@ __device__ __forceinline__ uint32_t cform_signs(uint32_t a, uint32_t b, uint32_t
 // The decoded planes of one column half (row masks PL / PR, plane k in word k) back to coefficients: the same 8 x 8
 // bit-matrix transpose as the encoder's prologue (bit_transpose_8x8x4 is its own inverse) turns eight plane words into
 // eight words of row bytes -- the magnitude byte of row 8 b + j is byte b of word j -- instead of a bit at a time.
+// the lane's two coefficients of one row: `out` addresses the lane's pair in row 0 of the codeblock (int32 array, or
+// the frame paths' int16 array when c16: one dword then)
+__device__ __forceinline__ void store_pair(void *out, int row, int AW, bool c16, int32_t v0, int32_t v1)
+{
+    if (c16) *reinterpret_cast<uint32_t *>((int16_t *)out + (size_t)row * (size_t)AW) = ((uint32_t)v0 & 0xFFFFu) | ((uint32_t)v1 << 16);
+    else *reinterpret_cast<int2 *>((int32_t *)out + (size_t)row * (size_t)AW) = make_int2(v0, v1);
+}
 template <int NP, int NA>
 __device__ __forceinline__ void write_rows(const uint32_t (&PL)[NA], const uint32_t (&PR)[NA],
                                            uint32_t sgL, uint32_t sgR, int row0, bool valid, int32_t sz,
-                                           const int32_t *stage, uint32_t t, int32_t *out, int AW)
+                                           const int32_t *stage, uint32_t t, void *out, int AW, bool c16 = false)
 {
     if (!valid) return;
     if (sz == 4096) {                                       // raw codeblock (expansionFix): words, not planes
@@ -1630,7 +1647,7 @@ __device__ __forceinline__ void write_rows(const uint32_t (&PL)[NA], const uint3
             int2 w = *reinterpret_cast<const int2 *>(stage + t * 128u + 2u * (uint32_t)i);
             int32_t v0 = (int32_t)(((uint32_t)w.x & 0xFFFFFFu) >> 1); if (w.x & 1) v0 = -v0;
             int32_t v1 = (int32_t)(((uint32_t)w.y & 0xFFFFFFu) >> 1); if (w.y & 1) v1 = -v1;
-            *reinterpret_cast<int2 *>(out + (size_t)i * (size_t)AW) = make_int2(v0, v1);
+            store_pair(out, i, AW, c16, v0, v1);
         }
         return;
     }
@@ -1644,7 +1661,6 @@ __device__ __forceinline__ void write_rows(const uint32_t (&PL)[NA], const uint3
     bit_transpose_8x8x4(X0);
     bit_transpose_8x8x4(X1);
     if (NP > 8) { bit_transpose_8x8x4(Y0); bit_transpose_8x8x4(Y1); }
-    int32_t *o = out + (size_t)row0 * (size_t)AW;
 #pragma unroll
     for (int b = 0; b < 4; b++) {
 #pragma unroll
@@ -1654,7 +1670,7 @@ __device__ __forceinline__ void write_rows(const uint32_t (&PL)[NA], const uint3
             if (NP > 8) { m0 |= ((Y0[j] >> (8 * b)) & 0xFFu) << 8; m1 |= ((Y1[j] >> (8 * b)) & 0xFFu) << 8; }
             const int32_t v0 = ((sgL >> ii) & 1u) ? -(int32_t)m0 : (int32_t)m0;
             const int32_t v1 = ((sgR >> ii) & 1u) ? -(int32_t)m1 : (int32_t)m1;
-            *reinterpret_cast<int2 *>(o + (size_t)ii * (size_t)AW) = make_int2(v0, v1);
+            store_pair(out, row0 + ii, AW, c16, v0, v1);
         }
     }
 }
@@ -1903,6 +1919,11 @@ void bpc_decode_kernel(BpcArgs a)
         // The planes come back from the scratch, eight (sixteen for a wave with a codeblock of MSB >= 8) of one
         // 32-row half at a time; planes above a codeblock's MSB were never written and read as zero.
         const bool have = coded;
+        const bool c16 = a.c16 != 0;
+        void *const outp = c16 ? (void *)((int16_t *)a.coeffs_out + cbase) : (void *)(a.coeffs_out + cbase);
+        // (an int16 array holds 15 magnitude bits: a codeblock with 16 planes -- which no frame within coef16_ok's
+        // bound codes -- is flagged like an MSB beyond the planes)
+        if (c16 && coded && msb >= 15) atomicOr(a.range_flag, 1);
         auto planes_of = [&](auto &A, auto &B, int hw, int n) {
 #pragma unroll
             for (int k = 0; k < (int)(sizeof(A) / sizeof(A[0])); k++) {
@@ -1919,7 +1940,7 @@ void bpc_decode_kernel(BpcArgs a)
                 uint32_t A[kMaxPlanes], B[kMaxPlanes];
                 planes_of(A, B, hw, kMaxPlanes);
                 write_rows<kMaxPlanes>(A, B, hw ? sgnL.hi : sgnL.lo, hw ? sgnR.hi : sgnR.lo, 32 * hw, valid, sz, stage, t,
-                                       a.coeffs_out + cbase, a.AW);
+                                       outp, a.AW, c16);
             }
         } else {
 #pragma unroll 1
@@ -1927,7 +1948,7 @@ void bpc_decode_kernel(BpcArgs a)
                 uint32_t A[kDecSmallPlanes], B[kDecSmallPlanes];
                 planes_of(A, B, hw, kDecSmallPlanes);
                 write_rows<kDecSmallPlanes>(A, B, hw ? sgnL.hi : sgnL.lo, hw ? sgnR.hi : sgnR.lo, 32 * hw, valid, sz, stage, t,
-                                            a.coeffs_out + cbase, a.AW);
+                                            outp, a.AW, c16);
             }
         }
     }

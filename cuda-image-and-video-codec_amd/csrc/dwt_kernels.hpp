@@ -84,7 +84,30 @@ struct DwtFwdArgs {
     // [pair_base, pair_end) of this level only; 0, 0 = the whole level.  Input rows are still addressed in
     // frame coordinates: the band's rows and its halo (2 rows either side for 5/3, 4 for 9/7) must be there.
     int pair_base, pair_end;
+    // frame paths: the CODED subbands (HL / LH / HH of every level, LL of the last) leave as 16-bit integers -- the
+    // value the coder's load makes of a coefficient anyway (truncation toward zero of a float one) -- in a Mallat array
+    // of int16 with row stride AW at `mallat`; the LL a next level reads stays T in the scratch.  Half the bytes the
+    // transform writes and the coder reads.  Only where the magnitudes are bounded below 2^15 (coef16_ok,
+    // launch_plan.hpp: 8-bit samples); the stage-by-stage API keeps the reference's T arrays.
+    int c16;
 };
+
+// two integer coefficients as one dword of int16 (v_cvt_pk_i16_i32: saturating, which coef16_ok's bound never needs)
+__device__ __forceinline__ uint32_t pack_i16(int x, int y)
+{
+#if defined(__AMDGCN__)
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    const s16x2 v = __builtin_amdgcn_cvt_pk_i16(x, y);
+    return __builtin_bit_cast(uint32_t, v);
+#else
+    auto sat = [](int v) -> uint32_t { return (uint32_t)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v)) & 0xFFFFu; };
+    return sat(x) | (sat(y) << 16);
+#endif
+}
+__device__ __forceinline__ uint32_t pack_c16(int x, int y) { return pack_i16(x, y); }
+__device__ __forceinline__ uint32_t pack_c16(float x, float y) { return pack_i16((int)x, (int)y); }     // BPCEngine.cu:49: toward zero
+__device__ __forceinline__ int c16_lo(uint32_t w) { return (int)(int16_t)(w & 0xFFFFu); }
+__device__ __forceinline__ int c16_hi(uint32_t w) { return (int)w >> 16; }
 
 // frame blockIdx.z of a batched launch
 __device__ __forceinline__ void dwt_fwd_select_frame(DwtFwdArgs &a)
@@ -114,6 +137,7 @@ struct DwtInvArgs {
     // dwt_inv97_kernel: qs is a power of two (the two de-quantising divisions are one: x / (q * qs) is exact scaling)
     int one_div;
     int exact_replay;       // debug: every wave of dwt_inv97_kernel runs its band a second time with true divisions
+    int c16;                // `mallat` is the frame paths' int16 array (row stride AW), see DwtFwdArgs::c16
 };
 
 // frame blockIdx.z of a batched launch
@@ -253,6 +277,14 @@ __device__ __forceinline__ void rb_store32(const RowBuf &b, uint32_t lane_off, u
     __builtin_amdgcn_raw_buffer_store_b32(x, b.rs, lane_off, row_off, 0);
 #else
     if (lane_off < kRbDrop) memcpy(b.base + row_off + lane_off, &x, 4);
+#endif
+}
+__device__ __forceinline__ void rb_store16(const RowBuf &b, uint32_t lane_off, uint32_t row_off, uint32_t x)
+{
+#if defined(__AMDGCN__)
+    __builtin_amdgcn_raw_buffer_store_b16((short)x, b.rs, lane_off, row_off, 0);
+#else
+    if (lane_off < kRbDrop) { const uint16_t h = (uint16_t)x; memcpy(b.base + row_off + lane_off, &h, 2); }
 #endif
 }
 __device__ __forceinline__ void rb_store64(const RowBuf &b, uint32_t lane_off, uint32_t row_off, uint32_t x, uint32_t y)
@@ -502,6 +534,15 @@ __device__ __forceinline__ void emit_pair(const DwtFwdArgs &a, int m, int pc, bo
     if constexpr (VEC) {
         // uniform row bases (SALU) + one unsigned 32-bit lane offset shared by the four stores
         const uint32_t vo = (uint32_t)pc;
+        if (a.c16) {                                         // (wave-uniform)
+            int16_t *q0 = (int16_t *)a.mallat + (size_t)m * (size_t)a.AW, *q1 = (int16_t *)a.mallat + (size_t)(m + hH) * (size_t)a.AW;
+            if (a.last) *reinterpret_cast<uint32_t *>(q0 + vo) = pack_c16(ll0, ll1);
+            else store2<T, true>((T *)a.ll + (size_t)m * (size_t)a.ll_stride + vo, ll0, ll1, true);
+            *reinterpret_cast<uint32_t *>(q0 + hW + vo) = pack_c16(hl0, hl1);
+            *reinterpret_cast<uint32_t *>(q1 + vo) = pack_c16(lh0, lh1);
+            *reinterpret_cast<uint32_t *>(q1 + hW + vo) = pack_c16(hh0, hh1);
+            return;
+        }
         T *rl = (T *)a.ll + (size_t)m * (size_t)a.ll_stride;
         T *r0 = mal + (size_t)m * (size_t)a.AW, *r1 = mal + (size_t)(m + hH) * (size_t)a.AW;
         store2<T, true>(rl + vo, ll0, ll1, true);
@@ -745,9 +786,10 @@ template <bool LOSSY, int NB> constexpr int f2_iters() { return NB + (LOSSY ? 5 
 // 28 KB with the second half's rows waiting in registers): 36-41 us against 35.6 for 9/7, 30.2-31.1 against 30.4
 // for 5/3 -- the launch's first 6-7 us are the frame's 45-55 MB of input arriving at HBM speed whoever issues the
 // loads, and the rest is its 135 MB of output leaving at the 6.3 TB/s the memory takes writes at.
-template <typename T, bool LOSSY, int NB, bool EDGE>
+template <typename T, bool LOSSY, int NB, bool EDGE, bool C16>
 __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdArgs &a1, int strip, int lane)
 {
+    constexpr uint32_t kCB = C16 ? 2u : 4u;                  // bytes of a coded coefficient
     constexpr int kIters = f2_iters<LOSSY, NB>();
     constexpr int kRel0 = LOSSY ? 7 : 3;                     // iteration i delivers the level-0 pairs 2 n0 + 2 i - kRel0, + 1
     constexpr int kLag1 = LOSSY ? 5 : 2;                     // ... and the level-1 pair n0 + i - kLag1
@@ -763,9 +805,12 @@ __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdA
 
     const RowBuf in = rowbuf(a.src), mal = rowbuf(a.mallat), ll2 = rowbuf(a1.ll);
     const uint32_t vin = (uint32_t)cl;
-    const uint32_t vlh = wr ? (uint32_t)(cl >> 1) * 4u : kRbDrop, vhl = wr ? (uint32_t)(hW + (cl >> 1)) * 4u : kRbDrop;
-    const uint32_t vlh1 = wr ? (uint32_t)(cl >> 2) * 4u : kRbDrop, vhl1 = wr ? (uint32_t)(hW1 + (cl >> 2)) * 4u : kRbDrop;
-    const uint32_t aw4 = (uint32_t)a.AW * 4u, ll4 = (uint32_t)a1.ll_stride * 4u;
+    const uint32_t vlh = wr ? (uint32_t)(cl >> 1) * kCB : kRbDrop, vhl = wr ? (uint32_t)(hW + (cl >> 1)) * kCB : kRbDrop;
+    const uint32_t vlh1 = wr ? (uint32_t)(cl >> 2) * kCB : kRbDrop, vhl1 = wr ? (uint32_t)(hW1 + (cl >> 2)) * kCB : kRbDrop;
+    // (level 1's LL: 32-bit in the scratch, unless level 1 is the transform's last and its LL a coded subband)
+    const bool ll16 = C16 && a1.last;
+    const uint32_t vll1 = wr ? (uint32_t)(cl >> 2) * (ll16 ? 2u : 4u) : kRbDrop;
+    const uint32_t aw4 = (uint32_t)a.AW * kCB, ll4 = ll16 ? aw4 : (uint32_t)a1.ll_stride * 4u;
     // level-1 LL: quantised on the transform's last level only; x * 1.0f * 1.0f is x
     const float qll = LOSSY && a1.last ? a1.q[0] : 1.0f, qsll = LOSSY && a1.last ? a1.qs : 1.0f;
     // level 0's steps and qs as vector registers: a multiply with a scalar-register operand issues at half rate
@@ -819,9 +864,15 @@ __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdA
                     hh0 = (T)(((float)hh0 * vq3) * vqs); hh1 = (T)(((float)hh1 * vq3) * vqs);
                 }
                 const uint32_t row0 = (uint32_t)(2 * n0 + r) * aw4, row1 = (uint32_t)(2 * n0 + r + hH) * aw4;
-                rb_store64(mal, vhl, row0, as_u32(hl0), as_u32(hl1));
-                rb_store64(mal, vlh, row1, as_u32(lh0), as_u32(lh1));
-                rb_store64(mal, vhl, row1, as_u32(hh0), as_u32(hh1));
+                if constexpr (C16) {
+                    rb_store32(mal, vhl, row0, pack_c16(hl0, hl1));
+                    rb_store32(mal, vlh, row1, pack_c16(lh0, lh1));
+                    rb_store32(mal, vhl, row1, pack_c16(hh0, hh1));
+                } else {
+                    rb_store64(mal, vhl, row0, as_u32(hl0), as_u32(hl1));
+                    rb_store64(mal, vlh, row1, as_u32(lh0), as_u32(lh1));
+                    rb_store64(mal, vhl, row1, as_u32(hh0), as_u32(hh1));
+                }
             }
         }
         // level 1: LL rows 2 n0 + rel (odd row of its pair) and + 1 (the even row after it).  Past the bottom
@@ -844,10 +895,18 @@ __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdA
                 hh = (T)(((float)hh * a1.q[3]) * vqs);
             }
             const uint32_t n = (uint32_t)(n0 + i - kLag1);
-            rb_store32(ll2, vlh1, n * ll4, as_u32(ll));
-            rb_store32(mal, vhl1, n * aw4, as_u32(hl));
-            rb_store32(mal, vlh1, (n + (uint32_t)hH1) * aw4, as_u32(lh));
-            rb_store32(mal, vhl1, (n + (uint32_t)hH1) * aw4, as_u32(hh));
+            if constexpr (C16) {
+                if (ll16) rb_store16(ll2, vll1, n * ll4, pack_c16(ll, ll));
+                else rb_store32(ll2, vll1, n * ll4, as_u32(ll));
+                rb_store16(mal, vhl1, n * aw4, pack_c16(hl, hl));
+                rb_store16(mal, vlh1, (n + (uint32_t)hH1) * aw4, pack_c16(lh, lh));
+                rb_store16(mal, vhl1, (n + (uint32_t)hH1) * aw4, pack_c16(hh, hh));
+            } else {
+                rb_store32(ll2, vll1, n * ll4, as_u32(ll));
+                rb_store32(mal, vhl1, n * aw4, as_u32(hl));
+                rb_store32(mal, vlh1, (n + (uint32_t)hH1) * aw4, as_u32(lh));
+                rb_store32(mal, vhl1, (n + (uint32_t)hH1) * aw4, as_u32(hh));
+            }
         }
     }
     PS_TRACE(4);
@@ -857,7 +916,7 @@ __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdA
 #endif
 }
 
-template <typename T, bool LOSSY, bool U8IN, int NB>
+template <typename T, bool LOSSY, bool U8IN, int NB, bool C16 = false>
 __global__ __launch_bounds__(256, (LOSSY ? PICSONG_DWT_F2_WAVES_LOSSY : PICSONG_DWT_F2_WAVES)) void dwt_fwd2_kernel(DwtFwd2Args a2)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -870,8 +929,8 @@ __global__ __launch_bounds__(256, (LOSSY ? PICSONG_DWT_F2_WAVES_LOSSY : PICSONG_
     static_assert(U8IN, "the fused head ingests u8 frames");
     if (strip * kF2Useful >= a2.l0.W) return;               // whole wave idle (no cross-lane use)
     if (!LOSSY || first <= 0 || first + kStripCols >= a2.l0.W)
-        dwt_fwd2_band<T, LOSSY, NB, true>(a2.l0, a2.l1, strip, lane);
-    else dwt_fwd2_band<T, LOSSY, NB, LOSSY ? false : true>(a2.l0, a2.l1, strip, lane);
+        dwt_fwd2_band<T, LOSSY, NB, true, C16>(a2.l0, a2.l1, strip, lane);
+    else dwt_fwd2_band<T, LOSSY, NB, LOSSY ? false : true, C16>(a2.l0, a2.l1, strip, lane);
 }
 
 // ---- the small levels of the forward transform ---------------------------------------------------------
@@ -918,6 +977,19 @@ __device__ __forceinline__ SubRaw load_sub_raw(const DwtInvArgs &a, int row_s_or
                                        : (const uint32_t *)a.ll + (size_t)row_s_or_d * (size_t)a.ll_stride;
     SubRaw r;
     if constexpr (VEC) {
+        if (a.c16) {                                         // (wave-uniform) int16 Mallat array: a dword = two coefficients
+            const int16_t *m16 = (const int16_t *)a.mallat + (size_t)(row_s_or_d + (high_row ? hH : 0)) * (size_t)a.AW;
+            const uint32_t d = *reinterpret_cast<const uint32_t *>(m16 + hW + pc);
+            r.d0 = (uint32_t)c16_lo(d); r.d1 = (uint32_t)c16_hi(d);
+            if (from_mallat) {
+                const uint32_t sv = *reinterpret_cast<const uint32_t *>(m16 + pc);
+                r.s0 = (uint32_t)c16_lo(sv); r.s1 = (uint32_t)c16_hi(sv);
+            } else {
+                const uint2 sv = *reinterpret_cast<const uint2 *>(srow + pc);
+                r.s0 = sv.x; r.s1 = sv.y;
+            }
+            return r;
+        }
         // pc is even and already clamped into [0, hW-2]: two aligned 8-byte loads per subband row
         const uint2 d = *reinterpret_cast<const uint2 *>(mrow + hW + pc);
         const uint2 sv = *reinterpret_cast<const uint2 *>(srow + pc);
@@ -1297,6 +1369,20 @@ __device__ __forceinline__ bool dwt_inv97_band(const DwtInvArgs &a, int strip, i
     SubRaw rawL[kGroup], rawH[kGroup];
     auto load_pair = [&](int j, SubRaw &L, SubRaw &H) {
         const uint32_t rl = (uint32_t)reflect_s(j, hH), rh = (uint32_t)(reflect_d(j, hH) + hH);
+        if (a.c16) {                                         // (wave-uniform) int16 Mallat array: a dword = two coefficients
+            const uint32_t aw2 = aw4 >> 1, vd2 = vd >> 1, vs2 = vs >> 1;
+            const uint32_t ld = rb_load32(mal, vd2, rl * aw2), hd = rb_load32(mal, vd2, rh * aw2), hs = rb_load32(mal, vs2, rh * aw2);
+            if constexpr (FIRST) {
+                const uint32_t ls = rb_load32(mal, vs2, rl * aw2);
+                L.s0 = (uint32_t)c16_lo(ls); L.s1 = (uint32_t)c16_hi(ls);
+            } else {
+                const uint2 ls = rb_load64(lls, vs, rl * ll4);
+                L.s0 = ls.x; L.s1 = ls.y;
+            }
+            L.d0 = (uint32_t)c16_lo(ld); L.d1 = (uint32_t)c16_hi(ld);
+            H.d0 = (uint32_t)c16_lo(hd); H.d1 = (uint32_t)c16_hi(hd); H.s0 = (uint32_t)c16_lo(hs); H.s1 = (uint32_t)c16_hi(hs);
+            return;
+        }
         const uint2 ld = rb_load64(mal, vd, rl * aw4), ls = rb_load64(lls, vs, rl * ll4);
         const uint2 hd = rb_load64(mal, vd, rh * aw4), hs = rb_load64(mal, vs, rh * aw4);
         L.d0 = ld.x; L.d1 = ld.y; L.s0 = ls.x; L.s1 = ls.y;

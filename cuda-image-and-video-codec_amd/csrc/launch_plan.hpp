@@ -73,8 +73,31 @@ inline int inv97_band_rows(int level, int strips, int H)
     return n >= (16L << 20) ? 32 : (n >= (4L << 20) ? 16 : (n >= (1L << 20) ? 8 : 4));
 }
 
+// May the frame paths carry their coded coefficients as 16-bit integers (DwtFwdArgs::c16)?  The largest magnitude a
+// subband sample can take is  max|sample| x G_x x G_y  x (9/7: the quantisation weight QSTEP[l][sb] x qs), G = the L1
+// gain of the multi-level 1-D analysis from the input to a level's low / high output: at most 1.3803 / 2.6253 for the
+// 9/7 transform as implemented here, 1.7141 / 2.8601 for 5/3 whatever the level (tools/dwt_gain_bounds.py applies the
+// transforms to the identity; the 5/3 floors move a sample by less than one per lifting step).  `in_max`: largest
+// sample magnitude after the level shift / colour transform (128 for a grey 8-bit frame, 255 for RCT chroma).
+// 2^15 with a margin for rounding; PICSONG_C16=0 keeps the 32-bit arrays (the tests cross-check both).
+inline bool coef16_ok(bool lossy, int wl, float qs, int in_max)
+{
+    if (const char *e = getenv("PICSONG_C16")) if (atoi(e) == 0) return false;
+    if (wl < 1 || wl > 10) return false;
+    if (!lossy) return (double)in_max * 2.8601 * 2.8601 + 64.0 < 30000.0;
+    if (!(qs > 0.0f)) return false;
+    const double gl = 1.3803, gh = 2.6253, g[4] = { gl * gl, gl * gh, gl * gh, gh * gh };
+    double worst = 0.0;
+    for (int l = 0; l < wl; l++)
+        for (int k = (l == wl - 1 ? 0 : 1); k < 4; k++) {
+            const double b = (double)in_max * g[k] * (double)kQSteps[l][k] * (double)qs;
+            worst = b > worst ? b : worst;
+        }
+    return worst < 30000.0;
+}
+
 inline std::vector<FwdLaunch> plan_dwt_forward(const void *d_in, bool u8in, void *d_out, int aw, int ah,
-                                               int wl, float qs)
+                                               int wl, float qs, bool c16 = false)
 {
     std::vector<FwdLaunch> v;
     int W = aw, H = ah;
@@ -90,7 +113,7 @@ inline std::vector<FwdLaunch> plan_dwt_forward(const void *d_in, bool u8in, void
         a.ll = last ? d_out : (void *)((char *)d_out + off * 4);
         a.ll_stride = last ? aw : (W >> 1);
         a.mallat = d_out; a.AW = aw; a.level = l; a.last = last ? 1 : 0; a.qs = qs;
-        a.src_z = 0; a.dst_z = 0; a.pair_base = 0; a.pair_end = 0;
+        a.src_z = 0; a.dst_z = 0; a.pair_base = 0; a.pair_end = 0; a.c16 = c16 ? 1 : 0;
         for (int k = 0; k < 4; k++) a.q[k] = kQSteps[l][k];
         const int strips = (W + kStripUseful - 1) / kStripUseful;
         f.band = fwd_band_rows(l, strips, H);
@@ -105,8 +128,13 @@ inline std::vector<FwdLaunch> plan_dwt_forward(const void *d_in, bool u8in, void
         src_stride = W >> 1;
         W >>= 1; H >>= 1;
     }
+    // (the 16-bit form exists in the vector-only kernel instantiations: every level or none)
+    bool all_vec = true;
+    for (const FwdLaunch &f : v) all_vec = all_vec && f.vec;
+    if (!all_vec) for (FwdLaunch &f : v) f.a.c16 = 0;
     return v;
 }
+inline bool plan_is_c16(const std::vector<FwdLaunch> &plan) { return !plan.empty() && plan[0].a.c16 != 0; }
 
 // Level 0 restricted to the input rows [row0, row0 + rows) (both even): the launch then produces the row
 // pairs [row0 / 2, (row0 + rows) / 2) of HL / LH / HH (Mallat) and of LL (scratch, or Mallat when wl = 1).
@@ -171,8 +199,18 @@ inline bool plan_dwt_fwd2(const std::vector<FwdLaunch> &plan, Fwd2Launch &f, boo
     return true;
 }
 
+// c16: d_in is the frame paths' int16 Mallat array (the caller has checked dwt_c16_geometry_ok)
+inline bool dwt_c16_geometry_ok(int aw, int ah, int wl)
+{   // every level on the vector path: level widths multiples of 4 (and rows 16-byte aligned: aw % 4 == 0)
+    if (const char *e = getenv("PICSONG_DWT_NOVEC")) if (atoi(e) != 0) return false;
+    for (int l = 0; l < wl; l++) {
+        const int W = aw >> l;
+        if (W < 4 || (W & 3) || ((W >> 1) & 1)) return false;
+    }
+    return (aw & 3) == 0 && (ah >> (wl - 1)) >= 2;
+}
 inline std::vector<InvLaunch> plan_dwt_inverse(const int32_t *d_in, void *d_out, int aw, int ah, int wl,
-                                               float qs, bool fast = false)
+                                               float qs, bool fast = false, bool c16 = false)
 {
     std::vector<InvLaunch> v;
     int W = aw >> (wl - 1), H = ah >> (wl - 1);
@@ -187,7 +225,7 @@ inline std::vector<InvLaunch> plan_dwt_inverse(const int32_t *d_in, void *d_out,
         a.first = first ? 1 : 0;
         a.W = W; a.H = H;
         a.dst = (char *)d_out + write_off * 4;
-        a.dst_u8 = nullptr; a.off = 0;
+        a.dst_u8 = nullptr; a.off = 0; a.c16 = c16 ? 1 : 0;
         a.mallat_z = a.ll_z = a.dst_z = a.u8_z = 0;
         {   // qs = 2^k: dividing by it is exact scaling, dwt_inv97_kernel folds it into the step
             int e = 0;
@@ -204,6 +242,7 @@ inline std::vector<InvLaunch> plan_dwt_inverse(const int32_t *d_in, void *d_out,
         f.gx = (unsigned)((strips + 3) / 4);
         f.gy = (unsigned)(((H >> 1) + f.band / 2 - 1) / (f.band / 2));
         f.vec = dwt_vec_ok(W, aw, d_in, d_out);
+        if (!f.vec) a.c16 = 0;                              // (callers check dwt_c16_geometry_ok first: never taken with c16)
         v.push_back(f);
         read_off = write_off;
         write_off += (size_t)W * (size_t)H;

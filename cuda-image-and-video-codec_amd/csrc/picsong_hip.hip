@@ -50,6 +50,7 @@ struct picsong_ctx {
     int aw, ah, ncb;
     size_t P, extra;
     bool fast_div;        // 9/7 synthesis: reciprocal form of the divisions verified for this qs
+    bool c16;             // frame paths: coded coefficients travel as int16 between transform and coder (coef16_ok)
     bool pipelined;       // picsong_ctx_set_pipelined: other frames share the GPU (throughput over latency)
     // LUT
     picsong_lut_info li[3];
@@ -138,6 +139,11 @@ static void launch_fwd(const picsong_ctx *c, const FwdLaunch &f, hipStream_t s, 
 static void launch_fwd2(bool lossy, const Fwd2Launch &f, hipStream_t s, unsigned frames = 1)
 {
     dim3 grid(f.gx, f.gy, frames);
+    if (f.a.l0.c16) {                     // frame paths: coded subbands as int16 (DwtFwdArgs::c16)
+        if (lossy) dwt_fwd2_kernel<float, true, true, kF2PairsLossy, true><<<grid, 256, 0, s>>>(f.a);
+        else dwt_fwd2_kernel<int, false, true, kF2Pairs, true><<<grid, 256, 0, s>>>(f.a);
+        return;
+    }
     if (lossy) dwt_fwd2_kernel<float, true, true, kF2PairsLossy><<<grid, 256, 0, s>>>(f.a);
     else dwt_fwd2_kernel<int, false, true, kF2Pairs><<<grid, 256, 0, s>>>(f.a);
 }
@@ -391,6 +397,9 @@ int picsong_ctx_create(const picsong_params *p, int device, picsong_ctx **out)
     c->P = (size_t)aw * (size_t)ah;
     c->extra = picsong_dwt_extra(aw, ah, p->wl);
     c->fast_div = p->lossy != 0 && dequant_fast_ok(p->qs, p->wl);
+    // 8-bit samples: 128 after the level shift; 255 covers the chroma differences of the RGB path's RCT
+    c->c16 = p->k <= 0.0f && p->cp != 3 && p->bit_depth == 8 && dwt_c16_geometry_ok(c->aw, c->ah, p->wl) &&
+             coef16_ok(p->lossy != 0, p->wl, p->qs, p->is_rgb ? 255 : 128);
     hipError_t e = hipMalloc(&c->d_offsets, sizeof(int32_t) * (size_t)c->ncb);
     if (e == hipSuccess) e = hipMalloc(&c->d_total, sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc(&c->d_flag, sizeof(int));
@@ -557,9 +566,10 @@ int picsong_level_shift_inv(picsong_ctx *c, void *d_data, void *stream)
 // ---------------------------------------------------------------------------------------------
 // DWT
 // ---------------------------------------------------------------------------------------------
-static int dwt_forward_impl(picsong_ctx *c, const void *d_in, bool u8in, void *d_out, hipStream_t s)
+static int dwt_forward_impl(picsong_ctx *c, const void *d_in, bool u8in, void *d_out, hipStream_t s, bool c16 = false)
 {
-    const std::vector<FwdLaunch> plan = plan_dwt_forward(d_in, u8in, d_out, c->aw, c->ah, c->p.wl, c->p.qs);
+    const std::vector<FwdLaunch> plan = plan_dwt_forward(d_in, u8in, d_out, c->aw, c->ah, c->p.wl, c->p.qs, c16);
+    if (c16 && !plan_is_c16(plan)) return fail(PICSONG_ERR_ARG, "the 16-bit coefficient form needs the vector kernels on every level");
     Fwd2Launch f2;
     const bool fused01 = plan_dwt_fwd2(plan, f2, true, c->p.lossy != 0);
     if (fused01) {                       // levels 0 and 1 in one launch, LL1 stays in registers
@@ -616,16 +626,17 @@ int picsong_dwt_forward_tail(picsong_ctx *c, void *d_out, void *stream)
 // frames > 1 (picsong_decode_frames): grid.z = frame; frame z's coded coefficients at d_in + z * P, its work buffer at
 // d_out + z * (P + extra) elements, its pixels at d_pixels + z * pix_stride bytes
 static int dwt_inverse_impl(picsong_ctx *c, const int32_t *d_in, void *d_out, uint8_t *d_pixels, bool *fused,
-                            hipStream_t s, unsigned frames = 1, size_t pix_stride = 0)
+                            hipStream_t s, unsigned frames = 1, size_t pix_stride = 0, bool c16 = false)
 {
     if (fused) *fused = false;
-    std::vector<InvLaunch> plan = plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs, c->fast_div);
+    std::vector<InvLaunch> plan = plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs, c->fast_div, c16);
     if (d_pixels && !plan.empty() && plan.back().vec && (((uintptr_t)d_pixels) & 3u) == 0 && (pix_stride & 3u) == 0) {
         plan.back().a.dst_u8 = d_pixels;
         plan.back().a.off = 1 << (c->p.bit_depth - 1);
         if (fused) *fused = true;
     }
     if (frames > 1) {
+        // (the int16 array of a frame sits at the start of its int32-sized slot)
         const unsigned long long in_z = (unsigned long long)c->P * 4ull, wrk_z = (unsigned long long)(c->P + c->extra) * 4ull;
         for (InvLaunch &f : plan) {
             f.a.mallat_z = in_z;
@@ -693,11 +704,13 @@ static int ensure_plane_scratch(picsong_ctx *c)
 }
 
 static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_staging, int32_t *d_sizes,
-                           bool memset_staging, hipStream_t s, int cb_begin = 0, int cb_count = -1, int comp = 0)
+                           bool memset_staging, hipStream_t s, int cb_begin = 0, int cb_count = -1, int comp = 0,
+                           bool c16 = false)
 {
     BpcArgs a;
     int rc = bpc_args(c, a, comp);
     if (rc) return rc;
+    a.c16 = c16 ? 1 : 0;
     if (cb_count < 0) cb_count = c->ncb - cb_begin;
     a.cb_base = cb_begin;
     a.nCB = cb_begin + cb_count;
@@ -727,11 +740,12 @@ int picsong_bpc_encode(picsong_ctx *c, const void *d_coeffs, int32_t *d_staging,
 }
 
 static int bpc_decode_impl(picsong_ctx *c, const int32_t *d_staging, const int32_t *d_sizes, int32_t *d_coeffs,
-                           hipStream_t s, int comp = 0)
+                           hipStream_t s, int comp = 0, bool c16 = false)
 {
     BpcArgs a;
     int rc = bpc_args(c, a, comp);
     if (rc) return rc;
+    a.c16 = c16 ? 1 : 0;
     a.coeffs_out = d_coeffs;
     a.staging = const_cast<int32_t *>(d_staging);
     a.sizes = const_cast<int32_t *>(d_sizes);
@@ -916,9 +930,10 @@ int picsong_encode_frame(picsong_ctx *c, const uint8_t *d_frame, int iter, uint1
     hipEvent_t *ev = nullptr;
     if (c->prof_cap > 0 && c->prof_n < c->prof_cap) ev = c->prof_ev->data() + 4 * (c->prof_n++);
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
-    if ((rc = dwt_forward_impl(c, d_frame, true, c->d_coef, s))) return rc;
+    // (coefficients between the transform and the coder as int16 where their magnitudes are bounded: c->c16)
+    if ((rc = dwt_forward_impl(c, d_frame, true, c->d_coef, s, c->c16))) return rc;
     if (ev) HIP_TRY(hipEventRecord(ev[1], s));
-    if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, s))) return rc;
+    if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, s, 0, -1, 0, c->c16))) return rc;
     if (ev) HIP_TRY(hipEventRecord(ev[2], s));
     uint16_t hdr[PICSONG_HDR_SHORTS];
     if (iter == 0) picsong_header_pack(&c->p, hdr);
@@ -935,9 +950,9 @@ int picsong_decode_frame(picsong_ctx *c, const uint16_t *d_stream, uint8_t *d_fr
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     if ((rc = unpack_impl(c, d_stream, c->d_staging, c->d_sizes, false, s))) return rc;
-    if ((rc = picsong_bpc_decode(c, c->d_staging, c->d_sizes, c->d_coef_i, stream))) return rc;
+    if ((rc = bpc_decode_impl(c, c->d_staging, c->d_sizes, c->d_coef_i, s, 0, c->c16))) return rc;
     bool fused = false;
-    if ((rc = dwt_inverse_impl(c, c->d_coef_i, c->d_coef, d_frame_out, &fused, s))) return rc;
+    if ((rc = dwt_inverse_impl(c, c->d_coef_i, c->d_coef, d_frame_out, &fused, s, 1, 0, c->c16))) return rc;
     if (fused) return PICSONG_OK;            // the finest level wrote the pixels itself
     const void *img = (const char *)c->d_coef + c->extra * 4;
     const size_t n4 = c->P / 4;
@@ -1057,7 +1072,8 @@ int picsong_encode_frames(picsong_ctx *c, int n, const uint8_t *d_frames, size_t
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
 
     // ---- DWT: the single-frame plan of frame 0 with grid.z = n
-    std::vector<FwdLaunch> plan = plan_dwt_forward(d_frames, true, c->b_coef, c->aw, c->ah, c->p.wl, c->p.qs);
+    std::vector<FwdLaunch> plan = plan_dwt_forward(d_frames, true, c->b_coef, c->aw, c->ah, c->p.wl, c->p.qs, c->c16);
+    a.c16 = plan_is_c16(plan) ? 1 : 0;
     for (size_t l = 0; l < plan.size(); l++) {
         plan[l].a.src_z = l == 0 ? (unsigned long long)frame_stride : (unsigned long long)coef_z;
         plan[l].a.dst_z = (unsigned long long)coef_z;
@@ -1147,12 +1163,13 @@ int picsong_decode_frames(picsong_ctx *c, int n, const uint16_t *d_streams, size
     a.cb_base = 0; a.nCB = c->ncb;
     a.coeffs_out = c->b_coef_i; a.staging = c->b_staging; a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch;
     a.frames = n; a.waves_per_frame = wpf; a.coef_z = (unsigned long long)c->P * 4ull;
+    a.c16 = c->c16 ? 1 : 0;
     const unsigned wgs = (unsigned)(((size_t)n * (size_t)wpf + kBpcDecWgWaves - 1) / kBpcDecWgWaves);
     bpc_decode_kernel<false, kDecSmallPlanes><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
     HIP_TRY(hipGetLastError());
     // ---- inverse transform, pixels out of the finest level where its vector kernel applies
     bool fused = false;
-    if ((rc = dwt_inverse_impl(c, c->b_coef_i, c->b_coef, d_frames_out, &fused, s, (unsigned)n, frame_stride))) return rc;
+    if ((rc = dwt_inverse_impl(c, c->b_coef_i, c->b_coef, d_frames_out, &fused, s, (unsigned)n, frame_stride, c->c16))) return rc;
     if (fused) return PICSONG_OK;
     const size_t n4 = c->P / 4;
     const int off = 1 << (c->p.bit_depth - 1);
@@ -1274,7 +1291,8 @@ int picsong_encode_rgb_frame(picsong_ctx *c, const uint8_t *d_r, const uint8_t *
     char *planes = (char *)c->b_coef_i;
     // ---- colour transform (level shift fused) into three planes, then the transform of all three per launch
     if ((rc = picsong_rgb_forward(c, d_r, d_g, d_b, planes, planes + c->P * 4, planes + 2 * c->P * 4, stream))) return rc;
-    std::vector<FwdLaunch> plan = plan_dwt_forward(planes, false, c->b_coef, c->aw, c->ah, c->p.wl, c->p.qs);
+    std::vector<FwdLaunch> plan = plan_dwt_forward(planes, false, c->b_coef, c->aw, c->ah, c->p.wl, c->p.qs, c->c16);
+    a.c16 = plan_is_c16(plan) ? 1 : 0;
     for (size_t l = 0; l < plan.size(); l++) {
         plan[l].a.src_z = l == 0 ? (unsigned long long)c->P * 4ull : (unsigned long long)coef_z;
         plan[l].a.dst_z = (unsigned long long)coef_z;
@@ -1326,9 +1344,10 @@ int picsong_decode_rgb_frame(picsong_ctx *c, const uint16_t *d_streams, size_t s
     HIP_TRY(hipGetLastError());
     a.coeffs_out = c->b_coef_i; a.staging = c->b_staging; a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch;
     a.coef_z = (unsigned long long)c->P * 4ull;
+    a.c16 = c->c16 ? 1 : 0;
     bpc_decode_kernel<false, kDecSmallPlanes><<<(unsigned)(3 * a.waves_per_frame / kBpcDecWgWaves), 64 * kBpcDecWgWaves, 0, s>>>(a);
     HIP_TRY(hipGetLastError());
-    if ((rc = dwt_inverse_impl(c, c->b_coef_i, c->b_coef, nullptr, nullptr, s, 3u, 0))) return rc;
+    if ((rc = dwt_inverse_impl(c, c->b_coef_i, c->b_coef, nullptr, nullptr, s, 3u, 0, c->c16))) return rc;
     const char *img = (const char *)c->b_coef + c->extra * 4;
     const size_t z = (c->P + c->extra) * 4;
     return picsong_rgb_inverse(c, img, img + z, img + 2 * z, d_r, d_g, d_b, stream);

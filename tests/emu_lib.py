@@ -32,6 +32,26 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+C16 = False
+
+
+def set_c16(on):
+    """The frame paths' form: coded coefficients as int16 between the transform and the coder (DwtFwdArgs::c16).
+    dwt_forward then returns a buffer whose first AW*AH int16 are the Mallat array (`mallat16`), bpc_encode / dwt_inverse
+    take int16 arrays and bpc_decode returns one."""
+    global C16
+    C16 = bool(on)
+    lib().emu_set_c16(int(C16))
+
+
+def mallat16(buf, AW, AH):
+    return buf.reshape(-1).view(np.int16)[:AW * AH].reshape(AH, AW)
+
+
+def coef16_ok(lossy, wl, qs, in_max, AW, AH):
+    return bool(lib().emu_coef16_ok(int(lossy), wl, C.c_float(qs), in_max, AW, AH))
+
+
 def _geo(lut):
     g = lut.geometry()
     return np.array([g["n_bitplanes"], g["n_subbands"], g["ctx_ref"], g["ctx_sign"], g["ctx_sig"],
@@ -95,7 +115,7 @@ def bpc_encode_range(coef, wl, lut, cb_begin, cb_count):
 
 def dwt_inverse(coef, wl, lossy, qs=1.0, extra=0):
     AH, AW = coef.shape
-    coef = aligned_copy(np.ascontiguousarray(coef, np.int32))
+    coef = aligned_copy(np.ascontiguousarray(coef, np.int16 if C16 else np.int32))
     out = aligned_zeros(AW * AH + extra, np.float32 if lossy else np.int32)
     lib().emu_dwt_inverse(_p(coef), _p(out), AW, AH, wl, int(lossy), C.c_float(qs))
     return out
@@ -104,7 +124,7 @@ def dwt_inverse(coef, wl, lossy, qs=1.0, extra=0):
 def dwt_inverse_u8(coef, wl, lossy, qs=1.0, extra=0):
     """Frame-path inverse: returns (pixels u8 (AH, AW), fused flag)."""
     AH, AW = coef.shape
-    coef = aligned_copy(np.ascontiguousarray(coef, np.int32))
+    coef = aligned_copy(np.ascontiguousarray(coef, np.int16 if C16 else np.int32))
     scratch = aligned_zeros(AW * AH + extra, np.float32 if lossy else np.int32)
     pix = aligned_zeros(AW * AH, np.uint8)
     fused = lib().emu_dwt_inverse_u8(_p(coef), _p(scratch), _p(pix), AW, AH, wl, int(lossy), C.c_float(qs))
@@ -193,7 +213,8 @@ def bpc_decode(staging, sizes, AW, AH, wl, lut, k=0.0):
     geo = _geo(lut)
     lib().emu_bpc_decode(_p(staging), _p(sizes), AW, AH, wl, _p(tab), _p(geo), _p(coef), _p(flag),
                          C.c_float(k), int(getattr(lut, "n_tables", 1)))
-    return coef
+    bpc_decode.last_flag = int(flag[0])
+    return mallat16(coef, AW, AH).copy() if C16 else coef
 
 
 def pack(staging, sizes, header=None):

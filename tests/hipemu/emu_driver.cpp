@@ -84,10 +84,23 @@ template <int BAND> static void emu_fwd(const FwdLaunch &f, int lossy)
     if (f.vec) emu_fwd_v<BAND, true>(f, lossy); else emu_fwd_v<BAND, false>(f, lossy);
 }
 
+// frame paths: coded coefficients as int16 (DwtFwdArgs::c16 / BpcArgs::c16), switched on by the tests
+static int g_c16 = 0;
+extern "C" void emu_set_c16(int on) { g_c16 = on; }
+extern "C" int emu_coef16_ok(int lossy, int wl, float qs, int in_max, int aw, int ah)
+{
+    return coef16_ok(lossy != 0, wl, qs, in_max) && dwt_c16_geometry_ok(aw, ah, wl) ? 1 : 0;
+}
+
 static void emu_fwd2(const Fwd2Launch &f, int lossy)
 {
     DwtFwd2Args a = f.a;
     const dim3 grid(f.gx, f.gy);
+    if (a.l0.c16) {
+        if (lossy) emu::launch(grid, dim3(256), [&] { dwt_fwd2_kernel<float, true, true, kF2PairsLossy, true>(a); });
+        else emu::launch(grid, dim3(256), [&] { dwt_fwd2_kernel<int, false, true, kF2Pairs, true>(a); });
+        return;
+    }
     if (lossy) emu::launch(grid, dim3(256), [&] { dwt_fwd2_kernel<float, true, true, kF2PairsLossy>(a); });
     else emu::launch(grid, dim3(256), [&] { dwt_fwd2_kernel<int, false, true, kF2Pairs>(a); });
 }
@@ -122,7 +135,7 @@ static void emu_fwd_levels(const std::vector<FwdLaunch> &plan, size_t from, int 
 // mirrors dwt_forward_impl (picsong_hip.hip); returns 1 when levels 0 and 1 went through the fused kernel
 int emu_dwt_forward(const void *in, int u8in, void *out, int aw, int ah, int wl, int lossy, float qs)
 {
-    const std::vector<FwdLaunch> plan = plan_dwt_forward(in, u8in != 0, out, aw, ah, wl, qs);
+    const std::vector<FwdLaunch> plan = plan_dwt_forward(in, u8in != 0, out, aw, ah, wl, qs, g_c16 != 0);
     Fwd2Launch f2;
     const bool fused01 = plan_dwt_fwd2(plan, f2, true, lossy != 0);
     if (fused01) {
@@ -148,7 +161,7 @@ void emu_dwt_forward_tail(void *out, int aw, int ah, int wl, int lossy, float qs
 
 void emu_dwt_inverse(const int32_t *in, void *out, int aw, int ah, int wl, int lossy, float qs)
 {
-    for (const InvLaunch &f : plan_dwt_inverse(in, out, aw, ah, wl, qs, emu_fast_div(lossy, qs, wl))) {
+    for (const InvLaunch &f : plan_dwt_inverse(in, out, aw, ah, wl, qs, emu_fast_div(lossy, qs, wl), g_c16 != 0)) {
         switch (f.band) {
         case 32: emu_inv<32>(f, lossy); break;
         case 16: emu_inv<16>(f, lossy); break;
@@ -162,7 +175,7 @@ void emu_dwt_inverse(const int32_t *in, void *out, int aw, int ah, int wl, int l
 // returns 1 when that fused kernel applied
 int emu_dwt_inverse_u8(const int32_t *in, void *scratch, uint8_t *pixels, int aw, int ah, int wl, int lossy, float qs)
 {
-    std::vector<InvLaunch> plan = plan_dwt_inverse(in, scratch, aw, ah, wl, qs, emu_fast_div(lossy, qs, wl));
+    std::vector<InvLaunch> plan = plan_dwt_inverse(in, scratch, aw, ah, wl, qs, emu_fast_div(lossy, qs, wl), g_c16 != 0);
     const bool fused = !plan.empty() && plan.back().vec && (((uintptr_t)pixels) & 3u) == 0;
     if (fused) { plan.back().a.dst_u8 = pixels; plan.back().a.off = 128; }
     for (const InvLaunch &f : plan) {
@@ -216,6 +229,7 @@ static BpcArgs mk(int aw, int ah, int wl, const int32_t *lut, const int *geo, in
     a.g.nBp = geo[0]; a.g.nSub = geo[1]; a.g.cRef = geo[2]; a.g.cSign = geo[3]; a.g.cSig = geo[4];
     a.g.prec = geo[5]; a.g.nRef = geo[6]; a.g.nSig = geo[7]; a.g.nSign = geo[8];
     a.staging = staging; a.sizes = sizes; a.range_flag = flag;
+    a.c16 = g_c16;
     return a;
 }
 

@@ -253,6 +253,50 @@ def test_whole_frame_codestream_identical_to_oracle(oracle, E):
     assert np.array_equal(out.astype(np.uint8), img)
 
 
+@pytest.mark.parametrize("W,H,wl,lossy,qs", [(192, 128, 2, False, 1.0), (320, 192, 3, True, 0.5), (256, 256, 5, False, 1.0),
+                                              (512, 320, 6, True, 0.5), (128, 64, 1, True, 2.0), (256, 128, 2, True, 0.5)])
+def test_frame_path_with_16_bit_coefficients(oracle, E, monkeypatch, W, H, wl, lossy, qs):
+    """The frame paths' compact form (DwtFwdArgs::c16): the transform writes its coded subbands as int16 -- the value
+    the coder's load makes of a coefficient anyway --, the coder reads them, the decoder writes int16 and the
+    synthesis reads them: codestream and pixels are the oracle's (fused head and per-level kernels)."""
+    assert E.coef16_ok(lossy, wl, qs, 128, W, H)
+    img = oracle.gen_frame(W, H, 13)
+    lut = oracle.lut_for(lossy, wl)
+    ref = oracle.encode_frame(img, wl, lossy, qs, lut)
+    extra = oracle.dwt_extra(W, H, wl)
+    ref_pix = oracle.decode_frame(ref, W, H, wl, lossy, qs, lut)
+    E.set_c16(True)
+    try:
+        for nofuse in ("0", "1"):
+            monkeypatch.setenv("PICSONG_DWT_NOFUSE01", nofuse)
+            buf = E.dwt_forward(img, wl, lossy, qs, extra=extra)
+            coef = E.mallat16(buf, W, H)
+            ref_coef = oracle.dwt_forward(oracle.level_shift_fwd(img, lossy), wl, qs)[:W * H].reshape(H, W)
+            assert np.array_equal(coef.astype(np.int32), ref_coef.astype(np.int32))       # (astype truncates toward zero)
+            st, sz, flag = E.bpc_encode(coef, wl, lut)
+            assert flag == 0
+            got = E.pack(st, sz, ref[:9])
+            assert np.array_equal(got, ref), f"nofuse={nofuse}"
+        st2, sz2 = E.unpack(got, sz.size)
+        c2 = E.bpc_decode(st2, sz2, W, H, wl, lut)
+        assert c2.dtype == np.int16 and E.bpc_decode.last_flag == 0
+        pix, fused = E.dwt_inverse_u8(c2, wl, lossy, qs, extra=extra)
+        assert fused and np.array_equal(pix, ref_pix)
+        out = E.dwt_inverse(c2, wl, lossy, qs, extra=extra)[extra:]
+        assert np.array_equal(E.clamp_to_u8(out).reshape(H, W), ref_pix)
+    finally:
+        E.set_c16(False)
+
+
+def test_16_bit_coefficient_bound(E):
+    """coef16_ok: the 16-bit form only where magnitudes are bounded below 2^15 (8-bit samples; 9/7: times the
+    quantisation weights): BASELINE's configurations qualify, a fine qs or a geometry off the vector kernels does not."""
+    assert E.coef16_ok(False, 5, 1.0, 128, 3840, 2176) and E.coef16_ok(True, 6, 0.5, 128, 7680, 4352)
+    assert E.coef16_ok(False, 5, 1.0, 255, 16384, 16384)
+    assert not E.coef16_ok(True, 6, 8.0, 128, 7680, 4352)         # 882 x 17.4 x 8 > 2^15
+    assert not E.coef16_ok(True, 3, 0.5, 128, 200, 128)           # a level width that is no multiple of 4
+
+
 @pytest.mark.parametrize("lossy", [False, True])
 def test_rgb_colour_transform_kernels(oracle, E, lossy):
     r, g, b = (oracle.gen_frame(128, 64, k) for k in (1, 2, 3))
