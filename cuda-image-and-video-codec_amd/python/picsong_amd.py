@@ -43,7 +43,7 @@ EXPORTS = [
     "picsong_ctx_set_lut_device", "picsong_bpc_encode_component", "picsong_bpc_decode_component",
     "picsong_encode_frames", "picsong_last_totals", "picsong_selftest_lds_order",
     "picsong_dwt_forward_band", "picsong_dwt_forward_tail", "picsong_encode_stripe_coded", "picsong_lut_load_cp",
-    "picsong_copy_last_totals", "picsong_decode_frames",
+    "picsong_copy_last_totals", "picsong_decode_frames", "picsong_encode_rgb_frame", "picsong_decode_rgb_frame",
 ]
 
 _lib = None
