@@ -620,6 +620,35 @@ def test_rgb_components_parity(oracle, pa, torch, lossy, qs):
     c.close()
 
 
+@pytest.mark.parametrize("W,H,wl,lossy,qs", [(3840, 2160, 5, False, 1.0), (1280, 704, 6, True, 0.5), (700, 500, 4, False, 1.0)])
+def test_16_bit_and_32_bit_coefficient_forms_agree(oracle, pa, torch, monkeypatch, W, H, wl, lossy, qs):
+    """The frame paths carry their coded coefficients as int16 between transform and coder (the encoder by default,
+    the decoder with PICSONG_C16_DECODE=1) or as the reference's 32-bit arrays (PICSONG_C16=0): same codestream -- the
+    oracle's --, same pixels, single frames and batched calls."""
+    img = oracle.gen_frame(W, H, 70)
+    frame = _dev(torch, oracle.pad_frame(img))
+    ref = oracle.encode_frame(img, wl, lossy, qs, oracle.lut_for(lossy, wl))
+    results = []
+    for c16, c16dec in (("1", "1"), ("0", "0"), ("1", "0")):
+        monkeypatch.setenv("PICSONG_C16", c16)
+        monkeypatch.setenv("PICSONG_C16_DECODE", c16dec)
+        c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=_lutdir(oracle, lossy))
+        s = c.encode_frame(frame, 0).clone()
+        assert np.array_equal(s.cpu().numpy().view(np.uint16), ref), (c16, c16dec)
+        two = torch.stack([frame.view(-1), frame.view(-1)])
+        out = torch.empty((2, c.max_stream_shorts()), dtype=torch.int16, device="cuda")
+        c.encode_frames_async(two, out, 0)
+        t = c.last_totals(2)
+        assert t[0] == s.numel() and torch.equal(out[0, :t[0]], s) and torch.equal(out[1, 9:t[1]], s[9:])
+        pix = c.decode_frame(s).clone()
+        both = c.decode_frames(out)
+        assert torch.equal(both[0], pix) and torch.equal(both[1], pix) and c.range_flag() == 0
+        results.append(pix)
+        c.close()
+    assert torch.equal(results[0], results[1]) and torch.equal(results[0], results[2])
+    assert np.array_equal(results[0].cpu().numpy()[:H, :W], oracle.decode_frame(ref, W, H, wl, lossy, qs, oracle.lut_for(lossy, wl)))
+
+
 @pytest.mark.parametrize("W,H,wl,lossy,qs,mask", [(320, 192, 3, False, 1.0, 1), (704, 448, 4, True, 0.5, 7), (1000, 300, 3, False, 1.0, 0)])
 def test_rgb_frame_through_the_batched_grid_equals_oracle(oracle, pa, torch, W, H, wl, lossy, qs, mask):
     """picsong_encode_rgb_frame / picsong_decode_rgb_frame: the three components of an RGB frame as the three frames
