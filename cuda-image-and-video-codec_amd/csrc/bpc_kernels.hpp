@@ -55,7 +55,7 @@ struct BpcArgs {
     const void *coeffs_in;         // encoder: Mallat T[AW*AH]
     int32_t *coeffs_out;           // decoder: Mallat int32[AW*AH]
     int is_float;                  // encoder input is float (truncated toward zero on load)
-    int c16;                       // frame paths: the Mallat array (coeffs_in / coeffs_out) is int16, row stride AW
+    int c16;                       // encode frame paths: the Mallat array coeffs_in is int16, row stride AW
     int AW, AH, wl, nCB, ncx;
     int cb_base;                   // first codeblock of this launch (intra-frame striping), nCB = end
     const int32_t *lut;
@@ -1627,17 +1627,10 @@ __device__ __forceinline__ uint32_t cform_signs(uint32_t a, uint32_t b, uint32_t
 // The decoded planes of one column half (row masks PL / PR, plane k in word k) back to coefficients: the same 8 x 8
 // bit-matrix transpose as the encoder's prologue (bit_transpose_8x8x4 is its own inverse) turns eight plane words into
 // eight words of row bytes -- the magnitude byte of row 8 b + j is byte b of word j -- instead of a bit at a time.
-// the lane's two coefficients of one row: `out` addresses the lane's pair in row 0 of the codeblock (int32 array, or
-// the frame paths' int16 array when c16: one dword then)
-__device__ __forceinline__ void store_pair(void *out, int row, int AW, bool c16, int32_t v0, int32_t v1)
-{
-    if (c16) *reinterpret_cast<uint32_t *>((int16_t *)out + (size_t)row * (size_t)AW) = ((uint32_t)v0 & 0xFFFFu) | ((uint32_t)v1 << 16);
-    else *reinterpret_cast<int2 *>((int32_t *)out + (size_t)row * (size_t)AW) = make_int2(v0, v1);
-}
 template <int NP, int NA>
 __device__ __forceinline__ void write_rows(const uint32_t (&PL)[NA], const uint32_t (&PR)[NA],
                                            uint32_t sgL, uint32_t sgR, int row0, bool valid, int32_t sz,
-                                           const int32_t *stage, uint32_t t, void *out, int AW, bool c16 = false)
+                                           const int32_t *stage, uint32_t t, int32_t *out, int AW)
 {
     if (!valid) return;
     if (sz == 4096) {                                       // raw codeblock (expansionFix): words, not planes
@@ -1647,7 +1640,7 @@ __device__ __forceinline__ void write_rows(const uint32_t (&PL)[NA], const uint3
             int2 w = *reinterpret_cast<const int2 *>(stage + t * 128u + 2u * (uint32_t)i);
             int32_t v0 = (int32_t)(((uint32_t)w.x & 0xFFFFFFu) >> 1); if (w.x & 1) v0 = -v0;
             int32_t v1 = (int32_t)(((uint32_t)w.y & 0xFFFFFFu) >> 1); if (w.y & 1) v1 = -v1;
-            store_pair(out, i, AW, c16, v0, v1);
+            *reinterpret_cast<int2 *>(out + (size_t)i * (size_t)AW) = make_int2(v0, v1);
         }
         return;
     }
@@ -1670,7 +1663,7 @@ __device__ __forceinline__ void write_rows(const uint32_t (&PL)[NA], const uint3
             if (NP > 8) { m0 |= ((Y0[j] >> (8 * b)) & 0xFFu) << 8; m1 |= ((Y1[j] >> (8 * b)) & 0xFFu) << 8; }
             const int32_t v0 = ((sgL >> ii) & 1u) ? -(int32_t)m0 : (int32_t)m0;
             const int32_t v1 = ((sgR >> ii) & 1u) ? -(int32_t)m1 : (int32_t)m1;
-            store_pair(out, row0 + ii, AW, c16, v0, v1);
+            *reinterpret_cast<int2 *>(out + (size_t)(row0 + ii) * (size_t)AW) = make_int2(v0, v1);
         }
     }
 }
@@ -1919,11 +1912,6 @@ void bpc_decode_kernel(BpcArgs a)
         // The planes come back from the scratch, eight (sixteen for a wave with a codeblock of MSB >= 8) of one
         // 32-row half at a time; planes above a codeblock's MSB were never written and read as zero.
         const bool have = coded;
-        const bool c16 = a.c16 != 0;
-        void *const outp = c16 ? (void *)((int16_t *)a.coeffs_out + cbase) : (void *)(a.coeffs_out + cbase);
-        // (an int16 array holds 15 magnitude bits: a codeblock with 16 planes -- which no frame within coef16_ok's
-        // bound codes -- is flagged like an MSB beyond the planes)
-        if (c16 && coded && msb >= 15) atomicOr(a.range_flag, 1);
         auto planes_of = [&](auto &A, auto &B, int hw, int n) {
 #pragma unroll
             for (int k = 0; k < (int)(sizeof(A) / sizeof(A[0])); k++) {
@@ -1940,7 +1928,7 @@ void bpc_decode_kernel(BpcArgs a)
                 uint32_t A[kMaxPlanes], B[kMaxPlanes];
                 planes_of(A, B, hw, kMaxPlanes);
                 write_rows<kMaxPlanes>(A, B, hw ? sgnL.hi : sgnL.lo, hw ? sgnR.hi : sgnR.lo, 32 * hw, valid, sz, stage, t,
-                                       outp, a.AW, c16);
+                                       a.coeffs_out + cbase, a.AW);
             }
         } else {
 #pragma unroll 1
@@ -1948,7 +1936,7 @@ void bpc_decode_kernel(BpcArgs a)
                 uint32_t A[kDecSmallPlanes], B[kDecSmallPlanes];
                 planes_of(A, B, hw, kDecSmallPlanes);
                 write_rows<kDecSmallPlanes>(A, B, hw ? sgnL.hi : sgnL.lo, hw ? sgnR.hi : sgnR.lo, 32 * hw, valid, sz, stage, t,
-                                            outp, a.AW, c16);
+                                            a.coeffs_out + cbase, a.AW);
             }
         }
     }

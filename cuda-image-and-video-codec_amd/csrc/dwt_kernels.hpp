@@ -137,7 +137,6 @@ struct DwtInvArgs {
     // dwt_inv97_kernel: qs is a power of two (the two de-quantising divisions are one: x / (q * qs) is exact scaling)
     int one_div;
     int exact_replay;       // debug: every wave of dwt_inv97_kernel runs its band a second time with true divisions
-    int c16;                // `mallat` is the frame paths' int16 array (row stride AW), see DwtFwdArgs::c16
 };
 
 // frame blockIdx.z of a batched launch
@@ -977,19 +976,6 @@ __device__ __forceinline__ SubRaw load_sub_raw(const DwtInvArgs &a, int row_s_or
                                        : (const uint32_t *)a.ll + (size_t)row_s_or_d * (size_t)a.ll_stride;
     SubRaw r;
     if constexpr (VEC) {
-        if (a.c16) {                                         // (wave-uniform) int16 Mallat array: a dword = two coefficients
-            const int16_t *m16 = (const int16_t *)a.mallat + (size_t)(row_s_or_d + (high_row ? hH : 0)) * (size_t)a.AW;
-            const uint32_t d = *reinterpret_cast<const uint32_t *>(m16 + hW + pc);
-            r.d0 = (uint32_t)c16_lo(d); r.d1 = (uint32_t)c16_hi(d);
-            if (from_mallat) {
-                const uint32_t sv = *reinterpret_cast<const uint32_t *>(m16 + pc);
-                r.s0 = (uint32_t)c16_lo(sv); r.s1 = (uint32_t)c16_hi(sv);
-            } else {
-                const uint2 sv = *reinterpret_cast<const uint2 *>(srow + pc);
-                r.s0 = sv.x; r.s1 = sv.y;
-            }
-            return r;
-        }
         // pc is even and already clamped into [0, hW-2]: two aligned 8-byte loads per subband row
         const uint2 d = *reinterpret_cast<const uint2 *>(mrow + hW + pc);
         const uint2 sv = *reinterpret_cast<const uint2 *>(srow + pc);
@@ -1369,20 +1355,6 @@ __device__ __forceinline__ bool dwt_inv97_band(const DwtInvArgs &a, int strip, i
     SubRaw rawL[kGroup], rawH[kGroup];
     auto load_pair = [&](int j, SubRaw &L, SubRaw &H) {
         const uint32_t rl = (uint32_t)reflect_s(j, hH), rh = (uint32_t)(reflect_d(j, hH) + hH);
-        if (a.c16) {                                         // (wave-uniform) int16 Mallat array: a dword = two coefficients
-            const uint32_t aw2 = aw4 >> 1, vd2 = vd >> 1, vs2 = vs >> 1;
-            const uint32_t ld = rb_load32(mal, vd2, rl * aw2), hd = rb_load32(mal, vd2, rh * aw2), hs = rb_load32(mal, vs2, rh * aw2);
-            if constexpr (FIRST) {
-                const uint32_t ls = rb_load32(mal, vs2, rl * aw2);
-                L.s0 = (uint32_t)c16_lo(ls); L.s1 = (uint32_t)c16_hi(ls);
-            } else {
-                const uint2 ls = rb_load64(lls, vs, rl * ll4);
-                L.s0 = ls.x; L.s1 = ls.y;
-            }
-            L.d0 = (uint32_t)c16_lo(ld); L.d1 = (uint32_t)c16_hi(ld);
-            H.d0 = (uint32_t)c16_lo(hd); H.d1 = (uint32_t)c16_hi(hd); H.s0 = (uint32_t)c16_lo(hs); H.s1 = (uint32_t)c16_hi(hs);
-            return;
-        }
         const uint2 ld = rb_load64(mal, vd, rl * aw4), ls = rb_load64(lls, vs, rl * ll4);
         const uint2 hd = rb_load64(mal, vd, rh * aw4), hs = rb_load64(mal, vs, rh * aw4);
         L.d0 = ld.x; L.d1 = ld.y; L.s0 = ls.x; L.s1 = ls.y;

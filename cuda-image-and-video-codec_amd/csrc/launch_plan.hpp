@@ -199,7 +199,7 @@ inline bool plan_dwt_fwd2(const std::vector<FwdLaunch> &plan, Fwd2Launch &f, boo
     return true;
 }
 
-// c16: d_in is the frame paths' int16 Mallat array (the caller has checked dwt_c16_geometry_ok)
+// the 16-bit form exists in the vector-only kernel instantiations: every level of the frame on the vector path
 inline bool dwt_c16_geometry_ok(int aw, int ah, int wl)
 {   // every level on the vector path: level widths multiples of 4 (and rows 16-byte aligned: aw % 4 == 0)
     if (const char *e = getenv("PICSONG_DWT_NOVEC")) if (atoi(e) != 0) return false;
@@ -210,7 +210,7 @@ inline bool dwt_c16_geometry_ok(int aw, int ah, int wl)
     return (aw & 3) == 0 && (ah >> (wl - 1)) >= 2;
 }
 inline std::vector<InvLaunch> plan_dwt_inverse(const int32_t *d_in, void *d_out, int aw, int ah, int wl,
-                                               float qs, bool fast = false, bool c16 = false)
+                                               float qs, bool fast = false)
 {
     std::vector<InvLaunch> v;
     int W = aw >> (wl - 1), H = ah >> (wl - 1);
@@ -225,7 +225,7 @@ inline std::vector<InvLaunch> plan_dwt_inverse(const int32_t *d_in, void *d_out,
         a.first = first ? 1 : 0;
         a.W = W; a.H = H;
         a.dst = (char *)d_out + write_off * 4;
-        a.dst_u8 = nullptr; a.off = 0; a.c16 = c16 ? 1 : 0;
+        a.dst_u8 = nullptr; a.off = 0;
         a.mallat_z = a.ll_z = a.dst_z = a.u8_z = 0;
         {   // qs = 2^k: dividing by it is exact scaling, dwt_inv97_kernel folds it into the step
             int e = 0;
@@ -242,7 +242,6 @@ inline std::vector<InvLaunch> plan_dwt_inverse(const int32_t *d_in, void *d_out,
         f.gx = (unsigned)((strips + 3) / 4);
         f.gy = (unsigned)(((H >> 1) + f.band / 2 - 1) / (f.band / 2));
         f.vec = dwt_vec_ok(W, aw, d_in, d_out);
-        if (!f.vec) a.c16 = 0;                              // (callers check dwt_c16_geometry_ok first: never taken with c16)
         v.push_back(f);
         read_off = write_off;
         write_off += (size_t)W * (size_t)H;

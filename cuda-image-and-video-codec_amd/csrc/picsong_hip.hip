@@ -51,7 +51,6 @@ struct picsong_ctx {
     size_t P, extra;
     bool fast_div;        // 9/7 synthesis: reciprocal form of the divisions verified for this qs
     bool c16;             // frame paths: coded coefficients travel as int16 between transform and coder (coef16_ok)
-    bool c16_dec;         // ... on the decode paths too (PICSONG_C16_DECODE=1; see picsong_ctx_create)
     bool pipelined;       // picsong_ctx_set_pipelined: other frames share the GPU (throughput over latency)
     // LUT
     picsong_lut_info li[3];
@@ -401,11 +400,6 @@ int picsong_ctx_create(const picsong_params *p, int device, picsong_ctx **out)
     // 8-bit samples: 128 after the level shift; 255 covers the chroma differences of the RGB path's RCT
     c->c16 = p->k <= 0.0f && p->cp != 3 && p->bit_depth == 8 && dwt_c16_geometry_ok(c->aw, c->ah, p->wl) &&
              coef16_ok(p->lossy != 0, p->wl, p->qs, p->is_rgb ? 255 : 128);
-    // Decoding, the 16-bit form is built and tested but NOT the default: a lone frame gains 1-2 % (half the bytes between
-    // the decoder and the synthesis), frames in flight LOSE 2-7 % -- the synthesis kernels unpack what they load, and
-    // with three calls sharing the GPU everything is bound by vector-instruction issue, not by memory (8K lossless,
-    // three streams: 135 -> 125 Gpixel/s; the level-0 / level-1 synthesis launches 114 -> 124 / 34 -> 45 us while sharing).
-    { const char *e = getenv("PICSONG_C16_DECODE"); c->c16_dec = c->c16 && e && atoi(e) != 0; }
     hipError_t e = hipMalloc(&c->d_offsets, sizeof(int32_t) * (size_t)c->ncb);
     if (e == hipSuccess) e = hipMalloc(&c->d_total, sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc(&c->d_flag, sizeof(int));
@@ -632,17 +626,16 @@ int picsong_dwt_forward_tail(picsong_ctx *c, void *d_out, void *stream)
 // frames > 1 (picsong_decode_frames): grid.z = frame; frame z's coded coefficients at d_in + z * P, its work buffer at
 // d_out + z * (P + extra) elements, its pixels at d_pixels + z * pix_stride bytes
 static int dwt_inverse_impl(picsong_ctx *c, const int32_t *d_in, void *d_out, uint8_t *d_pixels, bool *fused,
-                            hipStream_t s, unsigned frames = 1, size_t pix_stride = 0, bool c16 = false)
+                            hipStream_t s, unsigned frames = 1, size_t pix_stride = 0)
 {
     if (fused) *fused = false;
-    std::vector<InvLaunch> plan = plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs, c->fast_div, c16);
+    std::vector<InvLaunch> plan = plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs, c->fast_div);
     if (d_pixels && !plan.empty() && plan.back().vec && (((uintptr_t)d_pixels) & 3u) == 0 && (pix_stride & 3u) == 0) {
         plan.back().a.dst_u8 = d_pixels;
         plan.back().a.off = 1 << (c->p.bit_depth - 1);
         if (fused) *fused = true;
     }
     if (frames > 1) {
-        // (the int16 array of a frame sits at the start of its int32-sized slot)
         const unsigned long long in_z = (unsigned long long)c->P * 4ull, wrk_z = (unsigned long long)(c->P + c->extra) * 4ull;
         for (InvLaunch &f : plan) {
             f.a.mallat_z = in_z;
@@ -746,12 +739,11 @@ int picsong_bpc_encode(picsong_ctx *c, const void *d_coeffs, int32_t *d_staging,
 }
 
 static int bpc_decode_impl(picsong_ctx *c, const int32_t *d_staging, const int32_t *d_sizes, int32_t *d_coeffs,
-                           hipStream_t s, int comp = 0, bool c16 = false)
+                           hipStream_t s, int comp = 0)
 {
     BpcArgs a;
     int rc = bpc_args(c, a, comp);
     if (rc) return rc;
-    a.c16 = c16 ? 1 : 0;
     a.coeffs_out = d_coeffs;
     a.staging = const_cast<int32_t *>(d_staging);
     a.sizes = const_cast<int32_t *>(d_sizes);
@@ -956,9 +948,9 @@ int picsong_decode_frame(picsong_ctx *c, const uint16_t *d_stream, uint8_t *d_fr
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     if ((rc = unpack_impl(c, d_stream, c->d_staging, c->d_sizes, false, s))) return rc;
-    if ((rc = bpc_decode_impl(c, c->d_staging, c->d_sizes, c->d_coef_i, s, 0, c->c16_dec))) return rc;
+    if ((rc = bpc_decode_impl(c, c->d_staging, c->d_sizes, c->d_coef_i, s))) return rc;
     bool fused = false;
-    if ((rc = dwt_inverse_impl(c, c->d_coef_i, c->d_coef, d_frame_out, &fused, s, 1, 0, c->c16_dec))) return rc;
+    if ((rc = dwt_inverse_impl(c, c->d_coef_i, c->d_coef, d_frame_out, &fused, s))) return rc;
     if (fused) return PICSONG_OK;            // the finest level wrote the pixels itself
     const void *img = (const char *)c->d_coef + c->extra * 4;
     const size_t n4 = c->P / 4;
@@ -1169,13 +1161,12 @@ int picsong_decode_frames(picsong_ctx *c, int n, const uint16_t *d_streams, size
     a.cb_base = 0; a.nCB = c->ncb;
     a.coeffs_out = c->b_coef_i; a.staging = c->b_staging; a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch;
     a.frames = n; a.waves_per_frame = wpf; a.coef_z = (unsigned long long)c->P * 4ull;
-    a.c16 = c->c16_dec ? 1 : 0;
     const unsigned wgs = (unsigned)(((size_t)n * (size_t)wpf + kBpcDecWgWaves - 1) / kBpcDecWgWaves);
     bpc_decode_kernel<false, kDecSmallPlanes><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
     HIP_TRY(hipGetLastError());
     // ---- inverse transform, pixels out of the finest level where its vector kernel applies
     bool fused = false;
-    if ((rc = dwt_inverse_impl(c, c->b_coef_i, c->b_coef, d_frames_out, &fused, s, (unsigned)n, frame_stride, c->c16_dec))) return rc;
+    if ((rc = dwt_inverse_impl(c, c->b_coef_i, c->b_coef, d_frames_out, &fused, s, (unsigned)n, frame_stride))) return rc;
     if (fused) return PICSONG_OK;
     const size_t n4 = c->P / 4;
     const int off = 1 << (c->p.bit_depth - 1);
@@ -1350,10 +1341,9 @@ int picsong_decode_rgb_frame(picsong_ctx *c, const uint16_t *d_streams, size_t s
     HIP_TRY(hipGetLastError());
     a.coeffs_out = c->b_coef_i; a.staging = c->b_staging; a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch;
     a.coef_z = (unsigned long long)c->P * 4ull;
-    a.c16 = c->c16_dec ? 1 : 0;
     bpc_decode_kernel<false, kDecSmallPlanes><<<(unsigned)(3 * a.waves_per_frame / kBpcDecWgWaves), 64 * kBpcDecWgWaves, 0, s>>>(a);
     HIP_TRY(hipGetLastError());
-    if ((rc = dwt_inverse_impl(c, c->b_coef_i, c->b_coef, nullptr, nullptr, s, 3u, 0, c->c16_dec))) return rc;
+    if ((rc = dwt_inverse_impl(c, c->b_coef_i, c->b_coef, nullptr, nullptr, s, 3u, 0))) return rc;
     const char *img = (const char *)c->b_coef + c->extra * 4;
     const size_t z = (c->P + c->extra) * 4;
     return picsong_rgb_inverse(c, img, img + z, img + 2 * z, d_r, d_g, d_b, stream);

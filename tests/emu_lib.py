@@ -36,9 +36,9 @@ C16 = False
 
 
 def set_c16(on):
-    """The frame paths' form: coded coefficients as int16 between the transform and the coder (DwtFwdArgs::c16).
-    dwt_forward then returns a buffer whose first AW*AH int16 are the Mallat array (`mallat16`), bpc_encode / dwt_inverse
-    take int16 arrays and bpc_decode returns one."""
+    """The encode frame paths' form: coded coefficients as int16 between the transform and the coder (DwtFwdArgs::c16).
+    dwt_forward then returns a buffer whose first AW*AH int16 are the Mallat array (`mallat16`) and bpc_encode takes an
+    int16 array."""
     global C16
     C16 = bool(on)
     lib().emu_set_c16(int(C16))
@@ -115,7 +115,7 @@ def bpc_encode_range(coef, wl, lut, cb_begin, cb_count):
 
 def dwt_inverse(coef, wl, lossy, qs=1.0, extra=0):
     AH, AW = coef.shape
-    coef = aligned_copy(np.ascontiguousarray(coef, np.int16 if C16 else np.int32))
+    coef = aligned_copy(np.ascontiguousarray(coef, np.int32))
     out = aligned_zeros(AW * AH + extra, np.float32 if lossy else np.int32)
     lib().emu_dwt_inverse(_p(coef), _p(out), AW, AH, wl, int(lossy), C.c_float(qs))
     return out
@@ -124,7 +124,7 @@ def dwt_inverse(coef, wl, lossy, qs=1.0, extra=0):
 def dwt_inverse_u8(coef, wl, lossy, qs=1.0, extra=0):
     """Frame-path inverse: returns (pixels u8 (AH, AW), fused flag)."""
     AH, AW = coef.shape
-    coef = aligned_copy(np.ascontiguousarray(coef, np.int16 if C16 else np.int32))
+    coef = aligned_copy(np.ascontiguousarray(coef, np.int32))
     scratch = aligned_zeros(AW * AH + extra, np.float32 if lossy else np.int32)
     pix = aligned_zeros(AW * AH, np.uint8)
     fused = lib().emu_dwt_inverse_u8(_p(coef), _p(scratch), _p(pix), AW, AH, wl, int(lossy), C.c_float(qs))
@@ -214,7 +214,7 @@ def bpc_decode(staging, sizes, AW, AH, wl, lut, k=0.0):
     lib().emu_bpc_decode(_p(staging), _p(sizes), AW, AH, wl, _p(tab), _p(geo), _p(coef), _p(flag),
                          C.c_float(k), int(getattr(lut, "n_tables", 1)))
     bpc_decode.last_flag = int(flag[0])
-    return mallat16(coef, AW, AH).copy() if C16 else coef
+    return coef
 
 
 def pack(staging, sizes, header=None):

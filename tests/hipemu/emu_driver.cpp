@@ -161,7 +161,7 @@ void emu_dwt_forward_tail(void *out, int aw, int ah, int wl, int lossy, float qs
 
 void emu_dwt_inverse(const int32_t *in, void *out, int aw, int ah, int wl, int lossy, float qs)
 {
-    for (const InvLaunch &f : plan_dwt_inverse(in, out, aw, ah, wl, qs, emu_fast_div(lossy, qs, wl), g_c16 != 0)) {
+    for (const InvLaunch &f : plan_dwt_inverse(in, out, aw, ah, wl, qs, emu_fast_div(lossy, qs, wl))) {
         switch (f.band) {
         case 32: emu_inv<32>(f, lossy); break;
         case 16: emu_inv<16>(f, lossy); break;
@@ -175,7 +175,7 @@ void emu_dwt_inverse(const int32_t *in, void *out, int aw, int ah, int wl, int l
 // returns 1 when that fused kernel applied
 int emu_dwt_inverse_u8(const int32_t *in, void *scratch, uint8_t *pixels, int aw, int ah, int wl, int lossy, float qs)
 {
-    std::vector<InvLaunch> plan = plan_dwt_inverse(in, scratch, aw, ah, wl, qs, emu_fast_div(lossy, qs, wl), g_c16 != 0);
+    std::vector<InvLaunch> plan = plan_dwt_inverse(in, scratch, aw, ah, wl, qs, emu_fast_div(lossy, qs, wl));
     const bool fused = !plan.empty() && plan.back().vec && (((uintptr_t)pixels) & 3u) == 0;
     if (fused) { plan.back().a.dst_u8 = pixels; plan.back().a.off = 128; }
     for (const InvLaunch &f : plan) {
