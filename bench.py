@@ -123,12 +123,16 @@ def pmc_valu(workload):
     return None
 
 
-def pmc_pipelined(workload):
-    """Counter-derived occupancy of the vector ALUs by the coder while frames of three calls share the GPU
-    (profiles/*_pmc_sq_pipelined.csv: a rocprofv3 --pmc pass over the DEFAULT three-stream shape): per dispatch of
-    bpc_encode_kernel, the share of its waves' cycles spent issuing (SQ_ACTIVE_INST_ANY), issuing vector instructions
-    (SQ_INST_CYCLES_VALU / SQ_ACTIVE_INST_VALU), waiting on s_waitcnt (SQ_WAIT_ANY) or for an issue slot
-    (SQ_WAIT_INST_ANY).  OFFLINE, like `traffic`."""
+def pmc_valu_busy(workload, insts_per_frame_all, step_s):
+    """rocprof's VALUBusy for the coder -- 100 x sum(SQ_ACTIVE_INST_VALU) / CU_NUM / max(GRBM_GUI_ACTIVE): the share of
+    the time in which a SIMD has a vector instruction in its pipe, one instruction = one quad-cycle of one of a CU's
+    four SIMDs -- from the committed counter pass (profiles/*_pmc_sq_pipelined.csv, collected over the DEFAULT
+    three-stream command).  rocprofv3 SERIALISES the dispatches of a --pmc run (the pass's own kernel trace shows no two
+    kernels overlapping, against a hundred overlapping pairs in the plain trace of the same command), so the counters
+    describe every kernel running ALONE whatever --streams says: `lone_kernel`.  `pipelined` is the same definition
+    applied to the counter-measured instruction counts of all of a frame's kernels and this run's measured time per
+    frame; values near or above 1 mean the vector ALUs are the limit (full-rate instructions take less than a
+    quad-cycle: tools/valu_probe).  OFFLINE counters, like `traffic`."""
     import csv
     path = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_sq_pipelined.csv")
     if workload != "8k_lossless" or not os.path.exists(path):
@@ -137,19 +141,45 @@ def pmc_pipelined(workload):
     for r in csv.DictReader(ln for ln in open(path) if not ln.startswith("#")):
         if "bpc_encode_kernel" in r["Kernel_Name"]:
             c[r["Counter_Name"]] = float(r["MeanValue"])
-    if "SQ_WAVE_CYCLES" not in c:
+    if not c.get("SQ_ACTIVE_INST_VALU") or not c.get("GRBM_GUI_ACTIVE"):
         return None
-    wc = c["SQ_WAVE_CYCLES"]
-    out = {"source": "profiles/%s_pmc_sq_pipelined.csv" % PROFILE_TAG, "counters_per_dispatch": {k: int(v) for k, v in c.items()}}
-    for name, key in (("wave_cycles_issuing_any", "SQ_ACTIVE_INST_ANY"), ("wave_cycles_issuing_valu", "SQ_INST_CYCLES_VALU"),
-                      ("wave_cycles_waiting_waitcnt", "SQ_WAIT_ANY"), ("wave_cycles_waiting_issue", "SQ_WAIT_INST_ANY")):
-        if key in c and wc:
-            out[name] = round(c[key] / wc, 4)
-    # the SIMDs' view: vector-instruction issue cycles of ALL resident waves per cycle the CUs were busy -- one SIMD
-    # issues one vector instruction at a time, a CU has four
-    if "SQ_INST_CYCLES_VALU" in c and c.get("SQ_BUSY_CU_CYCLES"):
-        out["valu_busy_fraction_per_simd"] = round(c["SQ_INST_CYCLES_VALU"] / (4.0 * c["SQ_BUSY_CU_CYCLES"]), 4)
+    xcc, cus, simds = 8, 256, 1024
+    gui = c["GRBM_GUI_ACTIVE"] / xcc                      # (the summary adds the eight XCCs' values of a dispatch)
+    out = {"source": "profiles/%s_pmc_sq_pipelined.csv" % PROFILE_TAG,
+           "lone_kernel": {"VALUBusy": round(c["SQ_ACTIVE_INST_VALU"] / cus / gui, 4),
+                           "gpu_cycles_per_dispatch": int(gui)}}
+    wc = c.get("SQ_WAVE_CYCLES")
+    if wc:
+        for name, key in (("wave_cycles_issuing", "SQ_ACTIVE_INST_ANY"), ("wave_cycles_waiting_waitcnt", "SQ_WAIT_ANY"),
+                          ("wave_cycles_waiting_issue", "SQ_WAIT_INST_ANY")):
+            if key in c:
+                out["lone_kernel"][name] = round(c[key] / wc, 4)
+    if insts_per_frame_all and step_s:
+        pr = probe_rates() or {}
+        hz = (pr.get("shader_mhz") or 2400.0) * 1e6
+        out["pipelined"] = {"VALUBusy_same_definition": round(insts_per_frame_all * 4.0 / (simds * step_s * hz), 4),
+                            "valu_wave_insts_per_frame_all_kernels": int(insts_per_frame_all), "shader_hz": hz,
+                            "note": "instruction counts from the counter passes (coder + transform + pack), time per "
+                                    "frame from this run's timed loop"}
     return out
+
+
+def pmc_valu_all(workload):
+    """VALU wave-instructions per frame of ALL the encode path's kernels (coder, transform levels, scan, pack) from the
+    committed SQ pass (profiles/*_pmc_sq.csv: mean per dispatch x dispatches per frame)."""
+    import csv
+    path = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_sq.csv")
+    if workload != "8k_lossless" or not os.path.exists(path):
+        return None
+    rows = [r for r in csv.DictReader(ln for ln in open(path) if not ln.startswith("#")) if r["Counter_Name"] == "SQ_INSTS_VALU"]
+    frames = next((int(r["Dispatches"]) for r in rows if "bpc_encode_kernel" in r["Kernel_Name"]), 0)
+    if not frames:
+        return None
+    tot = 0.0
+    for r in rows:
+        if any(k in r["Kernel_Name"] for k in ("bpc_encode_kernel", "dwt_fwd", "scan_sizes", "pack_kernel")):
+            tot += float(r["MeanValue"]) * int(r["Dispatches"]) / frames
+    return tot
 
 
 def probe_rates():
@@ -649,7 +679,7 @@ def main():
                 "single_stream": {"avg_launch_ms": round(float(iso_ms[1]) * batch, 4),
                                   "codeblocks_per_s": round(nCB / (float(iso_ms[1]) * 1e-3), 1)},
                 "valu_issue": valu_issue(pmc_valu(args.workload), ms_per_frame * 1e-3, float(iso_ms[1]) * 1e-3),
-                "valu_busy_pipelined": pmc_pipelined(args.workload),
+                "valu_busy": pmc_valu_busy(args.workload, pmc_valu_all(args.workload), ms_per_frame * 1e-3),
                 "source": library_hashes(),
                 "note": "BPC is bound by vector-instruction issue, not HBM (SURVEY 8d): codeblocks/s and "
                         "valu_issue are the figures of merit, the HBM fraction is reported for completeness. "
