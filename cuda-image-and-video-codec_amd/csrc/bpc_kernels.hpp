@@ -75,11 +75,6 @@ struct BpcArgs {
     // codes with table lut_c[f] (same geometry); waves_per_frame is then a whole number of workgroups, a workgroup's
     // LDS copy of the table being its frame's.  lut_c[0] = nullptr: every frame uses `lut`
     const int32_t *lut_c[3];
-    // encoder, whole-frame launches: the scan of the sizes (offsets[cb] = sum_{i<cb} (sizes[i] - 1), total) by the LAST
-    // wave of the frame to finish, in place of a one-workgroup scan launch (enc_scan_when_last).  scan_done: one zeroed
-    // counter per frame of the launch (left zeroed); nullptr = off
-    int32_t *scan_offsets, *scan_total;
-    uint32_t *scan_done;
 };
 
 // ---- cross-lane helpers ---------------------------------------------------------------------
@@ -1073,61 +1068,12 @@ __device__ __forceinline__ void enc_transpose_pass(const BpcArgs &a, int pass, u
     }
 }
 
-// device-scope accesses (relaxed): a value another workgroup of the SAME launch reads goes to / comes from the
-// memory side, past the eight XCDs' L2s, which are not coherent with each other inside a launch
-__device__ __forceinline__ void dev_store(int32_t *p, int32_t v)
-{
-#if defined(__AMDGCN__)
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    *p = v;
-#endif
-}
-__device__ __forceinline__ int32_t dev_load(const int32_t *p)
-{
-#if defined(__AMDGCN__)
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    return *p;
-#endif
-}
-
-// The scan of a frame's codeblock lengths by the last of its `expected` waves to get here: every
-// wave, its sizes stored device-wide and acknowledged (wave_stores_issued), counts itself in; the wave that finds
-// expected - 1 before it is the last, reads all nCB lengths (device-scope loads, 128 per lane), scans them, writes
-// offsets[cb] = sum_{i<cb} (len_i - 1) and total = 9 + 2 nCB + sum + 1 for the pack launch that follows, and zeroes the
-// counter for the next launch.  In place of scan_sizes_kernel<<<1, 1024>>> (BitStreamBuilder.cu:290-323's scan).
-__device__ __forceinline__ void enc_scan_when_last(const BpcArgs &a, uint32_t lane, uint32_t expected)
-{
-    uint32_t old = 0u;
-#if defined(__AMDGCN__)
-    if (lane == 0u) old = __hip_atomic_fetch_add(a.scan_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    if (lane == 0u) { old = *a.scan_done; *a.scan_done = old + 1u; }
-#endif
-    old = __builtin_amdgcn_readfirstlane(old);
-    if (old != expected - 1u) return;
-    const int n = a.nCB, per = (n + 63) / 64;
-    const int b = (int)lane * per, e = b + per < n ? b + per : n;
-    int32_t sum = 0;
-    for (int i = b; i < e; i++) sum += dev_load(&a.sizes[i]) - 1;
-    int32_t inc = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int32_t o = __shfl_up(inc, d);
-        if ((int)lane >= d) inc += o;
-    }
-    int32_t run = inc - sum;
-    for (int i = b; i < e; i++) { a.scan_offsets[i] = run; run += dev_load(&a.sizes[i]) - 1; }
-    if (lane == 63u) *a.scan_total = 9 + 2 * n + inc + 1;
-    if (lane == 0u) {
-#if defined(__AMDGCN__)
-        __hip_atomic_store(a.scan_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-        *a.scan_done = 0u;
-#endif
-    }
-}
+// (Round 3 tried the scan of a frame's codeblock lengths by the LAST wave of the launch to finish -- sizes stored with
+// device-scope stores, an arrival counter, the last wave reading all nCB lengths back with device-scope loads, 2 x 128
+// per lane -- in place of the one-workgroup scan launch that follows the coder: byte-identical, neutral with frames in
+// flight (172.2 against 172.4 Gpixel/s), and 36 us SLOWER for a lone 8K frame: the coder's launch grew by 44 us, the
+// tail of ONE wave's loads from the memory side, where scan + pack shrank by 9.  Commit 'Experiment: the sizes' scan by
+// the coder's last wave' holds the code)
 
 // BULK = the -k > 0 instantiation (bulk scan after the ordinary planes, table s of the bit-plane
 // LUT files, LDS copy of that table); the k = 0 instantiation compiles to the plain coder.
@@ -1141,13 +1087,11 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     const int gwave = BULK ? (int)blockIdx.x
                            : (int)blockIdx.x * kBpcEncWgWaves + (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int wave = gwave;                                       // wave within its frame
-    bool counted = true;                                    // (enc_scan_when_last: the wave is one of its frame's)
     if (a.frames > 1) {
         const int f = gwave / a.waves_per_frame;            // wave-uniform
         wave = gwave - f * a.waves_per_frame;
-        if (f >= a.frames) { wave = a.waves_per_frame; counted = false; }    // padding wave of the last workgroup: codes nothing
+        if (f >= a.frames) { wave = a.waves_per_frame; }    // padding wave of the last workgroup: codes nothing
         else {
-            if (a.scan_done) { a.scan_done += f; a.scan_total += f; a.scan_offsets += (size_t)f * (size_t)a.nCB; }
             a.coeffs_in = (const char *)a.coeffs_in + (unsigned long long)f * a.coef_z;
             a.staging += (size_t)f * (size_t)a.AW * (size_t)a.AH;
             a.sizes += (size_t)f * (size_t)(a.nCB - a.cb_base);
@@ -1384,10 +1328,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     if (coded) *reinterpret_cast<int32_t *>(c.stw + c.off) = (int32_t)c.L;
     const uint32_t size = (half ? c.cnt_hi : c.cnt_lo) + 1u;
 #endif
-    if (valid && t == 0u) {
-        if (a.scan_done) dev_store(&a.sizes[cb], (int32_t)size);          // (read by another wave of this launch)
-        else a.sizes[cb] = (int32_t)size;
-    }
+    if (valid && t == 0u) a.sizes[cb] = (int32_t)size;
     // word 0 (the MSB) and expansionFix :1905-1912 (which overwrites the whole block) must land after every
     // codeword store of the block, the lanes' first-reservation stores to word 0 included
     wave_stores_issued();
@@ -1401,8 +1342,6 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     } else if (valid && t == 0u) {
         st[0] = msb;
     }
-    if (a.scan_done && counted)
-        enc_scan_when_last(a, lane, a.frames > 1 ? (uint32_t)a.waves_per_frame : (uint32_t)(gridDim.x * (BULK ? 1 : kBpcEncWgWaves)));
 }
 
 

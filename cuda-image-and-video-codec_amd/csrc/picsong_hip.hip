@@ -51,8 +51,6 @@ struct picsong_ctx {
     size_t P, extra;
     bool fast_div;        // 9/7 synthesis: reciprocal form of the divisions verified for this qs
     bool c16;             // frame paths: coded coefficients travel as int16 between transform and coder (coef16_ok)
-    bool scan_in_coder;   // frame paths: the sizes' scan by the coder's last wave (enc_scan_when_last), no scan launch
-    uint32_t *d_scan_done; // ... its per-frame arrival counters (64, zeroed once; the kernel leaves them zeroed)
     bool pipelined;       // picsong_ctx_set_pipelined: other frames share the GPU (throughput over latency)
     // LUT
     picsong_lut_info li[3];
@@ -399,7 +397,6 @@ int picsong_ctx_create(const picsong_params *p, int device, picsong_ctx **out)
     c->P = (size_t)aw * (size_t)ah;
     c->extra = picsong_dwt_extra(aw, ah, p->wl);
     c->fast_div = p->lossy != 0 && dequant_fast_ok(p->qs, p->wl);
-    { const char *e = getenv("PICSONG_SCAN_IN_CODER"); c->scan_in_coder = e && atoi(e) != 0; }
     // 8-bit samples: 128 after the level shift; 255 covers the chroma differences of the RGB path's RCT
     c->c16 = p->k <= 0.0f && p->cp != 3 && p->bit_depth == 8 && dwt_c16_geometry_ok(c->aw, c->ah, p->wl) &&
              coef16_ok(p->lossy != 0, p->wl, p->qs, p->is_rgb ? 255 : 128);
@@ -409,8 +406,6 @@ int picsong_ctx_create(const picsong_params *p, int device, picsong_ctx **out)
     if (e == hipSuccess) e = hipHostMalloc(&c->h_pinned, 2 * sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(c->d_flag, 0, sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->d_total, 0, sizeof(int32_t));
-    if (e == hipSuccess) e = hipMalloc(&c->d_scan_done, 64 * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(c->d_scan_done, 0, 64 * sizeof(uint32_t));
     if (e != hipSuccess) {
         picsong_ctx_destroy(c);
         return fail(PICSONG_ERR_HIP, "ctx_create: %s", hipGetErrorString(e));
@@ -428,7 +423,6 @@ void picsong_ctx_destroy(picsong_ctx *c)
     if (c->d_offsets) (void)hipFree(c->d_offsets);
     if (c->d_plane_scratch) (void)hipFree(c->d_plane_scratch);
     if (c->d_total) (void)hipFree(c->d_total);
-    if (c->d_scan_done) (void)hipFree(c->d_scan_done);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->d_coef) (void)hipFree(c->d_coef);
@@ -710,13 +704,12 @@ static int ensure_plane_scratch(picsong_ctx *c)
 
 static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_staging, int32_t *d_sizes,
                            bool memset_staging, hipStream_t s, int cb_begin = 0, int cb_count = -1, int comp = 0,
-                           bool c16 = false, bool scan = false)
+                           bool c16 = false)
 {
     BpcArgs a;
     int rc = bpc_args(c, a, comp);
     if (rc) return rc;
     a.c16 = c16 ? 1 : 0;
-    if (scan) { a.scan_offsets = c->d_offsets; a.scan_total = c->d_total; a.scan_done = c->d_scan_done; }   // (whole frames only)
     if (cb_count < 0) cb_count = c->ncb - cb_begin;
     a.cb_base = cb_begin;
     a.nCB = cb_begin + cb_count;
@@ -938,19 +931,10 @@ int picsong_encode_frame(picsong_ctx *c, const uint8_t *d_frame, int iter, uint1
     // (coefficients between the transform and the coder as int16 where their magnitudes are bounded: c->c16)
     if ((rc = dwt_forward_impl(c, d_frame, true, c->d_coef, s, c->c16))) return rc;
     if (ev) HIP_TRY(hipEventRecord(ev[1], s));
-    const bool scan = c->scan_in_coder && c->p.k <= 0.0f && c->p.cp != 3;
-    if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, s, 0, -1, 0, c->c16, scan))) return rc;
+    if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, s, 0, -1, 0, c->c16))) return rc;
     if (ev) HIP_TRY(hipEventRecord(ev[2], s));
     uint16_t hdr[PICSONG_HDR_SHORTS];
     if (iter == 0) picsong_header_pack(&c->p, hdr);
-    if (scan) {                               // offsets and total are there: the coder's last wave wrote them
-        HeaderArg h;
-        memset(&h, 0, sizeof h);
-        if (iter == 0) { memcpy(h.h, hdr, sizeof h.h); h.has = 1; }
-        pack_kernel<<<(unsigned)c->ncb, 256, 0, s>>>(c->d_staging, c->d_sizes, c->d_offsets, c->d_total, c->ncb, h, d_stream);
-        HIP_TRY(hipGetLastError());
-        rc = PICSONG_OK;
-    } else
     rc = picsong_bitstream_pack(c, c->d_staging, c->d_sizes, iter == 0 ? hdr : nullptr, d_stream, nullptr, stream);
     if (ev) HIP_TRY(hipEventRecord(ev[3], s));
     c->last_batch = 0;                                      // the most recent call's total is d_total
@@ -1107,8 +1091,6 @@ int picsong_encode_frames(picsong_ctx *c, int n, const uint8_t *d_frames, size_t
     a.coeffs_in = c->b_coef; a.is_float = c->p.lossy ? 1 : 0;
     a.staging = c->b_staging; a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch;
     a.frames = n; a.waves_per_frame = wpf; a.coef_z = coef_z;
-    const bool scan = c->scan_in_coder;
-    if (scan) { a.scan_offsets = c->b_offsets; a.scan_total = c->b_total; a.scan_done = c->d_scan_done; }
     const size_t waves = (size_t)n * (size_t)wpf;
     bpc_encode_kernel<false><<<(unsigned)((waves + kBpcEncWgWaves - 1) / kBpcEncWgWaves), 64 * kBpcEncWgWaves, 0, s>>>(a);
     HIP_TRY(hipGetLastError());
@@ -1123,7 +1105,7 @@ int picsong_encode_frames(picsong_ctx *c, int n, const uint8_t *d_frames, size_t
         memcpy(h.h, hdr, sizeof h.h);
         h.has = -first_iter + 1;
     }
-    if (!scan) scan_sizes_kernel<<<(unsigned)n, 1024, 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
+    scan_sizes_kernel<<<(unsigned)n, 1024, 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
     HIP_TRY(hipGetLastError());
     pack_kernel<<<dim3((unsigned)c->ncb, (unsigned)n), 256, 0, s>>>(c->b_staging, c->b_sizes, c->b_offsets, c->b_total,
                                                                     c->ncb, h, d_streams, c->P, stream_stride);

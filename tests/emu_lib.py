@@ -179,23 +179,6 @@ def bpc_encode(coef, wl, lut, k=0.0):
     return staging, sizes, int(flag[0])
 
 
-def bpc_encode_scanned(coef, wl, lut):
-    """k = 0 encode with the sizes' scan done by the launch's last wave: returns (staging, sizes, offsets, total)."""
-    AH, AW = coef.shape
-    coef = np.ascontiguousarray(coef)
-    n = (AW // 64) * (AH // 64)
-    staging = np.empty(AW * AH, np.int32)
-    sizes = np.empty(n, np.int32)
-    offsets = np.full(n, -7, np.int32)
-    total = np.zeros(1, np.int32)
-    flag = np.zeros(1, np.int32)
-    tab = np.ascontiguousarray(lut.table, np.int32)
-    geo = _geo(lut)
-    lib().emu_bpc_encode_scanned(_p(coef), int(coef.dtype == np.float32), AW, AH, wl, _p(tab), _p(geo), _p(staging),
-                                 _p(sizes), _p(flag), _p(offsets), _p(total))
-    return staging, sizes, offsets, int(total[0])
-
-
 def bpc3_encode(coef, wl, lut):
     """-cp 3 (lut: oracle_lib.lut_for_cp3)."""
     AH, AW = coef.shape

@@ -262,23 +262,6 @@ void emu_bpc_encode(const void *coeffs, int is_float, int aw, int ah, int wl, co
     else emu::launch(dim3((unsigned)(((a.nCB + 1) / 2 + kBpcEncWgWaves - 1) / kBpcEncWgWaves)), dim3(64 * kBpcEncWgWaves), [&] { bpc_encode_kernel<false>(a); });
 }
 
-// k = 0 with the scan of the sizes done by the launch's last wave (BpcArgs::scan_done): offsets[nCB] and total come back
-void emu_bpc_encode_scanned(const void *coeffs, int is_float, int aw, int ah, int wl, const int32_t *lut, const int *geo,
-                            int32_t *staging, int32_t *sizes, int *flag, int32_t *offsets, int32_t *total)
-{
-    BpcArgs a = mk(aw, ah, wl, lut, geo, staging, sizes, flag);
-    a.coeffs_in = coeffs; a.is_float = is_float;
-    a.k = 0.0f; a.n_tables = 1;
-    const unsigned wgs = (unsigned)(((a.nCB + 1) / 2 + kBpcEncWgWaves - 1) / kBpcEncWgWaves);
-    std::vector<uint32_t> plane_scratch((size_t)wgs * kBpcEncWgWaves * kEncScratchDwordsPerWave, 0xDEADBEEFu);
-    a.plane_scratch = plane_scratch.data();
-    uint32_t done = 0u;
-    a.scan_offsets = offsets; a.scan_total = total; a.scan_done = &done;
-    memset(staging, 0xFF, (size_t)aw * ah * 4);
-    emu::launch(dim3(wgs), dim3(64 * kBpcEncWgWaves), [&] { bpc_encode_kernel<false>(a); });
-    if (done != 0u) abort();                               // (the last wave leaves the counter zeroed)
-}
-
 void emu_bpc_decode(const int32_t *staging, const int32_t *sizes, int aw, int ah, int wl, const int32_t *lut,
                     const int *geo, int32_t *coeffs, int *flag, float k, int n_tables)
 {

@@ -285,21 +285,6 @@ def test_frame_path_with_16_bit_coefficients(oracle, E, monkeypatch, W, H, wl, l
     assert fused and np.array_equal(pix, ref_pix)
 
 
-@pytest.mark.parametrize("W,H", [(192, 128), (832, 576), (64, 64)])
-def test_scan_by_the_coders_last_wave(oracle, E, W, H):
-    """BpcArgs::scan_done: the launch's last wave to finish scans the sizes -- offsets[cb] = sum_{i<cb} (len_i - 1) and
-    total = 9 + 2 nCB + sum + 1, what scan_sizes_kernel delivers -- and leaves its arrival counter zeroed."""
-    wl = 2
-    img = oracle.gen_frame(W, H, 17)
-    lut = oracle.lut_for(False, wl)
-    coef = oracle.dwt_forward(oracle.level_shift_fwd(img, False), wl)[:W * H].reshape(H, W)
-    st0, sz0, _ = E.bpc_encode(coef, wl, lut)
-    st, sz, off, total = E.bpc_encode_scanned(coef, wl, lut)
-    assert np.array_equal(sz, sz0) and np.array_equal(st, st0)
-    want = np.concatenate([[0], np.cumsum(sz0 - 1)[:-1]])
-    assert np.array_equal(off, want) and total == 9 + 2 * sz0.size + int((sz0 - 1).sum()) + 1
-
-
 def test_16_bit_coefficient_bound(E):
     """coef16_ok: the 16-bit form only where magnitudes are bounded below 2^15 (8-bit samples; 9/7: times the
     quantisation weights): BASELINE's configurations qualify, a fine qs or a geometry off the vector kernels does not."""
