@@ -36,7 +36,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INST_CYC
 echo "pmc sq2 done"
 # the coder's bound as a measurement, in the DEFAULT shape (three streams, frames of three calls sharing the GPU)
 PP="--steps 1 --warmup 1 --frames-per-step 48 --pool 16 --streams 3 --batch 1 --no-cpu-baseline --no-b3"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU --output-format csv -d $out/pmc_sq_pipe -- python3 bench.py $PP > $out/pmc_sq_pipe.json 2> $out/pmc_sq_pipe.err || echo "pipelined sq pass failed"
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU --output-format csv -d $out/pmc_sq_pipe -- python3 bench.py $PP > $out/pmc_sq_pipe.json 2> $out/pmc_sq_pipe.err || echo "pipelined sq pass failed"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_INSTS_SALU SQ_WAVES --output-format csv -d $out/pmc_sq_pipe2 -- python3 bench.py $PP > $out/pmc_sq_pipe2.json 2> $out/pmc_sq_pipe2.err || echo "pipelined sq pass 2 failed"
 echo "pmc pipelined done"
 make -C tools valu_probe > /dev/null          # (from tools/valu_probe.hip; __graft_entry__.build() builds it too)
