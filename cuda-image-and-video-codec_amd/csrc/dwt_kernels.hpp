@@ -90,6 +90,9 @@ struct DwtFwdArgs {
     // transform writes and the coder reads.  Only where the magnitudes are bounded below 2^15 (coef16_ok,
     // launch_plan.hpp: 8-bit samples); the stage-by-stage API keeps the reference's T arrays.
     int c16;
+    // fused head, RGB frames (dwt_fwd2_kernel<..., RGB>): `src` is the R plane, these the G and B planes (padded u8,
+    // same stride); the launch's blockIdx.z is the COMPONENT the RCT delivers (src_z = 0: every component reads all three)
+    const void *src_g, *src_b;
 };
 
 // two integer coefficients as one dword of int16 (v_cvt_pk_i16_i32: saturating, which coef16_ok's bound never needs)
@@ -785,9 +788,30 @@ template <bool LOSSY, int NB> constexpr int f2_iters() { return NB + (LOSSY ? 5 
 // 28 KB with the second half's rows waiting in registers): 36-41 us against 35.6 for 9/7, 30.2-31.1 against 30.4
 // for 5/3 -- the launch's first 6-7 us are the frame's 45-55 MB of input arriving at HBM speed whoever issues the
 // loads, and the rest is its 135 MB of output leaving at the 6.3 TB/s the memory takes writes at.
-template <typename T, bool LOSSY, int NB, bool EDGE, bool C16>
+// One row of component `comp` of the reversible colour transform from the rows' R, G, B dwords (four samples each):
+// RGBTransformLossless Engines/CodingEngine.cu:357-403 with the level shift fused -- c0 = floor((R + 2G + B) / 4),
+// c1 = B - G, c2 = R - G on the shifted samples -- as ONE linear form with wave-uniform coefficients,
+// (cr R + cg G + cb B) >> sh, so that the component is no branch in the unrolled band.
+struct RctCoef { int cr, cg, cb, sh; };
+__device__ __forceinline__ RctCoef rct_coef(int comp)
+{
+    RctCoef k;
+    k.cr = comp == 1 ? 0 : 1; k.cg = comp == 0 ? 2 : -1; k.cb = comp == 2 ? 0 : 1; k.sh = comp == 0 ? 2 : 0;
+    return k;
+}
+__device__ __forceinline__ void unpack_rct(uint32_t wr, uint32_t wg, uint32_t wb, const RctCoef &k, int v[4])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int r = (int)((wr >> (8 * i)) & 0xFFu) - 128, g = (int)((wg >> (8 * i)) & 0xFFu) - 128, b = (int)((wb >> (8 * i)) & 0xFFu) - 128;
+        v[i] = (r * k.cr + g * k.cg + b * k.cb) >> k.sh;
+    }
+}
+
+template <typename T, bool LOSSY, int NB, bool EDGE, bool C16, bool RGB = false>
 __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdArgs &a1, int strip, int lane)
 {
+    static_assert(!RGB || (!LOSSY && std::is_same<T, int>::value), "the colour transform in the head's load stage: RCT only");
     constexpr uint32_t kCB = C16 ? 2u : 4u;                  // bytes of a coded coefficient
     constexpr int kIters = f2_iters<LOSSY, NB>();
     constexpr int kRel0 = LOSSY ? 7 : 3;                     // iteration i delivers the level-0 pairs 2 n0 + 2 i - kRel0, + 1
@@ -825,18 +849,30 @@ __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdA
     for (int k = 0; k < 2; k++) { xe1[k] = st1[0][k] = st1[1][k] = st1[2][k] = (T)0; }
 
     // all of the band's input rows go out before the first store (one in-order memory pipe), at raised priority
+    // (RGB: the rows of all three planes -- three times the registers, which is why that form runs 16-row bands)
     RawRow<true> r0, raw[kIters][4];
+    uint32_t g0 = 0u, b0 = 0u, rawG[RGB ? kIters : 1][4], rawB[RGB ? kIters : 1][4];
+    const RowBuf ing = rowbuf(RGB ? a.src_g : a.src), inb = rowbuf(RGB ? a.src_b : a.src);
+    const RctCoef rct = rct_coef(RGB ? (int)blockIdx.z : 0);
     PS_TRACE(0);
     __builtin_amdgcn_s_setprio(3);
     r0.w = rb_load32(in, vin, (uint32_t)reflect(y0, a.H) * (uint32_t)a.src_stride);
+    if constexpr (RGB) {
+        g0 = rb_load32(ing, vin, (uint32_t)reflect(y0, a.H) * (uint32_t)a.src_stride);
+        b0 = rb_load32(inb, vin, (uint32_t)reflect(y0, a.H) * (uint32_t)a.src_stride);
+    }
 #pragma unroll
     for (int p = 0; p < kIters; p++)
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            raw[p][q].w = rb_load32(in, vin, (uint32_t)reflect(y0 + 1 + 4 * p + q, a.H) * (uint32_t)a.src_stride);
+        for (int q = 0; q < 4; q++) {
+            const uint32_t ro = (uint32_t)reflect(y0 + 1 + 4 * p + q, a.H) * (uint32_t)a.src_stride;
+            raw[p][q].w = rb_load32(in, vin, ro);
+            if constexpr (RGB) { rawG[p][q] = rb_load32(ing, vin, ro); rawB[p][q] = rb_load32(inb, vin, ro); }
+        }
     __builtin_amdgcn_s_setprio(0);
     PS_TRACE(1);
-    unpack_row<T, true>(r0, xe);
+    if constexpr (RGB) unpack_rct(r0.w, g0, b0, rct, xe);
+    else unpack_row<T, true>(r0, xe);
     PS_TRACE(2);
 
 #pragma unroll
@@ -844,7 +880,10 @@ __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdA
         if (i == kIters / 2) PS_TRACE(3);
         T x[4][4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) unpack_row<T, true>(raw[i][q], x[q]);
+        for (int q = 0; q < 4; q++) {
+            if constexpr (RGB) unpack_rct(raw[i][q].w, rawG[i][q], rawB[i][q], rct, x[q]);
+            else unpack_row<T, true>(raw[i][q], x[q]);
+        }
         const int rel = 2 * i - kRel0;                       // (compile-time after unrolling)
         T LA[4], HA[4], LB[4], HB[4];
         vstep<T, LOSSY, 4>(xe, st0, x[0], x[1], LA, HA);
@@ -915,8 +954,10 @@ __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdA
 #endif
 }
 
-template <typename T, bool LOSSY, bool U8IN, int NB, bool C16 = false>
-__global__ __launch_bounds__(256, (LOSSY ? PICSONG_DWT_F2_WAVES_LOSSY : PICSONG_DWT_F2_WAVES)) void dwt_fwd2_kernel(DwtFwd2Args a2)
+// RGB: the RCT in the load stage (blockIdx.z = component; four waves per SIMD: a band holds three planes' rows)
+constexpr int kF2PairsRgb = 4;
+template <typename T, bool LOSSY, bool U8IN, int NB, bool C16 = false, bool RGB = false>
+__global__ __launch_bounds__(256, RGB ? 4 : (LOSSY ? PICSONG_DWT_F2_WAVES_LOSSY : PICSONG_DWT_F2_WAVES)) void dwt_fwd2_kernel(DwtFwd2Args a2)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int strip = blockIdx.x * 4 + wave;
@@ -928,8 +969,8 @@ __global__ __launch_bounds__(256, (LOSSY ? PICSONG_DWT_F2_WAVES_LOSSY : PICSONG_
     static_assert(U8IN, "the fused head ingests u8 frames");
     if (strip * kF2Useful >= a2.l0.W) return;               // whole wave idle (no cross-lane use)
     if (!LOSSY || first <= 0 || first + kStripCols >= a2.l0.W)
-        dwt_fwd2_band<T, LOSSY, NB, true, C16>(a2.l0, a2.l1, strip, lane);
-    else dwt_fwd2_band<T, LOSSY, NB, LOSSY ? false : true, C16>(a2.l0, a2.l1, strip, lane);
+        dwt_fwd2_band<T, LOSSY, NB, true, C16, RGB>(a2.l0, a2.l1, strip, lane);
+    else dwt_fwd2_band<T, LOSSY, NB, LOSSY ? false : true, C16, RGB>(a2.l0, a2.l1, strip, lane);
 }
 
 // ---- the small levels of the forward transform ---------------------------------------------------------

@@ -114,6 +114,7 @@ inline std::vector<FwdLaunch> plan_dwt_forward(const void *d_in, bool u8in, void
         a.ll_stride = last ? aw : (W >> 1);
         a.mallat = d_out; a.AW = aw; a.level = l; a.last = last ? 1 : 0; a.qs = qs;
         a.src_z = 0; a.dst_z = 0; a.pair_base = 0; a.pair_end = 0; a.c16 = c16 ? 1 : 0;
+        a.src_g = a.src_b = nullptr;
         for (int k = 0; k < 4; k++) a.q[k] = kQSteps[l][k];
         const int strips = (W + kStripUseful - 1) / kStripUseful;
         f.band = fwd_band_rows(l, strips, H);
@@ -181,7 +182,9 @@ inline bool dequant_fast_ok(float qs, int wl)
 // frames share the GPU, picsong_ctx_set_pipelined); PICSONG_DWT_NOFUSE01=1 / PICSONG_DWT_FUSE01=1 force
 // two launches / the fused one (the tests cross-check both).
 struct Fwd2Launch { DwtFwd2Args a; unsigned gx, gy; };
-inline bool plan_dwt_fwd2(const std::vector<FwdLaunch> &plan, Fwd2Launch &f, bool wanted = true, bool lossy = false)
+// nb_override > 0: level-1 row pairs per band (the RGB head: kF2PairsRgb)
+inline bool plan_dwt_fwd2(const std::vector<FwdLaunch> &plan, Fwd2Launch &f, bool wanted = true, bool lossy = false,
+                          int nb_override = 0)
 {
     if (const char *e = getenv("PICSONG_DWT_NOFUSE01")) if (atoi(e) != 0) return false;
     if (const char *e = getenv("PICSONG_DWT_FUSE01")) wanted = wanted || atoi(e) != 0;
@@ -193,7 +196,7 @@ inline bool plan_dwt_fwd2(const std::vector<FwdLaunch> &plan, Fwd2Launch &f, boo
     f.a.l0 = l0; f.a.l1 = plan[1].a;
     const int strips = (l0.W + kF2Useful - 1) / kF2Useful;
     f.gx = (unsigned)((strips + 3) / 4);
-    const int nb = lossy ? kF2PairsLossy : kF2Pairs;
+    const int nb = nb_override > 0 ? nb_override : (lossy ? kF2PairsLossy : kF2Pairs);
     if (pairs1 % nb) return false;                                  // whole bands only (dwt_fwd2_band)
     f.gy = (unsigned)((pairs1 + nb - 1) / nb);
     return true;

@@ -51,6 +51,10 @@ struct picsong_ctx {
     size_t P, extra;
     bool fast_div;        // 9/7 synthesis: reciprocal form of the divisions verified for this qs
     bool c16;             // frame paths: coded coefficients travel as int16 between transform and coder (coef16_ok)
+    // a lone frame (context not told that other frames share the GPU): the transform's small levels on a second stream
+    // under the coder's launch for the codeblocks that do not need them (picsong_encode_frame)
+    hipStream_t side;
+    hipEvent_t ev_head, ev_side;
     bool pipelined;       // picsong_ctx_set_pipelined: other frames share the GPU (throughput over latency)
     // LUT
     picsong_lut_info li[3];
@@ -438,6 +442,7 @@ void picsong_ctx_destroy(picsong_ctx *c)
     if (c->b_coef_i) (void)hipFree(c->b_coef_i);
     c->b_coef_i = nullptr; c->b_coef_i_cap = 0;
     if (c->h_totals) (void)hipHostFree(c->h_totals);
+    if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_head); (void)hipEventDestroy(c->ev_side); }
     if (c->prof_ev) {
         for (hipEvent_t e : *c->prof_ev) (void)hipEventDestroy(e);
         delete c->prof_ev;
@@ -704,7 +709,7 @@ static int ensure_plane_scratch(picsong_ctx *c)
 
 static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_staging, int32_t *d_sizes,
                            bool memset_staging, hipStream_t s, int cb_begin = 0, int cb_count = -1, int comp = 0,
-                           bool c16 = false)
+                           bool c16 = false, size_t scratch_wave0 = 0)
 {
     BpcArgs a;
     int rc = bpc_args(c, a, comp);
@@ -716,7 +721,8 @@ static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_stag
     a.coeffs_in = d_coeffs; a.is_float = c->p.lossy ? 1 : 0;
     a.staging = d_staging; a.sizes = d_sizes;
     if (int rc2 = ensure_plane_scratch(c)) return rc2;
-    a.plane_scratch = c->d_plane_scratch;
+    // (scratch_wave0: two launches of one frame side by side keep their waves' scratch apart)
+    a.plane_scratch = c->d_plane_scratch + scratch_wave0 * (size_t)kEncScratchDwordsPerWave;
     // BPCEngine::deviceMemoryAllocator BPCEngine.cu:2429-2441.  Slots beyond a codeblock's length
     // are never read downstream, so the fused frame path skips this 4*AW*AH-byte fill.
     if (memset_staging) HIP_TRY(hipMemsetAsync(d_staging, 0xFF, c->P * sizeof(int32_t), s));
@@ -929,9 +935,45 @@ int picsong_encode_frame(picsong_ctx *c, const uint8_t *d_frame, int iter, uint1
     if (c->prof_cap > 0 && c->prof_n < c->prof_cap) ev = c->prof_ev->data() + 4 * (c->prof_n++);
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
     // (coefficients between the transform and the coder as int16 where their magnitudes are bounded: c->c16)
-    if ((rc = dwt_forward_impl(c, d_frame, true, c->d_coef, s, c->c16))) return rc;
-    if (ev) HIP_TRY(hipEventRecord(ev[1], s));
-    if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, s, 0, -1, 0, c->c16))) return rc;
+    // A lone frame (the context has not been told that other frames share the GPU): once the fused head has run, 15/16 of
+    // the coefficients are final -- the codeblock rows below AH/4 hold nothing but level-0 / level-1 subbands (findSubband,
+    // BPC/BPCEngine.cu:143-170) -- so their coder launch starts at once, while the transform's small levels (three or four
+    // launches of 5 us that leave the GPU idle) and the coder launch for the top codeblock rows run on a second stream beside
+    // it.  Same kernels, same codestream; with frames in flight the gaps are filled anyway and the plain order is kept.
+    bool split = false;
+    if (!c->pipelined && c->p.k <= 0.0f && c->p.cp != 3 && !getenv("PICSONG_NO_SPLIT")) {
+        const std::vector<FwdLaunch> plan = plan_dwt_forward(d_frame, true, c->d_coef, c->aw, c->ah, c->p.wl, c->p.qs, c->c16);
+        Fwd2Launch f2;
+        const int top_rows = ((c->ah >> 2) + PICSONG_CB - 1) / PICSONG_CB;          // codeblock rows that hold levels >= 2
+        const int top_cbs = top_rows * (c->aw / PICSONG_CB);
+        if (plan.size() > 2 && plan_is_c16(plan) == c->c16 && plan_dwt_fwd2(plan, f2, true, c->p.lossy != 0) &&
+            top_cbs > 0 && top_cbs < c->ncb && (top_cbs & 1) == 0 && c->ncb >= 2048) {
+            if (!c->side) {
+                HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&c->ev_head, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
+            }
+            launch_fwd2(c->p.lossy != 0, f2, s);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(c->ev_head, s));
+            if (ev) HIP_TRY(hipEventRecord(ev[1], s));
+            // side stream: levels 2 .. wl - 1, then the top codeblock rows
+            HIP_TRY(hipStreamWaitEvent(c->side, c->ev_head, 0));
+            if ((rc = launch_fwd_levels(c, plan, 2, c->side))) return rc;
+            if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, c->side, 0, top_cbs, 0, c->c16))) return rc;
+            HIP_TRY(hipEventRecord(c->ev_side, c->side));
+            // caller's stream: every other codeblock (its waves' plane scratch lies behind the top rows')
+            if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, s, top_cbs, c->ncb - top_cbs, 0, c->c16,
+                                      (size_t)(top_cbs / 2)))) return rc;
+            HIP_TRY(hipStreamWaitEvent(s, c->ev_side, 0));
+            split = true;
+        }
+    }
+    if (!split) {
+        if ((rc = dwt_forward_impl(c, d_frame, true, c->d_coef, s, c->c16))) return rc;
+        if (ev) HIP_TRY(hipEventRecord(ev[1], s));
+        if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, s, 0, -1, 0, c->c16))) return rc;
+    }
     if (ev) HIP_TRY(hipEventRecord(ev[2], s));
     uint16_t hdr[PICSONG_HDR_SHORTS];
     if (iter == 0) picsong_header_pack(&c->p, hdr);
@@ -1286,6 +1328,28 @@ int picsong_encode_rgb_frame(picsong_ctx *c, const uint8_t *d_r, const uint8_t *
     hipStream_t s = (hipStream_t)stream;
     const size_t coef_z = (c->P + c->extra) * 4;
     char *planes = (char *)c->b_coef_i;
+    // ---- lossless: the colour transform in the fused head's load stage (dwt_fwd2_kernel<..., RGB>): the head reads the
+    // three u8 planes and delivers component blockIdx.z -- no component plane is ever written (the separate transform
+    // kernel reads 100 MB and writes 400 MB of them per 8K frame, and level 0 reads them back)
+    bool fused_rgb = false;
+    if (!c->p.lossy && c->c16 && !getenv("PICSONG_RGB_NOFUSE")) {
+        std::vector<FwdLaunch> plan = plan_dwt_forward(d_r, true, c->b_coef, c->aw, c->ah, c->p.wl, c->p.qs, true);
+        Fwd2Launch f2;
+        if (plan_is_c16(plan) && plan_dwt_fwd2(plan, f2, true, false, kF2PairsRgb)) {
+            for (size_t l = 0; l < plan.size(); l++) {
+                plan[l].a.src_z = l == 0 ? 0ull : (unsigned long long)coef_z;      // level 0: every component reads the three planes
+                plan[l].a.dst_z = (unsigned long long)coef_z;
+            }
+            plan[0].a.src_g = d_g; plan[0].a.src_b = d_b;
+            f2.a.l0 = plan[0].a; f2.a.l1 = plan[1].a;
+            dwt_fwd2_kernel<int, false, true, kF2PairsRgb, true, true><<<dim3(f2.gx, f2.gy, 3u), 256, 0, s>>>(f2.a);
+            HIP_TRY(hipGetLastError());
+            if ((rc = launch_fwd_levels(c, plan, 2, s, 3u))) return rc;
+            a.c16 = 1;
+            fused_rgb = true;
+        }
+    }
+    if (!fused_rgb) {
     // ---- colour transform (level shift fused) into three planes, then the transform of all three per launch
     if ((rc = picsong_rgb_forward(c, d_r, d_g, d_b, planes, planes + c->P * 4, planes + 2 * c->P * 4, stream))) return rc;
     std::vector<FwdLaunch> plan = plan_dwt_forward(planes, false, c->b_coef, c->aw, c->ah, c->p.wl, c->p.qs, c->c16);
@@ -1295,6 +1359,7 @@ int picsong_encode_rgb_frame(picsong_ctx *c, const uint8_t *d_r, const uint8_t *
         plan[l].a.dst_z = (unsigned long long)coef_z;
     }
     if ((rc = launch_fwd_levels(c, plan, 0, s, 3u))) return rc;
+    }
     // ---- coder: one grid over the three components' codeblock pairs, component f with table f
     a.coeffs_in = c->b_coef; a.is_float = c->p.lossy ? 1 : 0;
     a.staging = c->b_staging; a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch; a.coef_z = coef_z;

@@ -88,6 +88,18 @@ def dwt_forward(x, wl, lossy, qs=1.0, extra=0):
     return out
 
 
+def dwt_forward_rgb(r, g, b, wl, extra):
+    """The three components' int16 Mallat arrays of an RGB frame, RCT in the fused head's load stage (lossless);
+    None when that form does not apply to the geometry."""
+    AH, AW = r.shape
+    r, g, b = (aligned_copy(np.ascontiguousarray(x, np.uint8)) for x in (r, g, b))
+    stride = (AW * AH + extra) * 4
+    out = aligned_zeros(3 * (AW * AH + extra), np.int32)
+    if not lib().emu_dwt_forward_rgb(_p(r), _p(g), _p(b), _p(out), C.c_size_t(stride), AW, AH, wl):
+        return None
+    return [mallat16(out[k * (AW * AH + extra):(k + 1) * (AW * AH + extra)], AW, AH).copy() for k in range(3)]
+
+
 def dwt_forward_band(x_u8, out, wl, lossy, qs, row0, rows):
     """Level 0 of the input rows [row0, row0 + rows) of the (AH, AW) uint8 frame into `out` (Mallat + scratch)."""
     AH, AW = x_u8.shape

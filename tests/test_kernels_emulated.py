@@ -285,6 +285,19 @@ def test_frame_path_with_16_bit_coefficients(oracle, E, monkeypatch, W, H, wl, l
     assert fused and np.array_equal(pix, ref_pix)
 
 
+@pytest.mark.parametrize("W,H,wl", [(320, 192, 3), (256, 128, 2), (512, 320, 5)])
+def test_rgb_colour_transform_in_the_fused_heads_load_stage(oracle, E, W, H, wl):
+    """dwt_fwd2_kernel<..., RGB>: the head reads the R, G, B planes and delivers component blockIdx.z of the RCT --
+    the three components' coefficients equal the oracle's colour transform + 5/3 transform of each component."""
+    planes = [oracle.pad_frame(oracle.gen_frame(W, H, 80 + c)) for c in range(3)]
+    got = E.dwt_forward_rgb(*planes, wl, oracle.dwt_extra(W, H, wl))
+    assert got is not None
+    comps = oracle.rgb_forward(*planes, False)
+    for k in range(3):
+        ref = oracle.dwt_forward(comps[k], wl)[:W * H].reshape(H, W)
+        assert np.array_equal(got[k].astype(np.int32), ref), f"component {k}"
+
+
 def test_16_bit_coefficient_bound(E):
     """coef16_ok: the 16-bit form only where magnitudes are bounded below 2^15 (8-bit samples; 9/7: times the
     quantisation weights): BASELINE's configurations qualify, a fine qs or a geometry off the vector kernels does not."""
