@@ -51,10 +51,6 @@ struct picsong_ctx {
     size_t P, extra;
     bool fast_div;        // 9/7 synthesis: reciprocal form of the divisions verified for this qs
     bool c16;             // frame paths: coded coefficients travel as int16 between transform and coder (coef16_ok)
-    // a lone frame (context not told that other frames share the GPU): the transform's small levels on a second stream
-    // under the coder's launch for the codeblocks that do not need them (picsong_encode_frame)
-    hipStream_t side;
-    hipEvent_t ev_head, ev_side;
     bool pipelined;       // picsong_ctx_set_pipelined: other frames share the GPU (throughput over latency)
     // LUT
     picsong_lut_info li[3];
@@ -442,7 +438,6 @@ void picsong_ctx_destroy(picsong_ctx *c)
     if (c->b_coef_i) (void)hipFree(c->b_coef_i);
     c->b_coef_i = nullptr; c->b_coef_i_cap = 0;
     if (c->h_totals) (void)hipHostFree(c->h_totals);
-    if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_head); (void)hipEventDestroy(c->ev_side); }
     if (c->prof_ev) {
         for (hipEvent_t e : *c->prof_ev) (void)hipEventDestroy(e);
         delete c->prof_ev;
@@ -709,7 +704,7 @@ static int ensure_plane_scratch(picsong_ctx *c)
 
 static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_staging, int32_t *d_sizes,
                            bool memset_staging, hipStream_t s, int cb_begin = 0, int cb_count = -1, int comp = 0,
-                           bool c16 = false, size_t scratch_wave0 = 0)
+                           bool c16 = false)
 {
     BpcArgs a;
     int rc = bpc_args(c, a, comp);
@@ -721,8 +716,7 @@ static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_stag
     a.coeffs_in = d_coeffs; a.is_float = c->p.lossy ? 1 : 0;
     a.staging = d_staging; a.sizes = d_sizes;
     if (int rc2 = ensure_plane_scratch(c)) return rc2;
-    // (scratch_wave0: two launches of one frame side by side keep their waves' scratch apart)
-    a.plane_scratch = c->d_plane_scratch + scratch_wave0 * (size_t)kEncScratchDwordsPerWave;
+    a.plane_scratch = c->d_plane_scratch;
     // BPCEngine::deviceMemoryAllocator BPCEngine.cu:2429-2441.  Slots beyond a codeblock's length
     // are never read downstream, so the fused frame path skips this 4*AW*AH-byte fill.
     if (memset_staging) HIP_TRY(hipMemsetAsync(d_staging, 0xFF, c->P * sizeof(int32_t), s));
@@ -935,45 +929,13 @@ int picsong_encode_frame(picsong_ctx *c, const uint8_t *d_frame, int iter, uint1
     if (c->prof_cap > 0 && c->prof_n < c->prof_cap) ev = c->prof_ev->data() + 4 * (c->prof_n++);
     if (ev) HIP_TRY(hipEventRecord(ev[0], s));
     // (coefficients between the transform and the coder as int16 where their magnitudes are bounded: c->c16)
-    // A lone frame (the context has not been told that other frames share the GPU): once the fused head has run, 15/16 of
-    // the coefficients are final -- the codeblock rows below AH/4 hold nothing but level-0 / level-1 subbands (findSubband,
-    // BPC/BPCEngine.cu:143-170) -- so their coder launch starts at once, while the transform's small levels (three or four
-    // launches of 5 us that leave the GPU idle) and the coder launch for the top codeblock rows run on a second stream beside
-    // it.  Same kernels, same codestream; with frames in flight the gaps are filled anyway and the plain order is kept.
-    bool split = false;
-    if (!c->pipelined && c->p.k <= 0.0f && c->p.cp != 3 && !getenv("PICSONG_NO_SPLIT")) {
-        const std::vector<FwdLaunch> plan = plan_dwt_forward(d_frame, true, c->d_coef, c->aw, c->ah, c->p.wl, c->p.qs, c->c16);
-        Fwd2Launch f2;
-        const int top_rows = ((c->ah >> 2) + PICSONG_CB - 1) / PICSONG_CB;          // codeblock rows that hold levels >= 2
-        const int top_cbs = top_rows * (c->aw / PICSONG_CB);
-        if (plan.size() > 2 && plan_is_c16(plan) == c->c16 && plan_dwt_fwd2(plan, f2, true, c->p.lossy != 0) &&
-            top_cbs > 0 && top_cbs < c->ncb && (top_cbs & 1) == 0 && c->ncb >= 2048) {
-            if (!c->side) {
-                HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-                HIP_TRY(hipEventCreateWithFlags(&c->ev_head, hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
-            }
-            launch_fwd2(c->p.lossy != 0, f2, s);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(c->ev_head, s));
-            if (ev) HIP_TRY(hipEventRecord(ev[1], s));
-            // side stream: levels 2 .. wl - 1, then the top codeblock rows
-            HIP_TRY(hipStreamWaitEvent(c->side, c->ev_head, 0));
-            if ((rc = launch_fwd_levels(c, plan, 2, c->side))) return rc;
-            if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, c->side, 0, top_cbs, 0, c->c16))) return rc;
-            HIP_TRY(hipEventRecord(c->ev_side, c->side));
-            // caller's stream: every other codeblock (its waves' plane scratch lies behind the top rows')
-            if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, s, top_cbs, c->ncb - top_cbs, 0, c->c16,
-                                      (size_t)(top_cbs / 2)))) return rc;
-            HIP_TRY(hipStreamWaitEvent(s, c->ev_side, 0));
-            split = true;
-        }
-    }
-    if (!split) {
-        if ((rc = dwt_forward_impl(c, d_frame, true, c->d_coef, s, c->c16))) return rc;
-        if (ev) HIP_TRY(hipEventRecord(ev[1], s));
-        if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, s, 0, -1, 0, c->c16))) return rc;
-    }
+    // (Round 3 tried, for a lone frame, the coder's launch for the codeblock rows below AH/4 -- final once the fused head has
+    // run -- at once on the caller's stream, and the transform's small levels + the coder's launch for the top rows on a
+    // second stream beside it: byte-identical, and 70 us SLOWER at 8K (0.308 -> 0.379 ms): the top-left codeblocks are the
+    // ones with the most planes, the launch's critical waves, and the split starts exactly those 20-40 us late.)
+    if ((rc = dwt_forward_impl(c, d_frame, true, c->d_coef, s, c->c16))) return rc;
+    if (ev) HIP_TRY(hipEventRecord(ev[1], s));
+    if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, s, 0, -1, 0, c->c16))) return rc;
     if (ev) HIP_TRY(hipEventRecord(ev[2], s));
     uint16_t hdr[PICSONG_HDR_SHORTS];
     if (iter == 0) picsong_header_pack(&c->p, hdr);
