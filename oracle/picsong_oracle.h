@@ -67,6 +67,10 @@ typedef struct po_header {
 
 /* ---- threading of the CPU-baseline leg (OpenMP over codeblocks / DWT rows+columns); default 1 */
 void po_set_threads(int n);
+/* statistics of the encoder's lock-step scan since the last reset: call sites with a coding lane, coding lanes, sites
+ * that start a codeword (tools/lockstep_stats.py) */
+void po_stats_reset(void);
+void po_stats_get(unsigned long long *out3);
 int  po_get_threads(void);
 int  po_max_threads(void);
 
