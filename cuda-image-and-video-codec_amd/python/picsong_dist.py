@@ -16,6 +16,9 @@ import torch
 import torch.distributed as dist
 
 
+GATHER_CHUNK_FRAMES = 64       # gather_step: frames per grouped batch of point-to-point operations
+
+
 def shard_frames(n_frames, rank, world):
     """Frame indices owned by `rank` (round-robin, f mod N)."""
     return list(range(rank, n_frames, world))
@@ -81,9 +84,14 @@ def gather_step(streams, rank, world, device, recv_bufs=None, group=None, rotate
     lens = torch.zeros(world * n, dtype=torch.int32, device=device)
     dist.all_gather_into_tensor(lens, mine, group=group)
     lens = lens.view(world, n).tolist()
-    ops, out = [], None
+    # The point-to-point operations go out in groups of at most `chunk` frames (every rank cuts its step at the same
+    # frame indices, so the sends and receives of a group match): a step of the bench is 288 frames, and one
+    # batch_isend_irecv of several hundred operations per peer is more than a grouped launch needs to be.
+    chunk = GATHER_CHUNK_FRAMES
+    out = None
     if rotate:
         out = [[None] * n for _ in range(world)]
+        bufs, offs = {}, {}
         for r in range(world):                               # what lands here: frames rank, rank + world, ... of every rank
             if r == rank:
                 for f in range(rank, n, world):
@@ -92,37 +100,56 @@ def gather_step(streams, rank, world, device, recv_bufs=None, group=None, rotate
             # (every received stream starts on a 16-byte boundary of its buffer: RCCL's copies vectorise)
             tot = sum((lens[r][f] + 7) & ~7 for f in range(rank, n, world))
             b = r if r < rank else r - 1
-            buf = recv_bufs[b][:tot] if recv_bufs is not None else torch.empty(tot, dtype=torch.int16, device=device)
-            o = 0
-            for f in range(rank, n, world):
-                v = buf[o:o + lens[r][f]]
-                o += (lens[r][f] + 7) & ~7
-                out[r][f] = v
-                if lens[r][f]:
-                    ops.append(dist.P2POp(dist.irecv, v, r, group))
-        for f, t in enumerate(streams):                      # what leaves: in frame order per destination, as it is received
-            if f % world != rank and t.numel():
-                ops.append(dist.P2POp(dist.isend, t, f % world, group))
-    elif rank == 0:
+            bufs[r] = recv_bufs[b][:tot] if recv_bufs is not None else torch.empty(tot, dtype=torch.int16, device=device)
+            offs[r] = 0
+        for c0 in range(0, n, chunk):
+            ops = []
+            for r in range(world):
+                if r == rank:
+                    continue
+                for f in range(c0, min(c0 + chunk, n)):
+                    if f % world != rank:
+                        continue
+                    v = bufs[r][offs[r]:offs[r] + lens[r][f]]
+                    offs[r] += (lens[r][f] + 7) & ~7
+                    out[r][f] = v
+                    if lens[r][f]:
+                        ops.append(dist.P2POp(dist.irecv, v, r, group))
+            for f in range(c0, min(c0 + chunk, n)):          # what leaves: in frame order per destination, as it is received
+                t = streams[f]
+                if f % world != rank and t.numel():
+                    ops.append(dist.P2POp(dist.isend, t, f % world, group))
+            if ops:
+                for q in dist.batch_isend_irecv(ops):
+                    q.wait()
+        return out
+    views = None
+    if rank == 0:
         out = [list(streams)]
+        views = []
         for r in range(1, world):
             tot = sum(lens[r])
             buf = recv_bufs[r - 1][:tot] if recv_bufs is not None else torch.empty(tot, dtype=torch.int16, device=device)
-            views, o = [], 0
+            vr, o = [], 0
             for ln in lens[r]:
-                v = buf[o:o + ln]
+                vr.append(buf[o:o + ln])
                 o += ln
-                views.append(v)
-                if ln:
-                    ops.append(dist.P2POp(dist.irecv, v, r, group))
-            out.append(views)
-    else:
-        for t in streams:
-            if t.numel():
-                ops.append(dist.P2POp(dist.isend, t, 0, group))
-    if ops:
-        for q in dist.batch_isend_irecv(ops):
-            q.wait()
+            out.append(vr)
+            views.append(vr)
+    for c0 in range(0, n, chunk):
+        ops = []
+        if rank == 0:
+            for r in range(1, world):
+                for f in range(c0, min(c0 + chunk, n)):
+                    if lens[r][f]:
+                        ops.append(dist.P2POp(dist.irecv, views[r - 1][f], r, group))
+        else:
+            for f in range(c0, min(c0 + chunk, n)):
+                if streams[f].numel():
+                    ops.append(dist.P2POp(dist.isend, streams[f], 0, group))
+        if ops:
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
     return out
 
 

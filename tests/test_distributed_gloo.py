@@ -90,10 +90,11 @@ def test_frame_sharding_gather_matches_single_process(oracle, tmp_path, world, p
         assert np.array_equal(oracle.decode_frame(ref[f], W, H, WL, False, 1.0, lut), oracle.gen_frame(W, H, f))
 
 
-def _step_worker(rank, world, port, outdir):
+def _step_worker(rank, world, port, outdir, chunk=64):
     """One bucketed exchange (picsong_dist.gather_step): every rank's step of streams, ragged lengths and an empty one."""
     sys.path.insert(0, os.path.join(ROOT, "cuda-image-and-video-codec_amd", "python"))
     import picsong_dist as pd
+    pd.GATHER_CHUNK_FRAMES = chunk                           # (2: the step's operations go out in three grouped batches)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -119,12 +120,12 @@ def _step_worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_gather_step_moves_a_whole_step_in_one_exchange(tmp_path, world):
-    """gather_step: one all-gather of [world, n] lengths + one grouped batch of per-frame messages; rank 0 gets every
-    rank's per-frame views in rank and frame order (with and without preallocated receive buffers)."""
+@pytest.mark.parametrize("world,chunk", [(2, 64), (3, 64), (3, 2)])
+def test_gather_step_moves_a_whole_step_in_one_exchange(tmp_path, world, chunk):
+    """gather_step: one all-gather of [world, n] lengths + grouped batches of per-frame messages (`chunk` frames a
+    batch); rank 0 gets every rank's per-frame views in rank and frame order (with and without preallocated buffers)."""
     port = _free_port()
-    mp.spawn(_step_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_step_worker, args=(world, port, str(tmp_path), chunk), nprocs=world, join=True)
     sent = np.concatenate([np.load(tmp_path / f"sent_{r}.npy") for r in range(world)])
     lens = np.stack([np.load(tmp_path / f"sentlens_{r}.npy") for r in range(world)])
     for u in (0, 1):
@@ -132,10 +133,11 @@ def test_gather_step_moves_a_whole_step_in_one_exchange(tmp_path, world):
         assert np.array_equal(np.load(tmp_path / f"lens_{u}.npy"), lens)
 
 
-def _rotate_worker(rank, world, port, outdir):
+def _rotate_worker(rank, world, port, outdir, chunk=64):
     """picsong_dist.gather_step(rotate=True): frame f of every rank's step lands on rank f mod world."""
     sys.path.insert(0, os.path.join(ROOT, "cuda-image-and-video-codec_amd", "python"))
     import picsong_dist as pd
+    pd.GATHER_CHUNK_FRAMES = chunk
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -162,11 +164,12 @@ def _rotate_worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_gather_step_with_the_writer_role_rotating(tmp_path, world):
-    """Every (rank, frame) stream arrives, whole, at rank frame mod world and nowhere else (both buffer forms)."""
+@pytest.mark.parametrize("world,chunk", [(2, 64), (3, 64), (3, 3), (2, 1)])
+def test_gather_step_with_the_writer_role_rotating(tmp_path, world, chunk):
+    """Every (rank, frame) stream arrives, whole, at rank frame mod world and nowhere else (both buffer forms; the
+    step's operations in one grouped batch or cut into several at the same frame indices on every rank)."""
     port = _free_port()
-    mp.spawn(_rotate_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_rotate_worker, args=(world, port, str(tmp_path), chunk), nprocs=world, join=True)
     for u in (0, 1):
         for r in range(world):
             for f in range(7):
