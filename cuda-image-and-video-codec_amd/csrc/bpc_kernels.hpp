@@ -253,7 +253,8 @@ __device__ __forceinline__ void dec_ring_fill(const int32_t *cwarr, uint16_t *ri
 // length; what lies beyond the length is never used)
 __device__ __forceinline__ void dec_ring_init(Coder &c, const int32_t *cwarr)
 {
-#pragma unroll 1
+    // (unrolled: the sixteen loads go out together, not as eight round trips one after the other)
+#pragma unroll
     for (uint32_t f = 0; f < (uint32_t)kDecRing; f += 64u) dec_ring_fill(cwarr, c.ring, f, c.t);
     c.next_lo = c.next_hi = (uint32_t)kDecRing * kDecCntUnit;
     c.pend = 0u;
@@ -1022,6 +1023,11 @@ __device__ __forceinline__ void bit_transpose_8x8x4(uint32_t (&x)[8])
 // scratch as they come out ([plane][L rows 0-31, L rows 32-63, R rows 0-31, R rows 32-63][lane]: all eight planes of
 // the pass, whatever the codeblock's MSB turns out to be -- holding them back until it is known costs 32 registers
 // the kernel does not have); pass 0 also gathers the OR of the magnitudes and the sign masks.
+// (The OR of the magnitudes and the sign masks are gathered in EVERY pass -- the second pass, which only waves with a
+// codeblock of MSB >= 8 run, finds the same values again -- because `if (pass == 0)` inside the unrolled rows was a branch
+// after every load: the compiler does not unswitch the passes' loop, every load was waited for before the next one went
+// out, and the prologue of a lone frame was 64 round trips to the memory side one after the other.  As a template
+// parameter instead the six inlined variants cost the whole kernel its register allocation: 620 bytes of scratch.)
 template <int MODE>
 __device__ __forceinline__ void enc_transpose_pass(const BpcArgs &a, int pass, uint32_t cbyte, uint32_t rstride,
                                                    uint32_t *pscr, uint32_t &ormag, U64 &sgL, U64 &sgR)
@@ -1041,12 +1047,10 @@ __device__ __forceinline__ void enc_transpose_pass(const BpcArgs &a, int pass, u
                 int32_t v0, v1;
                 load_row_raw<MODE>(a, roff + (uint32_t)(8 * b) * rstride, v0, v1);
                 m0[b] = (uint32_t)(v0 < 0 ? -v0 : v0); m1[b] = (uint32_t)(v1 < 0 ? -v1 : v1);
-                if (pass == 0) {
-                    ormag |= m0[b] | m1[b];
-                    // acc = (acc << 1) | sign: one funnel shift; rows 8 b + 7 .. 8 b in turn leave row 8 b + j at bit j
-                    sa0[b] = __builtin_amdgcn_alignbit(sa0[b], (uint32_t)v0, 31u);
-                    sa1[b] = __builtin_amdgcn_alignbit(sa1[b], (uint32_t)v1, 31u);
-                }
+                ormag |= m0[b] | m1[b];
+                // acc = (acc << 1) | sign: one funnel shift; rows 8 b + 7 .. 8 b in turn leave row 8 b + j at bit j
+                sa0[b] = __builtin_amdgcn_alignbit(sa0[b], (uint32_t)v0, 31u);
+                sa1[b] = __builtin_amdgcn_alignbit(sa1[b], (uint32_t)v1, 31u);
             }
             roff -= rstride;
             B0[j] = __builtin_amdgcn_perm(m0[1], m0[0], sel_lo) | __builtin_amdgcn_perm(m0[3], m0[2], sel_hi);
@@ -1055,7 +1059,7 @@ __device__ __forceinline__ void enc_transpose_pass(const BpcArgs &a, int pass, u
             // and the scheduler would otherwise hoist every load to the top and spill
             if ((j & 1) == 0) sched_fence();
         }
-        if (pass == 0) {
+        {
             const uint32_t s0 = sa0[0] | (sa0[1] << 8) | (sa0[2] << 16) | (sa0[3] << 24);
             const uint32_t s1 = sa1[0] | (sa1[1] << 8) | (sa1[2] << 16) | (sa1[3] << 24);
             if (hw == 0) { sgL.lo = s0; sgR.lo = s1; } else { sgL.hi = s0; sgR.hi = s1; }

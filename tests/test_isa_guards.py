@@ -86,10 +86,24 @@ def test_lean_synthesis_kernels_do_not_spill(device_asm):
     assert seen >= 12
 
 
-def test_coder_kernels_keep_their_argument_struct_in_registers(device_asm):
-    """The coders' per-wave scratch is a few spilled dwords of the prologue / epilogue.  Indexing the by-value argument
-    struct with a run-time value (round 3: `a.lut_c[f]`) moves the whole struct to scratch memory and every use of an
-    argument in the plane loops becomes a scratch load -- 15 % of the encoder's rate, with every test still green."""
+def _kernel_body(asm, key):
+    start = next(i for i, ln in enumerate(asm) if re.match(r"^_ZN7picsong\S*" + key + r"\S*:", ln))
+    end = next(i for i in range(start, len(asm)) if "s_endpgm" in asm[i])
+    return asm[start:end]
+
+
+def test_coder_kernels_keep_their_plane_loops_free_of_scratch(device_asm):
+    """The coders' scratch is a few spilled dwords of their prologues / epilogues, once per wave.  Indexing the by-value
+    argument struct with a run-time value (round 3: `a.lut_c[f]`) moves the whole struct to scratch memory and every use
+    of an argument in the plane loops becomes a scratch load -- 15 % of the encoder's rate, with every test still green.
+    So: no more than a handful of scratch instructions from the first interval update (v_mul_u32_u24) on, and a bounded
+    frame."""
+    for key, first, most, frame in (("17bpc_encode_kernelILb0E", "v_mul_u32_u24", 8, 320),
+                                    ("17bpc_decode_kernelILb0ELi8", "v_bcnt_u32_b32", 48, 192)):
+        body = _kernel_body(device_asm, key)
+        i0 = next(i for i, ln in enumerate(body) if first in ln)
+        tail = [ln for ln in body[i0:] if re.match(r"^\s*scratch_", ln)]
+        assert len(tail) <= most, f"{key}: {len(tail)} scratch instructions after the first '{first}'"
     name, sizes = None, {}
     for line in device_asm:
         m = re.match(r"^\s*\.amdhsa_kernel (\S+)", line)
@@ -100,6 +114,4 @@ def test_coder_kernels_keep_their_argument_struct_in_registers(device_asm):
             sizes[name] = int(m.group(1))
     enc = [v for k, v in sizes.items() if "bpc_encode_kernelILb0E" in k]
     dec = [v for k, v in sizes.items() if "bpc_decode_kernelILb0ELi8" in k]
-    assert enc and dec
-    assert enc[0] <= 128, f"bpc_encode_kernel<false> uses {enc[0]} bytes of scratch"
-    assert dec[0] <= 192, f"bpc_decode_kernel<false, 8> uses {dec[0]} bytes of scratch"
+    assert enc and dec and enc[0] <= 320 and dec[0] <= 192, (enc, dec)
