@@ -67,7 +67,17 @@ __global__ __launch_bounds__(256) void pack_kernel(const int32_t *staging, const
     const int32_t *st = staging + (size_t)cb * 4096u;
     const int len = sizes[cb];
     uint16_t *dst = out + 9 + 2 * (size_t)n + (size_t)offsets[cb];
-    for (int j = 1 + tid; j < len; j += 256) dst[j - 1] = (uint16_t)st[j];
+    // a codeblock is at most 4096 words: 16 a thread, in two groups of eight whose loads all go out before the first
+    // store (one load, one wait, one store per trip left every wave parked on a round trip per element)
+#pragma unroll
+    for (int k = 0; k < 16; k += 8) {
+        if (1 + 256 * k >= len) break;                      // (uniform: the whole workgroup is done)
+        int32_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int j = 1 + tid + 256 * (k + q); v[q] = j < len ? st[j] : 0; }
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int j = 1 + tid + 256 * (k + q); if (j < len) dst[j - 1] = (uint16_t)v[q]; }
+    }
     if (tid == 0) {
         out[9 + 2 * cb] = (uint16_t)st[0];
         out[9 + 2 * cb + 1] = (uint16_t)len;
@@ -110,7 +120,15 @@ __global__ __launch_bounds__(256) void unpack_kernel(const uint16_t *stream, con
     int32_t *st = staging + (size_t)cb * 4096u;
     const int len = sizes[cb];
     const uint16_t *src = stream + 9 + 2 * (size_t)n + (size_t)offsets[cb];
-    for (int j = 1 + tid; j < len; j += 256) st[j] = (int32_t)src[j - 1];
+#pragma unroll
+    for (int k = 0; k < 16; k += 8) {                       // (as pack_kernel: eight loads in flight a thread)
+        if (1 + 256 * k >= len) break;
+        uint16_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int j = 1 + tid + 256 * (k + q); v[q] = j < len ? src[j - 1] : (uint16_t)0; }
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int j = 1 + tid + 256 * (k + q); if (j < len) st[j] = (int32_t)v[q]; }
+    }
     if (tid == 0) st[0] = (int32_t)stream[9 + 2 * cb];
 }
 
