@@ -559,6 +559,7 @@ struct EncCoder {
     uint32_t cnt_lo, cnt_hi;
     uint64_t emptym;            // ballot(S == 0) as of the end of the previous call site
     uint32_t halfoff4;          // byte offset of slot 0 of the lane's codeblock: half * 16384 + 4
+    uint32_t lim;               // LDS form: halfoff4 + 4 * 4094, the byte offset of the codeblock's last slot
     uint32_t pone;              // 1 << prec: the "probability" that leaves an idle lane's interval alone
     char *stw;                  // staging of the wave's first codeblock (wave-uniform)
 };
@@ -577,9 +578,12 @@ __device__ __forceinline__ void enc_reserve(EncCoder &c, uint64_t m, uint32_t up
     if (__builtin_amdgcn_inverse_ballot_w64(m)) {
         // the codeword this lane has just finished goes to the slot it reserved last time (slot starts at
         // -1: word 0 of the staging, see above)
-        const uint32_t sl = (int32_t)c.slot > 4094 ? 4094u : c.slot;
-        *reinterpret_cast<int32_t *>(c.stw + ((sl << 2) + c.halfoff4)) = (int32_t)c.L;
-        c.slot = __hip_atomic_fetch_add(c.ldscnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        // (the codeblock's LDS counter counts BYTES of the wave's staging from halfoff4 on, 4 a codeword: what a lane
+        // gets back is its slot's byte offset, and the guard against a 4096th codeword is one v_min with the lane's
+        // `lim` -- no shift-and-add, no literal)
+        const uint32_t sl = c.slot < c.lim ? c.slot : c.lim;
+        *reinterpret_cast<int32_t *>(c.stw + sl) = (int32_t)c.L;
+        c.slot = __hip_atomic_fetch_add(c.ldscnt, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         c.L = 0u; c.S = 0xFFFFu;
     }
 #else
@@ -1087,7 +1091,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
     __shared__ uint32_t lds_cnt[2 * (BULK ? 1 : kBpcEncWgWaves)];      // codeword counters of the workgroup's codeblocks
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
-    if (t == 0u) lds_cnt[(threadIdx.x >> 6) * 2u + half] = 0u;        // (the table copy below ends with a barrier)
+    if (t == 0u) lds_cnt[(threadIdx.x >> 6) * 2u + half] = half * 16384u + 4u;   // bytes of the staging (enc_reserve); (the table copy below ends with a barrier)
     const int gwave = BULK ? (int)blockIdx.x
                            : (int)blockIdx.x * kBpcEncWgWaves + (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int wave = gwave;                                       // wave within its frame
@@ -1177,9 +1181,9 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     EncCoder c;
     c.L = 0u; c.S = 0u; c.off = half * 16384u;                // a first reservation "stores" L = 0 to word 0 (see enc_reserve)
     c.cnt_lo = 0u; c.cnt_hi = 0u; c.emptym = ~0ull;
-    c.slot = 0xFFFFFFFFu;                                  // -1: (slot << 2) + halfoff4 = word 0 of the lane's codeblock
+    c.slot = half * 16384u;                                // word 0 of the lane's codeblock (LDS form: byte offsets)
     c.ldscnt = &lds_cnt[(threadIdx.x >> 6) * 2u + half];
-    c.halfoff4 = half * 16384u + 4u; c.pone = 1u << prec;
+    c.halfoff4 = half * 16384u + 4u; c.lim = c.halfoff4 + 4u * 4094u; c.pone = 1u << prec;
     c.stw = reinterpret_cast<char *>(stw);
     U64 AL = { 0u, 0u }, AR = { 0u, 0u };                 // significant before the current plane
     U64 BLn, BRn;
@@ -1197,7 +1201,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
             // plane or two of a dozen; their waves were the tail of the whole launch.)
 #if PS_ENC_LDS
             wave_lds_done();
-            const uint32_t used = *c.ldscnt;
+            const uint32_t used = (*c.ldscnt - c.halfoff4) >> 2;
 #else
             const uint32_t used = half ? c.cnt_hi : c.cnt_lo;
 #endif
@@ -1322,11 +1326,11 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     // flush (Encode BPCEngine.cu:1719) + sizeArray (:2010) + MSB slot (:1998)
 #if PS_ENC_LDS
     if (coded) {
-        const uint32_t sl = (int32_t)c.slot > 4094 ? 4094u : c.slot;
-        *reinterpret_cast<int32_t *>(c.stw + ((sl << 2) + c.halfoff4)) = (int32_t)c.L;
+        const uint32_t sl = c.slot < c.lim ? c.slot : c.lim;
+        *reinterpret_cast<int32_t *>(c.stw + sl) = (int32_t)c.L;
     }
     wave_lds_done();                                       // every lane's last atomic has landed
-    const uint32_t cw_count = *c.ldscnt;
+    const uint32_t cw_count = (*c.ldscnt - c.halfoff4) >> 2;
     const uint32_t size = (cw_count > 4095u ? 4095u : cw_count) + 1u;
 #else
     if (coded) *reinterpret_cast<int32_t *>(c.stw + c.off) = (int32_t)c.L;
@@ -2122,9 +2126,11 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
     } else {
         c.L = 0u; c.S = 0u; c.off = half * 16384u;
         c.cnt_lo = 0u; c.cnt_hi = 0u; c.emptym = ~0ull;
-        c.slot = 0xFFFFFFFFu;
+        c.slot = half * 16384u;
         c.ldscnt = &lds_cnt[(threadIdx.x >> 6) * 2u + half];
-        c.halfoff4 = half * 16384u + 4u; c.pone = 1u << prec;
+        c.halfoff4 = half * 16384u + 4u; c.lim = c.halfoff4 + 4u * 4094u; c.pone = 1u << prec;
+        if (t == 0u) *c.ldscnt = c.halfoff4;               // (an encoder's counter: bytes of the staging, enc_reserve)
+        wave_lds_done();
         c.stw = reinterpret_cast<char *>(stw);
     }
 
@@ -2234,11 +2240,11 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
         // flush + sizeArray + MSB word + expansion fallback, as bpc_encode_kernel
 #if PS_ENC_LDS
         if (coded) {
-            const uint32_t sl = (int32_t)c.slot > 4094 ? 4094u : c.slot;
-            *reinterpret_cast<int32_t *>(c.stw + ((sl << 2) + c.halfoff4)) = (int32_t)c.L;
+            const uint32_t sl = c.slot < c.lim ? c.slot : c.lim;
+            *reinterpret_cast<int32_t *>(c.stw + sl) = (int32_t)c.L;
         }
         wave_lds_done();
-        const uint32_t cw_count = *c.ldscnt;
+        const uint32_t cw_count = (*c.ldscnt - c.halfoff4) >> 2;
         const uint32_t size = (cw_count > 4095u ? 4095u : cw_count) + 1u;
 #else
         if (coded) *reinterpret_cast<int32_t *>(c.stw + c.off) = (int32_t)c.L;
