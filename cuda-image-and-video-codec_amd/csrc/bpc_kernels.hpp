@@ -560,6 +560,7 @@ struct EncCoder {
     uint64_t emptym;            // ballot(S == 0) as of the end of the previous call site
     uint32_t halfoff4;          // byte offset of slot 0 of the lane's codeblock: half * 16384 + 4
     uint32_t lim;               // LDS form: halfoff4 + 4 * 4094, the byte offset of the codeblock's last slot
+    uint32_t cntaddr, four;     // LDS form: the counter's LDS address; the constant 4 in a register (ds_add's operand)
     uint32_t pone;              // 1 << prec: the "probability" that leaves an idle lane's interval alone
     char *stw;                  // staging of the wave's first codeblock (wave-uniform)
 };
@@ -575,17 +576,25 @@ __device__ __forceinline__ void enc_reserve(EncCoder &c, uint64_t m, uint32_t up
 {
 #if PS_ENC_LDS
     (void)upper_mask;
-    if (__builtin_amdgcn_inverse_ballot_w64(m)) {
-        // the codeword this lane has just finished goes to the slot it reserved last time (slot starts at
-        // -1: word 0 of the staging, see above)
-        // (the codeblock's LDS counter counts BYTES of the wave's staging from halfoff4 on, 4 a codeword: what a lane
-        // gets back is its slot's byte offset, and the guard against a 4096th codeword is one v_min with the lane's
-        // `lim` -- no shift-and-add, no literal)
-        const uint32_t sl = c.slot < c.lim ? c.slot : c.lim;
-        *reinterpret_cast<int32_t *>(c.stw + sl) = (int32_t)c.L;
-        c.slot = __hip_atomic_fetch_add(c.ldscnt, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        c.L = 0u; c.S = 0xFFFFu;
-    }
+    // The codeword a lane of m has just finished goes to the slot it reserved last time (slot starts at word 0 of the
+    // staging, see above), and the lane takes its codeblock's next slot.  The codeblock's LDS counter counts BYTES of
+    // the wave's staging from halfoff4 on, 4 a codeword: what a lane gets back is its slot's byte offset, and the guard
+    // against a 4096th codeword is one v_min with the lane's `lim` -- no shift-and-add, no literal.  Written as the
+    // instructions themselves: exec is all ones at a call site (enc_update), so it is set, not saved and restored, and
+    // the compiler's skip of an empty region -- m != 0 here -- does not exist.  (The counter's return is waited for at
+    // the NEXT reservation; the kernel's epilogue waits before its own use of c.slot.)
+    uint32_t sl;
+    asm volatile("s_mov_b64 exec, %[m]\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "v_min_u32 %[sl], %[slot], %[lim]\n\t"
+                 "global_store_dword %[sl], %[L], %[stw]\n\t"
+                 "ds_add_rtn_u32 %[slot], %[cnt], %[four]\n\t"
+                 "v_mov_b32 %[S], 0xffff\n\t"
+                 "v_mov_b32 %[L], 0\n\t"
+                 "s_mov_b64 exec, -1"
+                 : [slot] "+v"(c.slot), [L] "+v"(c.L), [S] "+v"(c.S), [sl] "=&v"(sl)
+                 : [m] "s"(m), [lim] "v"(c.lim), [stw] "s"(c.stw), [cnt] "v"(c.cntaddr), [four] "v"(c.four)
+                 : "memory");
 #else
     const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
     const uint32_t nlo = (uint32_t)__builtin_popcount(mlo), nhi = (uint32_t)__builtin_popcount(mhi);
@@ -1184,6 +1193,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     c.slot = half * 16384u;                                // word 0 of the lane's codeblock (LDS form: byte offsets)
     c.ldscnt = &lds_cnt[(threadIdx.x >> 6) * 2u + half];
     c.halfoff4 = half * 16384u + 4u; c.lim = c.halfoff4 + 4u * 4094u; c.pone = 1u << prec;
+    c.cntaddr = lds_addr_of(c.ldscnt); c.four = 4u;
     c.stw = reinterpret_cast<char *>(stw);
     U64 AL = { 0u, 0u }, AR = { 0u, 0u };                 // significant before the current plane
     U64 BLn, BRn;
@@ -1325,6 +1335,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
 
     // flush (Encode BPCEngine.cu:1719) + sizeArray (:2010) + MSB slot (:1998)
 #if PS_ENC_LDS
+    wave_lds_done();                                       // (c.slot: the last reservation's return, enc_reserve)
     if (coded) {
         const uint32_t sl = c.slot < c.lim ? c.slot : c.lim;
         *reinterpret_cast<int32_t *>(c.stw + sl) = (int32_t)c.L;
@@ -2129,6 +2140,7 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
         c.slot = half * 16384u;
         c.ldscnt = &lds_cnt[(threadIdx.x >> 6) * 2u + half];
         c.halfoff4 = half * 16384u + 4u; c.lim = c.halfoff4 + 4u * 4094u; c.pone = 1u << prec;
+    c.cntaddr = lds_addr_of(c.ldscnt); c.four = 4u;
         if (t == 0u) *c.ldscnt = c.halfoff4;               // (an encoder's counter: bytes of the staging, enc_reserve)
         wave_lds_done();
         c.stw = reinterpret_cast<char *>(stw);
@@ -2239,6 +2251,7 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
     } else {
         // flush + sizeArray + MSB word + expansion fallback, as bpc_encode_kernel
 #if PS_ENC_LDS
+        wave_lds_done();
         if (coded) {
             const uint32_t sl = c.slot < c.lim ? c.slot : c.lim;
             *reinterpret_cast<int32_t *>(c.stw + sl) = (int32_t)c.L;
