@@ -75,6 +75,18 @@ struct BpcArgs {
     // codes with table lut_c[f] (same geometry); waves_per_frame is then a whole number of workgroups, a workgroup's
     // LDS copy of the table being its frame's.  lut_c[0] = nullptr: every frame uses `lut`
     const int32_t *lut_c[3];
+    // decoder, frame paths (k = 0, -cp 2): the codewords are read from the packed stream itself -- no unpack launch, no
+    // staging.  cw16 = the frame's stream (9 header shorts, nCB x (MSB, length), the codewords: BitStreamBuilder.cu:106-137),
+    // cw16_offsets[cb] = the scan of the lengths and *cw16_total the stream's length as they give it (scan_stream_kernel):
+    // a load stays inside those shorts -- the ring reads ahead of a codeblock's length, and the caller's buffer may end
+    // with the stream -- and inside cw16_max, a worst-case stream, whatever damaged lengths claim.  Frame f of a batched
+    // launch reads cw16 + f * cw16_stride shorts, cw16_offsets + f * nCB, cw16_total + f.  nullptr: the 32-bit staging
+    // (picsong_bpc_decode).
+    const uint16_t *cw16;
+    const int32_t *cw16_offsets;
+    const int32_t *cw16_total;
+    unsigned long long cw16_stride;
+    uint32_t cw16_max;
 };
 
 // ---- cross-lane helpers ---------------------------------------------------------------------
@@ -182,6 +194,12 @@ struct Coder {
     uint32_t *ldscnt;          // LDS form of the reservation: the lane's codeblock's codeword counter
     uint32_t ringaddr;         // LDS form: LDS byte address of the lane's ring (1 KB aligned)
     uint32_t pend;             // LDS form: the codeblock's counter as read at the start of the previous row (dec_ring_row)
+    // where the ring is filled from (dec_ring_fill): element srcoff + k of srcbase is the lane's codeblock's codeword k
+    // -- 32-bit staging words (picsong_bpc_decode: stage[1 + k]) or, src16, the 16-bit words of the packed stream
+    // itself (the frame paths: no unpack launch, no staging); srclim = the last element a load may start at.
+    // srcbase, srclim and src16 are wave-uniform.
+    const void *srcbase;
+    uint32_t srcoff, srclim, src16;
 };
 
 // LDS operations of the wave's other lanes have completed
@@ -242,34 +260,48 @@ constexpr uint32_t kDecCntUnit = 2u;
 #else
 constexpr uint32_t kDecCntUnit = 1u;
 #endif
-__device__ __forceinline__ void dec_ring_fill(const int32_t *cwarr, uint16_t *ring, uint32_t first, uint32_t t)
-{   // entries first .. first + 63 of the lane's codeblock (cwarr[k] = codeword k; k <= 4094 exists)
-    const uint32_t e0 = first + t, e1 = first + 32u + t;
-    const int32_t v0 = cwarr[e0 > 4094u ? 4094u : e0], v1 = cwarr[e1 > 4094u ? 4094u : e1];
-    ring[e0 & (kDecRing - 1)] = (uint16_t)v0;
-    ring[e1 & (kDecRing - 1)] = (uint16_t)v1;
+__device__ __forceinline__ void dec_ring_fill(const Coder &c, uint32_t first)
+{   // entries first .. first + 63 of the lane's codeblock.  What lies beyond the codeblock's length is never used, so a
+    // load is only kept inside the buffer: the staging's last word, the stream's last pair of shorts.
+    if (c.src16) {
+        // the stream's own 16-bit words: one dword a lane, entries first + 2 t and first + 2 t + 1, copied as they lie
+        // (a dword load from an address that is a multiple of 2, an aligned dword into the ring)
+        const uint32_t e = first + 2u * c.t;
+        uint32_t idx = c.srcoff + e;
+        idx = idx < c.srclim ? idx : c.srclim;
+        uint32_t v;
+        __builtin_memcpy(&v, static_cast<const uint16_t *>(c.srcbase) + idx, 4);
+        *reinterpret_cast<uint32_t *>(c.ring + (e & (kDecRing - 1))) = v;
+    } else {
+        const uint32_t e0 = first + c.t, e1 = first + 32u + c.t;
+        uint32_t i0 = c.srcoff + e0, i1 = c.srcoff + e1;
+        i0 = i0 < c.srclim ? i0 : c.srclim; i1 = i1 < c.srclim ? i1 : c.srclim;
+        const int32_t *const w = static_cast<const int32_t *>(c.srcbase);
+        const int32_t v0 = w[i0], v1 = w[i1];
+        c.ring[e0 & (kDecRing - 1)] = (uint16_t)v0;
+        c.ring[e1 & (kDecRing - 1)] = (uint16_t)v1;
+    }
 }
-// codewords 0 .. 511 of both codeblocks (reads stay inside the codeblock's 4096 staging words whatever its
-// length; what lies beyond the length is never used)
-__device__ __forceinline__ void dec_ring_init(Coder &c, const int32_t *cwarr)
+// codewords 0 .. 511 of both codeblocks
+__device__ __forceinline__ void dec_ring_init(Coder &c)
 {
-    // (unrolled: the sixteen loads go out together, not as eight round trips one after the other)
+    // (unrolled: the loads go out together, not as eight round trips one after the other)
 #pragma unroll
-    for (uint32_t f = 0; f < (uint32_t)kDecRing; f += 64u) dec_ring_fill(cwarr, c.ring, f, c.t);
+    for (uint32_t f = 0; f < (uint32_t)kDecRing; f += 64u) dec_ring_fill(c, f);
     c.next_lo = c.next_hi = (uint32_t)kDecRing * kDecCntUnit;
     c.pend = 0u;
 }
 // the window of both codeblocks at least `ahead` codewords ahead of the counters cnt_lo / cnt_hi (codewords; exact or
 // older values).  A fill overwrites entries next - 512 .. next - 449, all consumed: it happens only while
 // next - cnt < ahead <= 256.
-__device__ __forceinline__ void dec_ring_refill(Coder &c, const int32_t *cwarr, uint32_t upper_mask, uint32_t cnt_lo,
-                                                uint32_t cnt_hi, uint32_t ahead)
+__device__ __forceinline__ void dec_ring_refill(Coder &c, uint32_t upper_mask, uint32_t cnt_lo, uint32_t cnt_hi,
+                                                uint32_t ahead)
 {
     bool lo = c.next_lo - cnt_lo * kDecCntUnit < ahead * kDecCntUnit, hi = c.next_hi - cnt_hi * kDecCntUnit < ahead * kDecCntUnit;     // wave-uniform
     while (lo || hi) {
         wave_lds_done();                                   // every lane has read the codewords of its earlier sites
         const uint32_t edge = (upper_mask ? c.next_hi : c.next_lo) / kDecCntUnit;
-        if (upper_mask ? hi : lo) dec_ring_fill(cwarr, c.ring, edge, c.t);
+        if (upper_mask ? hi : lo) dec_ring_fill(c, edge);
         wave_lds_done();                                   // (a later reservation of another lane reads them)
         if (lo) c.next_lo = __builtin_amdgcn_readfirstlane(c.next_lo + 64u * kDecCntUnit);
         if (hi) c.next_hi = __builtin_amdgcn_readfirstlane(c.next_hi + 64u * kDecCntUnit);
@@ -277,10 +309,10 @@ __device__ __forceinline__ void dec_ring_refill(Coder &c, const int32_t *cwarr, 
     }
 }
 // per call site (dec_site_m<true>: -k's row scan, -cp 3): the exact counters c.cnt_lo / c.cnt_hi
-__device__ __forceinline__ void dec_ring_keep(Coder &c, const int32_t *cwarr, uint32_t upper_mask)
+__device__ __forceinline__ void dec_ring_keep(Coder &c, uint32_t upper_mask)
 {
     const uint32_t a = c.next_lo - c.cnt_lo * kDecCntUnit, b = c.next_hi - c.cnt_hi * kDecCntUnit;
-    if ((a < b ? a : b) < kDecRingAhead * kDecCntUnit) dec_ring_refill(c, cwarr, upper_mask, c.cnt_lo, c.cnt_hi, kDecRingAhead);
+    if ((a < b ? a : b) < kDecRingAhead * kDecCntUnit) dec_ring_refill(c, upper_mask, c.cnt_lo, c.cnt_hi, kDecRingAhead);
 }
 // Once per ROW of call sites of the plane loops (a row reserves at most 4 x 32 slots of a codeblock: two columns, bit
 // and sign).  LDS form: the call sites keep no scalar counters at all (two popcounts and two additions of the scalar
@@ -288,16 +320,16 @@ __device__ __forceinline__ void dec_ring_keep(Coder &c, const int32_t *cwarr, ui
 // counters are read here instead, and used ONE ROW LATE -- the read of row r is consumed at row r + 1, so no wait
 // for the LDS sits in a row's path: with v the value read at the start of row r - 1, the counter at the end of row
 // r is at most v + 256, and the window is kept 256 codewords ahead of v.
-__device__ __forceinline__ void dec_ring_row(Coder &c, const int32_t *cwarr, uint32_t upper_mask)
+__device__ __forceinline__ void dec_ring_row(Coder &c, uint32_t upper_mask)
 {
 #if PS_ENC_LDS
     const uint32_t vlo = __builtin_amdgcn_readlane(c.pend, 0), vhi = __builtin_amdgcn_readlane(c.pend, 32);   // bytes
     const uint32_t a = c.next_lo - vlo, b = c.next_hi - vhi;
-    if ((a < b ? a : b) < kDecRingAheadRow * kDecCntUnit) dec_ring_refill(c, cwarr, upper_mask, vlo / kDecCntUnit, vhi / kDecCntUnit, kDecRingAheadRow);
+    if ((a < b ? a : b) < kDecRingAheadRow * kDecCntUnit) dec_ring_refill(c, upper_mask, vlo / kDecCntUnit, vhi / kDecCntUnit, kDecRingAheadRow);
     c.pend = __hip_atomic_load(c.ldscnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 #else
     const uint32_t a = c.next_lo - c.cnt_lo, b = c.next_hi - c.cnt_hi;
-    if ((a < b ? a : b) < kDecRingAheadRow) dec_ring_refill(c, cwarr, upper_mask, c.cnt_lo, c.cnt_hi, kDecRingAheadRow);
+    if ((a < b ? a : b) < kDecRingAheadRow) dec_ring_refill(c, upper_mask, c.cnt_lo, c.cnt_hi, kDecRingAheadRow);
 #endif
 }
 // the exact counters for the per-site form that follows the plane loops (-k's row scan)
@@ -560,7 +592,6 @@ struct EncCoder {
     uint64_t emptym;            // ballot(S == 0) as of the end of the previous call site
     uint32_t halfoff4;          // byte offset of slot 0 of the lane's codeblock: half * 16384 + 4
     uint32_t lim;               // LDS form: halfoff4 + 4 * 4094, the byte offset of the codeblock's last slot
-    uint32_t cntaddr, four;     // LDS form: the counter's LDS address; the constant 4 in a register (ds_add's operand)
     uint32_t pone;              // 1 << prec: the "probability" that leaves an idle lane's interval alone
     char *stw;                  // staging of the wave's first codeblock (wave-uniform)
 };
@@ -576,25 +607,23 @@ __device__ __forceinline__ void enc_reserve(EncCoder &c, uint64_t m, uint32_t up
 {
 #if PS_ENC_LDS
     (void)upper_mask;
-    // The codeword a lane of m has just finished goes to the slot it reserved last time (slot starts at word 0 of the
-    // staging, see above), and the lane takes its codeblock's next slot.  The codeblock's LDS counter counts BYTES of
-    // the wave's staging from halfoff4 on, 4 a codeword: what a lane gets back is its slot's byte offset, and the guard
-    // against a 4096th codeword is one v_min with the lane's `lim` -- no shift-and-add, no literal.  Written as the
-    // instructions themselves: exec is all ones at a call site (enc_update), so it is set, not saved and restored, and
-    // the compiler's skip of an empty region -- m != 0 here -- does not exist.  (The counter's return is waited for at
-    // the NEXT reservation; the kernel's epilogue waits before its own use of c.slot.)
-    uint32_t sl;
-    asm volatile("s_mov_b64 exec, %[m]\n\t"
-                 "s_waitcnt lgkmcnt(0)\n\t"
-                 "v_min_u32 %[sl], %[slot], %[lim]\n\t"
-                 "global_store_dword %[sl], %[L], %[stw]\n\t"
-                 "ds_add_rtn_u32 %[slot], %[cnt], %[four]\n\t"
-                 "v_mov_b32 %[S], 0xffff\n\t"
-                 "v_mov_b32 %[L], 0\n\t"
-                 "s_mov_b64 exec, -1"
-                 : [slot] "+v"(c.slot), [L] "+v"(c.L), [S] "+v"(c.S), [sl] "=&v"(sl)
-                 : [m] "s"(m), [lim] "v"(c.lim), [stw] "s"(c.stw), [cnt] "v"(c.cntaddr), [four] "v"(c.four)
-                 : "memory");
+    if (__builtin_amdgcn_inverse_ballot_w64(m)) {
+        // the codeword this lane has just finished goes to the slot it reserved last time (slot starts at
+        // -1: word 0 of the staging, see above)
+        // (the codeblock's LDS counter counts BYTES of the wave's staging from halfoff4 on, 4 a codeword: what a lane
+        // gets back is its slot's byte offset, and the guard against a 4096th codeword is one v_min with the lane's
+        // `lim` -- no shift-and-add, no literal)
+        // (Round 3 also wrote this region as its instructions -- exec set instead of saved and restored, no skip of an
+        // empty region: 0.4 % faster and WRONG.  The counter's return lands in c.slot some hundred cycles after the
+        // ds_add, a wait the compiler places before the next use only if it issued the ds_add itself; blind to it, it
+        // moved the epilogue's min(c.slot, lim) above the hand-written wait, and one codeblock in some ten thousand
+        // flushed its last codeword to a stale slot -- caught by the 16K frame's codestream against the oracle, by none
+        // of the smaller cases.  The atomic stays the compiler's.)
+        const uint32_t sl = c.slot < c.lim ? c.slot : c.lim;
+        *reinterpret_cast<int32_t *>(c.stw + sl) = (int32_t)c.L;
+        c.slot = __hip_atomic_fetch_add(c.ldscnt, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        c.L = 0u; c.S = 0xFFFFu;
+    }
 #else
     const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
     const uint32_t nlo = (uint32_t)__builtin_popcount(mlo), nhi = (uint32_t)__builtin_popcount(mhi);
@@ -1193,7 +1222,6 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     c.slot = half * 16384u;                                // word 0 of the lane's codeblock (LDS form: byte offsets)
     c.ldscnt = &lds_cnt[(threadIdx.x >> 6) * 2u + half];
     c.halfoff4 = half * 16384u + 4u; c.lim = c.halfoff4 + 4u * 4094u; c.pone = 1u << prec;
-    c.cntaddr = lds_addr_of(c.ldscnt); c.four = 4u;
     c.stw = reinterpret_cast<char *>(stw);
     U64 AL = { 0u, 0u }, AR = { 0u, 0u };                 // significant before the current plane
     U64 BLn, BRn;
@@ -1335,7 +1363,6 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
 
     // flush (Encode BPCEngine.cu:1719) + sizeArray (:2010) + MSB slot (:1998)
 #if PS_ENC_LDS
-    wave_lds_done();                                       // (c.slot: the last reservation's return, enc_reserve)
     if (coded) {
         const uint32_t sl = c.slot < c.lim ? c.slot : c.lim;
         *reinterpret_cast<int32_t *>(c.stw + sl) = (int32_t)c.L;
@@ -1442,7 +1469,8 @@ __device__ __forceinline__ uint64_t dec_site_m(Coder &c, bool on, uint64_t onm, 
         reserve_enc(c, on && empty, m, upper_mask);
         if (on && empty) c.L = c.ring[c.slot & (kDecRing - 1)];          // D = cw - 0
 #endif
-        if constexpr (KEEP) dec_ring_keep(c, stage, upper_mask);       // stage = the codeword array (staging + 1)
+        if constexpr (KEEP) dec_ring_keep(c, upper_mask);
+        (void)stage;                                          // (the codewords come from c.srcbase: dec_ring_fill)
     }
 #if defined(__AMDGCN__)
     // a0 = (S * p) >> prec;  D > a0 decodes a 1: S' = S - a0 - 1, D' = D - a0 - 1;  else S' = a0
@@ -1578,7 +1606,7 @@ __device__ __forceinline__ void dec_spp_block(Coder &c, uint32_t rows, uint32_t 
         const uint32_t j = (uint32_t)__builtin_ctz(rows);
         rows &= rows - 1u;
         const uint32_t sh = 2u * j;
-        dec_ring_row(c, cw, upper_mask);
+        dec_ring_row(c, upper_mask);
         // ---- all lanes: left column; neighbours = lane-1's right column | own right column
         const uint32_t xo = __builtin_amdgcn_alignbit(l1, l0, sh), xp = __builtin_amdgcn_alignbit(p1, p0, sh);
         const uint32_t xr = __builtin_amdgcn_alignbit(r1, r0, sh);
@@ -1656,14 +1684,28 @@ __device__ __forceinline__ uint32_t cform_signs(uint32_t a, uint32_t b, uint32_t
 template <int NP, int NA>
 __device__ __forceinline__ void write_rows(const uint32_t (&PL)[NA], const uint32_t (&PR)[NA],
                                            uint32_t sgL, uint32_t sgR, int row0, bool valid, int32_t sz,
-                                           const int32_t *stage, uint32_t t, int32_t *out, int AW)
+                                           const int32_t *stage, uint32_t t, int32_t *out, int AW,
+                                           const uint16_t *raw16 = nullptr, uint32_t rawoff = 0u, uint32_t rawlast = 0u,
+                                           int32_t word0 = 0)
 {
     if (!valid) return;
     if (sz == 4096) {                                       // raw codeblock (expansionFix): words, not planes
 #pragma unroll 1
         for (int ii = 0; ii < 32; ii++) {
             const int i = row0 + ii;
-            int2 w = *reinterpret_cast<const int2 *>(stage + t * 128u + 2u * (uint32_t)i);
+            int2 w;
+            if (raw16) {
+                // the packed stream: words 1 .. 4095 are the codeblock's 4095 shorts, word 0 sits in the MSB's place
+                // (pack_kernel: out[9 + 2 cb] = st[0])
+                // (raw16 + rawoff = the codeblock's first short; rawlast = the buffer's last short: lengths are clamped
+                // to 4096 and the buffer holds a worst-case stream, so the guard only ever acts on a buffer that is not)
+                const uint32_t k = t * 128u + 2u * (uint32_t)i;
+                const uint32_t i0 = rawoff + k - 1u, i1 = rawoff + k;
+                w.x = k == 0u ? word0 : (int32_t)raw16[i0 < rawlast ? i0 : rawlast];
+                w.y = (int32_t)raw16[i1 < rawlast ? i1 : rawlast];
+            } else {
+                w = *reinterpret_cast<const int2 *>(stage + t * 128u + 2u * (uint32_t)i);
+            }
             int32_t v0 = (int32_t)(((uint32_t)w.x & 0xFFFFFFu) >> 1); if (w.x & 1) v0 = -v0;
             int32_t v1 = (int32_t)(((uint32_t)w.y & 0xFFFFFFu) >> 1); if (w.y & 1) v1 = -v1;
             *reinterpret_cast<int2 *>(out + (size_t)i * (size_t)AW) = make_int2(v0, v1);
@@ -1710,12 +1752,14 @@ __device__ __forceinline__ void write_rows(const uint32_t (&PL)[NA], const uint3
 // NP = 16 (4 waves / SIMD) takes the rest; the host launches both, a wave of the other class returns
 // at once.
 constexpr int kDecSmallPlanes = 8;
-template <bool BULK, int NP>
+// S16 (k = 0 only): the frame paths' instantiation, codewords read from the packed stream (BpcArgs::cw16)
+template <bool BULK, int NP, bool S16 = false>
 __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcDecWgWaves,
                              !BULK ? PICSONG_BPC_DEC_WAVES8 : (NP == kDecSmallPlanes ? 5 : PICSONG_BPC_DEC_WAVES))
 void bpc_decode_kernel(BpcArgs a)
 {
     static_assert(NP == kDecSmallPlanes || NP == kMaxPlanes, "two classes");
+    static_assert(!(BULK && S16), "-k > 0 decodes from the staging");
     __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
     __shared__ uint8_t sign_tab[256];
     __shared__ __attribute__((aligned(1024))) uint16_t cw_ring[(BULK ? 1 : kBpcDecWgWaves) * 2 * kDecRing];
@@ -1733,6 +1777,7 @@ void bpc_decode_kernel(BpcArgs a)
             a.coeffs_out = (int32_t *)((char *)a.coeffs_out + (unsigned long long)f * a.coef_z);
             a.staging += (size_t)f * (size_t)a.AW * (size_t)a.AH;
             a.sizes += (size_t)f * (size_t)(a.nCB - a.cb_base);
+            if (S16) { a.cw16 += (size_t)f * (size_t)a.cw16_stride; a.cw16_offsets += (size_t)f * (size_t)a.nCB; a.cw16_total += f; }
             // (scalar selects: indexing the argument struct with f would move all of it to scratch memory)
             if (a.lut_c[0]) a.lut = f == 0 ? a.lut_c[0] : (f == 1 ? a.lut_c[1] : a.lut_c[2]);
         }
@@ -1741,8 +1786,10 @@ void bpc_decode_kernel(BpcArgs a)
     const bool valid = cb < a.nCB;
     const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
     const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
-    const int32_t *stage = a.staging + (size_t)(valid ? cb : a.cb_base) * 4096u;
-    const int32_t *cw = stage + 1;                          // codeword array: slot k lives at stage[1 + k]
+    constexpr bool s16 = S16;                               // the stream itself, not the staging
+    const int cbs = valid ? cb : a.cb_base;
+    const int32_t *stage = s16 ? nullptr : a.staging + (size_t)cbs * 4096u;   // (32-bit form) word 0 = the MSB, slot k = stage[1 + k]
+    const int32_t *cw = s16 ? nullptr : stage + 1;
     const uint32_t prec = (uint32_t)a.g.prec;
     const uint32_t upper_mask = opaque_mask(half ? 0xFFFFFFFFu : 0u);
 
@@ -1763,7 +1810,8 @@ void bpc_decode_kernel(BpcArgs a)
     const DecEdge edge = { t == 0u ? 0u : 0x15u, t == 0u ? 0u : 0xCu, t == 31u ? 0u : 0x15u, t == 31u ? 0u : 0xCu };
     int msb = 32;
     int32_t sz = 0;
-    if (valid) { msb = stage[0]; sz = a.sizes[cb]; }
+    if (valid) { msb = s16 ? (int)a.cw16[9 + 2 * cb] : stage[0]; sz = a.sizes[cb]; }
+    const int32_t word0 = msb;                              // (a raw codeblock's word 0 travels in the MSB's place)
     if (valid && sz != 4096 && msb != 32 && (msb < 0 || msb > kMaxPlanes - 1)) {
         atomicOr(a.range_flag, 1);
         msb = kMaxPlanes - 1;
@@ -1778,7 +1826,16 @@ void bpc_decode_kernel(BpcArgs a)
     c.ldscnt = &lds_cnt[(threadIdx.x >> 6) * 2u + half];
     c.ring = cw_ring + ((threadIdx.x >> 6) * 2u + half) * kDecRing;
     c.ringaddr = lds_addr_of(c.ring);
-    dec_ring_init(c, cw);
+    c.src16 = s16 ? 1u : 0u;
+    if (s16) {
+        const uint32_t total = (uint32_t)*a.cw16_total;     // >= 9 + 2 nCB + 1
+        c.srcbase = a.cw16; c.srclim = (total < a.cw16_max ? total : a.cw16_max) - 2u;
+        c.srcoff = 9u + 2u * (uint32_t)a.nCB + (uint32_t)a.cw16_offsets[cbs];
+    } else {
+        c.srcbase = a.staging; c.srclim = (uint32_t)a.AW * (uint32_t)a.AH - 1u;
+        c.srcoff = (uint32_t)cbs * 4096u + 1u;
+    }
+    dec_ring_init(c);
     wave_lds_done();
     M64 sigL = { 0u, 0u }, sigR = { 0u, 0u }, refL = { 0u, 0u }, refR = { 0u, 0u };
 
@@ -1854,7 +1911,7 @@ void bpc_decode_kernel(BpcArgs a)
 #pragma unroll 1
                 for (int ii = 0; ii < last; ii++) {
                     bool one;
-                    dec_ring_row(c, cw, upper_mask);
+                    dec_ring_row(c, upper_mask);
                     const uint64_t mL = shl_carry(xL);
                     uint64_t dL = 0ull, dR = 0ull;
                     if (mL != 0ull) dL = dec_site_m<false>(c, __builtin_amdgcn_inverse_ballot_w64(mL), mL, pl.ref, prec, upper_mask, cw, one);
@@ -1873,7 +1930,7 @@ void bpc_decode_kernel(BpcArgs a)
                 rows &= rows - 1u;
                 const bool oL = ((rL >> ii) & 1u) != 0u, oR = ((rR >> ii) & 1u) != 0u;
                 const uint64_t mL = __builtin_amdgcn_ballot_w64(oL), mR = __builtin_amdgcn_ballot_w64(oR);
-                dec_ring_row(c, cw, upper_mask);
+                dec_ring_row(c, upper_mask);
                 if (mL != 0ull) curL |= dec_site_on<false>(c, oL, mL, pl.ref, prec, upper_mask, cw) ? (1u << ii) : 0u;
                 if (mR != 0ull) curR |= dec_site_on<false>(c, oR, mR, pl.ref, prec, upper_mask, cw) ? (1u << ii) : 0u;
             }
@@ -1948,13 +2005,14 @@ void bpc_decode_kernel(BpcArgs a)
                 }
             }
         };
+        const uint16_t *const raw16 = s16 ? a.cw16 : nullptr;
         if (np > kDecSmallPlanes) {
 #pragma unroll 1
             for (int hw = 0; hw < 2; hw++) {
                 uint32_t A[kMaxPlanes], B[kMaxPlanes];
                 planes_of(A, B, hw, kMaxPlanes);
                 write_rows<kMaxPlanes>(A, B, hw ? sgnL.hi : sgnL.lo, hw ? sgnR.hi : sgnR.lo, 32 * hw, valid, sz, stage, t,
-                                       a.coeffs_out + cbase, a.AW);
+                                       a.coeffs_out + cbase, a.AW, raw16, c.srcoff, c.srclim + 1u, word0);
             }
         } else {
 #pragma unroll 1
@@ -1962,7 +2020,7 @@ void bpc_decode_kernel(BpcArgs a)
                 uint32_t A[kDecSmallPlanes], B[kDecSmallPlanes];
                 planes_of(A, B, hw, kDecSmallPlanes);
                 write_rows<kDecSmallPlanes>(A, B, hw ? sgnL.hi : sgnL.lo, hw ? sgnR.hi : sgnR.lo, 32 * hw, valid, sz, stage, t,
-                                            a.coeffs_out + cbase, a.AW);
+                                            a.coeffs_out + cbase, a.AW, raw16, c.srcoff, c.srclim + 1u, word0);
             }
         }
     }
@@ -2132,7 +2190,9 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
         c.ldscnt = &lds_cnt[(threadIdx.x >> 6) * 2u + half];
         c.ring = cw_ring + ((threadIdx.x >> 6) * 2u + half) * kDecRing;
         c.ringaddr = lds_addr_of(c.ring);
-        dec_ring_init(c, cw);
+        c.srcbase = a.staging; c.src16 = 0u; c.srclim = (uint32_t)a.AW * (uint32_t)a.AH - 1u;
+        c.srcoff = (uint32_t)(valid ? cb : a.cb_base) * 4096u + 1u;
+        dec_ring_init(c);
         wave_lds_done();
     } else {
         c.L = 0u; c.S = 0u; c.off = half * 16384u;
@@ -2140,7 +2200,6 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
         c.slot = half * 16384u;
         c.ldscnt = &lds_cnt[(threadIdx.x >> 6) * 2u + half];
         c.halfoff4 = half * 16384u + 4u; c.lim = c.halfoff4 + 4u * 4094u; c.pone = 1u << prec;
-    c.cntaddr = lds_addr_of(c.ldscnt); c.four = 4u;
         if (t == 0u) *c.ldscnt = c.halfoff4;               // (an encoder's counter: bytes of the staging, enc_reserve)
         wave_lds_done();
         c.stw = reinterpret_cast<char *>(stw);
@@ -2251,7 +2310,6 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
     } else {
         // flush + sizeArray + MSB word + expansion fallback, as bpc_encode_kernel
 #if PS_ENC_LDS
-        wave_lds_done();
         if (coded) {
             const uint32_t sl = c.slot < c.lim ? c.slot : c.lim;
             *reinterpret_cast<int32_t *>(c.stw + sl) = (int32_t)c.L;

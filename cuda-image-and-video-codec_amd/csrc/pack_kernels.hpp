@@ -106,6 +106,42 @@ __global__ __launch_bounds__(256) void read_sizes_kernel(const uint16_t *stream,
     }
 }
 
+// read_sizes_kernel + scan_sizes_kernel in one launch, for the decoder that reads its codewords from the stream itself
+// (bpc_decode_kernel<false, NP, true>): the lengths as retrieveSizeArray reads them, clamped and flagged as above, and
+// their scan.  One block of 1024 threads per frame (blockIdx.x: the stream advances by stream_stride shorts).
+__global__ __launch_bounds__(1024) void scan_stream_kernel(const uint16_t *stream, int n, int32_t *sizes, int32_t *offsets,
+                                                           int32_t *total, int *flag, size_t stream_stride)
+{
+    __shared__ int32_t s_wave[16];
+    stream += (size_t)blockIdx.x * stream_stride;
+    sizes += (size_t)blockIdx.x * (size_t)n; offsets += (size_t)blockIdx.x * (size_t)n; total += blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = (n + 1023) / 1024;
+    const int b = tid * chunk, e = b + chunk < n ? b + chunk : n;
+    int32_t sum = 0;
+    bool bad = false;
+    for (int i = b; i < e; i++) {
+        int v = stream[10 + 2 * i];
+        if (v < 1 || v > 4096) { bad = true; v = v < 1 ? 1 : 4096; }
+        sizes[i] = v;
+        sum += v - 1;
+    }
+    if (bad) atomicOr(flag, 1);
+    int32_t inc = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int32_t o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int32_t base = 0;
+    for (int w = 0; w < wave; w++) base += s_wave[w];
+    int32_t run = base + inc - sum;
+    for (int i = b; i < e; i++) { offsets[i] = run; run += sizes[i] - 1; }
+    if (tid == 1023) *total = 9 + 2 * n + (base + inc) + 1;
+}
+
 // buildCodeStreamLUTBS BitStreamBuilder.cu:142-171 layout
 // (blockIdx.y = frame of a batched launch: stream += stream_stride shorts, sizes / offsets += n, staging += frame_words)
 __global__ __launch_bounds__(256) void unpack_kernel(const uint16_t *stream, const int32_t *sizes,

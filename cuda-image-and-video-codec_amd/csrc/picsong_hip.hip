@@ -738,8 +738,19 @@ int picsong_bpc_encode(picsong_ctx *c, const void *d_coeffs, int32_t *d_staging,
     return bpc_encode_impl(c, d_coeffs, d_staging, d_sizes, true, (hipStream_t)stream);
 }
 
+// PICSONG_DEC_STAGING=1: the frame paths unpack into the 32-bit staging first, as picsong_bitstream_unpack +
+// picsong_bpc_decode do (A/B of the decoder that reads the stream itself)
+static bool dec_from_stream(const picsong_ctx *c)
+{
+    static const bool staged = [] { const char *e = getenv("PICSONG_DEC_STAGING"); return e && atoi(e) != 0; }();
+    return !staged && c->p.k <= 0.0f && c->p.cp != 3;
+}
+
+// d_stream16 != nullptr (k = 0, -cp 2): the codewords come from the packed stream, d_offsets the scan of its lengths
+// (scan_stream_kernel); d_staging is then not read
 static int bpc_decode_impl(picsong_ctx *c, const int32_t *d_staging, const int32_t *d_sizes, int32_t *d_coeffs,
-                           hipStream_t s, int comp = 0)
+                           hipStream_t s, int comp = 0, const uint16_t *d_stream16 = nullptr,
+                           const int32_t *d_offsets = nullptr)
 {
     BpcArgs a;
     int rc = bpc_args(c, a, comp);
@@ -761,10 +772,32 @@ static int bpc_decode_impl(picsong_ctx *c, const int32_t *d_staging, const int32
         bpc_decode_kernel<true, kMaxPlanes><<<waves, 64, 0, s>>>(a);
     } else {
         const unsigned wgs = (waves + kBpcDecWgWaves - 1) / kBpcDecWgWaves;
-        bpc_decode_kernel<false, kDecSmallPlanes><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
+        if (d_stream16) {
+            a.cw16 = d_stream16; a.cw16_offsets = d_offsets; a.cw16_total = c->d_total;
+            a.cw16_max = (uint32_t)picsong_max_stream_shorts(c->aw, c->ah);
+            bpc_decode_kernel<false, kDecSmallPlanes, true><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
+        } else {
+            bpc_decode_kernel<false, kDecSmallPlanes><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
+        }
     }
     HIP_TRY(hipGetLastError());
     return PICSONG_OK;
+}
+
+// a frame path's decoder: lengths and offsets out of the stream (one launch), then the coder reading the stream itself;
+// or the unpack into the staging (-k > 0, -cp 3, PICSONG_DEC_STAGING)
+static int unpack_impl(picsong_ctx *c, const uint16_t *d_stream, int32_t *d_staging, int32_t *d_sizes,
+                       bool memset_staging, hipStream_t s);
+static int decode_stream_impl(picsong_ctx *c, const uint16_t *d_stream, int32_t *d_coeffs, hipStream_t s, int comp)
+{
+    int rc;
+    if (!dec_from_stream(c)) {
+        if ((rc = unpack_impl(c, d_stream, c->d_staging, c->d_sizes, false, s))) return rc;
+        return bpc_decode_impl(c, c->d_staging, c->d_sizes, d_coeffs, s, comp);
+    }
+    scan_stream_kernel<<<1, 1024, 0, s>>>(d_stream, c->ncb, c->d_sizes, c->d_offsets, c->d_total, c->d_flag, 0);
+    HIP_TRY(hipGetLastError());
+    return bpc_decode_impl(c, nullptr, c->d_sizes, d_coeffs, s, comp, d_stream, c->d_offsets);
 }
 
 int picsong_bpc_decode(picsong_ctx *c, const int32_t *d_staging, const int32_t *d_sizes, int32_t *d_coeffs,
@@ -951,8 +984,7 @@ int picsong_decode_frame(picsong_ctx *c, const uint16_t *d_stream, uint8_t *d_fr
     int rc = ensure_workspace(c, true);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = unpack_impl(c, d_stream, c->d_staging, c->d_sizes, false, s))) return rc;
-    if ((rc = bpc_decode_impl(c, c->d_staging, c->d_sizes, c->d_coef_i, s))) return rc;
+    if ((rc = decode_stream_impl(c, d_stream, c->d_coef_i, s, 0))) return rc;
     bool fused = false;
     if ((rc = dwt_inverse_impl(c, c->d_coef_i, c->d_coef, d_frame_out, &fused, s))) return rc;
     if (fused) return PICSONG_OK;            // the finest level wrote the pixels itself
@@ -1150,14 +1182,20 @@ int picsong_decode_frames(picsong_ctx *c, int n, const uint16_t *d_streams, size
     if ((rc = ensure_coef_i(c, n))) return rc;
     hipStream_t s = (hipStream_t)stream;
     // ---- unpack: lengths, offsets, codewords of the n streams
-    read_sizes_kernel<<<dim3((unsigned)((c->ncb + 255) / 256), (unsigned)n), 256, 0, s>>>(d_streams, c->ncb, c->b_sizes, c->d_flag,
-                                                                                      stream_stride);
-    HIP_TRY(hipGetLastError());
-    scan_sizes_kernel<<<(unsigned)n, 1024, 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
-    HIP_TRY(hipGetLastError());
-    unpack_kernel<<<dim3((unsigned)c->ncb, (unsigned)n), 256, 0, s>>>(d_streams, c->b_sizes, c->b_offsets, c->ncb, c->b_staging,
-                                                                     stream_stride, c->P);
-    HIP_TRY(hipGetLastError());
+    const bool direct = dec_from_stream(c);                 // the coder reads the streams themselves: no unpack, no staging
+    if (direct) {
+        scan_stream_kernel<<<(unsigned)n, 1024, 0, s>>>(d_streams, c->ncb, c->b_sizes, c->b_offsets, c->b_total, c->d_flag, stream_stride);
+        HIP_TRY(hipGetLastError());
+    } else {
+        read_sizes_kernel<<<dim3((unsigned)((c->ncb + 255) / 256), (unsigned)n), 256, 0, s>>>(d_streams, c->ncb, c->b_sizes, c->d_flag,
+                                                                                          stream_stride);
+        HIP_TRY(hipGetLastError());
+        scan_sizes_kernel<<<(unsigned)n, 1024, 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
+        HIP_TRY(hipGetLastError());
+        unpack_kernel<<<dim3((unsigned)c->ncb, (unsigned)n), 256, 0, s>>>(d_streams, c->b_sizes, c->b_offsets, c->ncb, c->b_staging,
+                                                                         stream_stride, c->P);
+        HIP_TRY(hipGetLastError());
+    }
     // ---- decoder: one grid over the n frames' codeblock pairs, both plane-count classes
     BpcArgs a;
     if ((rc = bpc_args(c, a, 0))) return rc;
@@ -1166,7 +1204,13 @@ int picsong_decode_frames(picsong_ctx *c, int n, const uint16_t *d_streams, size
     a.coeffs_out = c->b_coef_i; a.staging = c->b_staging; a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch;
     a.frames = n; a.waves_per_frame = wpf; a.coef_z = (unsigned long long)c->P * 4ull;
     const unsigned wgs = (unsigned)(((size_t)n * (size_t)wpf + kBpcDecWgWaves - 1) / kBpcDecWgWaves);
-    bpc_decode_kernel<false, kDecSmallPlanes><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
+    if (direct) {
+        a.cw16 = d_streams; a.cw16_offsets = c->b_offsets; a.cw16_total = c->b_total; a.cw16_stride = stream_stride;
+        a.cw16_max = (uint32_t)picsong_max_stream_shorts(c->aw, c->ah);
+        bpc_decode_kernel<false, kDecSmallPlanes, true><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
+    } else {
+        bpc_decode_kernel<false, kDecSmallPlanes><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
+    }
     HIP_TRY(hipGetLastError());
     // ---- inverse transform, pixels out of the finest level where its vector kernel applies
     bool fused = false;
@@ -1248,8 +1292,7 @@ int picsong_decode_plane(picsong_ctx *c, const uint16_t *d_stream, int comp, voi
     int rc = ensure_workspace(c, true);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = unpack_impl(c, d_stream, c->d_staging, c->d_sizes, false, s))) return rc;
-    if ((rc = bpc_decode_impl(c, c->d_staging, c->d_sizes, c->d_coef_i, s, comp))) return rc;
+    if ((rc = decode_stream_impl(c, d_stream, c->d_coef_i, s, comp))) return rc;
     return picsong_dwt_inverse(c, c->d_coef_i, d_plane_out, stream);
 }
 
@@ -1360,15 +1403,28 @@ int picsong_decode_rgb_frame(picsong_ctx *c, const uint16_t *d_streams, size_t s
     if ((rc = ensure_coef_i(c, 3))) return rc;
     c->last_batch = -1;
     hipStream_t s = (hipStream_t)stream;
-    read_sizes_kernel<<<dim3((unsigned)((c->ncb + 255) / 256), 3u), 256, 0, s>>>(d_streams, c->ncb, c->b_sizes, c->d_flag, stream_stride);
-    HIP_TRY(hipGetLastError());
-    scan_sizes_kernel<<<3, 1024, 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
-    HIP_TRY(hipGetLastError());
-    unpack_kernel<<<dim3((unsigned)c->ncb, 3u), 256, 0, s>>>(d_streams, c->b_sizes, c->b_offsets, c->ncb, c->b_staging, stream_stride, c->P);
-    HIP_TRY(hipGetLastError());
+    const bool direct = dec_from_stream(c);
+    if (direct) {
+        scan_stream_kernel<<<3, 1024, 0, s>>>(d_streams, c->ncb, c->b_sizes, c->b_offsets, c->b_total, c->d_flag, stream_stride);
+        HIP_TRY(hipGetLastError());
+    } else {
+        read_sizes_kernel<<<dim3((unsigned)((c->ncb + 255) / 256), 3u), 256, 0, s>>>(d_streams, c->ncb, c->b_sizes, c->d_flag, stream_stride);
+        HIP_TRY(hipGetLastError());
+        scan_sizes_kernel<<<3, 1024, 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
+        HIP_TRY(hipGetLastError());
+        unpack_kernel<<<dim3((unsigned)c->ncb, 3u), 256, 0, s>>>(d_streams, c->b_sizes, c->b_offsets, c->ncb, c->b_staging, stream_stride, c->P);
+        HIP_TRY(hipGetLastError());
+    }
     a.coeffs_out = c->b_coef_i; a.staging = c->b_staging; a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch;
     a.coef_z = (unsigned long long)c->P * 4ull;
-    bpc_decode_kernel<false, kDecSmallPlanes><<<(unsigned)(3 * a.waves_per_frame / kBpcDecWgWaves), 64 * kBpcDecWgWaves, 0, s>>>(a);
+    const unsigned wgs3 = (unsigned)(3 * a.waves_per_frame / kBpcDecWgWaves);
+    if (direct) {
+        a.cw16 = d_streams; a.cw16_offsets = c->b_offsets; a.cw16_total = c->b_total; a.cw16_stride = stream_stride;
+        a.cw16_max = (uint32_t)picsong_max_stream_shorts(c->aw, c->ah);
+        bpc_decode_kernel<false, kDecSmallPlanes, true><<<wgs3, 64 * kBpcDecWgWaves, 0, s>>>(a);
+    } else {
+        bpc_decode_kernel<false, kDecSmallPlanes><<<wgs3, 64 * kBpcDecWgWaves, 0, s>>>(a);
+    }
     HIP_TRY(hipGetLastError());
     if ((rc = dwt_inverse_impl(c, c->b_coef_i, c->b_coef, nullptr, nullptr, s, 3u, 0))) return rc;
     const char *img = (const char *)c->b_coef + c->extra * 4;

@@ -229,6 +229,19 @@ def bpc_decode(staging, sizes, AW, AH, wl, lut, k=0.0):
     return coef
 
 
+def bpc_decode_stream(stream, AW, AH, wl, lut):
+    """The frame paths' decoder: lengths, offsets and codewords straight from the packed stream (no unpack, no staging)."""
+    stream = np.ascontiguousarray(stream, np.uint16)
+    coef = np.empty((AH, AW), np.int32)
+    flag = np.zeros(1, np.int32)
+    tab = np.ascontiguousarray(lut.table, np.int32)
+    geo = _geo(lut)
+    bad = lib().emu_bpc_decode_stream(_p(stream), int(stream.size), AW, AH, wl, _p(tab), _p(geo), _p(coef), _p(flag))
+    bpc_decode_stream.last_flag = int(flag[0])
+    bpc_decode_stream.last_bad = int(bad)
+    return coef
+
+
 def pack(staging, sizes, header=None):
     staging = np.ascontiguousarray(staging, np.int32)
     sizes = np.ascontiguousarray(sizes, np.int32)

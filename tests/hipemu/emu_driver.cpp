@@ -311,6 +311,28 @@ void emu_bpc_decode(const int32_t *staging, const int32_t *sizes, int aw, int ah
     }
 }
 
+// the frame paths' decoder: lengths + offsets out of the stream (scan_stream_kernel), codewords read from the stream
+// itself (bpc_decode_kernel<false, NP, true>); `stream` holds stream_shorts shorts (a load may start at the last pair).
+// Returns the damaged-lengths flag.
+int emu_bpc_decode_stream(const uint16_t *stream, unsigned stream_shorts, int aw, int ah, int wl, const int32_t *lut,
+                          const int *geo, int32_t *coeffs, int *flag)
+{
+    const int ncb = (aw / 64) * (ah / 64);
+    std::vector<int32_t> sizes(ncb), offsets(ncb);
+    int32_t total = 0;
+    int bad = 0;
+    emu::launch(dim3(1), dim3(1024), [&] { scan_stream_kernel(stream, ncb, sizes.data(), offsets.data(), &total, &bad, 0); });
+    BpcArgs a = mk(aw, ah, wl, lut, geo, nullptr, sizes.data(), flag);
+    a.coeffs_out = coeffs;
+    a.k = 0.0f; a.n_tables = 1;
+    a.cw16 = stream; a.cw16_offsets = offsets.data(); a.cw16_total = &total; a.cw16_max = stream_shorts;
+    const dim3 wgs(((unsigned)((a.nCB + 1) / 2) + kBpcDecWgWaves - 1) / kBpcDecWgWaves);
+    std::vector<uint32_t> plane_scratch((size_t)wgs.x * kBpcDecWgWaves * kEncScratchDwordsPerWave, 0xDEADBEEFu);
+    a.plane_scratch = plane_scratch.data();
+    emu::launch(wgs, dim3(64 * kBpcDecWgWaves), [&] { bpc_decode_kernel<false, kDecSmallPlanes, true>(a); });
+    return bad;
+}
+
 // -cp 3: geo[6..8] = nRef, nSig, nSign; lut = [ref | sig | sign | cp_sig | cp_sign]
 void emu_bpc3_encode(const void *coeffs, int is_float, int aw, int ah, int wl, const int32_t *lut, const int *geo,
                      int32_t *staging, int32_t *sizes, int *flag)

@@ -215,6 +215,43 @@ def test_pack_unpack_kernels(oracle, E):
     assert np.array_equal(sz2, sizes) and np.array_equal(st2, staging)
 
 
+@pytest.mark.parametrize("W,H,wl", [(192, 128, 2), (192, 64, 2), (128, 64, 1)])
+def test_decoder_reads_the_packed_stream_itself(oracle, E, W, H, wl):
+    """The frame paths' decoder (scan_stream_kernel + bpc_decode_kernel<false, NP, true>): lengths, offsets and
+    codewords straight from the packed stream, which is exactly as long as its total -- the ring's loads ahead of a
+    codeblock's length are kept inside it.  (192 x 64: an odd codeblock count, the last wave's upper half idles.)"""
+    lut = oracle.lut_for(False, wl)
+    coef = _coef(oracle, oracle.gen_frame(W, H, 3), wl, False)
+    st, sz = oracle.bpc_encode(coef, wl, lut)
+    stream = oracle.bitstream_pack(st, sz)
+    assert stream.size == 9 + 2 * sz.size + int((sz - 1).sum()) + 1
+    got = E.bpc_decode_stream(stream, W, H, wl, lut)
+    assert E.bpc_decode_stream.last_bad == 0 and E.bpc_decode_stream.last_flag == 0
+    assert np.array_equal(got, coef)
+    assert np.array_equal(got, E.bpc_decode(st, sz, W, H, wl, lut))
+
+
+def test_stream_decoder_raw_blocks_and_damaged_lengths(oracle, E):
+    """A raw codeblock (size 4096: its word 0 travels in the MSB's place), an all-zero block and two coded ones read
+    from the stream; then the same stream with a damaged length: flagged, clamped, and decoded without reading
+    outside the buffer (the wrapper hands the kernel the buffer's exact length)."""
+    rng = np.random.default_rng(4)
+    coef = np.zeros((64, 256), np.int32)
+    coef[:, 0:64] = rng.integers(-30000, 30000, (64, 64))
+    coef[:, 128:192] = rng.integers(-1, 2, (64, 64))
+    coef[:, 192:256] = (rng.standard_normal((64, 64)) * 600).astype(np.int32)
+    lut = oracle.lut_for(False, 1)
+    st, sz = oracle.bpc_encode(coef, 1, lut)
+    assert sz[0] == 4096 and sz[1] == 1
+    stream = oracle.bitstream_pack(st, sz)
+    assert np.array_equal(E.bpc_decode_stream(stream, 256, 64, 1, lut), coef)
+    assert E.bpc_decode_stream.last_bad == 0
+    bad = stream.copy()
+    bad[10 + 2 * 2] = 60000                               # block 2 claims 60000 words
+    E.bpc_decode_stream(bad, 256, 64, 1, lut)
+    assert E.bpc_decode_stream.last_bad == 1
+
+
 def test_unpack_clamps_damaged_lengths(oracle, E):
     """A codeblock length outside 1..4096 is clamped and flagged: nothing is written outside the
     codeblock's own 4096 staging words."""
