@@ -178,7 +178,10 @@ int picsong_last_total(picsong_ctx *ctx, void *stream, int *h_total);
  *      (Engines/CodingEngine.cu:634-674,819-872) and DecodingEngine::runImage
  *      (Engines/DecodingEngine.cu:770-794).  d_frame: padded u8[AW*AH] (caller pads as
  *      IOManager::loadFrameCAdaptedSizes does, or uses picsong_pad_frame_host).  iter == 0
- *      writes the populated header.  Asynchronous; length via picsong_last_total(). ---- */
+ *      writes the populated header.  Asynchronous; length via picsong_last_total().
+ *      picsong_decode_frame reads the stream's own shorts and nothing beyond them (k = 0, -cp 2: the coder
+ *      takes its codewords from d_stream itself; otherwise through the staging, as
+ *      picsong_bitstream_unpack does); lengths outside 1..4096 are clamped and raise the range flag. ---- */
 int picsong_encode_frame(picsong_ctx *ctx, const uint8_t *d_frame, int iter, uint16_t *d_stream,
                          void *stream);
 int picsong_decode_frame(picsong_ctx *ctx, const uint16_t *d_stream, uint8_t *d_frame_out,
