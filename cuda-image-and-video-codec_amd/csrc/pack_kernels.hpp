@@ -24,16 +24,17 @@ struct HeaderArg { uint16_t h[9]; int has; };
 // offsets[cb] = sum_{i<cb} (sizes[i] - 1); *total = 9 + 2n + sum(sizes - 1) + 1
 // (BitStreamBuilder.cu:300-305).  One block of 1024 threads per frame (blockIdx.x = frame of a batched
 // launch: sizes / offsets advance by n, total by 1).
-__global__ __launch_bounds__(1024) void scan_sizes_kernel(const int32_t *sizes, int n, int32_t *offsets,
-                                                          int32_t *total)
+// The workgroup is 256 threads for frames of up to 16384 codeblocks (scan_threads), one wave a SIMD, and the kernels keep
+// to 32 registers (32-bit offsets from the scalar bases, eight loads in flight and no more): the launch sits between a frame's coder and its pack while other frames' coder waves -- five to a
+// SIMD at 96 registers -- hold all but 32 registers of every SIMD, and a workgroup starts only when ONE CU has room for
+// all of its waves.  (Measured with three calls in flight: the 1024-thread scan at 64 registers, four waves a SIMD that
+// fit nowhere until coder waves have drained, cost 13 % of the step, 183.0 -> 159.3 Gpixel/s.)
+__host__ __device__ inline unsigned scan_threads(int n) { return n <= 16384 ? 256u : 1024u; }
+// (A thread's lengths are read eight at a time, all eight loads before the first use: one load, its wait, its add per
+// trip is a round trip to the L2 per length -- 8 a thread at 8K, 64 at 16K -- in a launch that is nothing but latency.)
+__device__ __forceinline__ int32_t scan_block(int32_t sum, int32_t *s_wave, int32_t &base_out)
 {
-    __shared__ int32_t s_wave[16];
-    sizes += (size_t)blockIdx.x * (size_t)n; offsets += (size_t)blockIdx.x * (size_t)n; total += blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunk = (n + 1023) / 1024;
-    const int b = tid * chunk, e = b + chunk < n ? b + chunk : n;
-    int32_t sum = 0;
-    for (int i = b; i < e; i++) sum += sizes[i] - 1;
     int32_t inc = sum;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -44,9 +45,49 @@ __global__ __launch_bounds__(1024) void scan_sizes_kernel(const int32_t *sizes, 
     __syncthreads();
     int32_t base = 0;
     for (int w = 0; w < wave; w++) base += s_wave[w];
-    int32_t run = base + inc - sum;
-    for (int i = b; i < e; i++) { offsets[i] = run; run += sizes[i] - 1; }
-    if (tid == 1023) *total = 9 + 2 * n + (base + inc) + 1;
+    base_out = base;
+    return inc;                                             // inclusive within the wave; base = the waves before
+}
+// A thread's lengths b .. e - 1 go in groups of eight -- eight loads in flight from one 32-bit offset -- and what is left
+// over (the array's last thread or two) one by one.
+// offsets[i] = run, run += sizes[i] - 1
+__device__ __forceinline__ void scan_write_offsets(const int32_t *sizes, int32_t *offsets, uint32_t b, uint32_t e, int32_t run)
+{
+    uint32_t g = b;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (; g + 8u <= e; g += 8u) {
+        int32_t v[8], o[8];
+        __builtin_memcpy(v, sizes + g, 32);
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; q++) { o[q] = run; run += v[q] - 1; }
+        __builtin_memcpy(offsets + g, o, 32);
+    }
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (; g < e; g++) { offsets[g] = run; run += sizes[g] - 1; }
+}
+__global__ __launch_bounds__(1024) void scan_sizes_kernel(const int32_t *sizes, int n, int32_t *offsets,
+                                                          int32_t *total)
+{
+    __shared__ int32_t s_wave[16];
+    sizes += (size_t)blockIdx.x * (size_t)n; offsets += (size_t)blockIdx.x * (size_t)n; total += blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t chunk = ((uint32_t)n + blockDim.x - 1u) / blockDim.x;
+    const uint32_t b = (uint32_t)tid * chunk < (uint32_t)n ? (uint32_t)tid * chunk : (uint32_t)n, e = b + chunk < (uint32_t)n ? b + chunk : (uint32_t)n;
+    int32_t sum = 0;
+    uint32_t g = b;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (; g + 8u <= e; g += 8u) {
+        int32_t v[8];
+        __builtin_memcpy(v, sizes + g, 32);
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; q++) sum += v[q] - 1;
+    }
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (; g < e; g++) sum += sizes[g] - 1;
+    int32_t base;
+    const int32_t inc = scan_block(sum, s_wave, base);
+    scan_write_offsets(sizes, offsets, b, e, base + inc - sum);
+    if (tid == (int)blockDim.x - 1) *total = 9 + 2 * n + (base + inc) + 1;
 }
 
 // one workgroup per codeblock (buildBitStreamLUTBS BitStreamBuilder.cu:106-137 layout); blockIdx.y = frame
@@ -115,31 +156,37 @@ __global__ __launch_bounds__(1024) void scan_stream_kernel(const uint16_t *strea
     __shared__ int32_t s_wave[16];
     stream += (size_t)blockIdx.x * stream_stride;
     sizes += (size_t)blockIdx.x * (size_t)n; offsets += (size_t)blockIdx.x * (size_t)n; total += blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunk = (n + 1023) / 1024;
-    const int b = tid * chunk, e = b + chunk < n ? b + chunk : n;
+    const int tid = threadIdx.x;
+    const uint32_t chunk = ((uint32_t)n + blockDim.x - 1u) / blockDim.x;
+    const uint32_t b = (uint32_t)tid * chunk < (uint32_t)n ? (uint32_t)tid * chunk : (uint32_t)n, e = b + chunk < (uint32_t)n ? b + chunk : (uint32_t)n;
     int32_t sum = 0;
     bool bad = false;
-    for (int i = b; i < e; i++) {
-        int v = stream[10 + 2 * i];
-        if (v < 1 || v > 4096) { bad = true; v = v < 1 ? 1 : 4096; }
-        sizes[i] = v;
-        sum += v - 1;
+    uint32_t g = b;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (; g + 8u <= e; g += 8u) {
+        // eight (MSB, length) pairs as they lie: 32 bytes from short 9 + 2 g, the lengths their upper halves
+        uint32_t w[8];
+        __builtin_memcpy(w, stream + 9u + 2u * g, 32);
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; q++) {
+            const uint32_t x = w[q] >> 16;
+            w[q] = x < 1u ? 1u : (x > 4096u ? 4096u : x);
+            bad = bad || w[q] != x;
+            sum += (int32_t)w[q] - 1;
+        }
+        __builtin_memcpy(sizes + g, w, 32);
+    }
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (; g < e; g++) {
+        int x = stream[10u + 2u * g];
+        if (x < 1 || x > 4096) { bad = true; x = x < 1 ? 1 : 4096; }
+        sizes[g] = x; sum += x - 1;
     }
     if (bad) atomicOr(flag, 1);
-    int32_t inc = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int32_t o = __shfl_up(inc, d);
-        if (lane >= d) inc += o;
-    }
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    int32_t base = 0;
-    for (int w = 0; w < wave; w++) base += s_wave[w];
-    int32_t run = base + inc - sum;
-    for (int i = b; i < e; i++) { offsets[i] = run; run += sizes[i] - 1; }
-    if (tid == 1023) *total = 9 + 2 * n + (base + inc) + 1;
+    int32_t base;
+    const int32_t inc = scan_block(sum, s_wave, base);
+    scan_write_offsets(sizes, offsets, b, e, base + inc - sum);
+    if (tid == (int)blockDim.x - 1) *total = 9 + 2 * n + (base + inc) + 1;
 }
 
 // buildCodeStreamLUTBS BitStreamBuilder.cu:142-171 layout

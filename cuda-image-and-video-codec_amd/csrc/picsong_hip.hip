@@ -795,7 +795,7 @@ static int decode_stream_impl(picsong_ctx *c, const uint16_t *d_stream, int32_t 
         if ((rc = unpack_impl(c, d_stream, c->d_staging, c->d_sizes, false, s))) return rc;
         return bpc_decode_impl(c, c->d_staging, c->d_sizes, d_coeffs, s, comp);
     }
-    scan_stream_kernel<<<1, 1024, 0, s>>>(d_stream, c->ncb, c->d_sizes, c->d_offsets, c->d_total, c->d_flag, 0);
+    scan_stream_kernel<<<1, scan_threads(c->ncb), 0, s>>>(d_stream, c->ncb, c->d_sizes, c->d_offsets, c->d_total, c->d_flag, 0);
     HIP_TRY(hipGetLastError());
     return bpc_decode_impl(c, nullptr, c->d_sizes, d_coeffs, s, comp, d_stream, c->d_offsets);
 }
@@ -872,7 +872,7 @@ static int pack_range(picsong_ctx *c, const int32_t *d_staging, const int32_t *d
     memset(&h, 0, sizeof h);
     if (h_header) { memcpy(h.h, h_header, sizeof h.h); h.has = 1; }
     c->last_batch = 0;                                      // the most recent total is d_total (picsong_copy_last_totals)
-    scan_sizes_kernel<<<1, 1024, 0, s>>>(d_sizes, n, c->d_offsets, c->d_total);
+    scan_sizes_kernel<<<1, scan_threads(n), 0, s>>>(d_sizes, n, c->d_offsets, c->d_total);
     HIP_TRY(hipGetLastError());
     pack_kernel<<<(unsigned)n, 256, 0, s>>>(d_staging, d_sizes, c->d_offsets, c->d_total, n, h, d_stream);
     HIP_TRY(hipGetLastError());
@@ -897,7 +897,7 @@ static int unpack_impl(picsong_ctx *c, const uint16_t *d_stream, int32_t *d_stag
     if (memset_staging) HIP_TRY(hipMemsetAsync(d_staging, 0xFF, c->P * sizeof(int32_t), s));
     read_sizes_kernel<<<(unsigned)((c->ncb + 255) / 256), 256, 0, s>>>(d_stream, c->ncb, d_sizes, c->d_flag);
     HIP_TRY(hipGetLastError());
-    scan_sizes_kernel<<<1, 1024, 0, s>>>(d_sizes, c->ncb, c->d_offsets, c->d_total);
+    scan_sizes_kernel<<<1, scan_threads(c->ncb), 0, s>>>(d_sizes, c->ncb, c->d_offsets, c->d_total);
     HIP_TRY(hipGetLastError());
     unpack_kernel<<<(unsigned)c->ncb, 256, 0, s>>>(d_stream, d_sizes, c->d_offsets, c->ncb, d_staging);
     HIP_TRY(hipGetLastError());
@@ -1141,7 +1141,7 @@ int picsong_encode_frames(picsong_ctx *c, int n, const uint8_t *d_frames, size_t
         memcpy(h.h, hdr, sizeof h.h);
         h.has = -first_iter + 1;
     }
-    scan_sizes_kernel<<<(unsigned)n, 1024, 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
+    scan_sizes_kernel<<<(unsigned)n, scan_threads(c->ncb), 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
     HIP_TRY(hipGetLastError());
     pack_kernel<<<dim3((unsigned)c->ncb, (unsigned)n), 256, 0, s>>>(c->b_staging, c->b_sizes, c->b_offsets, c->b_total,
                                                                     c->ncb, h, d_streams, c->P, stream_stride);
@@ -1184,13 +1184,13 @@ int picsong_decode_frames(picsong_ctx *c, int n, const uint16_t *d_streams, size
     // ---- unpack: lengths, offsets, codewords of the n streams
     const bool direct = dec_from_stream(c);                 // the coder reads the streams themselves: no unpack, no staging
     if (direct) {
-        scan_stream_kernel<<<(unsigned)n, 1024, 0, s>>>(d_streams, c->ncb, c->b_sizes, c->b_offsets, c->b_total, c->d_flag, stream_stride);
+        scan_stream_kernel<<<(unsigned)n, scan_threads(c->ncb), 0, s>>>(d_streams, c->ncb, c->b_sizes, c->b_offsets, c->b_total, c->d_flag, stream_stride);
         HIP_TRY(hipGetLastError());
     } else {
         read_sizes_kernel<<<dim3((unsigned)((c->ncb + 255) / 256), (unsigned)n), 256, 0, s>>>(d_streams, c->ncb, c->b_sizes, c->d_flag,
                                                                                           stream_stride);
         HIP_TRY(hipGetLastError());
-        scan_sizes_kernel<<<(unsigned)n, 1024, 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
+        scan_sizes_kernel<<<(unsigned)n, scan_threads(c->ncb), 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
         HIP_TRY(hipGetLastError());
         unpack_kernel<<<dim3((unsigned)c->ncb, (unsigned)n), 256, 0, s>>>(d_streams, c->b_sizes, c->b_offsets, c->ncb, c->b_staging,
                                                                          stream_stride, c->P);
@@ -1379,7 +1379,7 @@ int picsong_encode_rgb_frame(picsong_ctx *c, const uint8_t *d_r, const uint8_t *
         memcpy(h.h, hdr, sizeof h.h);
         h.has = -(header_mask & 7);
     }
-    scan_sizes_kernel<<<3, 1024, 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
+    scan_sizes_kernel<<<3, scan_threads(c->ncb), 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
     HIP_TRY(hipGetLastError());
     pack_kernel<<<dim3((unsigned)c->ncb, 3u), 256, 0, s>>>(c->b_staging, c->b_sizes, c->b_offsets, c->b_total, c->ncb, h,
                                                           d_streams, c->P, stream_stride);
@@ -1405,12 +1405,12 @@ int picsong_decode_rgb_frame(picsong_ctx *c, const uint16_t *d_streams, size_t s
     hipStream_t s = (hipStream_t)stream;
     const bool direct = dec_from_stream(c);
     if (direct) {
-        scan_stream_kernel<<<3, 1024, 0, s>>>(d_streams, c->ncb, c->b_sizes, c->b_offsets, c->b_total, c->d_flag, stream_stride);
+        scan_stream_kernel<<<3, scan_threads(c->ncb), 0, s>>>(d_streams, c->ncb, c->b_sizes, c->b_offsets, c->b_total, c->d_flag, stream_stride);
         HIP_TRY(hipGetLastError());
     } else {
         read_sizes_kernel<<<dim3((unsigned)((c->ncb + 255) / 256), 3u), 256, 0, s>>>(d_streams, c->ncb, c->b_sizes, c->d_flag, stream_stride);
         HIP_TRY(hipGetLastError());
-        scan_sizes_kernel<<<3, 1024, 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
+        scan_sizes_kernel<<<3, scan_threads(c->ncb), 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
         HIP_TRY(hipGetLastError());
         unpack_kernel<<<dim3((unsigned)c->ncb, 3u), 256, 0, s>>>(d_streams, c->b_sizes, c->b_offsets, c->ncb, c->b_staging, stream_stride, c->P);
         HIP_TRY(hipGetLastError());

@@ -321,7 +321,7 @@ int emu_bpc_decode_stream(const uint16_t *stream, unsigned stream_shorts, int aw
     std::vector<int32_t> sizes(ncb), offsets(ncb);
     int32_t total = 0;
     int bad = 0;
-    emu::launch(dim3(1), dim3(1024), [&] { scan_stream_kernel(stream, ncb, sizes.data(), offsets.data(), &total, &bad, 0); });
+    emu::launch(dim3(1), dim3(scan_threads(ncb)), [&] { scan_stream_kernel(stream, ncb, sizes.data(), offsets.data(), &total, &bad, 0); });
     BpcArgs a = mk(aw, ah, wl, lut, geo, nullptr, sizes.data(), flag);
     a.coeffs_out = coeffs;
     a.k = 0.0f; a.n_tables = 1;
@@ -358,7 +358,7 @@ int emu_pack(const int32_t *staging, const int32_t *sizes, int ncb, const uint16
     HeaderArg h;
     memset(&h, 0, sizeof h);
     if (header) { memcpy(h.h, header, sizeof h.h); h.has = 1; }
-    emu::launch(dim3(1), dim3(1024), [&] { scan_sizes_kernel(sizes, ncb, offsets.data(), &total); });
+    emu::launch(dim3(1), dim3(scan_threads(ncb)), [&] { scan_sizes_kernel(sizes, ncb, offsets.data(), &total); });
     emu::launch(dim3((unsigned)ncb), dim3(256), [&] { pack_kernel(staging, sizes, offsets.data(), &total, ncb, h, out); });
     return total;
 }
@@ -370,7 +370,7 @@ int emu_unpack(const uint16_t *stream, int ncb, int32_t *staging, int32_t *sizes
     int flag = 0;
     memset(staging, 0xFF, (size_t)ncb * 4096 * 4);
     emu::launch(dim3((unsigned)((ncb + 255) / 256)), dim3(256), [&] { read_sizes_kernel(stream, ncb, sizes, &flag); });
-    emu::launch(dim3(1), dim3(1024), [&] { scan_sizes_kernel(sizes, ncb, offsets.data(), &total); });
+    emu::launch(dim3(1), dim3(scan_threads(ncb)), [&] { scan_sizes_kernel(sizes, ncb, offsets.data(), &total); });
     emu::launch(dim3((unsigned)ncb), dim3(256), [&] { unpack_kernel(stream, sizes, offsets.data(), ncb, staging); });
     return flag;
 }
