@@ -60,7 +60,13 @@ struct BpcArgs {
     int cb_base;                   // first codeblock of this launch (intra-frame striping), nCB = end
     const int32_t *lut;
     LutGeo g;
-    int32_t *staging;              // int32[nCB*4096]
+    int32_t *staging;              // DECODERS (staging form): int32[nCB*4096], the reference's array (BPCEngine.cu:2429-2441)
+    // ENCODERS: uint16[nCB*4096] -- a staging word never holds more than 16 bits (a codeword, the MSB, a raw block's
+    // (magnitude << 1 | sign) & 0xFFFF), and as 16-bit words the codeword stores of a frame are 20 MB instead of 40 and a
+    // sector of them is evicted half as often before it is full: coder WRITE 101.8 -> 83.8 MB per 8K frame, 183.6 -> 186.4
+    // Gpixel/s.  Word 0 of a codeblock = its MSB (or a raw block's word 0), word 1 + k = codeword k, as in the reference's
+    // array; picsong_bpc_encode widens into the caller's int32 array (widen_staging_kernel).
+    uint16_t *staging16;
     int32_t *sizes;                // int32[nCB]
     int *range_flag;               // set to 1 if a codeblock has MSB > 15
     uint32_t *plane_scratch;       // encoder: kEncScratchDwordsPerWave dwords per wave of the launch
@@ -584,14 +590,16 @@ __device__ __forceinline__ void reserve_enc(Coder &c, bool need, uint64_t m, uin
 // LDS sits in the call site's dependent chain.
 // (PICSONG_ENC_LDS_RESERVE / PS_ENC_LDS: defined at the top of this header)
 
+// the encoders' staging words are 16-bit (BpcArgs::staging16): bytes per word, bytes per codeblock
+constexpr uint32_t kStageBytes = 2u, kStageCb = 4096u * kStageBytes;
 struct EncCoder {
     uint32_t L, S, off;
     uint32_t slot;              // LDS form: raw pre-add value of the lane's reservation (clamped when used)
     uint32_t *ldscnt;           // LDS form: the lane's codeblock's codeword counter
     uint32_t cnt_lo, cnt_hi;
     uint64_t emptym;            // ballot(S == 0) as of the end of the previous call site
-    uint32_t halfoff4;          // byte offset of slot 0 of the lane's codeblock: half * 16384 + 4
-    uint32_t lim;               // LDS form: halfoff4 + 4 * 4094, the byte offset of the codeblock's last slot
+    uint32_t slot0;             // byte offset of slot 0 of the lane's codeblock in the wave's staging: half * 8192 + 2
+    uint32_t lim;               // LDS form: slot0 + 2 * 4094, the byte offset of the codeblock's last slot
     uint32_t pone;              // 1 << prec: the "probability" that leaves an idle lane's interval alone
     char *stw;                  // staging of the wave's first codeblock (wave-uniform)
 };
@@ -610,7 +618,7 @@ __device__ __forceinline__ void enc_reserve(EncCoder &c, uint64_t m, uint32_t up
     if (__builtin_amdgcn_inverse_ballot_w64(m)) {
         // the codeword this lane has just finished goes to the slot it reserved last time (slot starts at
         // -1: word 0 of the staging, see above)
-        // (the codeblock's LDS counter counts BYTES of the wave's staging from halfoff4 on, 4 a codeword: what a lane
+        // (the codeblock's LDS counter counts BYTES of the wave's staging from slot0 on, 2 a codeword: what a lane
         // gets back is its slot's byte offset, and the guard against a 4096th codeword is one v_min with the lane's
         // `lim` -- no shift-and-add, no literal)
         // (Round 3 also wrote this region as its instructions -- exec set instead of saved and restored, no skip of an
@@ -620,8 +628,8 @@ __device__ __forceinline__ void enc_reserve(EncCoder &c, uint64_t m, uint32_t up
         // flushed its last codeword to a stale slot -- caught by the 16K frame's codestream against the oracle, by none
         // of the smaller cases.  The atomic stays the compiler's.)
         const uint32_t sl = c.slot < c.lim ? c.slot : c.lim;
-        *reinterpret_cast<int32_t *>(c.stw + sl) = (int32_t)c.L;
-        c.slot = __hip_atomic_fetch_add(c.ldscnt, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        *reinterpret_cast<uint16_t *>(c.stw + sl) = (uint16_t)c.L;
+        c.slot = __hip_atomic_fetch_add(c.ldscnt, kStageBytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         c.L = 0u; c.S = 0xFFFFu;
     }
 #else
@@ -629,10 +637,10 @@ __device__ __forceinline__ void enc_reserve(EncCoder &c, uint64_t m, uint32_t up
     const uint32_t nlo = (uint32_t)__builtin_popcount(mlo), nhi = (uint32_t)__builtin_popcount(mhi);
     const uint32_t base = c.cnt_lo + (upper_mask & (c.cnt_hi - nlo - c.cnt_lo));
     if (__builtin_amdgcn_inverse_ballot_w64(m)) {
-        *reinterpret_cast<int32_t *>(c.stw + c.off) = (int32_t)c.L;
+        *reinterpret_cast<uint16_t *>(c.stw + c.off) = (uint16_t)c.L;
         uint32_t s = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, base));
         s = s > 4094u ? 4094u : s;
-        c.off = (s << 2) + c.halfoff4;
+        c.off = s * kStageBytes + c.slot0;
         c.L = 0u; c.S = 0xFFFFu;
     }
     const uint32_t a = c.cnt_lo + nlo, b = c.cnt_hi + nhi;
@@ -1129,7 +1137,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
     __shared__ uint32_t lds_cnt[2 * (BULK ? 1 : kBpcEncWgWaves)];      // codeword counters of the workgroup's codeblocks
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
-    if (t == 0u) lds_cnt[(threadIdx.x >> 6) * 2u + half] = half * 16384u + 4u;   // bytes of the staging (enc_reserve); (the table copy below ends with a barrier)
+    if (t == 0u) lds_cnt[(threadIdx.x >> 6) * 2u + half] = half * kStageCb + kStageBytes;   // bytes of the staging (enc_reserve); (the table copy below ends with a barrier)
     const int gwave = BULK ? (int)blockIdx.x
                            : (int)blockIdx.x * kBpcEncWgWaves + (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int wave = gwave;                                       // wave within its frame
@@ -1139,7 +1147,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
         if (f >= a.frames) { wave = a.waves_per_frame; }    // padding wave of the last workgroup: codes nothing
         else {
             a.coeffs_in = (const char *)a.coeffs_in + (unsigned long long)f * a.coef_z;
-            a.staging += (size_t)f * (size_t)a.AW * (size_t)a.AH;
+            a.staging16 += (size_t)f * (size_t)a.AW * (size_t)a.AH;
             a.sizes += (size_t)f * (size_t)(a.nCB - a.cb_base);
             // (scalar selects: indexing the argument struct with f would move all of it to scratch memory)
             if (a.lut_c[0]) a.lut = f == 0 ? a.lut_c[0] : (f == 1 ? a.lut_c[1] : a.lut_c[2]);
@@ -1151,8 +1159,8 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
     const uint32_t esz = a.c16 ? 2u : 4u;                    // bytes of a coefficient
     const uint32_t cbyte = (uint32_t)cbase * esz, rstride = (uint32_t)a.AW * esz;  // byte offset of row 0 / of a row step
-    int32_t *const stw = a.staging + (size_t)(a.cb_base + 2 * wave) * 4096u;     // wave-uniform: the pair's first codeblock
-    int32_t *const st = stw + (size_t)half * 4096u;                             // (an invalid upper half never touches it)
+    uint16_t *const stw = a.staging16 + (size_t)(a.cb_base + 2 * wave) * 4096u;  // wave-uniform: the pair's first codeblock
+    uint16_t *const st = stw + (size_t)half * 4096u;                            // (an invalid upper half never touches it)
     const uint32_t prec = (uint32_t)a.g.prec;
     const uint32_t upper_mask = opaque_mask(half ? 0xFFFFFFFFu : 0u);
     uint32_t *const pscr = a.plane_scratch + (size_t)gwave * (size_t)kEncScratchDwordsPerWave + lane;
@@ -1217,11 +1225,11 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
     };
 
     EncCoder c;
-    c.L = 0u; c.S = 0u; c.off = half * 16384u;                // a first reservation "stores" L = 0 to word 0 (see enc_reserve)
+    c.L = 0u; c.S = 0u; c.off = half * kStageCb;              // a first reservation "stores" L = 0 to word 0 (see enc_reserve)
     c.cnt_lo = 0u; c.cnt_hi = 0u; c.emptym = ~0ull;
-    c.slot = half * 16384u;                                // word 0 of the lane's codeblock (LDS form: byte offsets)
+    c.slot = half * kStageCb;                              // word 0 of the lane's codeblock (LDS form: byte offsets)
     c.ldscnt = &lds_cnt[(threadIdx.x >> 6) * 2u + half];
-    c.halfoff4 = half * 16384u + 4u; c.lim = c.halfoff4 + 4u * 4094u; c.pone = 1u << prec;
+    c.slot0 = half * kStageCb + kStageBytes; c.lim = c.slot0 + kStageBytes * 4094u; c.pone = 1u << prec;
     c.stw = reinterpret_cast<char *>(stw);
     U64 AL = { 0u, 0u }, AR = { 0u, 0u };                 // significant before the current plane
     U64 BLn, BRn;
@@ -1239,7 +1247,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
             // plane or two of a dozen; their waves were the tail of the whole launch.)
 #if PS_ENC_LDS
             wave_lds_done();
-            const uint32_t used = (*c.ldscnt - c.halfoff4) >> 2;
+            const uint32_t used = (*c.ldscnt - c.slot0) / kStageBytes;
 #else
             const uint32_t used = half ? c.cnt_hi : c.cnt_lo;
 #endif
@@ -1365,13 +1373,13 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
 #if PS_ENC_LDS
     if (coded) {
         const uint32_t sl = c.slot < c.lim ? c.slot : c.lim;
-        *reinterpret_cast<int32_t *>(c.stw + sl) = (int32_t)c.L;
+        *reinterpret_cast<uint16_t *>(c.stw + sl) = (uint16_t)c.L;
     }
     wave_lds_done();                                       // every lane's last atomic has landed
-    const uint32_t cw_count = (*c.ldscnt - c.halfoff4) >> 2;
+    const uint32_t cw_count = (*c.ldscnt - c.slot0) / kStageBytes;
     const uint32_t size = (cw_count > 4095u ? 4095u : cw_count) + 1u;
 #else
-    if (coded) *reinterpret_cast<int32_t *>(c.stw + c.off) = (int32_t)c.L;
+    if (coded) *reinterpret_cast<uint16_t *>(c.stw + c.off) = (uint16_t)c.L;
     const uint32_t size = (half ? c.cnt_hi : c.cnt_lo) + 1u;
 #endif
     if (valid && t == 0u) a.sizes[cb] = (int32_t)size;
@@ -1383,10 +1391,10 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WA
             uint32_t m0, m1, n0, n1;
             load_row(a, cbyte + (uint32_t)i * rstride, m0, m1, n0, n1);
             const uint32_t w0 = ((m0 << 1) + n0) & 0xFFFFu, w1 = ((m1 << 1) + n1) & 0xFFFFu;
-            *reinterpret_cast<int2 *>(st + t * 128u + 2u * (uint32_t)i) = make_int2((int)w0, (int)w1);
+            *reinterpret_cast<uint32_t *>(st + t * 128u + 2u * (uint32_t)i) = w0 | (w1 << 16);
         }
     } else if (valid && t == 0u) {
-        st[0] = msb;
+        st[0] = (uint16_t)msb;
     }
 }
 
@@ -2128,10 +2136,12 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
     const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
     const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
     const uint32_t cbyte = (uint32_t)cbase * 4u, rstride = (uint32_t)a.AW * 4u;
-    int32_t *const stw = a.staging + (size_t)(a.cb_base + 2 * wave) * 4096u;
-    int32_t *const st = stw + (size_t)half * 4096u;
+    // the decoder's staging (32-bit, the reference's array) / the encoder's (16-bit words, BpcArgs::staging16)
+    int32_t *const st = DEC ? a.staging + (size_t)(a.cb_base + 2 * wave + (int)half) * 4096u : nullptr;
+    uint16_t *const stw16 = DEC ? nullptr : a.staging16 + (size_t)(a.cb_base + 2 * wave) * 4096u;
+    uint16_t *const st16 = DEC ? nullptr : stw16 + (size_t)half * 4096u;
     // (a half beyond the last codeblock reads the launch's first codeblock: its ring is never used)
-    const int32_t *const cw = (valid ? st : a.staging + (size_t)a.cb_base * 4096u) + 1;
+    const int32_t *const cw = DEC ? (valid ? st : a.staging + (size_t)a.cb_base * 4096u) + 1 : nullptr;
     const uint32_t prec = (uint32_t)a.g.prec;
     const uint32_t upper_mask = opaque_mask(half ? 0xFFFFFFFFu : 0u);
     const int total = a.g.nRef + 2 * (a.g.nSig + a.g.nSign), aux = a.g.nSig + a.g.nSign;
@@ -2195,14 +2205,14 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
         dec_ring_init(c);
         wave_lds_done();
     } else {
-        c.L = 0u; c.S = 0u; c.off = half * 16384u;
+        c.L = 0u; c.S = 0u; c.off = half * kStageCb;
         c.cnt_lo = 0u; c.cnt_hi = 0u; c.emptym = ~0ull;
-        c.slot = half * 16384u;
+        c.slot = half * kStageCb;
         c.ldscnt = &lds_cnt[(threadIdx.x >> 6) * 2u + half];
-        c.halfoff4 = half * 16384u + 4u; c.lim = c.halfoff4 + 4u * 4094u; c.pone = 1u << prec;
-        if (t == 0u) *c.ldscnt = c.halfoff4;               // (an encoder's counter: bytes of the staging, enc_reserve)
+        c.slot0 = half * kStageCb + kStageBytes; c.lim = c.slot0 + kStageBytes * 4094u; c.pone = 1u << prec;
+        if (t == 0u) *c.ldscnt = c.slot0;               // (an encoder's counter: bytes of the staging, enc_reserve)
         wave_lds_done();
-        c.stw = reinterpret_cast<char *>(stw);
+        c.stw = reinterpret_cast<char *>(stw16);
     }
 
     int np = coded ? msb + 1 : 0;
@@ -2312,13 +2322,13 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
 #if PS_ENC_LDS
         if (coded) {
             const uint32_t sl = c.slot < c.lim ? c.slot : c.lim;
-            *reinterpret_cast<int32_t *>(c.stw + sl) = (int32_t)c.L;
+            *reinterpret_cast<uint16_t *>(c.stw + sl) = (uint16_t)c.L;
         }
         wave_lds_done();
-        const uint32_t cw_count = (*c.ldscnt - c.halfoff4) >> 2;
+        const uint32_t cw_count = (*c.ldscnt - c.slot0) / kStageBytes;
         const uint32_t size = (cw_count > 4095u ? 4095u : cw_count) + 1u;
 #else
-        if (coded) *reinterpret_cast<int32_t *>(c.stw + c.off) = (int32_t)c.L;
+        if (coded) *reinterpret_cast<uint16_t *>(c.stw + c.off) = (uint16_t)c.L;
         const uint32_t size = (half ? c.cnt_hi : c.cnt_lo) + 1u;
 #endif
         if (valid && t == 0u) a.sizes[cb] = (int32_t)size;
@@ -2328,10 +2338,10 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
                 uint32_t m0, m1, n0, n1;
                 load_row(a, cbyte + (uint32_t)i * rstride, m0, m1, n0, n1);
                 const uint32_t w0 = ((m0 << 1) + n0) & 0xFFFFu, w1 = ((m1 << 1) + n1) & 0xFFFFu;
-                *reinterpret_cast<int2 *>(st + t * 128u + 2u * (uint32_t)i) = make_int2((int)w0, (int)w1);
+                *reinterpret_cast<uint32_t *>(st16 + t * 128u + 2u * (uint32_t)i) = w0 | (w1 << 16);
             }
         } else if (valid && t == 0u) {
-            st[0] = msb;
+            st16[0] = (uint16_t)msb;
         }
     }
 }

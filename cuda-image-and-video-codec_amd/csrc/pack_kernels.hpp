@@ -94,7 +94,10 @@ __global__ __launch_bounds__(1024) void scan_sizes_kernel(const int32_t *sizes, 
 // of a batched launch (staging advances by frame_words, sizes / offsets by n, total by 1, out by
 // out_stride shorts; only the frame hdr.has - 1 == blockIdx.y carries the populated header -- has = 0: none;
 // has < 0: -has is a bit mask of the frames that carry it (the components of an RGB frame))
-__global__ __launch_bounds__(256) void pack_kernel(const int32_t *staging, const int32_t *sizes,
+// W = the staging's word: uint16_t, the encoders' own (BpcArgs::staging16: the frame paths), or int32_t, the reference's
+// array as a caller of picsong_bitstream_pack holds it
+template <typename W>
+__global__ __launch_bounds__(256) void pack_kernel(const W *staging, const int32_t *sizes,
                                                    const int32_t *offsets, const int32_t *total, int n,
                                                    HeaderArg hdr, uint16_t *out, size_t frame_words = 0,
                                                    size_t out_stride = 0)
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const int32_t *staging, const
         staging += f * frame_words; sizes += f * (size_t)n; offsets += f * (size_t)n; total += f; out += f * out_stride;
         hdr.has = hdr.has < 0 ? (int)(((unsigned)(-hdr.has) >> f) & 1u) : ((hdr.has != 0 && (size_t)(hdr.has - 1) == f) ? 1 : 0);
     }
-    const int32_t *st = staging + (size_t)cb * 4096u;
+    const W *st = staging + (size_t)cb * 4096u;
     const int len = sizes[cb];
     uint16_t *dst = out + 9 + 2 * (size_t)n + (size_t)offsets[cb];
     // a codeblock is at most 4096 words: 16 a thread, in two groups of eight whose loads all go out before the first
@@ -113,9 +116,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const int32_t *staging, const
 #pragma unroll
     for (int k = 0; k < 16; k += 8) {
         if (1 + 256 * k >= len) break;                      // (uniform: the whole workgroup is done)
-        int32_t v[8];
+        W v[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) { const int j = 1 + tid + 256 * (k + q); v[q] = j < len ? st[j] : 0; }
+        for (int q = 0; q < 8; q++) { const int j = 1 + tid + 256 * (k + q); v[q] = j < len ? st[j] : (W)0; }
 #pragma unroll
         for (int q = 0; q < 8; q++) { const int j = 1 + tid + 256 * (k + q); if (j < len) dst[j - 1] = (uint16_t)v[q]; }
     }
@@ -144,6 +147,27 @@ __global__ __launch_bounds__(256) void read_sizes_kernel(const uint16_t *stream,
         int v = stream[10 + 2 * i];
         if (v < 1 || v > 4096) { atomicOr(flag, 1); v = v < 1 ? 1 : 4096; }
         sizes[i] = v;
+    }
+}
+
+// picsong_bpc_encode's last step: the encoders' 16-bit staging widened into the caller's int32 array (the reference's
+// contract, BPCEngine.cu:2429-2441: 0xFFFFFFFF wherever nothing was written -- the caller's memset -- and words
+// 0 .. len - 1 of every codeblock).  One workgroup per codeblock, as pack_kernel.
+__global__ __launch_bounds__(256) void widen_staging_kernel(const uint16_t *staging16, const int32_t *sizes, int cb_base,
+                                                            int32_t *staging)
+{
+    const int cb = cb_base + (int)blockIdx.x, tid = threadIdx.x;
+    const uint16_t *src = staging16 + (size_t)cb * 4096u;
+    int32_t *dst = staging + (size_t)cb * 4096u;
+    const int len = sizes[cb];
+#pragma unroll
+    for (int k = 0; k < 16; k += 8) {
+        if (256 * k >= len) break;
+        uint16_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int j = tid + 256 * (k + q); v[q] = j < len ? src[j] : (uint16_t)0; }
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int j = tid + 256 * (k + q); if (j < len) dst[j] = (int32_t)v[q]; }
     }
 }
 

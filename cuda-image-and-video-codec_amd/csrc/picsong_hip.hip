@@ -702,9 +702,10 @@ static int ensure_plane_scratch(picsong_ctx *c)
     return PICSONG_OK;
 }
 
-static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_staging, int32_t *d_sizes,
-                           bool memset_staging, hipStream_t s, int cb_begin = 0, int cb_count = -1, int comp = 0,
-                           bool c16 = false)
+// d_stage16: the encoders' 16-bit staging, uint16[nCB * 4096] (BpcArgs::staging16) -- the context's own staging
+// buffers hold it on the frame paths; picsong_bpc_encode widens it into the caller's int32 array
+static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, uint16_t *d_stage16, int32_t *d_sizes,
+                           hipStream_t s, int cb_begin = 0, int cb_count = -1, int comp = 0, bool c16 = false)
 {
     BpcArgs a;
     int rc = bpc_args(c, a, comp);
@@ -714,12 +715,9 @@ static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_stag
     a.cb_base = cb_begin;
     a.nCB = cb_begin + cb_count;
     a.coeffs_in = d_coeffs; a.is_float = c->p.lossy ? 1 : 0;
-    a.staging = d_staging; a.sizes = d_sizes;
+    a.staging16 = d_stage16; a.sizes = d_sizes;
     if (int rc2 = ensure_plane_scratch(c)) return rc2;
     a.plane_scratch = c->d_plane_scratch;
-    // BPCEngine::deviceMemoryAllocator BPCEngine.cu:2429-2441.  Slots beyond a codeblock's length
-    // are never read downstream, so the fused frame path skips this 4*AW*AH-byte fill.
-    if (memset_staging) HIP_TRY(hipMemsetAsync(d_staging, 0xFF, c->P * sizeof(int32_t), s));
     if (c->p.cp == 3) {        // three coding passes: one kernel for both directions (bpc3_kernel)
         bpc3_kernel<false><<<(unsigned)(((cb_count + 1) / 2 + kBpc3WgWaves - 1) / kBpc3WgWaves), 64 * kBpc3WgWaves, 0, s>>>(a);
         HIP_TRY(hipGetLastError());
@@ -732,10 +730,27 @@ static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, int32_t *d_stag
     return PICSONG_OK;
 }
 
+// The stage-level call keeps the reference's contract -- an int32 array of 4096 words a codeblock, 0xFFFFFFFF wherever
+// nothing was written (BPCEngine::deviceMemoryAllocator BPCEngine.cu:2429-2441) -- on top of the encoders' 16-bit
+// staging: the coder writes the context's own buffer, widen_staging_kernel copies words 0 .. len - 1 of every codeblock.
+static int bpc_encode_widened(picsong_ctx *c, const void *d_coeffs, int32_t *d_staging, int32_t *d_sizes, hipStream_t s, int comp)
+{
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->d_staging) HIP_TRY(hipMalloc(&c->d_staging, c->P * sizeof(int32_t)));
+    if (d_staging == c->d_staging) return fail(PICSONG_ERR_ARG, "bpc_encode: the context's own staging passed as the output");
+    uint16_t *const st16 = reinterpret_cast<uint16_t *>(c->d_staging);
+    HIP_TRY(hipMemsetAsync(d_staging, 0xFF, c->P * sizeof(int32_t), s));
+    int rc = bpc_encode_impl(c, d_coeffs, st16, d_sizes, s, 0, -1, comp);
+    if (rc) return rc;
+    widen_staging_kernel<<<(unsigned)c->ncb, 256, 0, s>>>(st16, d_sizes, 0, d_staging);
+    HIP_TRY(hipGetLastError());
+    return PICSONG_OK;
+}
+
 int picsong_bpc_encode(picsong_ctx *c, const void *d_coeffs, int32_t *d_staging, int32_t *d_sizes, void *stream)
 {
     if (!c || !d_coeffs || !d_staging || !d_sizes) return fail(PICSONG_ERR_ARG, "bpc_encode: null argument");
-    return bpc_encode_impl(c, d_coeffs, d_staging, d_sizes, true, (hipStream_t)stream);
+    return bpc_encode_widened(c, d_coeffs, d_staging, d_sizes, (hipStream_t)stream, 0);
 }
 
 // PICSONG_DEC_STAGING=1: the frame paths unpack into the 32-bit staging first, as picsong_bitstream_unpack +
@@ -811,7 +826,7 @@ int picsong_bpc_encode_component(picsong_ctx *c, int comp, const void *d_coeffs,
                                  void *stream)
 {
     if (!c || !d_coeffs || !d_staging || !d_sizes) return fail(PICSONG_ERR_ARG, "bpc_encode: null argument");
-    return bpc_encode_impl(c, d_coeffs, d_staging, d_sizes, true, (hipStream_t)stream, 0, -1, comp);
+    return bpc_encode_widened(c, d_coeffs, d_staging, d_sizes, (hipStream_t)stream, comp);
 }
 
 int picsong_bpc_decode_component(picsong_ctx *c, int comp, const int32_t *d_staging, const int32_t *d_sizes,
@@ -865,7 +880,10 @@ int picsong_last_total(picsong_ctx *c, void *stream, int *h_total)
     return PICSONG_OK;
 }
 
-static int pack_range(picsong_ctx *c, const int32_t *d_staging, const int32_t *d_sizes, int n,
+// W: uint16_t = the encoders' own staging (the frame paths), int32_t = a caller's array (picsong_bitstream_pack)
+extern "C++" {
+template <typename W>
+static int pack_range(picsong_ctx *c, const W *d_staging, const int32_t *d_sizes, int n,
                       const uint16_t *h_header, uint16_t *d_stream, hipStream_t s)
 {
     HeaderArg h;
@@ -874,10 +892,11 @@ static int pack_range(picsong_ctx *c, const int32_t *d_staging, const int32_t *d
     c->last_batch = 0;                                      // the most recent total is d_total (picsong_copy_last_totals)
     scan_sizes_kernel<<<1, scan_threads(n), 0, s>>>(d_sizes, n, c->d_offsets, c->d_total);
     HIP_TRY(hipGetLastError());
-    pack_kernel<<<(unsigned)n, 256, 0, s>>>(d_staging, d_sizes, c->d_offsets, c->d_total, n, h, d_stream);
+    pack_kernel<W><<<(unsigned)n, 256, 0, s>>>(d_staging, d_sizes, c->d_offsets, c->d_total, n, h, d_stream);
     HIP_TRY(hipGetLastError());
     return PICSONG_OK;
 }
+}  // extern "C++"
 
 int picsong_bitstream_pack(picsong_ctx *c, const int32_t *d_staging, const int32_t *d_sizes,
                            const uint16_t *h_header, uint16_t *d_stream, int *h_total, void *stream)
@@ -968,11 +987,12 @@ int picsong_encode_frame(picsong_ctx *c, const uint8_t *d_frame, int iter, uint1
     // ones with the most planes, the launch's critical waves, and the split starts exactly those 20-40 us late.)
     if ((rc = dwt_forward_impl(c, d_frame, true, c->d_coef, s, c->c16))) return rc;
     if (ev) HIP_TRY(hipEventRecord(ev[1], s));
-    if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, s, 0, -1, 0, c->c16))) return rc;
+    uint16_t *const st16 = reinterpret_cast<uint16_t *>(c->d_staging);      // (the context's staging holds the 16-bit form)
+    if ((rc = bpc_encode_impl(c, c->d_coef, st16, c->d_sizes, s, 0, -1, 0, c->c16))) return rc;
     if (ev) HIP_TRY(hipEventRecord(ev[2], s));
     uint16_t hdr[PICSONG_HDR_SHORTS];
     if (iter == 0) picsong_header_pack(&c->p, hdr);
-    rc = picsong_bitstream_pack(c, c->d_staging, c->d_sizes, iter == 0 ? hdr : nullptr, d_stream, nullptr, stream);
+    rc = pack_range(c, st16, c->d_sizes, c->ncb, iter == 0 ? hdr : nullptr, d_stream, s);
     if (ev) HIP_TRY(hipEventRecord(ev[3], s));
     c->last_batch = 0;                                      // the most recent call's total is d_total
     return rc;
@@ -1008,8 +1028,9 @@ int picsong_encode_stripe_coded(picsong_ctx *c, const void *d_coeffs, int cb_beg
     int rc = ensure_workspace(c, false);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = bpc_encode_impl(c, d_coeffs, c->d_staging, c->d_sizes, false, s, cb_begin, cb_count))) return rc;
-    return pack_range(c, c->d_staging + (size_t)cb_begin * PICSONG_CB_WORDS, c->d_sizes + cb_begin, cb_count, nullptr,
+    uint16_t *const st16 = reinterpret_cast<uint16_t *>(c->d_staging);
+    if ((rc = bpc_encode_impl(c, d_coeffs, st16, c->d_sizes, s, cb_begin, cb_count))) return rc;
+    return pack_range(c, st16 + (size_t)cb_begin * PICSONG_CB_WORDS, c->d_sizes + cb_begin, cb_count, nullptr,
                       d_stream, s);
 }
 
@@ -1024,8 +1045,9 @@ int picsong_encode_frame_stripe(picsong_ctx *c, const uint8_t *d_frame, int cb_b
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     if ((rc = dwt_forward_impl(c, d_frame, true, c->d_coef, s))) return rc;
-    if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, s, cb_begin, cb_count))) return rc;
-    return pack_range(c, c->d_staging + (size_t)cb_begin * PICSONG_CB_WORDS, c->d_sizes + cb_begin, cb_count, nullptr,
+    uint16_t *const st16 = reinterpret_cast<uint16_t *>(c->d_staging);
+    if ((rc = bpc_encode_impl(c, c->d_coef, st16, c->d_sizes, s, cb_begin, cb_count))) return rc;
+    return pack_range(c, st16 + (size_t)cb_begin * PICSONG_CB_WORDS, c->d_sizes + cb_begin, cb_count, nullptr,
                       d_stream, s);
 }
 
@@ -1125,7 +1147,8 @@ int picsong_encode_frames(picsong_ctx *c, int n, const uint8_t *d_frames, size_t
     const int wpf = (c->ncb + 1) / 2;
     a.cb_base = 0; a.nCB = c->ncb;
     a.coeffs_in = c->b_coef; a.is_float = c->p.lossy ? 1 : 0;
-    a.staging = c->b_staging; a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch;
+    a.staging16 = reinterpret_cast<uint16_t *>(c->b_staging);   // (16-bit staging: frame f's at + f * P shorts)
+    a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch;
     a.frames = n; a.waves_per_frame = wpf; a.coef_z = coef_z;
     const size_t waves = (size_t)n * (size_t)wpf;
     bpc_encode_kernel<false><<<(unsigned)((waves + kBpcEncWgWaves - 1) / kBpcEncWgWaves), 64 * kBpcEncWgWaves, 0, s>>>(a);
@@ -1143,8 +1166,8 @@ int picsong_encode_frames(picsong_ctx *c, int n, const uint8_t *d_frames, size_t
     }
     scan_sizes_kernel<<<(unsigned)n, scan_threads(c->ncb), 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
     HIP_TRY(hipGetLastError());
-    pack_kernel<<<dim3((unsigned)c->ncb, (unsigned)n), 256, 0, s>>>(c->b_staging, c->b_sizes, c->b_offsets, c->b_total,
-                                                                    c->ncb, h, d_streams, c->P, stream_stride);
+    pack_kernel<uint16_t><<<dim3((unsigned)c->ncb, (unsigned)n), 256, 0, s>>>(a.staging16, c->b_sizes, c->b_offsets, c->b_total,
+                                                                              c->ncb, h, d_streams, c->P, stream_stride);
     HIP_TRY(hipGetLastError());
     if (ev) HIP_TRY(hipEventRecord(ev[3], s));
     c->last_batch = n;
@@ -1280,10 +1303,11 @@ int picsong_encode_plane(picsong_ctx *c, const void *d_plane, int comp, int with
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     if ((rc = dwt_forward_impl(c, d_plane, false, c->d_coef, s))) return rc;
-    if ((rc = bpc_encode_impl(c, c->d_coef, c->d_staging, c->d_sizes, false, s, 0, -1, comp))) return rc;
+    uint16_t *const st16 = reinterpret_cast<uint16_t *>(c->d_staging);
+    if ((rc = bpc_encode_impl(c, c->d_coef, st16, c->d_sizes, s, 0, -1, comp))) return rc;
     uint16_t hdr[PICSONG_HDR_SHORTS];
     if (with_header) picsong_header_pack(&c->p, hdr);
-    return pack_range(c, c->d_staging, c->d_sizes, c->ncb, with_header ? hdr : nullptr, d_stream, s);
+    return pack_range(c, st16, c->d_sizes, c->ncb, with_header ? hdr : nullptr, d_stream, s);
 }
 
 int picsong_decode_plane(picsong_ctx *c, const uint16_t *d_stream, int comp, void *d_plane_out, void *stream)
@@ -1367,7 +1391,8 @@ int picsong_encode_rgb_frame(picsong_ctx *c, const uint8_t *d_r, const uint8_t *
     }
     // ---- coder: one grid over the three components' codeblock pairs, component f with table f
     a.coeffs_in = c->b_coef; a.is_float = c->p.lossy ? 1 : 0;
-    a.staging = c->b_staging; a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch; a.coef_z = coef_z;
+    a.staging16 = reinterpret_cast<uint16_t *>(c->b_staging);
+    a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch; a.coef_z = coef_z;
     bpc_encode_kernel<false><<<(unsigned)(3 * a.waves_per_frame / kBpcEncWgWaves), 64 * kBpcEncWgWaves, 0, s>>>(a);
     HIP_TRY(hipGetLastError());
     // ---- pack: the populated header on the components of header_mask
@@ -1381,7 +1406,7 @@ int picsong_encode_rgb_frame(picsong_ctx *c, const uint8_t *d_r, const uint8_t *
     }
     scan_sizes_kernel<<<3, scan_threads(c->ncb), 0, s>>>(c->b_sizes, c->ncb, c->b_offsets, c->b_total);
     HIP_TRY(hipGetLastError());
-    pack_kernel<<<dim3((unsigned)c->ncb, 3u), 256, 0, s>>>(c->b_staging, c->b_sizes, c->b_offsets, c->b_total, c->ncb, h,
+    pack_kernel<uint16_t><<<dim3((unsigned)c->ncb, 3u), 256, 0, s>>>(a.staging16, c->b_sizes, c->b_offsets, c->b_total, c->ncb, h,
                                                           d_streams, c->P, stream_stride);
     HIP_TRY(hipGetLastError());
     c->last_batch = 3;

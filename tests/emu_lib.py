@@ -252,6 +252,17 @@ def pack(staging, sizes, header=None):
     return out[:total].copy()
 
 
+def pack16(staging16, sizes, header=None):
+    """pack_kernel over the encoders' 16-bit staging (the frame paths' form)."""
+    staging16 = np.ascontiguousarray(staging16, np.uint16)
+    sizes = np.ascontiguousarray(sizes, np.int32)
+    n = sizes.size
+    out = np.zeros(9 + 2 * n + int(sizes.sum()) + 1, np.uint16)
+    hp = _p(np.ascontiguousarray(header, np.uint16)) if header is not None else None
+    total = lib().emu_pack16(_p(staging16), _p(sizes), n, hp, _p(out))
+    return out[:total].copy()
+
+
 def unpack(stream, n_cb):
     stream = np.ascontiguousarray(stream, np.uint16)
     staging = np.empty(n_cb * 4096, np.int32)

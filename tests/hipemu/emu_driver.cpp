@@ -268,28 +268,35 @@ static BpcArgs mk(int aw, int ah, int wl, const int32_t *lut, const int *geo, in
 void emu_bpc_encode_range(const void *coeffs, int is_float, int aw, int ah, int wl, const int32_t *lut, const int *geo,
                           int32_t *staging, int32_t *sizes, int *flag, int cb_begin, int cb_count)
 {
-    BpcArgs a = mk(aw, ah, wl, lut, geo, staging, sizes, flag);
+    BpcArgs a = mk(aw, ah, wl, lut, geo, nullptr, sizes, flag);
     a.coeffs_in = coeffs; a.is_float = is_float;
     a.k = 0.0f; a.n_tables = 1;
     if (cb_count < 0) cb_count = a.nCB - cb_begin;
+    std::vector<uint16_t> st16((size_t)a.nCB * 4096, 0xDEADu);        // the encoders' 16-bit staging, poisoned
+    a.staging16 = st16.data();
     a.cb_base = cb_begin; a.nCB = cb_begin + cb_count;
     const unsigned wgs = (unsigned)(((cb_count + 1) / 2 + kBpcEncWgWaves - 1) / kBpcEncWgWaves);
     std::vector<uint32_t> plane_scratch((size_t)wgs * kBpcEncWgWaves * kEncScratchDwordsPerWave, 0xDEADBEEFu);
     a.plane_scratch = plane_scratch.data();
     emu::launch(dim3(wgs), dim3(64 * kBpcEncWgWaves), [&] { bpc_encode_kernel<false>(a); });
+    // (as picsong_bpc_encode: widened into the caller's int32 array, words 0 .. len - 1 of the range's codeblocks)
+    emu::launch(dim3((unsigned)cb_count), dim3(256), [&] { widen_staging_kernel(st16.data(), sizes, cb_begin, staging); });
 }
 
 void emu_bpc_encode(const void *coeffs, int is_float, int aw, int ah, int wl, const int32_t *lut, const int *geo,
                     int32_t *staging, int32_t *sizes, int *flag, float k, int n_tables)
 {
-    BpcArgs a = mk(aw, ah, wl, lut, geo, staging, sizes, flag);
+    BpcArgs a = mk(aw, ah, wl, lut, geo, nullptr, sizes, flag);
     a.coeffs_in = coeffs; a.is_float = is_float;
     a.k = k; a.n_tables = n_tables;
+    std::vector<uint16_t> st16((size_t)a.nCB * 4096, 0xDEADu);
+    a.staging16 = st16.data();
     std::vector<uint32_t> plane_scratch((size_t)(((a.nCB + 1) / 2 + kBpcEncWgWaves - 1) / kBpcEncWgWaves * kBpcEncWgWaves) * kEncScratchDwordsPerWave, 0xDEADBEEFu);
     a.plane_scratch = plane_scratch.data();
     memset(staging, 0xFF, (size_t)aw * ah * 4);
     if (k > 0.0f) emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_encode_kernel<true>(a); });
     else emu::launch(dim3((unsigned)(((a.nCB + 1) / 2 + kBpcEncWgWaves - 1) / kBpcEncWgWaves)), dim3(64 * kBpcEncWgWaves), [&] { bpc_encode_kernel<false>(a); });
+    emu::launch(dim3((unsigned)a.nCB), dim3(256), [&] { widen_staging_kernel(st16.data(), sizes, 0, staging); });
 }
 
 void emu_bpc_decode(const int32_t *staging, const int32_t *sizes, int aw, int ah, int wl, const int32_t *lut,
@@ -337,10 +344,13 @@ int emu_bpc_decode_stream(const uint16_t *stream, unsigned stream_shorts, int aw
 void emu_bpc3_encode(const void *coeffs, int is_float, int aw, int ah, int wl, const int32_t *lut, const int *geo,
                      int32_t *staging, int32_t *sizes, int *flag)
 {
-    BpcArgs a = mk(aw, ah, wl, lut, geo, staging, sizes, flag);
+    BpcArgs a = mk(aw, ah, wl, lut, geo, nullptr, sizes, flag);
     a.coeffs_in = coeffs; a.is_float = is_float; a.n_tables = 1;
+    std::vector<uint16_t> st16((size_t)a.nCB * 4096, 0xDEADu);
+    a.staging16 = st16.data();
     memset(staging, 0xFF, (size_t)aw * ah * 4);
     emu::launch(dim3((unsigned)(((a.nCB + 1) / 2 + kBpc3WgWaves - 1) / kBpc3WgWaves)), dim3(64 * kBpc3WgWaves), [&] { bpc3_kernel<false>(a); });
+    emu::launch(dim3((unsigned)a.nCB), dim3(256), [&] { widen_staging_kernel(st16.data(), sizes, 0, staging); });
 }
 
 void emu_bpc3_decode(const int32_t *staging, const int32_t *sizes, int aw, int ah, int wl, const int32_t *lut,
@@ -359,7 +369,20 @@ int emu_pack(const int32_t *staging, const int32_t *sizes, int ncb, const uint16
     memset(&h, 0, sizeof h);
     if (header) { memcpy(h.h, header, sizeof h.h); h.has = 1; }
     emu::launch(dim3(1), dim3(scan_threads(ncb)), [&] { scan_sizes_kernel(sizes, ncb, offsets.data(), &total); });
-    emu::launch(dim3((unsigned)ncb), dim3(256), [&] { pack_kernel(staging, sizes, offsets.data(), &total, ncb, h, out); });
+    emu::launch(dim3((unsigned)ncb), dim3(256), [&] { pack_kernel<int32_t>(staging, sizes, offsets.data(), &total, ncb, h, out); });
+    return total;
+}
+
+// the same from the encoders' 16-bit staging (the frame paths' pack)
+int emu_pack16(const uint16_t *staging16, const int32_t *sizes, int ncb, const uint16_t *header, uint16_t *out)
+{
+    std::vector<int32_t> offsets(ncb);
+    int32_t total = 0;
+    HeaderArg h;
+    memset(&h, 0, sizeof h);
+    if (header) { memcpy(h.h, header, sizeof h.h); h.has = 1; }
+    emu::launch(dim3(1), dim3(scan_threads(ncb)), [&] { scan_sizes_kernel(sizes, ncb, offsets.data(), &total); });
+    emu::launch(dim3((unsigned)ncb), dim3(256), [&] { pack_kernel<uint16_t>(staging16, sizes, offsets.data(), &total, ncb, h, out); });
     return total;
 }
 

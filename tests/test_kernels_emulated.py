@@ -211,6 +211,8 @@ def test_pack_unpack_kernels(oracle, E):
         ref = oracle.bitstream_pack(staging, sizes, h)
         got = E.pack(staging, sizes, h)
         assert np.array_equal(got, ref)
+        # the frame paths' form: the encoders' 16-bit staging (what lies beyond a codeblock's length is never read)
+        assert np.array_equal(E.pack16(staging.astype(np.uint16), sizes, h), ref)
     st2, sz2 = E.unpack(ref, n_cb)
     assert np.array_equal(sz2, sizes) and np.array_equal(st2, staging)
 
