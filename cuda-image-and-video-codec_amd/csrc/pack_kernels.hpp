@@ -111,16 +111,44 @@ __global__ __launch_bounds__(256) void pack_kernel(const W *staging, const int32
     const W *st = staging + (size_t)cb * 4096u;
     const int len = sizes[cb];
     uint16_t *dst = out + 9 + 2 * (size_t)n + (size_t)offsets[cb];
-    // a codeblock is at most 4096 words: 16 a thread, in two groups of eight whose loads all go out before the first
-    // store (one load, one wait, one store per trip left every wave parked on a round trip per element)
+    if constexpr (sizeof(W) == 2) {
+        // 16-bit staging: the copy moves PAIRS of words -- a dword load from staging word 1 + 2 p, a dword store to
+        // stream short 2 p (either may sit at an odd short: the target takes unaligned dword accesses) -- so a codeblock's
+        // 4095 words are at most eight pairs a thread, all eight loads ahead of the stores; an odd count's last word is
+        // stored as a short.
+        const int nw = len - 1, np = (nw + 1) >> 1;
+        uint32_t v[8];
+        if (np > 0) {
 #pragma unroll
-    for (int k = 0; k < 16; k += 8) {
-        if (1 + 256 * k >= len) break;                      // (uniform: the whole workgroup is done)
-        W v[8];
+            for (int q = 0; q < 8; q++) {
+                // (no branch around a load: a thread without a pair re-reads the last one; the one pair that would
+                // reach past the codeblock's 4096 words -- word 4095 of a raw block -- reads words 4094, 4095 instead)
+                const int pr = tid + 256 * q, pc = pr < np ? pr : np - 1;
+                const int w0 = 1 + 2 * pc, wl = w0 < 4094 ? w0 : 4094;
+                __builtin_memcpy(&v[q], st + wl, 4);
+                if (wl != w0) v[q] >>= 16;
+            }
+        }
 #pragma unroll
-        for (int q = 0; q < 8; q++) { const int j = 1 + tid + 256 * (k + q); v[q] = j < len ? st[j] : (W)0; }
+        for (int q = 0; q < 8; q++) {
+            const int pr = tid + 256 * q;
+            if (pr < np) {
+                if (2 * pr + 1 < nw) __builtin_memcpy(dst + 2 * pr, &v[q], 4);
+                else dst[2 * pr] = (uint16_t)v[q];
+            }
+        }
+    } else {
+        // a codeblock is at most 4096 words: 16 a thread, in two groups of eight whose loads all go out before the first
+        // store (one load, one wait, one store per trip left every wave parked on a round trip per element)
 #pragma unroll
-        for (int q = 0; q < 8; q++) { const int j = 1 + tid + 256 * (k + q); if (j < len) dst[j - 1] = (uint16_t)v[q]; }
+        for (int k = 0; k < 16; k += 8) {
+            if (1 + 256 * k >= len) break;                  // (uniform: the whole workgroup is done)
+            W v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { const int j = 1 + tid + 256 * (k + q); v[q] = j < len ? st[j] : (W)0; }
+#pragma unroll
+            for (int q = 0; q < 8; q++) { const int j = 1 + tid + 256 * (k + q); if (j < len) dst[j - 1] = (uint16_t)v[q]; }
+        }
     }
     if (tid == 0) {
         out[9 + 2 * cb] = (uint16_t)st[0];
