@@ -181,7 +181,10 @@ int picsong_last_total(picsong_ctx *ctx, void *stream, int *h_total);
  *      writes the populated header.  Asynchronous; length via picsong_last_total().
  *      picsong_decode_frame reads the stream's own shorts and nothing beyond them (k = 0, -cp 2: the coder
  *      takes its codewords from d_stream itself; otherwise through the staging, as
- *      picsong_bitstream_unpack does); lengths outside 1..4096 are clamped and raise the range flag. ---- */
+ *      picsong_bitstream_unpack does); lengths outside 1..4096 are clamped and raise the range flag.  A
+ *      DAMAGED length table can still claim more codewords than the stream holds: reads then reach up to
+ *      picsong_max_stream_shorts() shorts, so an untrusted stream belongs in a buffer of that size (as with
+ *      picsong_bitstream_unpack). ---- */
 int picsong_encode_frame(picsong_ctx *ctx, const uint8_t *d_frame, int iter, uint16_t *d_stream,
                          void *stream);
 int picsong_decode_frame(picsong_ctx *ctx, const uint16_t *d_stream, uint8_t *d_frame_out,
