@@ -1,3 +1,6 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/ab_c16.sh  -- the bench and the decode bench with the encode frame paths' int16 coefficients
+# off / on (PICSONG_C16=0 / 1), one summary line per run
 for v in 0 1; do
   echo "== PICSONG_C16=$v"
   PICSONG_C16=$v python tools/decode_bench.py --streams=3 2>&1 | grep decode

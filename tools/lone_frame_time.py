@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Single-frame encode / decode calls on one stream, timed from Python (wall clock over 30 calls, launch overhead
+included) at 8K and 4K: what an image codec's caller sees (profiles/r03_lone_frame.txt).  PICSONG_SO selects a library."""
 import os, sys, time
 sys.path.insert(0, "cuda-image-and-video-codec_amd/python"); sys.path.insert(0, "tests")
 import torch, oracle_lib as orc, picsong_amd as pa
