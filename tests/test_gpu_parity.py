@@ -760,6 +760,48 @@ def test_pipelined_hint_changes_launches_not_results(oracle, pa, torch):
         assert np.array_equal(got[0], ref) and np.array_equal(got[1], ref)
 
 
+def test_random_geometries_through_the_frame_paths(oracle, pa, torch):
+    """Seeded random W x H, wl, transform and content (synthetic, noise = raw blocks, flat = empty blocks, mixed) through
+    the frame paths: the codestream is the oracle's, the decode -- which reads it straight from an EXACT-length buffer --
+    the oracle's pixels, and a three-frame batched call writes the same payload (tools/fuzz_parity.py is the longer run)."""
+    rng = np.random.default_rng(11)
+    oracle.set_threads(oracle.usable_threads())
+    try:
+        for case in range(10):
+            W, H = int(rng.integers(65, 1500)), int(rng.integers(65, 900))
+            lossy = bool(rng.integers(0, 2))
+            wl = int(rng.integers(1, 7))
+            while (oracle.pad_dim(W) >> wl) < 2 or (oracle.pad_dim(H) >> wl) < 2:
+                wl -= 1
+            qs = float(rng.choice([1.0, 0.5])) if lossy else 1.0
+            kind = case % 4
+            img = oracle.gen_frame(W, H, case)
+            if kind == 1:
+                img = rng.integers(0, 256, (H, W), dtype=np.uint8)
+            elif kind == 2:
+                img = np.full((H, W), 77, np.uint8)
+            elif kind == 3:
+                img[: H // 2] = rng.integers(0, 256, (H // 2, W), dtype=np.uint8)
+            lut = oracle.lut_for(lossy, wl)
+            ref = oracle.encode_frame(img, wl, lossy, qs, lut)
+            c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=_lutdir(oracle, lossy))
+            frame = _dev(torch, oracle.pad_frame(img))
+            s = c.encode_frame(frame)
+            what = f"case {case}: {W}x{H} wl {wl} lossy {lossy} qs {qs} kind {kind}"
+            assert s.numel() == ref.size and np.array_equal(s.cpu().numpy().view(np.uint16), ref), what
+            got = c.decode_frame(s.clone()).cpu().numpy()[:H, :W]
+            want = img if not lossy else oracle.decode_frame(ref, W, H, wl, lossy, qs, lut)
+            assert np.array_equal(got, want), what
+            frames = torch.stack([frame.view(-1)] * 3)
+            out = torch.empty((3, c.max_stream_shorts()), dtype=torch.int16, device="cuda")
+            c.encode_frames_async(frames, out, 1)
+            torch.cuda.synchronize()
+            assert torch.equal(out[2, 9:s.numel()], s[9:]), what   # (frames 1.. of a video carry no header)
+            c.close()
+    finally:
+        oracle.set_threads(1)
+
+
 def test_damaged_streams_decode_without_leaving_their_buffers(oracle, pa, torch):
     """Garbage in: every length is clamped into 1..4096 and every MSB into 0..15 (range flag set), the
     decoder's loops are bounded by 16 planes x 64 rows, codeword slots by 4094 -- so a damaged stream
