@@ -392,7 +392,18 @@ __device__ __forceinline__ PlaneLut plane_lut(const LutView &v, const LutGeo &g,
 // k = 0: every codeblock of the workgroup uses table 0; every thread copies its share of it
 __device__ __forceinline__ void lut_to_lds(const int32_t *lut, int total, uint8_t *lds)
 {
-    for (int j = (int)threadIdx.x; j < total; j += (int)blockDim.x) lds[j] = (uint8_t)((uint32_t)lut[j] & 0xFFu);
+    // Eight loads in flight a thread, no branch around a load (an index that stays inside).  The plain loop -- a load, its
+    // wait, a byte store per trip -- was 13 round trips to the L2 one after the other at the start of every workgroup of
+    // both coders (105 at the start of every -k > 0 wave: bulk_setup).
+    const int nt = (int)blockDim.x;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (int base = (int)threadIdx.x; base < total; base += 8 * nt) {
+        int32_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int j = base + q * nt; v[q] = lut[j < total ? j : total - 1]; }
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int j = base + q * nt; if (j < total) lds[j] = (uint8_t)((uint32_t)v[q] & 0xFFu); }
+    }
     __syncthreads();
 }
 // Workgroup shape of the k = 0 coder kernels: 4 waves = 8 codeblocks, so that the dispatcher hands a
@@ -977,7 +988,15 @@ __device__ __forceinline__ int bulk_setup(const BpcArgs &a, bool coded, int msb,
         if (s > a.n_tables - 1) s = a.n_tables - 1;
     }
     loff = s * total;
-    for (int j = (int)t; j < total; j += 32) lds_half[j] = (uint8_t)((uint32_t)a.lut[loff + j] & 0xFFu);
+    // (eight loads in flight a lane, as lut_to_lds)
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+    for (int base = (int)t; base < total; base += 8 * 32) {
+        int32_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int j = base + q * 32; v[q] = a.lut[loff + (j < total ? j : total - 1)]; }
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int j = base + q * 32; if (j < total) lds_half[j] = (uint8_t)((uint32_t)v[q] & 0xFFu); }
+    }
     __syncthreads();
     b.Bh = coded ? (msb < cbp - 1 ? msb : cbp - 1) : -1;
     b.cRef = (uint32_t)a.g.cRef; b.cSig = (uint32_t)a.g.cSig; b.cSign = (uint32_t)a.g.cSign;

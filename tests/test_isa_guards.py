@@ -100,8 +100,8 @@ def test_coder_kernels_keep_their_plane_loops_free_of_scratch(device_asm):
     frame."""
     # (the decoder twice: from the 32-bit staging, and the frame paths' instantiation that reads the packed stream)
     for key, first, most, frame in (("17bpc_encode_kernelILb0E", "v_mul_u32_u24", 8, 320),
-                                    ("17bpc_decode_kernelILb0ELi8ELb0E", "v_bcnt_u32_b32", 64, 192),
-                                    ("17bpc_decode_kernelILb0ELi8ELb1E", "v_bcnt_u32_b32", 72, 192)):
+                                    ("17bpc_decode_kernelILb0ELi8ELb0E", "v_bcnt_u32_b32", 80, 192),
+                                    ("17bpc_decode_kernelILb0ELi8ELb1E", "v_bcnt_u32_b32", 80, 192)):
         body = _kernel_body(device_asm, key)
         i0 = next(i for i, ln in enumerate(body) if first in ln)
         tail = [ln for ln in body[i0:] if re.match(r"^\s*scratch_", ln)]
