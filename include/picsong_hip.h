@@ -147,7 +147,9 @@ int picsong_dwt_forward_u8(picsong_ctx *ctx, const uint8_t *d_in, void *d_out, v
 /* ---- BPC: BPCEngine<T>::kernelLauncher(CODE|DECODE) BPC/BPCEngine.cu:2307-2424 preceded by
  *      deviceMemoryAllocator's 0xFF memset (:2429-2441).  d_coeffs: Mallat T[AW*AH];
  *      d_staging: int32[AW*AH] (4096 per codeblock: [0] = MSB, [1..len) codewords);
- *      d_sizes: int32[nCB]. ---- */
+ *      d_sizes: int32[nCB].  (The encoders themselves keep a 16-bit staging -- no staging word holds more
+ *      than 16 bits -- in a buffer of the context; picsong_bpc_encode fills d_staging with 0xFF bytes and
+ *      widens words [0, len) of every codeblock into it: the array a caller sees is the reference's.) ---- */
 int picsong_bpc_encode(picsong_ctx *ctx, const void *d_coeffs, int32_t *d_staging,
                        int32_t *d_sizes, void *stream);
 int picsong_bpc_decode(picsong_ctx *ctx, const int32_t *d_staging, const int32_t *d_sizes,
