@@ -1009,8 +1009,12 @@ __device__ __forceinline__ int bulk_setup(const BpcArgs &a, bool coded, int msb,
 
 // Waves per SIMD the register allocator must leave room for (512 VGPRs per SIMD lane: 8 waves = 64,
 // 7 = 72, 6 = 80, 5 = 96).  Round 1 (8 planes resident): 5.  With one plane resident the kernel fits 64.
+// The k = 0 encoder: 6 (80 registers) since the end of round 3 -- its plane loops need fewer, the prologue spills a few
+// dwords more (frame 244 -> 304 bytes, five scratch instructions in the loops as before), and with three calls in flight
+// 4 / 5 / 6 / 7 / 8 waves give 167.7 / 188.0 / 191.8 / 187.0 / 183.9 Gpixel/s at 8K (4K: 186.1 -> 190.5; a lone frame
+// loses 1 %).  The -k > 0 instantiation keeps 5.
 #ifndef PICSONG_BPC_ENC_WAVES
-#define PICSONG_BPC_ENC_WAVES 5
+#define PICSONG_BPC_ENC_WAVES 6
 #endif
 
 // one row (two coefficients of the lane) of the coefficient array as magnitudes and sign bits
@@ -1151,7 +1155,7 @@ __device__ __forceinline__ void enc_transpose_pass(const BpcArgs &a, int pass, u
 // BULK = the -k > 0 instantiation (bulk scan after the ordinary planes, table s of the bit-plane
 // LUT files, LDS copy of that table); the k = 0 instantiation compiles to the plain coder.
 template <bool BULK>
-__global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(BpcArgs a)
+__global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, BULK ? 5 : PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(BpcArgs a)
 {
     __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
     __shared__ uint32_t lds_cnt[2 * (BULK ? 1 : kBpcEncWgWaves)];      // codeword counters of the workgroup's codeblocks
