@@ -410,9 +410,11 @@ def main():
 
     W, H, wl, lossy, qs = WORKLOADS[args.workload]
     lut_dir = os.path.join(orc.LUT_DIR, "n1_lossy" if lossy else "n1_lossless")
-    # defaults by workload (measured, tools/ab.sh): an 8K frame is 4080 coder waves, a 4K frame 1020 -- one
-    # per SIMD -- so 4K frames go four to a call
-    batch = args.batch if args.batch > 0 else (4 if W * H <= 3840 * 2160 else 1)
+    # defaults by workload (measured at the end of round 3, three streams): an 8K frame is 4080 coder waves, a 4K frame
+    # 1020 -- one per SIMD -- so 4K frames go six to a call (4 / 6 / 8 / 12: 187.8 / 194.5 / 194.1 / 192.9 Gpixel/s); 8K
+    # frames three (1 / 2 / 3 / 6: 192.7 / 195.0 / 195.3 / 194.8: the transform's level launches serve three frames),
+    # 8K 9/7 frames six (1 / 2 / 3 / 4 / 6: 197.1 / 208.8 / 215.9 / 219.1 / 221.5: its transform is what gains)
+    batch = args.batch if args.batch > 0 else (6 if (W * H <= 3840 * 2160 or lossy) else 3)
     nstreams = args.streams if args.streams > 0 else 3
     fps = max(batch, (args.frames_per_step // batch) * batch)          # frames per step: whole calls
     pool_n = max(batch, (max(args.pool, 1) + batch - 1) // batch * batch)
@@ -698,7 +700,15 @@ def main():
                     "single_stream": {"avg_launch_ms": round(float(iso_ms[0]) * batch, 4),
                                       "achieved": round(dwt_b / (float(iso_ms[0]) * batch * 1e-3) / 1e9, 2),
                                       "frac": round(dwt_b / (float(iso_ms[0]) * batch * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-                    "three_frames_per_call": None if b3_ms is None else {
+                    # a lone frame per call (lone_frame's transform stage): what the launches cost with nothing to share
+                    "lone_frame": {"ms": round(float(lone_ms[0]), 4),
+                                   "achieved": round(dwt_b / batch / (float(lone_ms[0]) * 1e-3) / 1e9, 2),
+                                   "frac": round(dwt_b / batch / (float(lone_ms[0]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                    # (batch = 3: `single_stream` IS the three-frames-per-call shape; batch = 1: measured on the side)
+                    "three_frames_per_call": ({"ms_per_frame": round(float(iso_ms[0]), 4),
+                                               "achieved": round(dwt_b / batch / (float(iso_ms[0]) * 1e-3) / 1e9, 2),
+                                               "frac": round(dwt_b / batch / (float(iso_ms[0]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                                              if batch == 3 else None) if b3_ms is None else {
                         "ms_per_frame": round(float(b3_ms[0]), 4),
                         "achieved": round(dwt_b / batch / (float(b3_ms[0]) * 1e-3) / 1e9, 2),
                         "frac": round(dwt_b / batch / (float(b3_ms[0]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
@@ -708,7 +718,8 @@ def main():
                     "note": "all of a frame's level launches counted as one; `achieved` uses HIP-event times "
                             "inside the timed region, where the calls of the other stream(s) share the GPU; "
                             "`single_stream` is the same call shape on one stream with nothing else running, "
-                            "`three_frames_per_call` likewise with picsong_encode_frames over three frames (the level "
+                            "`lone_frame` one frame per call, "
+                            "`three_frames_per_call` picsong_encode_frames over three frames on one stream (the level "
                             "launches serve three frames each); the "
                             "input frames rotate over a pool larger than the Infinity Cache, so every frame's "
                             "pixels come from HBM; `measured_roof` is a plain device copy / fill of a 134 MB plane"}

@@ -15,9 +15,9 @@ echo "bench done"
 S="--steps 2 --warmup 1 --frames-per-step 12 --no-cpu-baseline --no-b3"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_default -- python3 bench.py $S > $out/bench_prof_default.json 2> $out/prof_default.err
 echo "prof default done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_single -- python3 bench.py $S --streams 1 > $out/bench_prof_single.json 2> $out/prof_single.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_single -- python3 bench.py $S --streams 1 --batch 1 > $out/bench_prof_single.json 2> $out/prof_single.err
 echo "prof single done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_lossy -- python3 bench.py $S --streams 1 --workload 8k_lossy > $out/bench_prof_lossy.json 2> $out/prof_lossy.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_lossy -- python3 bench.py $S --streams 1 --batch 1 --workload 8k_lossy > $out/bench_prof_lossy.json 2> $out/prof_lossy.err
 echo "prof lossy done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_4k -- python3 bench.py $S --workload 4k_lossless > $out/bench_prof_4k.json 2> $out/prof_4k.err
 echo "prof 4k done"

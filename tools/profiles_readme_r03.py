@@ -50,8 +50,8 @@ hW = [hb[k] for k in hk if k[1] == "WRITE_SIZE"][0]
 dec_lines = [l.strip() for l in open(P + "decode.txt") if l.startswith("decode")]
 vb = b["roofline"]["valu_busy"]
 rows = []
-rows.append(f"| `r03_bench.json` | the default bench line: 8K lossless, 3 streams x 1 frame per call, {b['steps']} steps x {b['config']['frames_per_step']} frames ({b['timed_seconds']} s timed): **{b['value'] / 1e3:.1f} Gpixel/s, {b['ms_per_frame']:.4f} ms/frame** (round 2: 160.0); a lone frame (`lone_frame`) {lf['ms']:.3f} ms = {lf['mpixels_per_s'] / 1e3:.1f} Gpixel/s: DWT {lf['stage_ms']['dwt']:.4f} / coder {lf['stage_ms']['bpc']:.4f} / pack {lf['stage_ms']['pack']:.4f} ms; DWT of a lone frame {rd['single_stream']['frac']:.2f} of 8 TB/s, three frames per call {rd['three_frames_per_call']['ms_per_frame']:.4f} ms per frame = {rd['three_frames_per_call']['frac']:.2f} (the coded subbands leave the transform as int16: fewer bytes move than the algorithmic count assumes); coder `traffic` {b['roofline']['traffic'] / 1e6:.1f} MB = {b['roofline']['traffic'] / b['roofline']['algorithmic_bytes_per_launch']:.2f} x algorithmic; `valu_busy` {vb['lone_kernel']['VALUBusy']:.2f} lone / {vb['pipelined']['VALUBusy_same_definition']:.2f} pipelined; CPU baseline {b['cpu_baseline']['value']:.1f} Mpixel/s on 16 threads, same codestream; `roofline.source`: the counters quoted are this library's |")
-rows.append(f"| `r03_bench_4k.json`, `r03_bench_8k_lossy.json` | `--workload 4k_lossless`: **{b4['value'] / 1e3:.1f} Gpixel/s** (a lone 4K frame {b4['lone_frame']['mpixels_per_s'] / 1e3:.1f}); `--workload 8k_lossy`: **{bl['value'] / 1e3:.1f} Gpixel/s**, PSNR {bl.get('psnr_db')} dB, DWT lone {rdl['single_stream']['frac']:.3f} / three frames per call **{rdl['three_frames_per_call']['frac']:.3f}** of 8 TB/s by the bench's events |")
+rows.append(f"| `r03_bench.json` | the default bench line: 8K lossless, 3 streams x {b['config']['frames_per_call']} frames per call, {b['steps']} steps x {b['config']['frames_per_step']} frames ({b['timed_seconds']} s timed): **{b['value'] / 1e3:.1f} Gpixel/s, {b['ms_per_frame']:.4f} ms/frame** (round 2: 160.0); a lone frame (`lone_frame`) {lf['ms']:.3f} ms = {lf['mpixels_per_s'] / 1e3:.1f} Gpixel/s: DWT {lf['stage_ms']['dwt']:.4f} / coder {lf['stage_ms']['bpc']:.4f} / pack {lf['stage_ms']['pack']:.4f} ms; DWT of a lone frame {rd['lone_frame']['frac']:.2f} of 8 TB/s, three frames per call {rd['three_frames_per_call']['ms_per_frame']:.4f} ms per frame = {rd['three_frames_per_call']['frac']:.2f} (the coded subbands leave the transform as int16: fewer bytes move than the algorithmic count assumes); coder `traffic` {b['roofline']['traffic'] / 1e6:.1f} MB = {b['roofline']['traffic'] / b['roofline']['algorithmic_bytes_per_launch']:.2f} x algorithmic; `valu_busy` {vb['lone_kernel']['VALUBusy']:.2f} lone / {vb['pipelined']['VALUBusy_same_definition']:.2f} pipelined; CPU baseline {b['cpu_baseline']['value']:.1f} Mpixel/s on 16 threads, same codestream; `roofline.source`: the counters quoted are this library's |")
+rows.append(f"| `r03_bench_4k.json`, `r03_bench_8k_lossy.json` | `--workload 4k_lossless`: **{b4['value'] / 1e3:.1f} Gpixel/s** (a lone 4K frame {b4['lone_frame']['mpixels_per_s'] / 1e3:.1f}); `--workload 8k_lossy`: **{bl['value'] / 1e3:.1f} Gpixel/s**, PSNR {bl.get('psnr_db')} dB, DWT lone {rdl['lone_frame']['frac']:.3f} / {bl['config']['frames_per_call']} frames per call **{rdl['single_stream']['frac']:.3f}** of 8 TB/s by the bench's events |")
 rows.append(f"| `r03_bench_8k_b3.json`, `r03_bench_8k_lossy_b3.json` | `--streams 1 --batch 3`: {b3['value'] / 1e3:.1f} / {bl3['value'] / 1e3:.1f} Gpixel/s |")
 rows.append(f"| `r03_kernel_stats_single_stream.csv` | `rocprofv3 --kernel-trace --stats`, `--streams 1`: `bpc_encode_kernel<false>` **{coder:.1f} us** (r02: 254), `dwt_fwd2_kernel<int, ..., true>` (levels 0 + 1, int16 subbands) **{head:.1f} us** (r02: 31.3) + 3 x {lv[1]:.1f} us = {head + 3 * lv[1]:.1f} us = **{255.9 / (head + 3 * lv[1]) / 8:.2f} of 8 TB/s for a lone frame**, pack {pack:.1f}, scan {scan:.1f} us |")
 h3, l3 = g(sb3, "dwt_fwd2_kernel")[1], g(sb3, "dwt_fwd_kernel")[1]
@@ -59,7 +59,7 @@ per = (h3 + 3 * l3) / 3
 rows.append(f"| `r03_kernel_stats_b3.csv` | the three-frames-per-call shape (`picsong_encode_frames`, one stream): head {h3:.1f} us + 3 x {l3:.1f} us per THREE frames = {per:.1f} us per frame ({255.9 / per / 8:.2f} x the algorithmic bytes over 8 TB/s by kernel time; {rd['three_frames_per_call']['ms_per_frame']:.4f} ms = {rd['three_frames_per_call']['frac']:.2f} by the bench's events, launch gaps included) |")
 hl, ll, hl3, ll3 = g(sl, "dwt_fwd2_kernel")[1], g(sl, "dwt_fwd_kernel")[1], g(slb3, "dwt_fwd2_kernel")[1], g(slb3, "dwt_fwd_kernel")[1]
 perl = (hl3 + 4 * ll3) / 3
-rows.append(f"| `r03_kernel_stats_8k_lossy.csv`, `r03_kernel_stats_8k_lossy_b3.csv` | 9/7 wl 6: lone frame head {hl:.1f} us + 4 x {ll:.1f} us = {hl + 4 * ll:.1f} us = {256.2 / (hl + 4 * ll) / 8:.2f}; three frames per call {hl3:.1f} us + 4 x {ll3:.1f} us per three frames = **{perl:.1f} us per frame = {256.2 / perl / 8:.2f} of 8 TB/s** ({rdl['three_frames_per_call']['ms_per_frame']:.4f} ms = {rdl['three_frames_per_call']['frac']:.2f} by events) -- the north star's 0.80 for the 9/7 transform, in the batched shape |")
+rows.append(f"| `r03_kernel_stats_8k_lossy.csv`, `r03_kernel_stats_8k_lossy_b3.csv` | 9/7 wl 6: lone frame head {hl:.1f} us + 4 x {ll:.1f} us = {hl + 4 * ll:.1f} us = {256.2 / (hl + 4 * ll) / 8:.2f}; three frames per call {hl3:.1f} us + 4 x {ll3:.1f} us per three frames = **{perl:.1f} us per frame = {256.2 / perl / 8:.2f} of 8 TB/s** ({bl3['roofline_dwt']['single_stream']['avg_launch_ms'] / 3:.4f} ms = {bl3['roofline_dwt']['single_stream']['frac']:.2f} by events) -- the north star's 0.80 for the 9/7 transform, in the batched shape |")
 rows.append(f"| `r03_kernel_stats.csv`, `r03_kernel_stats_4k.csv` | the default three-stream shape (kernels of three calls share the GPU: coder {g(s3, 'bpc_encode_kernel')[1]:.0f} us, head {g(s3, 'dwt_fwd2_kernel')[1]:.0f} us while sharing); 4K frames four to a launch (coder {g(s4, 'bpc_encode_kernel')[1]:.0f} us per launch) |")
 dk, dkl = g(sd, "bpc_decode_kernel")[1], g(sdl, "bpc_decode_kernel")[1]
 tot = sum(v[0] * v[1] for k, v in sd.items() if "dwt_inv" in k) / g(sd, "bpc_decode_kernel")[0]
