@@ -690,7 +690,7 @@ def main():
                         "are read once, the transposed bit-planes go through a 16 KB-per-wave scratch.  "
                         "frames_per_step x the isolated launch time exceeds ms_per_step: legal because the coder "
                         "kernels of the calls in flight on the %d streams CO-RESIDE (a frame's launch fills 4 of a "
-                        "SIMD's 6 wave slots; the next call's waves take slots as they free up), so `avg_launch_ms` "
+                        "SIMD's 7 wave slots; the next call's waves take slots as they free up), so `avg_launch_ms` "
                         "(HIP events around a launch that shares the GPU) is longer than a frame's share of the step" % nstreams}
     roofline_dwt = {"kernel": "dwt_fwd_kernel / dwt_fwd2_kernel (all levels, u8 ingest fused)", "bound": "hbm",
                     "achieved": round(dwt_b / (dwt_launch_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,

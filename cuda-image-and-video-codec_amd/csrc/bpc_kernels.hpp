@@ -1009,12 +1009,12 @@ __device__ __forceinline__ int bulk_setup(const BpcArgs &a, bool coded, int msb,
 
 // Waves per SIMD the register allocator must leave room for (512 VGPRs per SIMD lane: 8 waves = 64,
 // 7 = 72, 6 = 80, 5 = 96).  Round 1 (8 planes resident): 5.  With one plane resident the kernel fits 64.
-// The k = 0 encoder: 6 (80 registers) since the end of round 3 -- its plane loops need fewer, the prologue spills a few
-// dwords more (frame 244 -> 304 bytes, five scratch instructions in the loops as before), and with three calls in flight
-// 4 / 5 / 6 / 7 / 8 waves give 167.7 / 188.0 / 191.8 / 187.0 / 183.9 Gpixel/s at 8K (4K: 186.1 -> 190.5; a lone frame
-// loses 1 %).  The -k > 0 instantiation keeps 5.
+// The k = 0 encoder: 7 (72 registers) since the end of round 3.  Its plane loops need fewer; what stood in the way was the
+// prologue's spilling.  With three calls in flight, 8K: 4 / 5 / 6 / 7 / 8 waves gave 167.7 / 188.0 / 191.8 / 187.0 / 183.9
+// Gpixel/s while the prologue's halves were two unrolled copies (6 it was), and 190.7 (5) / 195.0 (6) / 203.0 (7) / 194.7 (8)
+// once they were a loop (enc_transpose_pass).  The -k > 0 instantiation keeps 5.
 #ifndef PICSONG_BPC_ENC_WAVES
-#define PICSONG_BPC_ENC_WAVES 6
+#define PICSONG_BPC_ENC_WAVES 7
 #endif
 
 // one row (two coefficients of the lane) of the coefficient array as magnitudes and sign bits

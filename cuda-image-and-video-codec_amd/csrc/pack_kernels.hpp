@@ -25,8 +25,8 @@ struct HeaderArg { uint16_t h[9]; int has; };
 // (BitStreamBuilder.cu:300-305).  One block of 1024 threads per frame (blockIdx.x = frame of a batched
 // launch: sizes / offsets advance by n, total by 1).
 // The workgroup is 256 threads for frames of up to 16384 codeblocks (scan_threads), one wave a SIMD, and the kernels keep
-// to 32 registers (32-bit offsets from the scalar bases, eight loads in flight and no more): the launch sits between a frame's coder and its pack while other frames' coder waves -- six to a
-// SIMD at 80 registers -- hold all but 32 registers of every SIMD, and a workgroup starts only when ONE CU has room for
+// to 32 registers (32-bit offsets from the scalar bases, eight loads in flight and no more): the launch sits between a frame's coder and its pack while other frames' coder waves -- seven to a
+// SIMD at 72 registers -- hold all but 8 registers of every SIMD (a scan's wave starts when one of them ends), and a workgroup starts only when ONE CU has room for
 // all of its waves.  (Measured with three calls in flight: the 1024-thread scan at 64 registers, four waves a SIMD that
 // fit nowhere until coder waves have drained, cost 13 % of the step, 183.0 -> 159.3 Gpixel/s.)
 __host__ __device__ inline unsigned scan_threads(int n) { return n <= 16384 ? 256u : 1024u; }
