@@ -5,8 +5,8 @@ Metric (BASELINE.json): Mpixels/s, encode (level shift + DWT + BPC + pack), 8K g
 -type 0 (5/3 lossless), device-resident u8 frame in -> device-resident uint16 codestream out;
 decode must round-trip bit-exactly (checked outside the timed region, reported as roundtrip_ok).
 
-A "step" = one batch of --frames-per-step 7680x4320 frames per rank (default 324, about 56 ms of coding: the
-driver's `--steps 20` times 1.1 s), taken from a pool of --pool distinct device-resident frames (default 16 = 535 MB at 8K, past the
+A "step" = one batch of --frames-per-step 7680x4320 frames per rank (default 360, about 58 ms of coding: the
+driver's `--steps 20` times 1.15 s), taken from a pool of --pool distinct device-resident frames (default 16 = 535 MB at 8K, past the
 256 MiB Infinity Cache, so that every frame's input comes from HBM) and coded --batch frames per call of
 picsong_encode_frames, the calls alternating over --streams HIP streams.  With N > 1 (launched by
 torch.distributed.run, one rank per GPU) every rank codes its own frames ("weak"), and each step ends
@@ -328,13 +328,13 @@ def dry_main(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # a step = --frames-per-step frames; the default timed region is > 1 s (22 x 324 8K frames at ~0.17 ms)
+    # a step = --frames-per-step frames; the default timed region is > 1 s (22 x 360 8K frames at ~0.16 ms)
     ap.add_argument("--steps", type=int, default=None,
                     help="timed steps (default 22 at 8K, 80 at 4K: about 1.2 s of coding)")
     ap.add_argument("--warmup", type=int, default=2)
-    # 324 frames (whole calls at 1, 3 and 4 frames per call): the driver's `--steps 20` then times more than a second
-    # (6480 8K frames at ~0.17 ms; 288 frames did until the coder got faster than 0.174 ms a frame)
-    ap.add_argument("--frames-per-step", type=int, default=324)
+    # 360 frames (whole calls at 1, 2, 3, 4 and 6 frames per call): the driver's `--steps 20` then times more than a second
+    # (7200 8K frames at ~0.16 ms; 288, then 324 frames did while a frame took more than 0.174 / 0.155 ms)
+    ap.add_argument("--frames-per-step", type=int, default=360)
     ap.add_argument("--batch", type=int, default=0,
                     help="frames per picsong_encode_frames call (0 = the workload's default)")
     ap.add_argument("--pool", type=int, default=16, help="distinct device-resident input frames the steps rotate over")
