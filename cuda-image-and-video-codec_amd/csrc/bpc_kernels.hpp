@@ -1012,7 +1012,8 @@ __device__ __forceinline__ int bulk_setup(const BpcArgs &a, bool coded, int msb,
 // The k = 0 encoder: 7 (72 registers) since the end of round 3.  Its plane loops need fewer; what stood in the way was the
 // prologue's spilling.  With three calls in flight, 8K: 4 / 5 / 6 / 7 / 8 waves gave 167.7 / 188.0 / 191.8 / 187.0 / 183.9
 // Gpixel/s while the prologue's halves were two unrolled copies (6 it was), and 190.7 (5) / 195.0 (6) / 203.0 (7) / 194.7 (8)
-// once they were a loop (enc_transpose_pass).  The -k > 0 instantiation keeps 5.
+// once they were a loop (enc_transpose_pass).  The -k > 0 instantiation asks for 6 (it gets 4: its planes live in registers;
+// the request alone takes a lone frame from 0.536 to 0.465 ms at k = 0.5).
 #ifndef PICSONG_BPC_ENC_WAVES
 #define PICSONG_BPC_ENC_WAVES 7
 #endif
@@ -1159,7 +1160,7 @@ __device__ __forceinline__ void enc_transpose_pass(const BpcArgs &a, int pass, u
 // BULK = the -k > 0 instantiation (bulk scan after the ordinary planes, table s of the bit-plane
 // LUT files, LDS copy of that table); the k = 0 instantiation compiles to the plain coder.
 template <bool BULK>
-__global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, BULK ? 5 : PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(BpcArgs a)
+__global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, BULK ? 6 : PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(BpcArgs a)
 {
     __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
     __shared__ uint32_t lds_cnt[2 * (BULK ? 1 : kBpcEncWgWaves)];      // codeword counters of the workgroup's codeblocks
