@@ -140,6 +140,10 @@ struct DwtInvArgs {
     // dwt_inv97_kernel: qs is a power of two (the two de-quantising divisions are one: x / (q * qs) is exact scaling)
     int one_div;
     int exact_replay;       // debug: every wave of dwt_inv97_kernel runs its band a second time with true divisions
+    // decode frame paths: the coded coefficients at `mallat` are 16-bit integers (an int16 Mallat array, row stride AW) --
+    // what the decoder's C16 instantiation writes where every magnitude stays below 2^15 (coef16_ok); the C16
+    // instantiations of the synthesis kernels read them.  The LL a level hands the next stays T in the scratch.
+    int c16;
 };
 
 // frame blockIdx.z of a batched launch
@@ -237,6 +241,17 @@ __device__ __forceinline__ uint4 rb_load128(const RowBuf &b, uint32_t lane_off, 
     uint4 r = { 0u, 0u, 0u, 0u };
     if (lane_off < kRbDrop) memcpy(&r, b.base + row_off + lane_off, 16);
     return r;
+#endif
+}
+// a 16-bit word, sign-extended
+__device__ __forceinline__ int rb_load16s(const RowBuf &b, uint32_t lane_off, uint32_t row_off)
+{
+#if defined(__AMDGCN__)
+    return (int)(short)__builtin_amdgcn_raw_buffer_load_b16(b.rs, lane_off, row_off, 0);
+#else
+    int16_t v = 0;
+    if (lane_off < kRbDrop) memcpy(&v, b.base + row_off + lane_off, 2);
+    return (int)v;
 #endif
 }
 __device__ __forceinline__ uint2 rb_load64(const RowBuf &b, uint32_t lane_off, uint32_t row_off)
@@ -1006,11 +1021,26 @@ __device__ __forceinline__ float dequant(int32_t v, float q, float rq, float qs,
 // loads of several row pairs can be in flight.
 struct SubRaw { uint32_t d0, d1, s0, s1; };
 
-template <typename T, bool VEC>
+// C16 (vector kernels only): the coded coefficients are an int16 Mallat array; a pair of them stays PACKED in d0 (and
+// in s0 when the s-type values are coded ones too: LH, or the coarsest level's LL) until convert_sub unpacks it -- an
+// unpack at the load would put a wait for the load right behind it
+template <typename T, bool VEC, bool C16 = false>
 __device__ __forceinline__ SubRaw load_sub_raw(const DwtInvArgs &a, int row_s_or_d, bool high_row, int pc, bool inside)
 {
     // row index already reflected by the caller.  low row: s = LL, d = HL; high row: s = LH, d = HH
     const int hW = a.W >> 1, hH = a.H >> 1;
+    if constexpr (C16) {
+        static_assert(VEC, "the 16-bit coefficient form exists in the vector kernels");
+        const int16_t *mrow = reinterpret_cast<const int16_t *>(a.mallat) + (size_t)(row_s_or_d + (high_row ? hH : 0)) * (size_t)a.AW;
+        SubRaw r;
+        r.d0 = *reinterpret_cast<const uint32_t *>(mrow + hW + pc); r.d1 = 0u;
+        if (high_row || a.first) { r.s0 = *reinterpret_cast<const uint32_t *>(mrow + pc); r.s1 = 0u; }
+        else {
+            const uint2 sv = *reinterpret_cast<const uint2 *>((const uint32_t *)a.ll + (size_t)row_s_or_d * (size_t)a.ll_stride + pc);
+            r.s0 = sv.x; r.s1 = sv.y;
+        }
+        return r;
+    }
     const int32_t *mrow = a.mallat + (size_t)(row_s_or_d + (high_row ? hH : 0)) * (size_t)a.AW;
     const bool from_mallat = high_row || a.first;
     const uint32_t *srow = from_mallat ? (const uint32_t *)mrow
@@ -1035,11 +1065,16 @@ __device__ __forceinline__ SubRaw load_sub_raw(const DwtInvArgs &a, int row_s_or
 
 // (s0, d0, s1, d1) of the lane's two pairs as samples: coded coefficients are int32 (de-quantised when
 // lossy), the previous level's LL is already T
-template <typename T, bool LOSSY, bool FAST>
-__device__ __forceinline__ void convert_sub(const DwtInvArgs &a, const SubRaw &r, bool high_row, T v[4])
+template <typename T, bool LOSSY, bool FAST, bool C16 = false>
+__device__ __forceinline__ void convert_sub(const DwtInvArgs &a, const SubRaw &r0, bool high_row, T v[4])
 {
     const float qd = high_row ? a.q[3] : a.q[1], rqd = high_row ? a.rq[3] : a.rq[1];
     const float qsb = high_row ? a.q[2] : a.q[0], rqsb = high_row ? a.rq[2] : a.rq[0];
+    SubRaw r = r0;
+    if constexpr (C16) {                                     // the packed pairs of load_sub_raw<.., C16>
+        r.d1 = (uint32_t)c16_hi(r0.d0); r.d0 = (uint32_t)c16_lo(r0.d0);
+        if (high_row || a.first) { r.s1 = (uint32_t)c16_hi(r0.s0); r.s0 = (uint32_t)c16_lo(r0.s0); }
+    }
     if (LOSSY) { v[1] = (T)dequant<FAST>((int32_t)r.d0, qd, rqd, a.qs, a.rqs); v[3] = (T)dequant<FAST>((int32_t)r.d1, qd, rqd, a.qs, a.rqs); }
     else { v[1] = (T)(int32_t)r.d0; v[3] = (T)(int32_t)r.d1; }
     if (high_row || a.first) {
@@ -1109,7 +1144,7 @@ __device__ __forceinline__ void store_row4_u8(const DwtInvArgs &a, int y, int c0
     *reinterpret_cast<uint32_t *>(a.dst_u8 + (size_t)y * (size_t)a.W + (uint32_t)c0) = w;
 }
 
-template <typename T, bool LOSSY, int BAND, bool VEC, bool U8OUT = false, bool FAST = false>
+template <typename T, bool LOSSY, int BAND, bool VEC, bool U8OUT = false, bool FAST = false, bool C16 = false>
 __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
 {
     constexpr int kInvBandRows = BAND;
@@ -1145,8 +1180,8 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
     __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int p = 0; p < kInvAhead; p++) {
-        rawL[p] = load_sub_raw<T, VEC>(a, reflect_s(j0 + p, hH), false, pl, inside);
-        rawH[p] = load_sub_raw<T, VEC>(a, reflect_d(j0 + p, hH), true, pl, inside);
+        rawL[p] = load_sub_raw<T, VEC, C16>(a, reflect_s(j0 + p, hH), false, pl, inside);
+        rawH[p] = load_sub_raw<T, VEC, C16>(a, reflect_d(j0 + p, hH), true, pl, inside);
     }
     __builtin_amdgcn_s_setprio(0);
 
@@ -1159,11 +1194,11 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
         for (int it = 0; it < kIters; it++) {
             const int j = j0 + it;
             T Lr[4], Hr[4];
-            convert_sub<T, LOSSY, FAST>(a, rawL[it % kInvAhead], false, Lr);
-            convert_sub<T, LOSSY, FAST>(a, rawH[it % kInvAhead], true, Hr);
+            convert_sub<T, LOSSY, FAST, C16>(a, rawL[it % kInvAhead], false, Lr);
+            convert_sub<T, LOSSY, FAST, C16>(a, rawH[it % kInvAhead], true, Hr);
             if (it + kInvAhead < kIters) {
-                rawL[it % kInvAhead] = load_sub_raw<T, VEC>(a, reflect_s(j + kInvAhead, hH), false, pl, inside);
-                rawH[it % kInvAhead] = load_sub_raw<T, VEC>(a, reflect_d(j + kInvAhead, hH), true, pl, inside);
+                rawL[it % kInvAhead] = load_sub_raw<T, VEC, C16>(a, reflect_s(j + kInvAhead, hH), false, pl, inside);
+                rawH[it % kInvAhead] = load_sub_raw<T, VEC, C16>(a, reflect_d(j + kInvAhead, hH), true, pl, inside);
             }
             hinv<FAST>(Lr, le, re);
             hinv<FAST>(Hr, le, re);
@@ -1197,11 +1232,11 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
             const int it = g * kInvAhead + r;
             const int j = j0 + it;
             T Lr[4], Hr[4];
-            convert_sub<T, LOSSY, FAST>(a, rawL[r], false, Lr);
-            convert_sub<T, LOSSY, FAST>(a, rawH[r], true, Hr);
+            convert_sub<T, LOSSY, FAST, C16>(a, rawL[r], false, Lr);
+            convert_sub<T, LOSSY, FAST, C16>(a, rawH[r], true, Hr);
             if (g + 1 < kIters / kInvAhead) {
-                rawL[r] = load_sub_raw<T, VEC>(a, reflect_s(j + kInvAhead, hH), false, pl, inside);
-                rawH[r] = load_sub_raw<T, VEC>(a, reflect_d(j + kInvAhead, hH), true, pl, inside);
+                rawL[r] = load_sub_raw<T, VEC, C16>(a, reflect_s(j + kInvAhead, hH), false, pl, inside);
+                rawH[r] = load_sub_raw<T, VEC, C16>(a, reflect_d(j + kInvAhead, hH), true, pl, inside);
             }
             hinv<FAST>(Lr, le, re);
             hinv<FAST>(Hr, le, re);
@@ -1276,11 +1311,13 @@ __device__ __forceinline__ float fmax3abs(float m, float a, float b)
 {   // max(m, |a|, |b|): one v_max3_f32 with source modifiers
     return __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(a)), __builtin_fabsf(b));
 }
-// two coefficients of one subband; vmax: the largest magnitude the wave's lanes have de-quantised
+// two coefficients of one subband; vmax: the largest magnitude the wave's lanes have de-quantised (TRACK; 16-bit
+// coefficients cannot leave the verified domain)
+template <bool TRACK = true>
 __device__ __forceinline__ void dequant1x2(uint32_t raw0, uint32_t raw1, const DivK &k, float &x0, float &x1, float &vmax)
 {   // (|v| + 0.5) sgn v = v + clamp(v, -0.5, 0.5), exact for |v| < 2^23; 0 stays 0
     const float y0 = (float)(int)raw0, y1 = (float)(int)raw1;
-    vmax = fmax3abs(vmax, y0, y1);
+    if constexpr (TRACK) vmax = fmax3abs(vmax, y0, y1);
     x0 = div_rcv(y0 + fmed3(y0, -0.5f, 0.5f), k);
     x1 = div_rcv(y1 + fmed3(y1, -0.5f, 0.5f), k);
 }
@@ -1336,9 +1373,14 @@ struct Inv97Steps { DivK ll, hl, lh, hh, qs; };
 
 // one subband row pair-segment to samples (s0, d0, s1, d1); HIGH: LH / HH row, else LL / HL (LL de-quantised on
 // the coarsest level only: DEQ_S)
-template <bool HIGH, bool DEQ_S, bool ONE_DIV, bool EXACT>
-__device__ __forceinline__ void convert97(const DwtInvArgs &a, const Inv97Steps &k, const SubRaw &r, float v[4], float &vmax)
+template <bool HIGH, bool DEQ_S, bool ONE_DIV, bool EXACT, bool C16 = false>
+__device__ __forceinline__ void convert97(const DwtInvArgs &a, const Inv97Steps &k, const SubRaw &r0, float v[4], float &vmax)
 {
+    SubRaw r = r0;
+    if constexpr (C16) {                                     // packed pairs of 16-bit coefficients (load_pair)
+        r.d1 = (uint32_t)c16_hi(r0.d0); r.d0 = (uint32_t)c16_lo(r0.d0);
+        if (DEQ_S) { r.s1 = (uint32_t)c16_hi(r0.s0); r.s0 = (uint32_t)c16_lo(r0.s0); }
+    }
     if constexpr (EXACT) {
         const float qd = HIGH ? a.q[3] : a.q[1], qsb = HIGH ? a.q[2] : a.q[0];
         v[1] = dequant<false>((int32_t)r.d0, qd, 0.0f, a.qs, 0.0f); v[3] = dequant<false>((int32_t)r.d1, qd, 0.0f, a.qs, 0.0f);
@@ -1347,8 +1389,8 @@ __device__ __forceinline__ void convert97(const DwtInvArgs &a, const Inv97Steps 
         return;
     }
     const DivK &kd = HIGH ? k.hh : k.hl, &ks = HIGH ? k.lh : k.ll;
-    dequant1x2(r.d0, r.d1, kd, v[1], v[3], vmax);
-    if (DEQ_S) dequant1x2(r.s0, r.s1, ks, v[0], v[2], vmax);
+    dequant1x2<!C16>(r.d0, r.d1, kd, v[1], v[3], vmax);
+    if (DEQ_S) dequant1x2<!C16>(r.s0, r.s1, ks, v[0], v[2], vmax);
     else { v[0] = __uint_as_float(r.s0); v[2] = __uint_as_float(r.s1); }
     if (!ONE_DIV) {
         v[1] = div_rcv(v[1], k.qs); v[3] = div_rcv(v[3], k.qs);
@@ -1358,7 +1400,7 @@ __device__ __forceinline__ void convert97(const DwtInvArgs &a, const Inv97Steps 
 
 // returns (wave-uniform) whether some lane divided a value too small for the reciprocal form: the band must be
 // run again with EXACT
-template <int BAND, bool U8OUT, bool FIRST, bool ONE_DIV, bool EDGE, bool EXACT>
+template <int BAND, bool U8OUT, bool FIRST, bool ONE_DIV, bool EDGE, bool EXACT, bool C16 = false>
 __device__ __forceinline__ bool dwt_inv97_band(const DwtInvArgs &a, int strip, int lane)
 {
     const int c0 = strip * kStripUseful - 4 * kEdgeLanes + 4 * lane;
@@ -1372,9 +1414,10 @@ __device__ __forceinline__ bool dwt_inv97_band(const DwtInvArgs &a, int strip, i
 
     const RowBuf mal = rowbuf(a.mallat), lls = rowbuf(FIRST ? (const void *)a.mallat : a.ll);
     const RowBuf out = rowbuf(U8OUT ? (const void *)a.dst_u8 : (const void *)a.dst);
-    const uint32_t vd = (uint32_t)(hW + pl) * 4u, vs = (uint32_t)pl * 4u;
+    constexpr uint32_t kCB = C16 ? 2u : 4u;                  // bytes of a coded coefficient
+    const uint32_t vd = (uint32_t)(hW + pl) * kCB, vs = (uint32_t)pl * kCB, vsl = FIRST ? vs : (uint32_t)pl * 4u;
     const uint32_t vo = wr ? (U8OUT ? (uint32_t)c0 : (uint32_t)c0 * 4u) : kRbDrop;
-    const uint32_t aw4 = (uint32_t)a.AW * 4u, ll4 = FIRST ? aw4 : (uint32_t)a.ll_stride * 4u;
+    const uint32_t aw4 = (uint32_t)a.AW * kCB, ll4 = FIRST ? aw4 : (uint32_t)a.ll_stride * 4u;
     const uint32_t ow = U8OUT ? (uint32_t)a.W : (uint32_t)a.W * 4u;
 
     // the steps (times qs when that is exact scaling) as reciprocal / negative pairs in vector registers
@@ -1396,10 +1439,18 @@ __device__ __forceinline__ bool dwt_inv97_band(const DwtInvArgs &a, int strip, i
     SubRaw rawL[kGroup], rawH[kGroup];
     auto load_pair = [&](int j, SubRaw &L, SubRaw &H) {
         const uint32_t rl = (uint32_t)reflect_s(j, hH), rh = (uint32_t)(reflect_d(j, hH) + hH);
-        const uint2 ld = rb_load64(mal, vd, rl * aw4), ls = rb_load64(lls, vs, rl * ll4);
-        const uint2 hd = rb_load64(mal, vd, rh * aw4), hs = rb_load64(mal, vs, rh * aw4);
-        L.d0 = ld.x; L.d1 = ld.y; L.s0 = ls.x; L.s1 = ls.y;
-        H.d0 = hd.x; H.d1 = hd.y; H.s0 = hs.x; H.s1 = hs.y;
+        if constexpr (C16) {                                 // a pair of 16-bit coefficients = one dword, unpacked by convert97
+            L.d0 = rb_load32(mal, vd, rl * aw4); L.d1 = 0u;
+            if constexpr (FIRST) { L.s0 = rb_load32(lls, vsl, rl * ll4); L.s1 = 0u; }
+            else { const uint2 ls = rb_load64(lls, vsl, rl * ll4); L.s0 = ls.x; L.s1 = ls.y; }
+            H.d0 = rb_load32(mal, vd, rh * aw4); H.d1 = 0u;
+            H.s0 = rb_load32(mal, vs, rh * aw4); H.s1 = 0u;
+        } else {
+            const uint2 ld = rb_load64(mal, vd, rl * aw4), ls = rb_load64(lls, vsl, rl * ll4);
+            const uint2 hd = rb_load64(mal, vd, rh * aw4), hs = rb_load64(mal, vs, rh * aw4);
+            L.d0 = ld.x; L.d1 = ld.y; L.s0 = ls.x; L.s1 = ls.y;
+            H.d0 = hd.x; H.d1 = hd.y; H.s0 = hs.x; H.s1 = hs.y;
+        }
     };
     __builtin_amdgcn_s_setprio(3);
 #pragma unroll
@@ -1419,8 +1470,8 @@ __device__ __forceinline__ bool dwt_inv97_band(const DwtInvArgs &a, int strip, i
             const int it = g * kGroup + r;
             const int j = j0 + it;
             float ln[4], hn[4];
-            convert97<false, FIRST, ONE_DIV, EXACT>(a, k, rawL[r], ln, vmax);
-            convert97<true, true, ONE_DIV, EXACT>(a, k, rawH[r], hn, vmax);
+            convert97<false, FIRST, ONE_DIV, EXACT, C16>(a, k, rawL[r], ln, vmax);
+            convert97<true, true, ONE_DIV, EXACT, C16>(a, k, rawH[r], hn, vmax);
             // (also in the last trip, whose rows nobody uses: an `if` here makes the compiler merge loaded and kept
             // registers with copies behind a full s_waitcnt, which serialises the prefetch; reflect_* keep every
             // row inside the subband).  Fenced: left to itself the scheduler sinks the loads to the end of the trip.
@@ -1471,7 +1522,7 @@ __device__ __forceinline__ bool dwt_inv97_band(const DwtInvArgs &a, int strip, i
 #ifndef PICSONG_DWT_INV97_WAVES
 #define PICSONG_DWT_INV97_WAVES 5     // dwt_inv97_kernel: resident waves per SIMD the register budget is set for
 #endif
-template <int BAND, bool U8OUT, bool FIRST, bool ONE_DIV>
+template <int BAND, bool U8OUT, bool FIRST, bool ONE_DIV, bool C16 = false>
 __global__ __launch_bounds__(256, PICSONG_DWT_INV97_WAVES) void dwt_inv97_kernel(DwtInvArgs a)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1480,10 +1531,290 @@ __global__ __launch_bounds__(256, PICSONG_DWT_INV97_WAVES) void dwt_inv97_kernel
     dwt_inv_select_frame(a);
     const int first = strip * kStripUseful - 4 * kEdgeLanes;
     bool again;
-    if (first <= 0 || first + kStripCols >= a.W) again = dwt_inv97_band<BAND, U8OUT, FIRST, ONE_DIV, true, false>(a, strip, lane);
-    else again = dwt_inv97_band<BAND, U8OUT, FIRST, ONE_DIV, false, false>(a, strip, lane);
+    if (first <= 0 || first + kStripCols >= a.W) again = dwt_inv97_band<BAND, U8OUT, FIRST, ONE_DIV, true, false, C16>(a, strip, lane);
+    else again = dwt_inv97_band<BAND, U8OUT, FIRST, ONE_DIV, false, false, C16>(a, strip, lane);
     // (a.exact_replay: PICSONG_DWT_EXACT_REPLAY=1, the tests' way into the second pass)
-    if (__builtin_expect(again || a.exact_replay, 0)) dwt_inv97_band<BAND, U8OUT, FIRST, ONE_DIV, true, true>(a, strip, lane);
+    if (__builtin_expect(again || a.exact_replay, 0)) dwt_inv97_band<BAND, U8OUT, FIRST, ONE_DIV, true, true, C16>(a, strip, lane);
+}
+
+// ---- synthesis levels 1 and 0 in one launch (the decode frame paths' tail; round 4) ----------------------------
+// The mirror of dwt_fwd2_kernel.  The rows level 1 delivers -- LL0, the low-low input of level 0 -- never leave the
+// registers: as a band streams down, every level-1 step hands two LL0 rows to two level-0 steps, whose other inputs
+// (HL0 / LH0 / HH0) come from the coded array.  Saves the write and the read of the LL0 plane (2 x 33.4 MB of an 8K
+// frame's 32-bit words) and a launch; with the coded coefficients as int16 (the decoder's C16 instantiation) the finest
+// level reads 50 MB of subbands where the 32-bit form reads 134 MB, and writes 33 MB of pixels.  Costs recomputed
+// run-in: a band of NB level-1 row pairs (4 NB output rows) runs NB + 4 (5/3) / NB + 6 (9/7) level-1 steps and
+// 2 NB + 4 / 2 NB + 6 level-0 steps.  A lane owns 4 output columns = 2 level-0 column pairs = 1 level-1 pair; 1 (5/3)
+// / 3 (9/7) recomputed lanes per side.  Arithmetic, value for value: dwt_inv_kernel's (5/3) and dwt_inv97_band's (9/7:
+// reciprocal divisions, optimistic execution, the band run again with true divisions for a wave that met a value below
+// 2^-96).  Reference: DWTEngine::DWTReverse DWT/DWTGenerator.cu:1349-1424, kernelDWTReverse(Lossy) :1002-1124.
+//
+// Iteration it of a band (n0 = its first level-1 pair, M0 = 2 n0):  level-1 step j1 = n0 - R1 + it completes level-1
+// pair j1 - G1 = LL0 rows m, m + 1 with m = M0 - 2 (R1 + G1) + 2 it;  level-0 steps m and m + 1 complete the output
+// pairs m - G0 and m + 1 - G0.  5/3: R1 = 2, G1 = G0 = 1;  9/7: R1 = 3, G1 = G0 = 2.  The first real LL0 rows are
+// M0 - G0 .. at it = F0 = R1 + G1 - ... (2 / 4): the iterations before are level 1's run-in and touch no level-0 data.
+// The image's top needs nothing special (mirrored subband rows make level 1 deliver the mirrored LL0 rows level 0 wants);
+// at the bottom level 0 wants LL0[K] = LL0[K - 1], LL0[K + 1] = LL0[K - 2] where mirrored level-1 rows would deliver
+// LL0[K - 2], LL0[K - 3]: the last band's last iteration takes the rows of the iteration before, swapped.
+template <bool LOSSY> constexpr int i2_edge() { return LOSSY ? 3 : 1; }
+template <bool LOSSY> constexpr int i2_useful() { return kStripCols - 8 * i2_edge<LOSSY>(); }
+constexpr int kI2Pairs = 8;                               // level-1 row pairs per band: 32 output rows
+struct DwtInv2Args { DwtInvArgs l1, l0; };
+
+__device__ __forceinline__ void hinv2(int v[2], bool le, bool re)
+{   // hinv<>(int) on ONE (s, d) pair per lane
+    const int dp = prv<int>(v[1], v[1], le);
+    v[0] -= (v[1] + dp + 2) >> 2;
+    const int sn = nxt<int>(v[0], v[0], re);
+    v[1] += (v[0] + sn) >> 1;
+}
+template <bool EDGE, bool EXACT>
+__device__ __forceinline__ void hinv97_2(float v[2], bool le, bool re)
+{   // hinv97 on ONE (s, d) pair per lane
+    v[1] = div_n1<EXACT>(v[1]);
+    v[0] = div_n2<EXACT>(v[0]);
+    const bool l = EDGE && le, r = EDGE && re;
+    float dp = prv<float>(v[1], v[1], l);
+    v[0] = fmaf(-(v[1] + dp), PS_A4, v[0]);
+    float sn = nxt<float>(v[0], v[0], r);
+    v[1] = fmaf(-(v[0] + sn), PS_A3, v[1]);
+    dp = prv<float>(v[1], v[1], l);
+    v[0] = fmaf(-(v[1] + dp), PS_A2, v[0]);
+    sn = nxt<float>(v[0], v[0], r);
+    v[1] = fmaf(-(v[0] + sn), PS_A1, v[1]);
+}
+// one vertical synthesis step over N columns: rows L (vertically low) and H (high) of step j; delivers the row pair
+// j - 1 (5/3: st = H[j-1], s[j-1]) / j - 2 (9/7: st = dd, s1, d1, s0 of the steps before) as ev / od
+template <bool LOSSY, bool EXACT, int N, typename T>
+__device__ __forceinline__ void vinv_step(T (&st)[4][N], const T (&L)[N], const T (&H)[N], T (&ev)[N], T (&od)[N])
+{
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        if constexpr (LOSSY) {                               // dwt_inv97_band's step, DWTGenerator.cu:230-272
+            const float dd = div_n1<EXACT>(H[k]);
+            const float s1 = fmaf(-(st[0][k] + dd), PS_A4, div_n2<EXACT>(L[k]));
+            const float d1 = fmaf(-(st[1][k] + s1), PS_A3, st[0][k]);
+            const float s0 = fmaf(-(st[2][k] + d1), PS_A2, st[1][k]);
+            const float xo = fmaf(-(st[3][k] + s0), PS_A1, st[2][k]);
+            ev[k] = st[3][k];
+            od[k] = xo;
+            st[0][k] = dd; st[1][k] = s1; st[2][k] = d1; st[3][k] = s0;
+        } else {                                             // dwt_inv_kernel's step, DWTGenerator.cu:160-181
+            const T sv = L[k] - ((st[0][k] + H[k] + 2) >> 2);
+            ev[k] = st[1][k];
+            od[k] = st[0][k] + ((st[1][k] + sv) >> 1);
+            st[1][k] = sv; st[0][k] = H[k];
+        }
+    }
+}
+struct Inv2Steps { DivK hl1, lh1, hh1, hl0, lh0, hh0, qs; };
+// the raw words of one iteration: level 1's four subband samples of the lane's pair (LL1 a T word, the coded ones
+// sign-extended 16-bit loads), level 0's HL / LH / HH pairs (packed int16) of its two steps
+struct Inv2Raw { uint32_t ll1; int hl1, lh1, hh1; uint32_t hl0[2], lh0[2], hh0[2]; };
+
+template <bool LOSSY, bool ONE_DIV, bool EXACT>
+__device__ __forceinline__ float i2_deq(int c, const DivK &k, const DivK &kqs, float q, const DwtInvArgs &a)
+{   // dequant1x2's arithmetic for one 16-bit coefficient (EXACT: readSubbands' own divisions)
+    if constexpr (EXACT) return dequant<false>(c, q, 0.0f, a.qs, 0.0f);
+    const float y = (float)c;
+    float x = div_rcv(y + fmed3(y, -0.5f, 0.5f), k);
+    if (!ONE_DIV) x = div_rcv(x, kqs);
+    return x;
+}
+
+template <bool LOSSY, bool ONE_DIV, bool EDGE, bool EXACT>
+__device__ __forceinline__ bool dwt_inv2_band(const DwtInvArgs &a1, const DwtInvArgs &a0, int strip, int lane)
+{
+    using T = typename std::conditional<LOSSY, float, int>::type;
+    constexpr int NB = kI2Pairs, kE = i2_edge<LOSSY>();
+    constexpr int R1 = LOSSY ? 3 : 2, G1 = LOSSY ? 2 : 1, G0 = G1, F0 = LOSSY ? 4 : 2;
+    constexpr int kIters = NB + R1 + G1 + 1;                 // NB + 4 / NB + 6
+    constexpr int kMain = kIters - F0;                       // NB + 2 iterations with level-0 work
+    constexpr int kG = 2;                                    // iterations whose loads are in flight ahead of the arithmetic
+    static_assert(kMain % kG == 0 && F0 % kG == 0, "the main loop runs in groups of kG iterations");
+    const int c0 = strip * i2_useful<LOSSY>() - 4 * kE + 4 * lane;
+    const int W0 = a0.W, hW0 = W0 >> 1, hH0 = a0.H >> 1, hW1 = a1.W >> 1, hH1 = a1.H >> 1;
+    const int n0 = (int)blockIdx.y * NB, M0 = 2 * n0;
+    const bool lastb = 2 * (M0 + 2 * NB) >= a0.H;            // the band that ends at the bottom of the image
+    const bool wr = lane >= kE && lane <= 63 - kE && c0 >= 0 && c0 < W0;
+    const bool le = EDGE && c0 == 0, re = EDGE && c0 + 4 == W0;
+    const int pc = c0 >> 1;
+    const int pl = pc < 0 ? 0 : (pc > hW0 - 2 ? hW0 - 2 : pc), ql = pl >> 1;
+
+    const RowBuf mal = rowbuf(a0.mallat), ll1b = rowbuf(a1.ll), out = rowbuf(a0.dst_u8);
+    const uint32_t aw2 = (uint32_t)a0.AW * 2u, l1s = (uint32_t)a1.ll_stride * 4u;
+    const uint32_t vll1 = (uint32_t)ql * 4u, vlh1 = (uint32_t)ql * 2u, vhl1 = (uint32_t)(hW1 + ql) * 2u;
+    const uint32_t vlh0 = (uint32_t)pl * 2u, vhl0 = (uint32_t)(hW0 + pl) * 2u;
+    const uint32_t vo = wr ? (uint32_t)c0 : kRbDrop, ow = (uint32_t)W0;
+
+    Inv2Steps k;
+    if constexpr (LOSSY && !EXACT) {
+        const float vsc = in_vgpr(ONE_DIV ? a0.qs : 1.0f), vrsc = in_vgpr(ONE_DIV ? a0.rqs : 1.0f);
+        k.hl1.rc = in_vgpr(a1.rq[1]) * vrsc; k.hl1.nc = -(in_vgpr(a1.q[1]) * vsc);
+        k.lh1.rc = in_vgpr(a1.rq[2]) * vrsc; k.lh1.nc = -(in_vgpr(a1.q[2]) * vsc);
+        k.hh1.rc = in_vgpr(a1.rq[3]) * vrsc; k.hh1.nc = -(in_vgpr(a1.q[3]) * vsc);
+        k.hl0.rc = in_vgpr(a0.rq[1]) * vrsc; k.hl0.nc = -(in_vgpr(a0.q[1]) * vsc);
+        k.lh0.rc = in_vgpr(a0.rq[2]) * vrsc; k.lh0.nc = -(in_vgpr(a0.q[2]) * vsc);
+        k.hh0.rc = in_vgpr(a0.rq[3]) * vrsc; k.hh0.nc = -(in_vgpr(a0.q[3]) * vsc);
+        k.qs.rc = in_vgpr(a0.rqs); k.qs.nc = in_vgpr(-a0.qs);
+    }
+    const float foff = LOSSY ? in_vgpr((float)a0.off) : 0.0f;
+
+    // loads of iteration `it`: level 1's rows of step j1, level 0's rows of steps m, m + 1 (any row index: reflected)
+    auto load1 = [&](int it, Inv2Raw &r) {
+        const int j1 = n0 - R1 + it;
+        const uint32_t rl = (uint32_t)reflect_s(j1, hH1), rh = (uint32_t)(reflect_d(j1, hH1) + hH1);
+        r.ll1 = rb_load32(ll1b, vll1, rl * l1s);
+        r.hl1 = rb_load16s(mal, vhl1, rl * aw2);
+        r.lh1 = rb_load16s(mal, vlh1, rh * aw2);
+        r.hh1 = rb_load16s(mal, vhl1, rh * aw2);
+    };
+    auto load0 = [&](int it, Inv2Raw &r) {
+        const int m = M0 - 2 * (R1 + G1) + 2 * it;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t rl = (uint32_t)reflect_s(m + h, hH0), rh = (uint32_t)(reflect_d(m + h, hH0) + hH0);
+            r.hl0[h] = rb_load32(mal, vhl0, rl * aw2);
+            r.lh0[h] = rb_load32(mal, vlh0, rh * aw2);
+            r.hh0[h] = rb_load32(mal, vhl0, rh * aw2);
+        }
+    };
+    Inv2Raw raw[kG];
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int p = 0; p < kG; p++) { load1(p, raw[p]); raw[p].hl0[0] = raw[p].hl0[1] = raw[p].lh0[0] = raw[p].lh0[1] = raw[p].hh0[0] = raw[p].hh0[1] = 0u; }
+    __builtin_amdgcn_s_setprio(0);
+
+    T st1[4][2], st0[4][4], pev[2], pod[2];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        st1[q][0] = st1[q][1] = (T)0;
+        st0[q][0] = st0[q][1] = st0[q][2] = st0[q][3] = (T)0;
+    }
+    pev[0] = pev[1] = pod[0] = pod[1] = (T)0;
+    int emin = 0;                                            // smallest exponent a lifting division has seen (9/7)
+
+    // one level-1 step on the raw words of an iteration: the LL0 rows m (ev) and m + 1 (od)
+    auto level1 = [&](const Inv2Raw &r, T (&ev)[2], T (&od)[2]) {
+        T L[2], H[2];
+        if constexpr (LOSSY) {
+            L[0] = __uint_as_float(r.ll1);
+            L[1] = i2_deq<LOSSY, ONE_DIV, EXACT>(r.hl1, k.hl1, k.qs, a1.q[1], a1);
+            H[0] = i2_deq<LOSSY, ONE_DIV, EXACT>(r.lh1, k.lh1, k.qs, a1.q[2], a1);
+            H[1] = i2_deq<LOSSY, ONE_DIV, EXACT>(r.hh1, k.hh1, k.qs, a1.q[3], a1);
+            if (!EXACT) emin = imin(emin, frexp_exp(L[0]));  // the previous level's LL sample: the only one that can be tiny here
+            hinv97_2<EDGE, EXACT>(L, le, re);
+            hinv97_2<EDGE, EXACT>(H, le, re);
+            if (!EXACT) emin = imin(emin, imin(imin(frexp_exp(L[0]), frexp_exp(L[1])), imin(frexp_exp(H[0]), frexp_exp(H[1]))));
+        } else {
+            L[0] = (T)(int)r.ll1; L[1] = (T)r.hl1; H[0] = (T)r.lh1; H[1] = (T)r.hh1;
+            hinv2(L, le, re);
+            hinv2(H, le, re);
+        }
+        vinv_step<LOSSY, EXACT, 2, T>(st1, L, H, ev, od);
+    };
+    // one level-0 step: LL0 row `ll` with the raw HL / LH / HH words of row m + h; stores the output pair `rel` of the band
+    auto level0 = [&](const T (&ll)[2], const Inv2Raw &r, int h, int rel) {
+        T L[4], H[4];
+        if constexpr (LOSSY) {
+            L[0] = ll[0]; L[2] = ll[1];
+            L[1] = i2_deq<LOSSY, ONE_DIV, EXACT>(c16_lo(r.hl0[h]), k.hl0, k.qs, a0.q[1], a0);
+            L[3] = i2_deq<LOSSY, ONE_DIV, EXACT>(c16_hi(r.hl0[h]), k.hl0, k.qs, a0.q[1], a0);
+            H[0] = i2_deq<LOSSY, ONE_DIV, EXACT>(c16_lo(r.lh0[h]), k.lh0, k.qs, a0.q[2], a0);
+            H[2] = i2_deq<LOSSY, ONE_DIV, EXACT>(c16_hi(r.lh0[h]), k.lh0, k.qs, a0.q[2], a0);
+            H[1] = i2_deq<LOSSY, ONE_DIV, EXACT>(c16_lo(r.hh0[h]), k.hh0, k.qs, a0.q[3], a0);
+            H[3] = i2_deq<LOSSY, ONE_DIV, EXACT>(c16_hi(r.hh0[h]), k.hh0, k.qs, a0.q[3], a0);
+            if (!EXACT) emin = imin(emin, imin(frexp_exp(L[0]), frexp_exp(L[2])));
+            hinv97<EDGE, EXACT>(L, le, re);
+            hinv97<EDGE, EXACT>(H, le, re);
+            if (!EXACT) {
+                emin = imin(emin, imin(imin(frexp_exp(H[0]), frexp_exp(H[1])), imin(frexp_exp(H[2]), frexp_exp(H[3]))));
+                emin = imin(emin, imin(imin(frexp_exp(L[0]), frexp_exp(L[1])), imin(frexp_exp(L[2]), frexp_exp(L[3]))));
+            }
+        } else {
+            L[0] = ll[0]; L[2] = ll[1]; L[1] = (T)c16_lo(r.hl0[h]); L[3] = (T)c16_hi(r.hl0[h]);
+            H[0] = (T)c16_lo(r.lh0[h]); H[2] = (T)c16_hi(r.lh0[h]); H[1] = (T)c16_lo(r.hh0[h]); H[3] = (T)c16_hi(r.hh0[h]);
+            hinv<false>(L, le, re);
+            hinv<false>(H, le, re);
+        }
+        T ev[4], od[4];
+        vinv_step<LOSSY, EXACT, 4, T>(st0, L, H, ev, od);
+        if (rel >= 0 && rel < 2 * NB) {                      // (wave-uniform)
+            const uint32_t y = (uint32_t)(2 * (M0 + rel));
+            if constexpr (LOSSY) {
+                rb_store32(out, vo, y * ow, pack_pixels(ev, foff));
+                rb_store32(out, vo, (y + 1u) * ow, pack_pixels(od, foff));
+            } else {
+                rb_store32(out, vo, y * ow, to_pixel(ev[0], a0.off) | (to_pixel(ev[1], a0.off) << 8) | (to_pixel(ev[2], a0.off) << 16) | (to_pixel(ev[3], a0.off) << 24));
+                rb_store32(out, vo, (y + 1u) * ow, to_pixel(od[0], a0.off) | (to_pixel(od[1], a0.off) << 8) | (to_pixel(od[2], a0.off) << 16) | (to_pixel(od[3], a0.off) << 24));
+            }
+        }
+    };
+    auto fence = [] {
+#if defined(__AMDGCN__)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    };
+
+    // ---- level 1's run-in: F0 iterations without level-0 work.  Their loads' successors are the first main
+    // iterations', level-0 rows included
+#pragma unroll
+    for (int it = 0; it < F0; it++) {
+        const Inv2Raw r = raw[it % kG];
+        fence();
+        load1(it + kG, raw[it % kG]);
+        if (it + kG >= F0) load0(it + kG, raw[it % kG]);
+        fence();
+        T ev[2], od[2];
+        level1(r, ev, od);
+    }
+    // ---- the band: kMain iterations of one level-1 step and two level-0 steps
+#pragma unroll 1
+    for (int g = 0; g < kMain / kG; g++) {
+#pragma unroll
+        for (int q = 0; q < kG; q++) {
+            const int it = F0 + g * kG + q;
+            const Inv2Raw r = raw[q];                         // ((F0 + q) % kG == q: F0 is a multiple of kG)
+            // (the loads of the last trips reach past the band: rows nobody uses, kept inside the subbands by reflect_*;
+            // a condition here would make the compiler merge loaded and kept registers behind a full wait)
+            fence();
+            load1(it + kG, raw[q]);
+            load0(it + kG, raw[q]);
+            fence();
+            T ev[2], od[2];
+            level1(r, ev, od);
+            if (lastb && it == kIters - 1) {                 // LL0 rows K, K + 1 = rows K - 1, K - 2 (see above)
+                ev[0] = pod[0]; ev[1] = pod[1]; od[0] = pev[0]; od[1] = pev[1];
+            }
+            pev[0] = ev[0]; pev[1] = ev[1]; pod[0] = od[0]; pod[1] = od[1];
+            const int rel = 2 * it - 2 * (R1 + G1) - G0;     // output pair of the first level-0 step, relative to M0
+            level0(ev, r, 0, rel);
+            level0(od, r, 1, rel + 1);
+        }
+    }
+    return LOSSY && !EXACT && __builtin_amdgcn_ballot_w64(emin <= kTinyExp) != 0ull;
+}
+
+#ifndef PICSONG_DWT_INV2_WAVES
+#define PICSONG_DWT_INV2_WAVES 5
+#endif
+template <bool LOSSY, bool ONE_DIV>
+__global__ __launch_bounds__(256, PICSONG_DWT_INV2_WAVES) void dwt_inv2_kernel(DwtInv2Args a2)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int strip = blockIdx.x * 4 + wave;
+    if (strip * i2_useful<LOSSY>() >= a2.l0.W) return;       // whole wave idle (no cross-lane use)
+    dwt_inv_select_frame(a2.l1);
+    dwt_inv_select_frame(a2.l0);
+    if constexpr (!LOSSY) {
+        (void)dwt_inv2_band<false, false, true, false>(a2.l1, a2.l0, strip, lane);
+    } else {
+        const int first = strip * i2_useful<LOSSY>() - 4 * i2_edge<LOSSY>();
+        bool again;
+        if (first <= 0 || first + kStripCols >= a2.l0.W) again = dwt_inv2_band<true, ONE_DIV, true, false>(a2.l1, a2.l0, strip, lane);
+        else again = dwt_inv2_band<true, ONE_DIV, false, false>(a2.l1, a2.l0, strip, lane);
+        if (__builtin_expect(again || a2.l0.exact_replay, 0)) (void)dwt_inv2_band<true, ONE_DIV, true, true>(a2.l1, a2.l0, strip, lane);
+    }
 }
 
 // ---- level shift kernels (used when the stages are called one by one) -------------------------

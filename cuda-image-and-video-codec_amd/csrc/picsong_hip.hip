@@ -566,10 +566,16 @@ int picsong_level_shift_inv(picsong_ctx *c, void *d_data, void *stream)
 // ---------------------------------------------------------------------------------------------
 // DWT
 // ---------------------------------------------------------------------------------------------
-static int dwt_forward_impl(picsong_ctx *c, const void *d_in, bool u8in, void *d_out, hipStream_t s, bool c16 = false)
+// want_c16: the context's choice of the 16-bit coefficient form (picsong_ctx::c16); *got_c16: what THIS call's plan
+// delivers -- the form exists in the vector kernels only, and whether those apply also depends on the caller's pointers
+// (16-byte alignment) and on PICSONG_DWT_NOVEC at call time, so a call may fall back to the 32-bit arrays and the
+// coder must be told (plan_dwt_forward clears c16 on every level then)
+static int dwt_forward_impl(picsong_ctx *c, const void *d_in, bool u8in, void *d_out, hipStream_t s, bool want_c16 = false,
+                            bool *got_c16 = nullptr)
 {
-    const std::vector<FwdLaunch> plan = plan_dwt_forward(d_in, u8in, d_out, c->aw, c->ah, c->p.wl, c->p.qs, c16);
-    if (c16 && !plan_is_c16(plan)) return fail(PICSONG_ERR_ARG, "the 16-bit coefficient form needs the vector kernels on every level");
+    const std::vector<FwdLaunch> plan = plan_dwt_forward(d_in, u8in, d_out, c->aw, c->ah, c->p.wl, c->p.qs, want_c16);
+    if (got_c16) *got_c16 = plan_is_c16(plan);
+    else if (want_c16 && !plan_is_c16(plan)) return fail(PICSONG_ERR_ARG, "the 16-bit coefficient form needs the vector kernels on every level");
     Fwd2Launch f2;
     const bool fused01 = plan_dwt_fwd2(plan, f2, true, c->p.lossy != 0);
     if (fused01) {                       // levels 0 and 1 in one launch, LL1 stays in registers
@@ -985,10 +991,13 @@ int picsong_encode_frame(picsong_ctx *c, const uint8_t *d_frame, int iter, uint1
     // run -- at once on the caller's stream, and the transform's small levels + the coder's launch for the top rows on a
     // second stream beside it: byte-identical, and 70 us SLOWER at 8K (0.308 -> 0.379 ms): the top-left codeblocks are the
     // ones with the most planes, the launch's critical waves, and the split starts exactly those 20-40 us late.)
-    if ((rc = dwt_forward_impl(c, d_frame, true, c->d_coef, s, c->c16))) return rc;
+    // (an unaligned frame pointer, or PICSONG_DWT_NOVEC set after the context was created, takes the per-column kernels
+    // and with them the 32-bit arrays: `c16` is what this call's plan delivers, as in picsong_encode_frames)
+    bool c16 = false;
+    if ((rc = dwt_forward_impl(c, d_frame, true, c->d_coef, s, c->c16, &c16))) return rc;
     if (ev) HIP_TRY(hipEventRecord(ev[1], s));
     uint16_t *const st16 = reinterpret_cast<uint16_t *>(c->d_staging);      // (the context's staging holds the 16-bit form)
-    if ((rc = bpc_encode_impl(c, c->d_coef, st16, c->d_sizes, s, 0, -1, 0, c->c16))) return rc;
+    if ((rc = bpc_encode_impl(c, c->d_coef, st16, c->d_sizes, s, 0, -1, 0, c16))) return rc;
     if (ev) HIP_TRY(hipEventRecord(ev[2], s));
     uint16_t hdr[PICSONG_HDR_SHORTS];
     if (iter == 0) picsong_header_pack(&c->p, hdr);
@@ -1361,7 +1370,10 @@ int picsong_encode_rgb_frame(picsong_ctx *c, const uint8_t *d_r, const uint8_t *
     // three u8 planes and delivers component blockIdx.z -- no component plane is ever written (the separate transform
     // kernel reads 100 MB and writes 400 MB of them per 8K frame, and level 0 reads them back)
     bool fused_rgb = false;
-    if (!c->p.lossy && c->c16 && !getenv("PICSONG_RGB_NOFUSE")) {
+    // (the fused head's buffer loads want all three planes 16-byte aligned like a grey frame's; others take the
+    // separate colour transform below)
+    const bool planes_aligned = ((((uintptr_t)d_r) | ((uintptr_t)d_g) | ((uintptr_t)d_b)) & 15u) == 0;
+    if (!c->p.lossy && c->c16 && planes_aligned && !getenv("PICSONG_RGB_NOFUSE")) {
         std::vector<FwdLaunch> plan = plan_dwt_forward(d_r, true, c->b_coef, c->aw, c->ah, c->p.wl, c->p.qs, true);
         Fwd2Launch f2;
         if (plan_is_c16(plan) && plan_dwt_fwd2(plan, f2, true, false, kF2PairsRgb)) {

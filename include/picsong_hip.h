@@ -186,7 +186,10 @@ int picsong_last_total(picsong_ctx *ctx, void *stream, int *h_total);
  *      picsong_bitstream_unpack does); lengths outside 1..4096 are clamped and raise the range flag.  A
  *      DAMAGED length table can still claim more codewords than the stream holds: reads then reach up to
  *      picsong_max_stream_shorts() shorts, so an untrusted stream belongs in a buffer of that size (as with
- *      picsong_bitstream_unpack). ---- */
+ *      picsong_bitstream_unpack).
+ *      Alignment: none required of d_frame.  A 16-byte aligned frame (what an allocator returns) takes the vector
+ *      kernels and the 16-bit coefficient form; any other pointer -- a view at an odd offset -- takes the per-column
+ *      kernels with the 32-bit arrays: same codestream, slower. ---- */
 int picsong_encode_frame(picsong_ctx *ctx, const uint8_t *d_frame, int iter, uint16_t *d_stream,
                          void *stream);
 int picsong_decode_frame(picsong_ctx *ctx, const uint16_t *d_stream, uint8_t *d_frame_out,
@@ -238,7 +241,9 @@ int picsong_decode_plane(picsong_ctx *ctx, const uint16_t *d_stream, int compone
  * codestream lands at d_streams + c * stream_stride (shorts, >= picsong_max_stream_shorts); header_mask bit c = that
  * component carries the populated header (image: 1 -- component 0 only, iter = component; video frame 0: 7; else 0).
  * Lengths: picsong_last_totals(ctx, stream, 3, ..) / picsong_copy_last_totals.  Byte-identical to the plane-by-plane
- * calls; -cp 2, k = 0 RGB contexts whose three tables share one geometry.  The decoder's mirror takes the three
+ * calls; -cp 2, k = 0 RGB contexts whose three tables share one geometry.  The planes need 4-byte alignment; the
+ * lossless form's fused head (the colour transform in the transform's load stage) runs when all three are 16-byte
+ * aligned, the separate colour-transform kernel otherwise (same streams).  The decoder's mirror takes the three
  * codestreams (same stride) to the three padded u8 planes (Engines/DecodingEngine.cu:599-701, 736-769). */
 int picsong_encode_rgb_frame(picsong_ctx *ctx, const uint8_t *d_r, const uint8_t *d_g, const uint8_t *d_b, int header_mask,
                              uint16_t *d_streams, size_t stream_stride, void *stream);

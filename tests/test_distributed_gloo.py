@@ -349,6 +349,39 @@ def test_bench_launches_its_own_ranks_dry_gloo():
     assert d["exchange"]["payloads_ok"] is True and d["scaling"] == "weak"
 
 
+def test_bench_intra_frame_workload_dry_gloo():
+    """BASELINE configs[4] has a driver-launchable form: `python bench.py --workload 16k_intra --gpus 2` starts two ranks
+    that run picsong_dist.encode_frame_banded per step (LL1 all-gather, two gathers, splice).  Here with --dry over gloo:
+    a stand-in codec whose mini-streams depend on a checksum of the all-gathered plane, so `splice_ok` holds only if
+    every exchange moved what it should; "strong" scaling, one JSON line."""
+    import json
+    r = _run_bench("--workload", "16k_intra", "--gpus", "2", "--backend", "gloo", "--dry", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["dry"] is True and d["scaling"] == "strong"
+    assert d["exchange"]["splice_ok"] is True and d["exchange"]["ranks_seen"] == 2
+
+
+def test_bench_gpu_count_comes_from_sysfs_not_from_hip():
+    """The launcher counts GPUs without opening the HIP runtime (a process that has touched the GPU must not fork + exec
+    its ranks): KFD topology nodes with SIMDs, or None where there is no KFD (this container)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    n = b.count_gpus_without_hip()
+    assert n is None or (isinstance(n, int) and n >= 0)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    launch = src[src.index("def launch_ranks"):src.index("def rccl_witness")]
+    assert "device_count" not in launch and "import torch" not in launch
+    # the transform's byte counts of the line: S8(d)'s, and what the fused int16 design must move (never above it)
+    P = 7680 * 4352
+    assert abs(b.dwt_bytes(P, 5, 1) / 1e6 - 255.9) < 0.1 and abs(b.dwt_required_bytes(P, 5) / 1e6 - 122.2) < 0.1
+    assert b.dwt_required_bytes(P, 5, False, False) == b.dwt_bytes(P, 5, 1)
+
+
 def test_bench_refuses_more_gpus_than_the_node_has():
     """No quiet world = 1 run: asking for more GPUs than the node has is an error (here: none visible, or one)."""
     if torch.cuda.device_count() >= 64:

@@ -647,6 +647,32 @@ def test_16_bit_and_32_bit_coefficient_forms_agree(oracle, pa, torch, monkeypatc
     assert np.array_equal(results[0].cpu().numpy()[:H, :W], oracle.decode_frame(ref, W, H, wl, lossy, qs, oracle.lut_for(lossy, wl)))
 
 
+@pytest.mark.parametrize("W,H,wl,lossy,qs", [(1280, 704, 5, False, 1.0), (640, 384, 4, True, 0.5)])
+def test_unaligned_frame_pointer_and_late_novec_fall_back_to_the_32_bit_form(oracle, pa, torch, monkeypatch, W, H, wl, lossy, qs):
+    """A context chooses the 16-bit coefficient form from its geometry; whether a CALL can use it also depends on the
+    caller's frame pointer (the vector kernels want 16-byte alignment) and on PICSONG_DWT_NOVEC at call time.  Such a
+    call takes the per-column kernels with the 32-bit arrays -- same codestream, no error (the header states no
+    alignment requirement for picsong_encode_frame)."""
+    img = oracle.gen_frame(W, H, 71)
+    ref = oracle.encode_frame(img, wl, lossy, qs, oracle.lut_for(lossy, wl))
+    pad = oracle.pad_frame(img)
+    c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=_lutdir(oracle, lossy))
+    for off in (1, 2, 4, 8):                                   # a view at an odd / a 2- / 4- / 8-byte offset
+        buf = torch.zeros(pad.size + 64, dtype=torch.uint8, device="cuda")
+        assert buf.data_ptr() % 16 == 0
+        view = buf[off:off + pad.size]
+        view.copy_(_dev(torch, pad).view(-1))
+        got = c.encode_frame(view, 0).cpu().numpy().view(np.uint16)
+        assert np.array_equal(got, ref), off
+    frame = _dev(torch, pad)
+    assert np.array_equal(c.encode_frame(frame, 0).cpu().numpy().view(np.uint16), ref)
+    monkeypatch.setenv("PICSONG_DWT_NOVEC", "1")               # after the context was created
+    assert np.array_equal(c.encode_frame(frame, 0).cpu().numpy().view(np.uint16), ref)
+    monkeypatch.delenv("PICSONG_DWT_NOVEC")
+    assert np.array_equal(c.encode_frame(frame, 0).cpu().numpy().view(np.uint16), ref)
+    c.close()
+
+
 @pytest.mark.parametrize("W,H,wl,lossy,qs,mask", [(320, 192, 3, False, 1.0, 1), (704, 448, 4, True, 0.5, 7), (1000, 300, 3, False, 1.0, 0)])
 def test_rgb_frame_through_the_batched_grid_equals_oracle(oracle, pa, torch, W, H, wl, lossy, qs, mask):
     """picsong_encode_rgb_frame / picsong_decode_rgb_frame: the three components of an RGB frame as the three frames
