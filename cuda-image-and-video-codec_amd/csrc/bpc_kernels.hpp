@@ -1717,7 +1717,15 @@ __device__ __forceinline__ uint32_t cform_signs(uint32_t a, uint32_t b, uint32_t
 // The decoded planes of one column half (row masks PL / PR, plane k in word k) back to coefficients: the same 8 x 8
 // bit-matrix transpose as the encoder's prologue (bit_transpose_8x8x4 is its own inverse) turns eight plane words into
 // eight words of row bytes -- the magnitude byte of row 8 b + j is byte b of word j -- instead of a bit at a time.
-template <int NP, int NA>
+// C16: `out` is the lane's place in an int16 Mallat array (row stride AW 16-bit words): a row's two coefficients leave
+// as ONE dword -- the decode frame paths where every magnitude stays below 2^15 (BpcArgs::c16)
+template <bool C16>
+__device__ __forceinline__ void store_coef_pair(int32_t *out, size_t row, int AW, int32_t v0, int32_t v1)
+{
+    if constexpr (C16) *reinterpret_cast<uint32_t *>(reinterpret_cast<int16_t *>(out) + row * (size_t)AW) = ((uint32_t)v0 & 0xFFFFu) | ((uint32_t)v1 << 16);
+    else *reinterpret_cast<int2 *>(out + row * (size_t)AW) = make_int2(v0, v1);
+}
+template <int NP, int NA, bool C16 = false>
 __device__ __forceinline__ void write_rows(const uint32_t (&PL)[NA], const uint32_t (&PR)[NA],
                                            uint32_t sgL, uint32_t sgR, int row0, bool valid, int32_t sz,
                                            const int32_t *stage, uint32_t t, int32_t *out, int AW,
@@ -1744,7 +1752,7 @@ __device__ __forceinline__ void write_rows(const uint32_t (&PL)[NA], const uint3
             }
             int32_t v0 = (int32_t)(((uint32_t)w.x & 0xFFFFFFu) >> 1); if (w.x & 1) v0 = -v0;
             int32_t v1 = (int32_t)(((uint32_t)w.y & 0xFFFFFFu) >> 1); if (w.y & 1) v1 = -v1;
-            *reinterpret_cast<int2 *>(out + (size_t)i * (size_t)AW) = make_int2(v0, v1);
+            store_coef_pair<C16>(out, (size_t)i, AW, v0, v1);
         }
         return;
     }
@@ -1767,7 +1775,7 @@ __device__ __forceinline__ void write_rows(const uint32_t (&PL)[NA], const uint3
             if (NP > 8) { m0 |= ((Y0[j] >> (8 * b)) & 0xFFu) << 8; m1 |= ((Y1[j] >> (8 * b)) & 0xFFu) << 8; }
             const int32_t v0 = ((sgL >> ii) & 1u) ? -(int32_t)m0 : (int32_t)m0;
             const int32_t v1 = ((sgR >> ii) & 1u) ? -(int32_t)m1 : (int32_t)m1;
-            *reinterpret_cast<int2 *>(out + (size_t)(row0 + ii) * (size_t)AW) = make_int2(v0, v1);
+            store_coef_pair<C16>(out, (size_t)(row0 + ii), AW, v0, v1);
         }
     }
 }
@@ -1789,13 +1797,18 @@ __device__ __forceinline__ void write_rows(const uint32_t (&PL)[NA], const uint3
 // at once.
 constexpr int kDecSmallPlanes = 8;
 // S16 (k = 0 only): the frame paths' instantiation, codewords read from the packed stream (BpcArgs::cw16)
-template <bool BULK, int NP, bool S16 = false>
+// C16 (with S16): the coefficients leave as an int16 Mallat array (row stride AW) at coeffs_out, for the synthesis
+// kernels' C16 instantiations -- half the bytes the decoder writes and the transform reads.  Only in contexts whose
+// magnitudes are bounded below 2^15 (coef16_ok: an honest stream's codeblocks have MSB <= 14 there; a damaged table
+// that claims more raises the range flag and decodes to wrapped values -- "something", as every damaged stream does)
+template <bool BULK, int NP, bool S16 = false, bool C16 = false>
 __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcDecWgWaves,
                              !BULK ? PICSONG_BPC_DEC_WAVES8 : (NP == kDecSmallPlanes ? 5 : PICSONG_BPC_DEC_WAVES))
 void bpc_decode_kernel(BpcArgs a)
 {
     static_assert(NP == kDecSmallPlanes || NP == kMaxPlanes, "two classes");
     static_assert(!(BULK && S16), "-k > 0 decodes from the staging");
+    static_assert(!C16 || S16, "the 16-bit coefficient form belongs to the frame paths");
     __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
     __shared__ uint8_t sign_tab[256];
     __shared__ __attribute__((aligned(1024))) uint16_t cw_ring[(BULK ? 1 : kBpcDecWgWaves) * 2 * kDecRing];
@@ -1821,7 +1834,9 @@ void bpc_decode_kernel(BpcArgs a)
     const int cb = a.cb_base + 2 * wave + (int)half;
     const bool valid = cb < a.nCB;
     const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
+    // (C16: the lane's first coefficient in 16-bit words, expressed in the 32-bit words of coeffs_out's type)
     const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
+    int32_t *const obase = C16 ? reinterpret_cast<int32_t *>(reinterpret_cast<int16_t *>(a.coeffs_out) + cbase) : a.coeffs_out + cbase;
     constexpr bool s16 = S16;                               // the stream itself, not the staging
     const int cbs = valid ? cb : a.cb_base;
     const int32_t *stage = s16 ? nullptr : a.staging + (size_t)cbs * 4096u;   // (32-bit form) word 0 = the MSB, slot k = stage[1 + k]
@@ -1852,6 +1867,7 @@ void bpc_decode_kernel(BpcArgs a)
         atomicOr(a.range_flag, 1);
         msb = kMaxPlanes - 1;
     }
+    if (C16 && valid && sz != 4096 && msb == kMaxPlanes - 1) atomicOr(a.range_flag, 1);     // magnitudes of 16 bits: not in an int16
     const bool coded = valid && msb != 32 && sz != 4096;
 
     int level, sb;
@@ -2047,16 +2063,16 @@ void bpc_decode_kernel(BpcArgs a)
             for (int hw = 0; hw < 2; hw++) {
                 uint32_t A[kMaxPlanes], B[kMaxPlanes];
                 planes_of(A, B, hw, kMaxPlanes);
-                write_rows<kMaxPlanes>(A, B, hw ? sgnL.hi : sgnL.lo, hw ? sgnR.hi : sgnR.lo, 32 * hw, valid, sz, stage, t,
-                                       a.coeffs_out + cbase, a.AW, raw16, c.srcoff, c.srclim + 1u, word0);
+                write_rows<kMaxPlanes, kMaxPlanes, C16>(A, B, hw ? sgnL.hi : sgnL.lo, hw ? sgnR.hi : sgnR.lo, 32 * hw, valid, sz, stage, t,
+                                                        obase, a.AW, raw16, c.srcoff, c.srclim + 1u, word0);
             }
         } else {
 #pragma unroll 1
             for (int hw = 0; hw < 2; hw++) {
                 uint32_t A[kDecSmallPlanes], B[kDecSmallPlanes];
                 planes_of(A, B, hw, kDecSmallPlanes);
-                write_rows<kDecSmallPlanes>(A, B, hw ? sgnL.hi : sgnL.lo, hw ? sgnR.hi : sgnR.lo, 32 * hw, valid, sz, stage, t,
-                                            a.coeffs_out + cbase, a.AW, raw16, c.srcoff, c.srclim + 1u, word0);
+                write_rows<kDecSmallPlanes, kDecSmallPlanes, C16>(A, B, hw ? sgnL.hi : sgnL.lo, hw ? sgnR.hi : sgnR.lo, 32 * hw, valid, sz, stage, t,
+                                                                  obase, a.AW, raw16, c.srcoff, c.srclim + 1u, word0);
             }
         }
     }

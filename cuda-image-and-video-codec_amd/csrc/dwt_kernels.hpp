@@ -1795,11 +1795,16 @@ __device__ __forceinline__ bool dwt_inv2_band(const DwtInvArgs &a1, const DwtInv
     return LOSSY && !EXACT && __builtin_amdgcn_ballot_w64(emin <= kTinyExp) != 0ull;
 }
 
+// resident waves per SIMD the register budget is set for: the 5/3 form fits 64 registers; the 9/7 form carries both
+// levels' window state (24), two iterations' raw words (20) and seven step constants (14): 128 registers, 4 waves
 #ifndef PICSONG_DWT_INV2_WAVES
-#define PICSONG_DWT_INV2_WAVES 5
+#define PICSONG_DWT_INV2_WAVES 8
+#endif
+#ifndef PICSONG_DWT_INV2_WAVES_LOSSY
+#define PICSONG_DWT_INV2_WAVES_LOSSY 4
 #endif
 template <bool LOSSY, bool ONE_DIV>
-__global__ __launch_bounds__(256, PICSONG_DWT_INV2_WAVES) void dwt_inv2_kernel(DwtInv2Args a2)
+__global__ __launch_bounds__(256, LOSSY ? PICSONG_DWT_INV2_WAVES_LOSSY : PICSONG_DWT_INV2_WAVES) void dwt_inv2_kernel(DwtInv2Args a2)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int strip = blockIdx.x * 4 + wave;

@@ -212,8 +212,10 @@ inline bool dwt_c16_geometry_ok(int aw, int ah, int wl)
     }
     return (aw & 3) == 0 && (ah >> (wl - 1)) >= 2;
 }
+// c16: the coded coefficients at d_in are an int16 Mallat array (the decode frame paths, DwtInvArgs::c16): the vector
+// kernels' C16 instantiations on every level, or not at all (the caller looks at plan_inv_is_c16)
 inline std::vector<InvLaunch> plan_dwt_inverse(const int32_t *d_in, void *d_out, int aw, int ah, int wl,
-                                               float qs, bool fast = false)
+                                               float qs, bool fast = false, bool c16 = false)
 {
     std::vector<InvLaunch> v;
     int W = aw >> (wl - 1), H = ah >> (wl - 1);
@@ -245,12 +247,56 @@ inline std::vector<InvLaunch> plan_dwt_inverse(const int32_t *d_in, void *d_out,
         f.gx = (unsigned)((strips + 3) / 4);
         f.gy = (unsigned)(((H >> 1) + f.band / 2 - 1) / (f.band / 2));
         f.vec = dwt_vec_ok(W, aw, d_in, d_out);
+        a.c16 = c16 ? 1 : 0;
         v.push_back(f);
         read_off = write_off;
         write_off += (size_t)W * (size_t)H;
         W <<= 1; H <<= 1;
     }
+    bool all_vec = true;
+    for (const InvLaunch &f : v) all_vec = all_vec && f.vec;
+    if (!all_vec) for (InvLaunch &f : v) f.a.c16 = 0;
     return v;
+}
+inline bool plan_inv_is_c16(const std::vector<InvLaunch> &plan) { return !plan.empty() && plan[0].a.c16 != 0; }
+
+// May a decode context take the 16-bit coefficient form between its decoder and its synthesis?  The bound of coef16_ok
+// (an honest stream of such a context has no magnitude of 2^15 or more), the vector kernels on every level, at least
+// two levels (the coarsest level that also writes pixels has no C16 instantiation), and for 9/7 the verified
+// reciprocal divisions (the lean kernels are the ones with a C16 form).  PICSONG_DEC_C16=0 keeps the 32-bit arrays.
+inline bool dec_c16_ok(bool lossy, int wl, float qs, int in_max, int aw, int ah, bool fast_div)
+{
+    if (const char *e = getenv("PICSONG_DEC_C16")) if (atoi(e) == 0) return false;
+    if (const char *e = getenv("PICSONG_DWT_INV97")) if (atoi(e) == 0) return false;
+    return wl >= 2 && (!lossy || fast_div) && coef16_ok(lossy, wl, qs, in_max) && dwt_c16_geometry_ok(aw, ah, wl);
+}
+
+// Synthesis levels 1 and 0 of an inverse plan as ONE launch of dwt_inv2_kernel (dwt_kernels.hpp): the decode frame
+// paths (16-bit coefficients in, pixels out), level 1 not the coarsest, whole 32-row bands.  PICSONG_DWT_NOFUSE_INV=1
+// keeps the two launches (the tests cross-check both).
+struct Inv2Launch { DwtInv2Args a; unsigned gx, gy; };
+inline bool plan_dwt_inv2(const std::vector<InvLaunch> &plan, Inv2Launch &f, bool lossy)
+{
+    if (const char *e = getenv("PICSONG_DWT_NOFUSE_INV")) if (atoi(e) != 0) return false;
+    if (plan.size() < 3) return false;
+    const InvLaunch &p1 = plan[plan.size() - 2], &p0 = plan.back();
+    if (!p0.vec || !p1.vec || !p0.a.c16 || !p0.a.dst_u8 || p1.a.first) return false;
+    // 9/7: built, bit-identical and NOT the default -- the 9/7 synthesis is bound by its arithmetic (three-instruction
+    // divisions the reference's rounding demands), not by traffic, and the fused form pays for the LL0 bytes it saves
+    // with level 1's longer run-in (14 steps for 8 row pairs) and 128 registers (4 waves a SIMD): an 8K frame's
+    // levels 1 + 0 take 48.0 us fused against 15.3 + 35.1 us, decode with three calls in flight 150 against 157
+    // Gpixel/s (round 4, profiles/NOTES.md).  PICSONG_DWT_FUSE_INV97=1 selects it (the tests run both).
+    if (lossy) {
+        const char *e = getenv("PICSONG_DWT_FUSE_INV97");
+        if (!(e && atoi(e) != 0) || !p0.fast) return false;
+    }
+    if (p0.a.W < 16 || (p0.a.W & 7) || p0.a.H < 64 || (p0.a.H % (4 * kI2Pairs))) return false;
+    f.a.l1 = p1.a; f.a.l0 = p0.a;
+    const int useful = lossy ? i2_useful<true>() : i2_useful<false>();
+    const int strips = (p0.a.W + useful - 1) / useful;
+    f.gx = (unsigned)((strips + 3) / 4);
+    f.gy = (unsigned)(p0.a.H / (4 * kI2Pairs));
+    return true;
 }
 
 }  // namespace picsong

@@ -51,6 +51,7 @@ struct picsong_ctx {
     size_t P, extra;
     bool fast_div;        // 9/7 synthesis: reciprocal form of the divisions verified for this qs
     bool c16;             // frame paths: coded coefficients travel as int16 between transform and coder (coef16_ok)
+    bool c16_dec;         // decode frame paths: ... and between decoder and synthesis (dec_c16_ok)
     bool pipelined;       // picsong_ctx_set_pipelined: other frames share the GPU (throughput over latency)
     // LUT
     picsong_lut_info li[3];
@@ -90,6 +91,24 @@ static void launch_inv(const picsong_ctx *c, const InvLaunch &f, hipStream_t s, 
     static const bool lean97 = !(getenv("PICSONG_DWT_INV97") && atoi(getenv("PICSONG_DWT_INV97")) == 0);
     // (a coarsest level that also writes pixels, wl = 1, stays with dwt_inv_kernel)
     const bool l97 = c->p.lossy && f.fast && lean97 && f.vec && !(f.a.first && f.a.dst_u8);
+    if (f.a.c16) {
+        // the decode frame paths' 16-bit coefficients (dec_c16_ok: vector kernels, 9/7 through the lean kernel, the
+        // coarsest level never the one that writes pixels)
+        if (c->p.lossy) {
+            if (f.a.dst_u8) {
+                if (f.a.one_div) dwt_inv97_kernel<BAND, true, false, true, true><<<grid, 256, 0, s>>>(f.a);
+                else dwt_inv97_kernel<BAND, true, false, false, true><<<grid, 256, 0, s>>>(f.a);
+            } else if (f.a.first) {
+                if (f.a.one_div) dwt_inv97_kernel<BAND, false, true, true, true><<<grid, 256, 0, s>>>(f.a);
+                else dwt_inv97_kernel<BAND, false, true, false, true><<<grid, 256, 0, s>>>(f.a);
+            } else {
+                if (f.a.one_div) dwt_inv97_kernel<BAND, false, false, true, true><<<grid, 256, 0, s>>>(f.a);
+                else dwt_inv97_kernel<BAND, false, false, false, true><<<grid, 256, 0, s>>>(f.a);
+            }
+        } else if (f.a.dst_u8) dwt_inv_kernel<int, false, BAND, true, true, false, true><<<grid, 256, 0, s>>>(f.a);
+        else dwt_inv_kernel<int, false, BAND, true, false, false, true><<<grid, 256, 0, s>>>(f.a);
+        return;
+    }
     if (l97) {
         if (f.a.dst_u8) {
             if (f.a.one_div) dwt_inv97_kernel<BAND, true, false, true><<<grid, 256, 0, s>>>(f.a);
@@ -400,6 +419,8 @@ int picsong_ctx_create(const picsong_params *p, int device, picsong_ctx **out)
     // 8-bit samples: 128 after the level shift; 255 covers the chroma differences of the RGB path's RCT
     c->c16 = p->k <= 0.0f && p->cp != 3 && p->bit_depth == 8 && dwt_c16_geometry_ok(c->aw, c->ah, p->wl) &&
              coef16_ok(p->lossy != 0, p->wl, p->qs, p->is_rgb ? 255 : 128);
+    c->c16_dec = p->k <= 0.0f && p->cp != 3 && p->bit_depth == 8 && !p->is_rgb &&
+                 dec_c16_ok(p->lossy != 0, p->wl, p->qs, 128, c->aw, c->ah, c->fast_div);
     hipError_t e = hipMalloc(&c->d_offsets, sizeof(int32_t) * (size_t)c->ncb);
     if (e == hipSuccess) e = hipMalloc(&c->d_total, sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc(&c->d_flag, sizeof(int));
@@ -627,22 +648,26 @@ int picsong_dwt_forward_tail(picsong_ctx *c, void *d_out, void *stream)
     return launch_fwd_levels(c, plan, 1, (hipStream_t)stream);
 }
 
-// d_pixels != nullptr: the finest level writes clamped u8 pixels there (level shift + clamp fused,
-// when its vector kernel applies) instead of T samples into d_out; returns 1 in *fused then.
-// frames > 1 (picsong_decode_frames): grid.z = frame; frame z's coded coefficients at d_in + z * P, its work buffer at
-// d_out + z * (P + extra) elements, its pixels at d_pixels + z * pix_stride bytes
-static int dwt_inverse_impl(picsong_ctx *c, const int32_t *d_in, void *d_out, uint8_t *d_pixels, bool *fused,
-                            hipStream_t s, unsigned frames = 1, size_t pix_stride = 0)
+// The frame paths' synthesis.  d_pixels != nullptr: the finest level writes clamped u8 pixels there (level shift +
+// clamp fused, when its vector kernel applies) instead of T samples into d_out; *fused says so.
+// frames > 1 (picsong_decode_frames): grid.z = frame; frame z's coded coefficients at d_in + z * P coefficients, its
+// work buffer at d_out + z * (P + extra) elements, its pixels at d_pixels + z * pix_stride bytes.
+// want_c16: the decoder may write 16-bit coefficients (picsong_ctx::c16_dec) -- the plan says whether this call's
+// pointers allow it (plan_inv_is_c16), BEFORE the decoder is launched: inverse_plan, then the decoder, then run_inverse.
+static std::vector<InvLaunch> inverse_plan(picsong_ctx *c, const int32_t *d_in, void *d_out, uint8_t *d_pixels, bool *fused,
+                                           unsigned frames, size_t pix_stride, bool want_c16)
 {
     if (fused) *fused = false;
-    std::vector<InvLaunch> plan = plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs, c->fast_div);
-    if (d_pixels && !plan.empty() && plan.back().vec && (((uintptr_t)d_pixels) & 3u) == 0 && (pix_stride & 3u) == 0) {
+    const bool px = d_pixels && (((uintptr_t)d_pixels) & 3u) == 0 && (pix_stride & 3u) == 0;
+    std::vector<InvLaunch> plan = plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs, c->fast_div, want_c16 && px);
+    if (px && !plan.empty() && plan.back().vec) {
         plan.back().a.dst_u8 = d_pixels;
         plan.back().a.off = 1 << (c->p.bit_depth - 1);
         if (fused) *fused = true;
     }
     if (frames > 1) {
-        const unsigned long long in_z = (unsigned long long)c->P * 4ull, wrk_z = (unsigned long long)(c->P + c->extra) * 4ull;
+        const unsigned long long in_z = (unsigned long long)c->P * (plan_inv_is_c16(plan) ? 2ull : 4ull);
+        const unsigned long long wrk_z = (unsigned long long)(c->P + c->extra) * 4ull;
         for (InvLaunch &f : plan) {
             f.a.mallat_z = in_z;
             f.a.ll_z = f.a.first ? in_z : wrk_z;            // the coarsest level's LL comes from the coded array
@@ -650,7 +675,17 @@ static int dwt_inverse_impl(picsong_ctx *c, const int32_t *d_in, void *d_out, ui
             f.a.u8_z = (unsigned long long)pix_stride;
         }
     }
-    for (const InvLaunch &f : plan) {
+    return plan;
+}
+
+static int run_inverse(picsong_ctx *c, const std::vector<InvLaunch> &plan, hipStream_t s, unsigned frames = 1)
+{
+    // 16-bit coefficients in, pixels out: synthesis levels 1 and 0 as one launch (dwt_inv2_kernel), LL0 in registers
+    Inv2Launch f2;
+    const bool fused10 = plan_dwt_inv2(plan, f2, c->p.lossy != 0);
+    const size_t n = fused10 ? plan.size() - 2 : plan.size();
+    for (size_t l = 0; l < n; l++) {
+        const InvLaunch &f = plan[l];
         switch (f.band) {
         case 32: launch_inv<32>(c, f, s, frames); break;
         case 16: launch_inv<16>(c, f, s, frames); break;
@@ -659,7 +694,20 @@ static int dwt_inverse_impl(picsong_ctx *c, const int32_t *d_in, void *d_out, ui
         }
         HIP_TRY(hipGetLastError());
     }
+    if (fused10) {
+        const dim3 grid(f2.gx, f2.gy, frames);
+        if (!c->p.lossy) dwt_inv2_kernel<false, false><<<grid, 256, 0, s>>>(f2.a);
+        else if (f2.a.l0.one_div) dwt_inv2_kernel<true, true><<<grid, 256, 0, s>>>(f2.a);
+        else dwt_inv2_kernel<true, false><<<grid, 256, 0, s>>>(f2.a);
+        HIP_TRY(hipGetLastError());
+    }
     return PICSONG_OK;
+}
+
+static int dwt_inverse_impl(picsong_ctx *c, const int32_t *d_in, void *d_out, uint8_t *d_pixels, bool *fused,
+                            hipStream_t s, unsigned frames = 1, size_t pix_stride = 0)
+{
+    return run_inverse(c, inverse_plan(c, d_in, d_out, d_pixels, fused, frames, pix_stride, false), s, frames);
 }
 
 int picsong_dwt_inverse(picsong_ctx *c, const int32_t *d_in, void *d_out, void *stream)
@@ -769,9 +817,10 @@ static bool dec_from_stream(const picsong_ctx *c)
 
 // d_stream16 != nullptr (k = 0, -cp 2): the codewords come from the packed stream, d_offsets the scan of its lengths
 // (scan_stream_kernel); d_staging is then not read
+// c16 (with d_stream16): the coefficients leave as an int16 Mallat array at d_coeffs (bpc_decode_kernel's C16 form)
 static int bpc_decode_impl(picsong_ctx *c, const int32_t *d_staging, const int32_t *d_sizes, int32_t *d_coeffs,
                            hipStream_t s, int comp = 0, const uint16_t *d_stream16 = nullptr,
-                           const int32_t *d_offsets = nullptr)
+                           const int32_t *d_offsets = nullptr, bool c16 = false)
 {
     BpcArgs a;
     int rc = bpc_args(c, a, comp);
@@ -796,8 +845,10 @@ static int bpc_decode_impl(picsong_ctx *c, const int32_t *d_staging, const int32
         if (d_stream16) {
             a.cw16 = d_stream16; a.cw16_offsets = d_offsets; a.cw16_total = c->d_total;
             a.cw16_max = (uint32_t)picsong_max_stream_shorts(c->aw, c->ah);
-            bpc_decode_kernel<false, kDecSmallPlanes, true><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
+            if (c16) bpc_decode_kernel<false, kDecSmallPlanes, true, true><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
+            else bpc_decode_kernel<false, kDecSmallPlanes, true><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
         } else {
+            if (c16) return fail(PICSONG_ERR_ARG, "the 16-bit coefficient form decodes from the stream itself");
             bpc_decode_kernel<false, kDecSmallPlanes><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
         }
     }
@@ -809,16 +860,18 @@ static int bpc_decode_impl(picsong_ctx *c, const int32_t *d_staging, const int32
 // or the unpack into the staging (-k > 0, -cp 3, PICSONG_DEC_STAGING)
 static int unpack_impl(picsong_ctx *c, const uint16_t *d_stream, int32_t *d_staging, int32_t *d_sizes,
                        bool memset_staging, hipStream_t s);
-static int decode_stream_impl(picsong_ctx *c, const uint16_t *d_stream, int32_t *d_coeffs, hipStream_t s, int comp)
+static int decode_stream_impl(picsong_ctx *c, const uint16_t *d_stream, int32_t *d_coeffs, hipStream_t s, int comp,
+                              bool c16 = false)
 {
     int rc;
     if (!dec_from_stream(c)) {
+        if (c16) return fail(PICSONG_ERR_ARG, "the 16-bit coefficient form decodes from the stream itself");
         if ((rc = unpack_impl(c, d_stream, c->d_staging, c->d_sizes, false, s))) return rc;
         return bpc_decode_impl(c, c->d_staging, c->d_sizes, d_coeffs, s, comp);
     }
     scan_stream_kernel<<<1, scan_threads(c->ncb), 0, s>>>(d_stream, c->ncb, c->d_sizes, c->d_offsets, c->d_total, c->d_flag, 0);
     HIP_TRY(hipGetLastError());
-    return bpc_decode_impl(c, nullptr, c->d_sizes, d_coeffs, s, comp, d_stream, c->d_offsets);
+    return bpc_decode_impl(c, nullptr, c->d_sizes, d_coeffs, s, comp, d_stream, c->d_offsets, c16);
 }
 
 int picsong_bpc_decode(picsong_ctx *c, const int32_t *d_staging, const int32_t *d_sizes, int32_t *d_coeffs,
@@ -1013,9 +1066,13 @@ int picsong_decode_frame(picsong_ctx *c, const uint16_t *d_stream, uint8_t *d_fr
     int rc = ensure_workspace(c, true);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = decode_stream_impl(c, d_stream, c->d_coef_i, s, 0))) return rc;
+    // (16-bit coefficients between the decoder and the synthesis where the context's magnitudes are bounded and this
+    // call's pointers take the vector kernels: c->c16_dec, plan_inv_is_c16)
     bool fused = false;
-    if ((rc = dwt_inverse_impl(c, c->d_coef_i, c->d_coef, d_frame_out, &fused, s))) return rc;
+    const std::vector<InvLaunch> plan = inverse_plan(c, c->d_coef_i, c->d_coef, d_frame_out, &fused, 1, 0,
+                                                     c->c16_dec && dec_from_stream(c));
+    if ((rc = decode_stream_impl(c, d_stream, c->d_coef_i, s, 0, plan_inv_is_c16(plan)))) return rc;
+    if ((rc = run_inverse(c, plan, s))) return rc;
     if (fused) return PICSONG_OK;            // the finest level wrote the pixels itself
     const void *img = (const char *)c->d_coef + c->extra * 4;
     const size_t n4 = c->P / 4;
@@ -1234,19 +1291,24 @@ int picsong_decode_frames(picsong_ctx *c, int n, const uint16_t *d_streams, size
     const int wpf = (c->ncb + 1) / 2;
     a.cb_base = 0; a.nCB = c->ncb;
     a.coeffs_out = c->b_coef_i; a.staging = c->b_staging; a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch;
-    a.frames = n; a.waves_per_frame = wpf; a.coef_z = (unsigned long long)c->P * 4ull;
+    // (the synthesis is planned first: it says whether this call's coefficients can travel as int16)
+    bool fused = false;
+    const std::vector<InvLaunch> plan = inverse_plan(c, c->b_coef_i, c->b_coef, d_frames_out, &fused, (unsigned)n, frame_stride,
+                                                     c->c16_dec && direct);
+    const bool c16 = plan_inv_is_c16(plan);
+    a.frames = n; a.waves_per_frame = wpf; a.coef_z = (unsigned long long)c->P * (c16 ? 2ull : 4ull);
     const unsigned wgs = (unsigned)(((size_t)n * (size_t)wpf + kBpcDecWgWaves - 1) / kBpcDecWgWaves);
     if (direct) {
         a.cw16 = d_streams; a.cw16_offsets = c->b_offsets; a.cw16_total = c->b_total; a.cw16_stride = stream_stride;
         a.cw16_max = (uint32_t)picsong_max_stream_shorts(c->aw, c->ah);
-        bpc_decode_kernel<false, kDecSmallPlanes, true><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
+        if (c16) bpc_decode_kernel<false, kDecSmallPlanes, true, true><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
+        else bpc_decode_kernel<false, kDecSmallPlanes, true><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
     } else {
         bpc_decode_kernel<false, kDecSmallPlanes><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
     }
     HIP_TRY(hipGetLastError());
     // ---- inverse transform, pixels out of the finest level where its vector kernel applies
-    bool fused = false;
-    if ((rc = dwt_inverse_impl(c, c->b_coef_i, c->b_coef, d_frames_out, &fused, s, (unsigned)n, frame_stride))) return rc;
+    if ((rc = run_inverse(c, plan, s, (unsigned)n))) return rc;
     if (fused) return PICSONG_OK;
     const size_t n4 = c->P / 4;
     const int off = 1 << (c->p.bit_depth - 1);

@@ -143,6 +143,31 @@ def dwt_inverse_u8(coef, wl, lossy, qs=1.0, extra=0):
     return pix.reshape(AH, AW), bool(fused)
 
 
+def dwt_inverse_u8_c16(coef16, wl, lossy, qs=1.0, extra=0):
+    """The decode frame paths with 16-bit coefficients: `coef16` an int16 (AH, AW) Mallat array.  Returns (pixels u8
+    (AH, AW), flags): bit 0 the finest level wrote the pixels, bit 1 synthesis levels 1 and 0 ran as one launch
+    (dwt_inv2_kernel), bit 2 the 16-bit form applied at all (0: nothing was run)."""
+    AH, AW = coef16.shape
+    coef16 = aligned_copy(np.ascontiguousarray(coef16, np.int16))
+    scratch = aligned_zeros(AW * AH + extra, np.float32 if lossy else np.int32)
+    pix = aligned_zeros(AW * AH, np.uint8)
+    flags = lib().emu_dwt_inverse_u8_c16(_p(coef16), _p(scratch), _p(pix), AW, AH, wl, int(lossy), C.c_float(qs))
+    return pix.reshape(AH, AW), int(flags)
+
+
+def bpc_decode_stream16(stream, AW, AH, wl, lut):
+    """bpc_decode_stream with the coefficients leaving as int16 (the decoder's C16 instantiation)."""
+    stream = np.ascontiguousarray(stream, np.uint16)
+    coef = np.full((AH, AW), 0x5A5A, np.int16)
+    flag = np.zeros(1, np.int32)
+    tab = np.ascontiguousarray(lut.table, np.int32)
+    geo = _geo(lut)
+    bad = lib().emu_bpc_decode_stream16(_p(stream), int(stream.size), AW, AH, wl, _p(tab), _p(geo), _p(coef), _p(flag))
+    bpc_decode_stream16.last_flag = int(flag[0])
+    bpc_decode_stream16.last_bad = int(bad)
+    return coef
+
+
 def level_shift_inv(x):
     x = np.ascontiguousarray(x).copy()
     lib().emu_level_shift_inv(_p(x), C.c_size_t(x.size), int(x.dtype == np.float32))

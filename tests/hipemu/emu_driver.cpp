@@ -48,6 +48,23 @@ static bool emu_lean97() { const char *e = getenv("PICSONG_DWT_INV97"); return !
 template <int BAND> static void emu_inv(const InvLaunch &f, int lossy)
 {
     DwtInvArgs a = f.a;
+    if (a.c16) {                        // the decode frame paths' 16-bit coefficients (mirrors launch_inv)
+        const dim3 grid(f.gx, f.gy);
+        if (lossy) {
+            if (a.dst_u8) {
+                if (a.one_div) emu::launch(grid, dim3(256), [&] { dwt_inv97_kernel<BAND, true, false, true, true>(a); });
+                else emu::launch(grid, dim3(256), [&] { dwt_inv97_kernel<BAND, true, false, false, true>(a); });
+            } else if (a.first) {
+                if (a.one_div) emu::launch(grid, dim3(256), [&] { dwt_inv97_kernel<BAND, false, true, true, true>(a); });
+                else emu::launch(grid, dim3(256), [&] { dwt_inv97_kernel<BAND, false, true, false, true>(a); });
+            } else {
+                if (a.one_div) emu::launch(grid, dim3(256), [&] { dwt_inv97_kernel<BAND, false, false, true, true>(a); });
+                else emu::launch(grid, dim3(256), [&] { dwt_inv97_kernel<BAND, false, false, false, true>(a); });
+            }
+        } else if (a.dst_u8) emu::launch(grid, dim3(256), [&] { dwt_inv_kernel<int, false, BAND, true, true, false, true>(a); });
+        else emu::launch(grid, dim3(256), [&] { dwt_inv_kernel<int, false, BAND, true, false, false, true>(a); });
+        return;
+    }
     if (f.vec && lossy && f.fast && emu_lean97() && !(a.first && a.dst_u8)) {
         const dim3 grid(f.gx, f.gy);
         if (a.dst_u8) {
@@ -219,6 +236,40 @@ int emu_dwt_inverse_u8(const int32_t *in, void *scratch, uint8_t *pixels, int aw
     return fused ? 1 : 0;
 }
 
+// the decode frame paths with 16-bit coefficients (mirrors inverse_plan + run_inverse, picsong_hip.hip): `in16` is an
+// int16 Mallat array; returns bit 0: the finest level wrote the pixels, bit 1: levels 1 and 0 ran as ONE launch
+// (dwt_inv2_kernel), bit 2: the plan took the 16-bit form (0: the caller's geometry / context does not allow it)
+int emu_dwt_inverse_u8_c16(const int16_t *in16, void *scratch, uint8_t *pixels, int aw, int ah, int wl, int lossy, float qs)
+{
+    const bool fast = emu_fast_div(lossy, qs, wl);
+    if (!dec_c16_ok(lossy != 0, wl, qs, 128, aw, ah, fast)) return 0;
+    std::vector<InvLaunch> plan = plan_dwt_inverse((const int32_t *)in16, scratch, aw, ah, wl, qs, fast, true);
+    if (!plan_inv_is_c16(plan)) return 0;
+    int res = 4;
+    if (plan.back().vec && (((uintptr_t)pixels) & 3u) == 0) { plan.back().a.dst_u8 = pixels; plan.back().a.off = 128; res |= 1; }
+    Inv2Launch f2;
+    const bool fused10 = plan_dwt_inv2(plan, f2, lossy != 0);
+    const size_t n = fused10 ? plan.size() - 2 : plan.size();
+    for (size_t l = 0; l < n; l++) {
+        const InvLaunch &f = plan[l];
+        switch (f.band) {
+        case 32: emu_inv<32>(f, lossy); break;
+        case 16: emu_inv<16>(f, lossy); break;
+        case 8: emu_inv<8>(f, lossy); break;
+        default: emu_inv<4>(f, lossy); break;
+        }
+    }
+    if (fused10) {
+        DwtInv2Args a2 = f2.a;
+        const dim3 grid(f2.gx, f2.gy);
+        if (!lossy) emu::launch(grid, dim3(256), [&] { dwt_inv2_kernel<false, false>(a2); });
+        else if (a2.l0.one_div) emu::launch(grid, dim3(256), [&] { dwt_inv2_kernel<true, true>(a2); });
+        else emu::launch(grid, dim3(256), [&] { dwt_inv2_kernel<true, false>(a2); });
+        res |= 2;
+    }
+    return res;
+}
+
 void emu_level_shift_inv(void *data, size_t n, int lossy)
 {
     if (lossy) emu::launch(dim3(4), dim3(256), [&] { level_shift_inv_f32_kernel((float *)data, n, 128.0f); });
@@ -337,6 +388,26 @@ int emu_bpc_decode_stream(const uint16_t *stream, unsigned stream_shorts, int aw
     std::vector<uint32_t> plane_scratch((size_t)wgs.x * kBpcDecWgWaves * kEncScratchDwordsPerWave, 0xDEADBEEFu);
     a.plane_scratch = plane_scratch.data();
     emu::launch(wgs, dim3(64 * kBpcDecWgWaves), [&] { bpc_decode_kernel<false, kDecSmallPlanes, true>(a); });
+    return bad;
+}
+
+// the same, the coefficients leaving as an int16 Mallat array (bpc_decode_kernel's C16 form)
+int emu_bpc_decode_stream16(const uint16_t *stream, unsigned stream_shorts, int aw, int ah, int wl, const int32_t *lut,
+                            const int *geo, int16_t *coeffs16, int *flag)
+{
+    const int ncb = (aw / 64) * (ah / 64);
+    std::vector<int32_t> sizes(ncb), offsets(ncb);
+    int32_t total = 0;
+    int bad = 0;
+    emu::launch(dim3(1), dim3(scan_threads(ncb)), [&] { scan_stream_kernel(stream, ncb, sizes.data(), offsets.data(), &total, &bad, 0); });
+    BpcArgs a = mk(aw, ah, wl, lut, geo, nullptr, sizes.data(), flag);
+    a.coeffs_out = reinterpret_cast<int32_t *>(coeffs16);
+    a.k = 0.0f; a.n_tables = 1;
+    a.cw16 = stream; a.cw16_offsets = offsets.data(); a.cw16_total = &total; a.cw16_max = stream_shorts;
+    const dim3 wgs(((unsigned)((a.nCB + 1) / 2) + kBpcDecWgWaves - 1) / kBpcDecWgWaves);
+    std::vector<uint32_t> plane_scratch((size_t)wgs.x * kBpcDecWgWaves * kEncScratchDwordsPerWave, 0xDEADBEEFu);
+    a.plane_scratch = plane_scratch.data();
+    emu::launch(wgs, dim3(64 * kBpcDecWgWaves), [&] { bpc_decode_kernel<false, kDecSmallPlanes, true, true>(a); });
     return bad;
 }
 

@@ -647,6 +647,34 @@ def test_16_bit_and_32_bit_coefficient_forms_agree(oracle, pa, torch, monkeypatc
     assert np.array_equal(results[0].cpu().numpy()[:H, :W], oracle.decode_frame(ref, W, H, wl, lossy, qs, oracle.lut_for(lossy, wl)))
 
 
+@pytest.mark.parametrize("W,H,wl,lossy,qs", [(3840, 2160, 5, False, 1.0), (1920, 1080, 6, True, 0.5), (700, 500, 4, False, 1.0),
+                                             (1000, 300, 3, True, 0.5), (512, 512, 2, False, 1.0)])
+def test_decode_forms_agree_16_bit_fused_and_32_bit(oracle, pa, torch, monkeypatch, W, H, wl, lossy, qs):
+    """The decode frame paths carry their coefficients as int16 between decoder and synthesis and run synthesis levels
+    1 + 0 as one launch (5/3 by default, 9/7 with PICSONG_DWT_FUSE_INV97=1); PICSONG_DWT_NOFUSE_INV=1 keeps one launch per
+    level, PICSONG_DEC_C16=0 the reference's 32-bit arrays: the oracle's pixels in every form, single frames and batched
+    calls, from an exact-length buffer."""
+    img = oracle.gen_frame(W, H, 72)
+    lut = oracle.lut_for(lossy, wl)
+    ref = oracle.encode_frame(img, wl, lossy, qs, lut)
+    want = oracle.decode_frame(ref, W, H, wl, lossy, qs, lut)
+    s = _dev(torch, ref.view(np.int16))
+    for env in ({}, {"PICSONG_DWT_FUSE_INV97": "1"}, {"PICSONG_DWT_NOFUSE_INV": "1"}, {"PICSONG_DEC_C16": "0"},
+                {"PICSONG_DWT_FUSE_INV97": "1", "PICSONG_DWT_EXACT_REPLAY": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=_lutdir(oracle, lossy))
+        pix = c.decode_frame(s.clone())
+        assert np.array_equal(pix.cpu().numpy()[:H, :W], want), env
+        three = torch.zeros((3, c.max_stream_shorts()), dtype=torch.int16, device="cuda")
+        three[:, :s.numel()] = s
+        out = c.decode_frames(three)
+        assert all(torch.equal(out[j], pix) for j in range(3)) and c.range_flag() == 0, env
+        c.close()
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 @pytest.mark.parametrize("W,H,wl,lossy,qs", [(1280, 704, 5, False, 1.0), (640, 384, 4, True, 0.5)])
 def test_unaligned_frame_pointer_and_late_novec_fall_back_to_the_32_bit_form(oracle, pa, torch, monkeypatch, W, H, wl, lossy, qs):
     """A context chooses the 16-bit coefficient form from its geometry; whether a CALL can use it also depends on the

@@ -648,3 +648,41 @@ def test_three_coding_passes_stress_blocks(oracle, E):
         n = int(sz[cb])
         assert np.array_equal(st[cb * 4096:cb * 4096 + n], st_ref[cb * 4096:cb * 4096 + n]), f"codeblock {cb}"
     assert np.array_equal(E.bpc3_decode(st_ref, sz_ref, 256, 64, 1, lut), oracle.bpc_decode(st_ref, sz_ref, 256, 64, 1, lut))
+
+
+@pytest.mark.parametrize("W,H,wl,lossy,qs", [(320, 192, 3, False, 1.0), (512, 128, 4, False, 1.0), (256, 64, 3, True, 0.5),
+                                             (576, 192, 5, True, 0.5), (320, 128, 3, True, 0.3), (256, 128, 2, False, 1.0),
+                                             (64, 64, 3, False, 1.0)])
+def test_decode_frame_path_with_16_bit_coefficients_and_fused_levels(oracle, E, monkeypatch, W, H, wl, lossy, qs):
+    """The decode frame paths' 16-bit form (round 4): the decoder's C16 instantiation writes an int16 Mallat array from
+    the packed stream, the synthesis kernels' C16 instantiations read it, and synthesis levels 1 and 0 run as ONE launch
+    (dwt_inv2_kernel: LL0 never leaves the registers; not when level 1 is the coarsest, wl = 2) -- the oracle's pixels
+    either way, with the fused launch and with the two launches (PICSONG_DWT_NOFUSE_INV=1), and through the second,
+    truly dividing pass of the 9/7 kernels (PICSONG_DWT_EXACT_REPLAY=1)."""
+    img = oracle.gen_frame(W, H, 21)
+    if W >= 512:
+        img[:7, :9] = 255; img[-5:, -11:] = 0                  # clamping at both ends, at the image's corners
+    lut = oracle.lut_for(lossy, wl)
+    ref = oracle.encode_frame(img, wl, lossy, qs, lut)
+    ref_pix = oracle.decode_frame(ref, W, H, wl, lossy, qs, lut)
+    extra = oracle.dwt_extra(W, H, wl)
+    c32 = E.bpc_decode_stream(ref, W, H, wl, lut)
+    c16 = E.bpc_decode_stream16(ref, W, H, wl, lut)
+    assert E.bpc_decode_stream16.last_bad == 0 and E.bpc_decode_stream16.last_flag == 0
+    assert np.array_equal(c16.astype(np.int32), c32)
+    monkeypatch.setenv("PICSONG_DWT_FUSE_INV97", "1")        # (9/7: the fused form is built and not the default)
+    for nofuse, replay in (("0", "0"), ("1", "0"), ("0", "1")):
+        if replay == "1" and not lossy:
+            continue
+        monkeypatch.setenv("PICSONG_DWT_NOFUSE_INV", nofuse)
+        monkeypatch.setenv("PICSONG_DWT_EXACT_REPLAY", replay)
+        pix, flags = E.dwt_inverse_u8_c16(c16, wl, lossy, qs, extra=extra)
+        assert flags & 4 and flags & 1, (nofuse, replay, flags)
+        assert bool(flags & 2) == (nofuse == "0" and wl >= 3), (nofuse, flags)
+        assert np.array_equal(pix, ref_pix), (nofuse, replay)
+    if lossy:                                                # the default 9/7 form: 16-bit coefficients, one launch per level
+        monkeypatch.delenv("PICSONG_DWT_FUSE_INV97")
+        monkeypatch.setenv("PICSONG_DWT_NOFUSE_INV", "0")
+        monkeypatch.setenv("PICSONG_DWT_EXACT_REPLAY", "0")
+        pix, flags = E.dwt_inverse_u8_c16(c16, wl, lossy, qs, extra=extra)
+        assert flags == 5 and np.array_equal(pix, ref_pix)
