@@ -1157,6 +1157,26 @@ __device__ __forceinline__ void enc_transpose_pass(const BpcArgs &a, int pass, u
 // tail of ONE wave's loads from the memory side, where scan + pack shrank by 9.  Commit 'Experiment: the sizes' scan by
 // the coder's last wave' holds the code)
 
+// Wave priority by plane count (round 4).  A lone frame's coder launch lasts as long as its DEEPEST waves: all of a frame's
+// waves are resident at once (four to a SIMD at 8K), the typical one codes five planes, the few that hold the coarse
+// levels' codeblocks ten or eleven -- and those spend the first two thirds of their life taking turns with three
+// others for the SIMD's issue slots.  A wave that knows it has more planes than most asks for priority: the SIMD's
+// arbiter serves it first, the shallow waves fill the gaps (same work, same throughput), and the launch's critical
+// wave runs nearly as if alone.  PICSONG_BPC_PRIO=0 builds without.
+#ifndef PICSONG_BPC_PRIO
+#define PICSONG_BPC_PRIO 1
+#endif
+__device__ __forceinline__ void prio_by_planes(int np)
+{
+#if PICSONG_BPC_PRIO && defined(__AMDGCN__)
+    if (np >= 9) __builtin_amdgcn_s_setprio(3);
+    else if (np >= 7) __builtin_amdgcn_s_setprio(2);
+    else if (np >= 6) __builtin_amdgcn_s_setprio(1);
+#else
+    (void)np;
+#endif
+}
+
 // BULK = the -k > 0 instantiation (bulk scan after the ordinary planes, table s of the bit-plane
 // LUT files, LDS copy of that table); the k = 0 instantiation compiles to the plain coder.
 template <bool BULK>
@@ -1241,6 +1261,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, BULK ? 6 : PICSONG
     int np = coded ? (msb + 1 - cbp > 0 ? msb + 1 - cbp : 0) : 0;
     { int o = __shfl_xor(np, 32); np = np > o ? np : o; }
     np = (int)__builtin_amdgcn_readfirstlane((uint32_t)np);      // wave-uniform: keep it scalar
+    prio_by_planes(np);
 
     // the plane a lane codes at step p is plane msb - p of ITS codeblock
     auto load_plane = [&](int p, U64 &bL, U64 &bR) {
@@ -1902,6 +1923,7 @@ void bpc_decode_kernel(BpcArgs a)
     { int o = __shfl_xor(np, 32); np = np > o ? np : o; }
     np = (int)__builtin_amdgcn_readfirstlane((uint32_t)np);
     if (BULK && (NP == kDecSmallPlanes) != (np <= kDecSmallPlanes)) return;      // (-k > 0) the other instantiation's wave
+    prio_by_planes(np);
 
     for (int p = 0; p < np; p++) {
         const int bp = msb - p;

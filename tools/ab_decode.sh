@@ -6,6 +6,8 @@
 cd $GRAFT_REPO_ROOT
 run() { echo "== $1"; shift; env "$@" python tools/decode_bench.py --streams=3 2>/dev/null | grep decode; env "$@" python tools/decode_bench.py lossy --streams=3 2>/dev/null | grep decode; env "$@" python tools/decode_bench.py 4k --streams=3 --batch=4 2>/dev/null | grep "per call"; }
 run "default (c16 + fused levels 1+0)" X=1
+if [ -z "$AB_ONLY_SO" ]; then
 run "c16, two launches" PICSONG_DWT_NOFUSE_INV=1
 run "32-bit arrays (round 3 form)" PICSONG_DEC_C16=0
+fi
 for n in $AB_SO; do run "variant $n" PICSONG_SO=$GRAFT_REPO_ROOT/cuda-image-and-video-codec_amd/csrc/variants/$n.so; done
