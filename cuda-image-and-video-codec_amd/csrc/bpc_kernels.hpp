@@ -367,12 +367,17 @@ struct LutView {
 // SINGLE: the array is ONE table and the LDS copy holds all of it (k = 0, -cp 3), so an index outside the table
 // clamps into the LDS copy exactly as lut_at clamps it into the array -- no branch and no global fallback (which cost
 // an exec-masked region with a 64-bit address per entry: 14 entries a plane, 140 vector and 110 scalar instructions)
+// !SINGLE (-k > 0: table s of several): the LDS copy holds the table AND the kLutSlack entries behind it as lut_at would
+// deliver them (the next table's first entries; the array's last entry past its end: bulk_setup).  No index the coders
+// form is negative, and none reaches further than one bit-plane group past its section's end -- bit-plane 15 of a
+// 15-plane table, at most 9 entries -- so the read is a plain LDS byte, no branch and no global fallback
+// (which was an exec-masked region with two compares, a 64-bit address and a wait at EVERY call site of the bulk scan).
+constexpr int kLutSlack = 16;
 template <bool SINGLE = false>
 __device__ __forceinline__ uint32_t lut_get(const LutView &v, int idx)
 {
     if constexpr (SINGLE) return v.lds[idx < 0 ? 0 : (idx >= v.total ? v.total - 1 : idx)];
-    if (idx >= 0 && idx < v.total) return v.lds[idx];
-    return lut_at(v.glob, v.loff + idx, v.glob_total);
+    return v.lds[idx];
 }
 template <bool SINGLE = false>
 __device__ __forceinline__ PlaneLut plane_lut(const LutView &v, const LutGeo &g, int grp, int bp, int aux = 0)
@@ -841,6 +846,9 @@ __device__ __forceinline__ void enc_spp_coeff(EncCoder &c, uint32_t rowbit, uint
 
 __device__ __forceinline__ uint32_t dec_site(Coder &c, uint32_t inact, uint32_t p, uint32_t prec,
                                              uint32_t upper_mask, const int32_t *stage);
+template <bool KEEP>
+__device__ __forceinline__ uint64_t dec_site_m(Coder &c, bool on, uint64_t onm, uint32_t p, uint32_t prec,
+                                               uint32_t upper_mask, const int32_t *stage, bool &one);
 
 // =============================================================================================
 // Complexity-scalable mode, -k > 0 (Encode BPCEngine.cu:1684-1716, Decode :1794-1835,
@@ -892,7 +900,7 @@ struct BulkLane {
     LutView v;                     // this codeblock's table
 };
 
-__device__ __forceinline__ uint32_t bulk_lut(const BulkLane &b, uint32_t idx) { return lut_get(b.v, (int)idx); }
+__device__ __forceinline__ uint32_t bulk_lut(const BulkLane &b, uint32_t idx) { return b.v.lds[idx]; }   // (the LDS copy's slack: lut_get)
 // computeContextBulk / computeContext term of one neighbour word
 __device__ __forceinline__ uint32_t bulk_cc(uint32_t pw, uint32_t sh) { return ((pw >> 1) | (pw >> sh)) & 1u; }
 // computeSignContextBulk term of one neighbour word at plane q: -1 / 0 / +1
@@ -905,46 +913,66 @@ __device__ __forceinline__ int bulk_sc(uint32_t pw, uint32_t q)
 // All remaining planes of ONE coefficient (encodeBulkProcessing :1285-1314 / decodeBulkProcessing
 // :1454-1500).  u: the coefficient's unprocessed word; low: its low magnitude bits (encoder).
 // Returns the processed word.
+// Round 4: the lanes' roles at a plane are LANE MASKS (scalar registers) -- refinement = on & significant, significance =
+// on & ~significant, sign = became significant -- combined by scalar instructions; the encoder reads a plane's bits off
+// the carries of its shifted low word (shl_carry) and forms its sign context ONCE per coefficient, at the plane where the
+// coefficient becomes significant (its own top low bit: the only plane at which the lane codes a sign), the decoder
+// shifts its decoded bits in (shl_in); the call sites are the two-pass kernels' (enc_site2 / dec_site_m).  Before, every
+// site rebuilt its masks from 0 / 1 integers and computed the sign context per site: ~30 vector instructions a site.
 template <bool DEC, class CT>
 __device__ __forceinline__ uint32_t bulk_coeff(CT &c, uint32_t u, uint32_t low, uint32_t ctx, uint32_t up,
                                                uint32_t lf, uint32_t rt, uint32_t dn, const BulkLane &b, int Bmax,
                                                uint32_t prec, uint32_t upper_mask,
                                                int32_t *st)
 {
-    uint32_t sig = (u >> 1) & 1u, neg = u & 1u;
-    if (DEC) low = 0u;
+    uint64_t sigm = __builtin_amdgcn_ballot_w64((u & 2u) != 0u);
+    uint32_t neg = u & 1u;
+    uint32_t lowx = 0u, acc = 0u, saddr = 0u;
+    uint64_t ssymm = 0ull;
+    if constexpr (!DEC) {
+        lowx = low << (31 - Bmax);                          // plane Bmax at bit 31: a plane's bit is the next carry
+        const uint32_t qs = low ? 31u - (uint32_t)__builtin_clz(low) : 0u;      // (a lane that never becomes significant: unused)
+        const uint32_t sc = sign_ctx(bulk_sc(lf, qs) + bulk_sc(rt, qs), bulk_sc(up, qs) + bulk_sc(dn, qs));
+        saddr = b.sign0 + (sc >> 1);
+        ssymm = __builtin_amdgcn_ballot_w64(((neg ^ sc) & 1u) != 0u);           // :1308
+    }
+    const uint32_t sgaddr = b.sig0 + ctx;
     for (int q = Bmax; q >= 0; q--) {
-        const uint32_t on = q <= b.Bh ? 1u : 0u;
-        const uint32_t bit = (low >> q) & 1u;
+        const uint64_t onq = __builtin_amdgcn_ballot_w64(q <= b.Bh);
+        uint64_t bitm = 0ull, dm = 0ull, nsm = 0ull;
+        if constexpr (!DEC) bitm = shl_carry(lowx);
         // refinement call site: coefficients that are significant by now
-        const uint32_t iA = (on & sig) ^ 1u;
-        if (__builtin_amdgcn_ballot_w64(iA == 0u) != 0ull) {
+        const uint64_t mA = onq & sigm;
+        if (mA != 0ull) {
             const uint32_t p = bulk_lut(b, b.ref0 + (uint32_t)q * b.cRef);
-            if constexpr (DEC) low |= dec_site(c, iA, p, prec, upper_mask, st) << q;
-            else enc_site(c, iA, bit, p, prec, upper_mask, st);
+            if constexpr (DEC) { bool one; dm = dec_site_m<true>(c, __builtin_amdgcn_inverse_ballot_w64(mA), mA, p, prec, upper_mask, st, one); }
+            else enc_site2(c, mA, mA & bitm, p, prec, upper_mask);
         }
         // significance call site: the others
-        const uint32_t iB = (on & (sig ^ 1u)) ^ 1u;
-        uint32_t ns = 0u;
-        if (__builtin_amdgcn_ballot_w64(iB == 0u) != 0ull) {
-            const uint32_t p = bulk_lut(b, b.sig0 + (uint32_t)q * b.cSig + ctx);
-            if constexpr (DEC) { ns = dec_site(c, iB, p, prec, upper_mask, st); low |= ns << q; }
-            else { enc_site(c, iB, bit, p, prec, upper_mask, st); ns = (iB ^ 1u) & bit; }
+        const uint64_t mB = onq & ~sigm;
+        if (mB != 0ull) {
+            const uint32_t p = bulk_lut(b, sgaddr + (uint32_t)q * b.cSig);
+            if constexpr (DEC) { bool one; nsm = dec_site_m<true>(c, __builtin_amdgcn_inverse_ballot_w64(mB), mB, p, prec, upper_mask, st, one); dm |= nsm; }
+            else { enc_site2(c, mB, mB & bitm, p, prec, upper_mask); nsm = mB & bitm; }
         }
         // sign call site: coefficients that just became significant
-        if (__builtin_amdgcn_ballot_w64(ns != 0u) != 0ull) {
-            const uint32_t sc = sign_ctx(bulk_sc(lf, (uint32_t)q) + bulk_sc(rt, (uint32_t)q),
-                                         bulk_sc(up, (uint32_t)q) + bulk_sc(dn, (uint32_t)q));
-            const uint32_t p = bulk_lut(b, b.sign0 + (uint32_t)q * b.cSign + (sc >> 1));
+        if (nsm != 0ull) {
             if constexpr (DEC) {
-                const uint32_t s2 = dec_site(c, ns ^ 1u, p, prec, upper_mask, st);
-                if (ns) neg = s2 ^ (sc & 1u);                  // :1488-1490
+                const uint32_t sc = sign_ctx(bulk_sc(lf, (uint32_t)q) + bulk_sc(rt, (uint32_t)q),
+                                             bulk_sc(up, (uint32_t)q) + bulk_sc(dn, (uint32_t)q));
+                const uint32_t p = bulk_lut(b, b.sign0 + (uint32_t)q * b.cSign + (sc >> 1));
+                bool one;
+                const uint64_t s2m = dec_site_m<true>(c, __builtin_amdgcn_inverse_ballot_w64(nsm), nsm, p, prec, upper_mask, st, one);
+                if (__builtin_amdgcn_inverse_ballot_w64(nsm)) neg = (__builtin_amdgcn_inverse_ballot_w64(s2m) ? 1u : 0u) ^ (sc & 1u);   // :1488-1490
             } else {
-                enc_site(c, ns ^ 1u, neg ^ (sc & 1u), p, prec, upper_mask, st);   // :1308
+                const uint32_t p = bulk_lut(b, saddr + (uint32_t)q * b.cSign);
+                enc_site2(c, nsm, nsm & ssymm, p, prec, upper_mask);
             }
-            sig |= ns;
+            sigm |= nsm;
         }
+        if constexpr (DEC) shl_in(acc, dm);                 // (plane Bmax first: after the loop plane q sits at bit q)
     }
+    if constexpr (DEC) low = acc;
     return neg | (u & 2u) | (low << 2);
 }
 
@@ -988,14 +1016,16 @@ __device__ __forceinline__ int bulk_setup(const BpcArgs &a, bool coded, int msb,
         if (s > a.n_tables - 1) s = a.n_tables - 1;
     }
     loff = s * total;
-    // (eight loads in flight a lane, as lut_to_lds)
+    // (eight loads in flight a lane, as lut_to_lds; the kLutSlack entries behind the table as lut_at delivers them: the
+    // next table's, or the array's last entry past its end)
+    const int ncopy = total + kLutSlack, glast = total * a.n_tables - 1;
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-    for (int base = (int)t; base < total; base += 8 * 32) {
+    for (int base = (int)t; base < ncopy; base += 8 * 32) {
         int32_t v[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) { const int j = base + q * 32; v[q] = a.lut[loff + (j < total ? j : total - 1)]; }
+        for (int q = 0; q < 8; q++) { const int j = loff + base + q * 32; v[q] = a.lut[j < glast ? j : glast]; }
 #pragma unroll
-        for (int q = 0; q < 8; q++) { const int j = base + q * 32; if (j < total) lds_half[j] = (uint8_t)((uint32_t)v[q] & 0xFFu); }
+        for (int q = 0; q < 8; q++) { const int j = base + q * 32; if (j < ncopy) lds_half[j] = (uint8_t)((uint32_t)v[q] & 0xFFu); }
     }
     __syncthreads();
     b.Bh = coded ? (msb < cbp - 1 ? msb : cbp - 1) : -1;
@@ -1232,7 +1262,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, BULK ? 6 : PICSONG
         // 8 b + j at bit 8 b + j: the plane's row mask.  2.3 instructions per coefficient and pass.
         if (valid) {
             // (the coefficient type is wave-uniform: one branch around the whole pass, not one per row)
-            if (!BULK && a.c16) enc_transpose_pass<2>(a, pass, cbyte, rstride, pscr, ormag, sgL, sgR);
+            if (a.c16) enc_transpose_pass<2>(a, pass, cbyte, rstride, pscr, ormag, sgL, sgR);
             else if (a.is_float) enc_transpose_pass<1>(a, pass, cbyte, rstride, pscr, ormag, sgL, sgR);
             else enc_transpose_pass<0>(a, pass, cbyte, rstride, pscr, ormag, sgL, sgR);
         }
@@ -1406,14 +1436,17 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, BULK ? 6 : PICSONG
             };
             // unprocessed word: sign | significant-before-the-scan << 1
             auto unp = [&](uint32_t w) -> uint32_t { return (w & 1u) | ((w >> sbsh) != 0u ? 2u : 0u); };
-            uint32_t pUL = 0u, pUR = 0u, c0, c1, n0 = 0u, n1 = 0u;
+            // (the rows come two ahead: a row's scan needs the row below it at once, and a load issued at the top of the
+            // row it is needed in was an L2 round trip in every row's path)
+            uint32_t pUL = 0u, pUR = 0u, c0, c1, n0 = 0u, n1 = 0u, m0 = 0u, m1 = 0u;
             row_words(0, c0, c1);
+            row_words(1, n0, n1);
             for (int i = 0; i < 64; i++) {
-                if (i < 63) row_words(i + 1, n0, n1); else { n0 = 0u; n1 = 0u; }
+                if (i < 62) row_words(i + 2, m0, m1); else { m0 = 0u; m1 = 0u; }
                 bulk_row<false>(c, t, unp(c0), unp(c1), (c0 >> 1) & lowmask, (c1 >> 1) & lowmask,
                                 i < 63 ? unp(n0) : 0u, i < 63 ? unp(n1) : 0u, pUL, pUR, bl, Bmax, prec,
                                 upper_mask, (int32_t *)nullptr);
-                c0 = n0; c1 = n1;
+                c0 = n0; c1 = n1; n0 = m0; n1 = m1;
             }
         }
     }
@@ -1498,7 +1531,7 @@ __global__ __launch_bounds__(256) void lds_order_selftest_kernel(int iters, uint
 // that is off is never used) so that the ballot is the compare's own mask: a bool that leaves an
 // exec-masked region costs a select and a second compare to get back into a mask.
 // KEEP: look after the codeword window here (callers without a per-row dec_ring_keep)
-template <bool KEEP = true>
+template <bool KEEP>
 __device__ __forceinline__ uint64_t dec_site_m(Coder &c, bool on, uint64_t onm, uint32_t p, uint32_t prec,
                                                uint32_t upper_mask, const int32_t *stage, bool &one)
 {
@@ -2148,7 +2181,7 @@ __device__ __forceinline__ uint64_t cp3_coeff(CT &c, bool idle, uint32_t ii, M64
     bool one;
     uint64_t onem;
     if constexpr (DEC) {
-        onem = dec_site_m(c, on, onm, p, prec, upper_mask, cwarr, one);
+        onem = dec_site_m<true>(c, on, onm, p, prec, upper_mask, cwarr, one);
     } else {
         one = on && ((cur >> ii) & 1u) != 0u;
         onem = __builtin_amdgcn_ballot_w64(one);

@@ -417,7 +417,7 @@ int picsong_ctx_create(const picsong_params *p, int device, picsong_ctx **out)
     c->extra = picsong_dwt_extra(aw, ah, p->wl);
     c->fast_div = p->lossy != 0 && dequant_fast_ok(p->qs, p->wl);
     // 8-bit samples: 128 after the level shift; 255 covers the chroma differences of the RGB path's RCT
-    c->c16 = p->k <= 0.0f && p->cp != 3 && p->bit_depth == 8 && dwt_c16_geometry_ok(c->aw, c->ah, p->wl) &&
+    c->c16 = p->cp != 3 && p->bit_depth == 8 && dwt_c16_geometry_ok(c->aw, c->ah, p->wl) &&
              coef16_ok(p->lossy != 0, p->wl, p->qs, p->is_rgb ? 255 : 128);
     c->c16_dec = p->k <= 0.0f && p->cp != 3 && p->bit_depth == 8 && !p->is_rgb &&
                  dec_c16_ok(p->lossy != 0, p->wl, p->qs, 128, c->aw, c->ah, c->fast_div);
@@ -481,9 +481,9 @@ int picsong_ctx_set_lut_component(picsong_ctx *c, int comp, const picsong_lut_in
                     c->p.cp, info->cp == 3 ? 3 : 2);
     const size_t one = (size_t)info->n_ref + (cp3 ? 2 : 1) * ((size_t)info->n_sig + info->n_sign);
     const int n_tables = info->n_tables > 0 ? info->n_tables : 1;
-    if (one > (size_t)(cp3 ? kLutLdsMax3 : kLutLdsMax))
+    if (one + (size_t)kLutSlack > (size_t)(cp3 ? kLutLdsMax3 : kLutLdsMax))
         return fail(PICSONG_ERR_ARG, "LUT table of %zu entries exceeds the %d the coder kernels hold in LDS", one,
-                    cp3 ? kLutLdsMax3 : kLutLdsMax);
+                    (cp3 ? kLutLdsMax3 : kLutLdsMax) - kLutSlack);
     const size_t total = one * (size_t)n_tables;
     for (size_t i = 0; i < total; i++)
         if (host_table[i] < 0 || host_table[i] > 255)
@@ -523,9 +523,9 @@ int picsong_ctx_set_lut_device(picsong_ctx *c, int comp, const picsong_lut_info 
                     info->cp == 3 ? 3 : 2);
     li.cp = c->p.cp;
     const size_t one = (size_t)li.n_ref + (cp3 ? 2 : 1) * ((size_t)li.n_sig + li.n_sign);
-    if (one > (size_t)(cp3 ? kLutLdsMax3 : kLutLdsMax))
+    if (one + (size_t)kLutSlack > (size_t)(cp3 ? kLutLdsMax3 : kLutLdsMax))
         return fail(PICSONG_ERR_ARG, "LUT table of %zu entries exceeds the %d the coder kernels hold in LDS", one,
-                    cp3 ? kLutLdsMax3 : kLutLdsMax);
+                    (cp3 ? kLutLdsMax3 : kLutLdsMax) - kLutSlack);
     if (li.n_tables <= 0) li.n_tables = 1;
     if (c->d_lut[comp] && !c->lut_borrowed[comp]) (void)hipFree(c->d_lut[comp]);
     c->d_lut[comp] = const_cast<int32_t *>(d_table);
