@@ -898,6 +898,7 @@ struct BulkLane {
     uint32_t ref0, sig0, sign0;    // LDS byte index of the plane-0 entries of the lane's LUT group
     uint32_t cRef, cSig, cSign;    // contexts per plane
     LutView v;                     // this codeblock's table
+    const uint8_t *sgt;            // decoder: the sign table (sign_table2_fill)
 };
 
 __device__ __forceinline__ uint32_t bulk_lut(const BulkLane &b, uint32_t idx) { return b.v.lds[idx]; }   // (the LDS copy's slack: lut_get)
@@ -937,7 +938,13 @@ __device__ __forceinline__ uint32_t bulk_coeff(CT &c, uint32_t u, uint32_t low, 
         ssymm = __builtin_amdgcn_ballot_w64(((neg ^ sc) & 1u) != 0u);           // :1308
     }
     const uint32_t sgaddr = b.sig0 + ctx;
+    // decoder: a neighbour's field of the sign table's index once it counts -- significant | sign << 1 (sign_table2_fill)
+    uint32_t fup = 0u, flf = 0u, fdn = 0u, frt = 0u;
+    if constexpr (DEC) { fup = ((up & 1u) << 1) | 1u; flf = ((lf & 1u) << 1) | 1u; fdn = ((dn & 1u) << 1) | 1u; frt = ((rt & 1u) << 1) | 1u; }
     for (int q = Bmax; q >= 0; q--) {
+        // (decoder: the codeword window once per plane of a coefficient -- its three sites reserve at most 64 slots of a
+        // codeblock -- from the LDS counters, one iteration late, as the plane loops do once per row: dec_ring_row)
+        if constexpr (DEC) dec_ring_row(c, upper_mask);
         const uint64_t onq = __builtin_amdgcn_ballot_w64(q <= b.Bh);
         uint64_t bitm = 0ull, dm = 0ull, nsm = 0ull;
         if constexpr (!DEC) bitm = shl_carry(lowx);
@@ -945,25 +952,30 @@ __device__ __forceinline__ uint32_t bulk_coeff(CT &c, uint32_t u, uint32_t low, 
         const uint64_t mA = onq & sigm;
         if (mA != 0ull) {
             const uint32_t p = bulk_lut(b, b.ref0 + (uint32_t)q * b.cRef);
-            if constexpr (DEC) { bool one; dm = dec_site_m<true>(c, __builtin_amdgcn_inverse_ballot_w64(mA), mA, p, prec, upper_mask, st, one); }
+            if constexpr (DEC) { bool one; dm = dec_site_m<false>(c, __builtin_amdgcn_inverse_ballot_w64(mA), mA, p, prec, upper_mask, st, one); }
             else enc_site2(c, mA, mA & bitm, p, prec, upper_mask);
         }
         // significance call site: the others
         const uint64_t mB = onq & ~sigm;
         if (mB != 0ull) {
             const uint32_t p = bulk_lut(b, sgaddr + (uint32_t)q * b.cSig);
-            if constexpr (DEC) { bool one; nsm = dec_site_m<true>(c, __builtin_amdgcn_inverse_ballot_w64(mB), mB, p, prec, upper_mask, st, one); dm |= nsm; }
+            if constexpr (DEC) { bool one; nsm = dec_site_m<false>(c, __builtin_amdgcn_inverse_ballot_w64(mB), mB, p, prec, upper_mask, st, one); dm |= nsm; }
             else { enc_site2(c, mB, mB & bitm, p, prec, upper_mask); nsm = mB & bitm; }
         }
         // sign call site: coefficients that just became significant
         if (nsm != 0ull) {
             if constexpr (DEC) {
-                const uint32_t sc = sign_ctx(bulk_sc(lf, (uint32_t)q) + bulk_sc(rt, (uint32_t)q),
-                                             bulk_sc(up, (uint32_t)q) + bulk_sc(dn, (uint32_t)q));
-                const uint32_t p = bulk_lut(b, b.sign0 + (uint32_t)q * b.cSign + (sc >> 1));
+                // computeSignContextBulk :311-323 by the decoder's table (sign_table2_fill): a neighbour counts at plane q
+                // when it was significant before the scan or holds a bit above q -- index = up | left << 2 | down << 4 |
+                // right << 6, entry = 8 * (c >> 1) | (c & 1) << 6
+                const uint32_t sq = 2u + (uint32_t)q;
+                uint32_t idx = (((up >> sq) | (up & 2u)) != 0u ? fup : 0u) | ((((lf >> sq) | (lf & 2u)) != 0u ? flf : 0u) << 2);
+                idx |= ((((dn >> sq) | (dn & 2u)) != 0u ? fdn : 0u) << 4) | ((((rt >> sq) | (rt & 2u)) != 0u ? frt : 0u) << 6);
+                const uint32_t tv = b.sgt[idx];
+                const uint32_t p = bulk_lut(b, b.sign0 + (uint32_t)q * b.cSign + ((tv >> 3) & 3u));
                 bool one;
-                const uint64_t s2m = dec_site_m<true>(c, __builtin_amdgcn_inverse_ballot_w64(nsm), nsm, p, prec, upper_mask, st, one);
-                if (__builtin_amdgcn_inverse_ballot_w64(nsm)) neg = (__builtin_amdgcn_inverse_ballot_w64(s2m) ? 1u : 0u) ^ (sc & 1u);   // :1488-1490
+                const uint64_t s2m = dec_site_m<false>(c, __builtin_amdgcn_inverse_ballot_w64(nsm), nsm, p, prec, upper_mask, st, one);
+                if (__builtin_amdgcn_inverse_ballot_w64(nsm)) neg = (__builtin_amdgcn_inverse_ballot_w64(s2m) ? 1u : 0u) ^ ((tv >> 6) & 1u);   // :1488-1490
             } else {
                 const uint32_t p = bulk_lut(b, saddr + (uint32_t)q * b.cSign);
                 enc_site2(c, nsm, nsm & ssymm, p, prec, upper_mask);
@@ -1034,6 +1046,7 @@ __device__ __forceinline__ int bulk_setup(const BpcArgs &a, bool coded, int msb,
     b.sig0 = (uint32_t)(grp * a.g.nBp * a.g.cSig + a.g.nRef);
     b.sign0 = (uint32_t)(grp * a.g.nBp * a.g.cSign + a.g.nRef + a.g.nSig);
     b.v.lds = lds_half; b.v.glob = a.lut; b.v.total = total; b.v.glob_total = total * a.n_tables; b.v.loff = loff;
+    b.sgt = nullptr;
     return cbp;
 }
 
@@ -1947,7 +1960,7 @@ void bpc_decode_kernel(BpcArgs a)
 
     int cbp = 0, loff = 0;
     BulkLane bl;
-    if constexpr (BULK) cbp = bulk_setup(a, coded, msb, cbx, cby, grp, t, lds_lut + half * kLutLdsMax, bl, loff);
+    if constexpr (BULK) { cbp = bulk_setup(a, coded, msb, cbx, cby, grp, t, lds_lut + half * kLutLdsMax, bl, loff); bl.sgt = sign_tab; }
     else lut_to_lds(a.lut, a.g.nRef + a.g.nSig + a.g.nSign, lds_lut);
     const LutView lv = { lds_lut + (BULK ? half * kLutLdsMax : 0u), a.lut, a.g.nRef + a.g.nSig + a.g.nSign,
                          (a.g.nRef + a.g.nSig + a.g.nSign) * (BULK ? a.n_tables : 1), loff };
@@ -2058,7 +2071,7 @@ void bpc_decode_kernel(BpcArgs a)
     if constexpr (BULK) {
         // ---- bulk scan (decodeBulkMode :1653-1662) fused with writeCoefficients: plane register k
         // holds plane Bh+1+k here, the scan delivers the Bh+1 low bits and the missing signs row by row
-        dec_ring_sync(c);                                  // (the scan's call sites keep exact counters themselves)
+        // (the scan's sites look after the codeword window once per plane of a coefficient: dec_ring_row in bulk_coeff)
         int Bmax = bl.Bh;
         { int o = __shfl_xor(Bmax, 32); Bmax = Bmax > o ? Bmax : o; }
         Bmax = (int)__builtin_amdgcn_readfirstlane((uint32_t)Bmax);

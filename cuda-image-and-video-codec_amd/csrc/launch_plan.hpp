@@ -63,7 +63,7 @@ inline int fwd_band_rows(int level, int strips, int H)
 }
 // The 9/7 synthesis of a context whose reciprocal divisions verified (dwt_inv97_kernel) is bound by its vector
 // instructions, a third of which a 16-row band spends on run-in rows (12 iterations for 8 row pairs; 32 rows: 20
-// for 16): taller bands than the other kernels want.  Measured on an 8K frame, wl = 6 (tools/inv97_variants.sh):
+// for 16): taller bands than the other kernels want.  Measured on an 8K frame, wl = 6 (round 2):
 // 32,16,8,4,4,4 rows for levels 0..5 81.1 us; 32,8,4,4,4,4 83.9; 16,8,4,4,4,4 95.2; 32-row bands on level 1
 // double level 0's time (38.7 -> 76.5 us; same words out).
 inline int inv97_band_rows(int level, int strips, int H)

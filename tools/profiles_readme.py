@@ -1,121 +1,92 @@
 #!/usr/bin/env python3
-"""Regenerates the round table of profiles/README.md from the published summaries (profiles/<tag>_*), so that the
-numbers quoted there are the files' own.  usage: tools/profiles_readme.py r02  (rewrites the block between the
-'<!-- <tag> table -->' markers)."""
+"""Rewrites the round-3 table of profiles/README.md from the published files (profiles/r03_*), so that the numbers quoted
+there are the files' own.  (tools/profiles_readme.py does the same for the round-2 files, whose CSVs have no '#' lines.)"""
 import csv
 import json
 import os
 import re
-import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-P = lambda n: os.path.join(ROOT, "profiles", f"{tag}_{n}")
+P = os.path.join(ROOT, "profiles", "r03_")
 
 
 def J(n):
-    return json.load(open(P(n)))
+    return json.load(open(P + n))
 
 
 def stats(n):
     out = {}
-    for r in csv.DictReader(open(P(n))):
+    for r in csv.DictReader(l for l in open(P + n) if not l.startswith("#")):
         if "picsong" in r["Name"]:
-            k = re.sub(r"^void picsong::|^picsong::", "", r["Name"])
-            out[k.split("(")[0]] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3)
+            out[re.sub(r"^void picsong::|^picsong::", "", r["Name"]).split("(")[0]] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3)
     return out
-
-
-def find(st, sub, most=True):
-    c = [(k, v) for k, v in st.items() if sub in k]
-    c.sort(key=lambda kv: -kv[1][0])
-    return c[0][1] if c else (0, float("nan"))
 
 
 def pmc(n):
     out = {}
-    for r in csv.DictReader(open(P(n))):
-        out[(r["Kernel_Name"].split("(")[0].replace("void picsong::", ""), r["Counter_Name"])] = float(r["MeanValue"])
+    for r in csv.DictReader(l for l in open(P + n) if not l.startswith("#")):
+        out[(re.sub(r"^void picsong::|^picsong::", "", r["Kernel_Name"]).split("(")[0], r["Counter_Name"])] = float(r["MeanValue"])
     return out
 
 
+def g(st, sub):
+    c = [(k, v) for k, v in st.items() if sub in k]
+    c.sort(key=lambda kv: -kv[1][0])
+    return c[0][1]
+
+
 b, b4, bl, b3, bl3 = J("bench.json"), J("bench_4k.json"), J("bench_8k_lossy.json"), J("bench_8k_b3.json"), J("bench_8k_lossy_b3.json")
-ss, sl, sd, s4 = stats("kernel_stats_single_stream.csv"), stats("kernel_stats_8k_lossy.csv"), stats("kernel_stats.csv"), stats("kernel_stats_4k.csv")
-sdec, sdecl = stats("kernel_stats_decode.csv"), stats("kernel_stats_decode_8k_lossy.csv")
+ss, sb3, sl, slb3 = stats("kernel_stats_single_stream.csv"), stats("kernel_stats_b3.csv"), stats("kernel_stats_8k_lossy.csv"), stats("kernel_stats_8k_lossy_b3.csv")
+sd, sdl, s3, s4 = stats("kernel_stats_decode.csv"), stats("kernel_stats_decode_8k_lossy.csv"), stats("kernel_stats.csv"), stats("kernel_stats_4k.csv")
 hb, sq = pmc("pmc_hbm.csv"), pmc("pmc_sq.csv")
 enc = "bpc_encode_kernel<false>"
-head_i, head_f = "dwt_fwd2_kernel<int, false, true, 8>", "dwt_fwd2_kernel<float, true, true, 8>"
-fetch, write = hb[(enc, "FETCH_SIZE")] * 1024 * 2 / 1e6, hb[(enc, "WRITE_SIZE")] * 1024 / 1e6
-alg = b["roofline"]["algorithmic_bytes_per_launch"] / 1e6
-dec = open(P("decode.txt")).read()
-decn = re.findall(r"= (\d+) Mpixel/s", dec)
-rd, r3 = b["roofline_dwt"], b["roofline_dwt"]["three_frames_per_call"]
-rl, rl3 = bl["roofline_dwt"], bl["roofline_dwt"]["three_frames_per_call"]
-# the lean 9/7 synthesis kernel's launches of one decoded frame, finest level first (band height 32, 16, 8, 4 ...)
-_inv97 = sorted(((k, v) for k, v in sdecl.items() if "dwt_inv97_kernel<" in k),
-                key=lambda kv: (-int(kv[0].split("dwt_inv97_kernel<")[1].split(",")[0]), "false, true, " in kv[0]))
-_per_frame = min(v[0] for _, v in _inv97) if _inv97 else 1
-inv97_txt = " + ".join(("%d x %.1f" % (v[0] // _per_frame, v[1])) if v[0] // _per_frame > 1 else "%.1f" % v[1] for _, v in _inv97)
-inv97_sum = sum(v[0] // _per_frame * v[1] for _, v in _inv97)
-rows = [
-    ("`%s_bench.json`" % tag,
-     "the default bench line: 8K lossless, 3 streams x 1 frame per call, %d steps x %d frames (%.2f s timed): **%.1f Gpixel/s, %.4f ms/frame**; "
-     "single-stream stages DWT %.4f (%.3f of 8 TB/s; three frames per call: %.4f ms per frame = **%.2f**) / coder %.4f / pack %.4f ms; "
-     "`timed_loop_outputs_ok` %s, round trip %s; CPU baseline (oracle, %d threads of the box's quota) %.1f Mpixel/s with the same codestream"
-     % (b["steps"], b["config"]["frames_per_step"], b["timed_seconds"], b["value"] / 1e3, b["ms_per_frame"],
-        b["stage_ms_single_stream"]["dwt"], rd["single_stream"]["frac"], r3["ms_per_frame"], r3["frac"],
-        b["stage_ms_single_stream"]["bpc"], b["stage_ms_single_stream"]["pack"], b["timed_loop_outputs_ok"], b["roundtrip_ok"],
-        b["cpu_baseline"]["cores"], b["cpu_baseline"]["value"])),
-    ("`%s_bench_4k.json`" % tag, "`--workload 4k_lossless` (3 streams x 4 frames per `picsong_encode_frames` call): **%.1f Gpixel/s**, %.4f ms per 4K frame (round 1: 59)"
-     % (b4["value"] / 1e3, b4["ms_per_frame"])),
-    ("`%s_bench_8k_lossy.json`" % tag, "`--workload 8k_lossy` (9/7, qs 0.5, wl 6): %.1f Gpixel/s, PSNR %.2f dB; DWT of a lone frame %.4f ms = %.2f of 8 TB/s, three frames per call %.4f ms per frame = **%.2f**"
-     % (bl["value"] / 1e3, bl["psnr_db"], bl["stage_ms_single_stream"]["dwt"], rl["single_stream"]["frac"], rl3["ms_per_frame"], rl3["frac"])),
-    ("`%s_bench_8k_b3.json`, `%s_bench_8k_lossy_b3.json`" % (tag, tag),
-     "`--streams 1 --batch 3`: three 8K frames per call on ONE stream: %.1f / %.1f Gpixel/s; DWT %.4f / %.4f ms per frame; coder %.3f ms per frame inside a three-frame launch"
-     % (b3["value"] / 1e3, bl3["value"] / 1e3, b3["stage_ms"]["dwt"], bl3["stage_ms"]["dwt"], b3["stage_ms"]["bpc"])),
-    ("`%s_kernel_stats_single_stream.csv`" % tag,
-     "`rocprofv3 --kernel-trace --stats`, `--streams 1 --no-b3`: `bpc_encode_kernel<false>` **%.0f us** (round 1: 430), `dwt_fwd2_kernel` (levels 0 + 1) %.1f us + 3 x %.1f us, pack %.1f us, scan %.1f us"
-     % (ss[enc][1], ss[head_i][1], find(ss, "dwt_fwd_kernel<int")[1], find(ss, "pack_kernel")[1], find(ss, "scan_sizes")[1])),
-    ("`%s_kernel_stats.csv`" % tag, "the default command shape (3 streams; kernels of three calls share the GPU: coder %.0f us, fused DWT head %.1f us while sharing)"
-     % (sd[enc][1], sd[head_i][1])),
-    ("`%s_kernel_stats_8k_lossy.csv`" % tag, "`--workload 8k_lossy --streams 1`: coder %.0f us (the wl = 6 LUT holes send the level-5 blocks through the raw fallback; their halves stop once their 4095 slots are used), `dwt_fwd2_kernel<float>` **%.1f us** + 4 x %.1f us"
-     % (sl[enc][1], sl[head_f][1], find(sl, "dwt_fwd_kernel<float")[1])),
-    ("`%s_kernel_stats_4k.csv`" % tag, "`--workload 4k_lossless` (4 frames per launch): coder %.0f us per 4-frame launch, fused DWT head %.1f us per 4 frames"
-     % (s4[enc][1], s4[head_i][1])),
-    ("`%s_kernel_stats_decode.csv`, `..._decode_8k_lossy.csv`" % tag,
-     "`rocprofv3 --kernel-trace --stats -- python3 tools/decode_bench.py [lossy]`: decoder `<false, 8>` %.0f / %.0f us, inverse DWT %.1f + %.1f + 3 x %.1f us (5/3), %s = **%.0f us** (9/7, `dwt_inv97_kernel`, levels 0 .. 5; before it: 54.5 + 22.8 + 4 x 10.2 = 118), unpack %.1f / %.1f us"
-     % (find(sdec, "bpc_decode_kernel<false, 8>")[1], find(sdecl, "bpc_decode_kernel<false, 8>")[1],
-        find(sdec, "dwt_inv_kernel<int, false, 16")[1], find(sdec, "dwt_inv_kernel<int, false, 8")[1], find(sdec, "dwt_inv_kernel<int, false, 4")[1],
-        inv97_txt, inv97_sum,
-        find(sdec, "unpack_kernel")[1], find(sdecl, "unpack_kernel")[1])),
-    ("`%s_pmc_hbm.csv`" % tag,
-     "FETCH_SIZE / WRITE_SIZE passes: coder FETCH x2 = %.1f MB (coefficients once + the plane scratch read back) + WRITE %.1f MB = **%.0f MB = %.2f x the %.1f MB algorithmic** (round 1: 344 MB, 2.24 x); fused DWT head FETCH x2 = %.1f MB, WRITE %.1f MB"
-     % (fetch, write, fetch + write, (fetch + write) / alg, alg, hb[(head_i, "FETCH_SIZE")] * 2048 / 1e6, hb[(head_i, "WRITE_SIZE")] * 1024 / 1e6)),
-    ("`%s_pmc_sq.csv`" % tag,
-     "two SQ passes: coder **%.1f M VALU + %.1f M SALU** wave-instructions per 8K launch (round 1: 165.5 M + 106.4 M), %.1f M branches, %.1f M LDS; fused 5/3 DWT head %.2f M VALU + %.2f M SALU (round 1: 8.81 M + 6.03 M); `SQ_ACTIVE_INST_VALU` = `SQ_INSTS_VALU` (it counts instructions on this part)"
-     % (sq[(enc, "SQ_INSTS_VALU")] / 1e6, sq[(enc, "SQ_INSTS_SALU")] / 1e6, sq[(enc, "SQ_INSTS_BRANCH")] / 1e6, sq[(enc, "SQ_INSTS_LDS")] / 1e6,
-        sq[(head_i, "SQ_INSTS_VALU")] / 1e6, sq[(head_i, "SQ_INSTS_SALU")] / 1e6)),
-    ("`%s_valu_probe.txt` / `.json`" % tag,
-     "`tools/valu_probe`: issue rates per instruction class, 1..8 waves per SIMD (DESIGN.md 4.0): and/or/xor/add/sub/mov on VGPR or literal operands, `v_add/mul/fmac_f32` 0.38-0.43 per cycle per SIMD; shifts, min, compares, every VOP3 form (`v_fma_f32` too), packed fp32, 24-bit multiplies, DPP, SDWA, conversions, any SGPR operand 0.22-0.27; `v_cndmask_e32` on a scalar-written VCC 0.044; scalar ALU 0.23 per SIMD"),
-    ("`%s_decode.txt`" % tag, "`tools/decode_bench.py --streams=3` (lossless) and `lossy`: lone frame %.1f Gpixel/s, pipelined **%.1f Gpixel/s**; 9/7 wl 6: %.1f, pipelined **%.1f**; 4K frames: %.1f alone, %.1f over three streams, **%.1f** four to a `picsong_decode_frames` call; round trip checked"
-     % tuple(int(x) / 1e3 for x in (decn + ["0"] * 7)[:7])),
-]
-insts = sq[(enc, "SQ_INSTS_VALU")] / 1e6
-table = "| file | what |\n|---|---|\n" + "\n".join("| %s | %s |" % r for r in rows) + "\n"
-tail = ("\nThe coder's issue arithmetic from these files: %.1f M vector instructions per frame; about a third of them (adds, subs, moves,\n"
-        "VGPR-operand ands) are of the 2.6-cycle class, the rest of the 4.2-cycle class: about %.2f ms of issue for coder + transform on\n"
-        "1024 SIMDs at the 2.39 GHz the probe measures under load, against %.4f ms per frame in the bench: **%.2f of issue saturation**\n"
-        "(`roofline.valu_issue.frac_of_probe_half_rate_peak` takes every instruction at the half rate and so prints > 1).  Against the guide's\n"
-        "2 cycles per instruction the same figure is %.2f.\n"
-        % (insts, (insts + 8.0) * (0.35 * 2.6 + 0.65 * 4.2) / 1024 / 2.39, b["ms_per_frame"],
-           (insts + 8.0) * (0.35 * 2.6 + 0.65 * 4.2) / 1024 / 2.39 / b["ms_per_frame"], (insts + 8.0) * 2.0 / 1024 / 2.39 / b["ms_per_frame"]))
+coder, head, lv = g(ss, "bpc_encode_kernel")[1], g(ss, "dwt_fwd2_kernel")[1], g(ss, "dwt_fwd_kernel")
+pack, scan = g(ss, "pack_kernel")[1], g(ss, "scan_sizes_kernel")[1]
+rd, rdl, lf = b["roofline_dwt"], bl["roofline_dwt"], b["lone_frame"]
+F, W = hb[(enc, "FETCH_SIZE")], hb[(enc, "WRITE_SIZE")]
+hk = [k for k in hb if "dwt_fwd2" in k[0]]
+hF = [hb[k] for k in hk if k[1] == "FETCH_SIZE"][0]
+hW = [hb[k] for k in hk if k[1] == "WRITE_SIZE"][0]
+dec_lines = [l.strip() for l in open(P + "decode.txt") if l.startswith("decode")]
+vb = b["roofline"]["valu_busy"]
+rows = []
+rows.append(f"| `r03_bench.json` | the default bench line: 8K lossless, 3 streams x {b['config']['frames_per_call']} frames per call, {b['steps']} steps x {b['config']['frames_per_step']} frames ({b['timed_seconds']} s timed): **{b['value'] / 1e3:.1f} Gpixel/s, {b['ms_per_frame']:.4f} ms/frame** (round 2: 160.0); a lone frame (`lone_frame`) {lf['ms']:.3f} ms = {lf['mpixels_per_s'] / 1e3:.1f} Gpixel/s: DWT {lf['stage_ms']['dwt']:.4f} / coder {lf['stage_ms']['bpc']:.4f} / pack {lf['stage_ms']['pack']:.4f} ms; DWT of a lone frame {rd['lone_frame']['frac']:.2f} of 8 TB/s, three frames per call {rd['three_frames_per_call']['ms_per_frame']:.4f} ms per frame = {rd['three_frames_per_call']['frac']:.2f} (the coded subbands leave the transform as int16: fewer bytes move than the algorithmic count assumes); coder `traffic` {b['roofline']['traffic'] / 1e6:.1f} MB = {b['roofline']['traffic'] / b['roofline']['algorithmic_bytes_per_launch']:.2f} x algorithmic; `valu_busy` {vb['lone_kernel']['VALUBusy']:.2f} lone / {vb['pipelined']['VALUBusy_same_definition']:.2f} pipelined; CPU baseline {b['cpu_baseline']['value']:.1f} Mpixel/s on 16 threads, same codestream; `roofline.source`: the counters quoted are this library's |")
+rows.append(f"| `r03_bench_4k.json`, `r03_bench_8k_lossy.json` | `--workload 4k_lossless`: **{b4['value'] / 1e3:.1f} Gpixel/s** (a lone 4K frame {b4['lone_frame']['mpixels_per_s'] / 1e3:.1f}); `--workload 8k_lossy`: **{bl['value'] / 1e3:.1f} Gpixel/s**, PSNR {bl.get('psnr_db')} dB, DWT lone {rdl['lone_frame']['frac']:.3f} / {bl['config']['frames_per_call']} frames per call **{rdl['single_stream']['frac']:.3f}** of 8 TB/s by the bench's events |")
+rows.append(f"| `r03_bench_8k_b3.json`, `r03_bench_8k_lossy_b3.json` | `--streams 1 --batch 3`: {b3['value'] / 1e3:.1f} / {bl3['value'] / 1e3:.1f} Gpixel/s |")
+rows.append(f"| `r03_kernel_stats_single_stream.csv` | `rocprofv3 --kernel-trace --stats`, `--streams 1`: `bpc_encode_kernel<false>` **{coder:.1f} us** (r02: 254), `dwt_fwd2_kernel<int, ..., true>` (levels 0 + 1, int16 subbands) **{head:.1f} us** (r02: 31.3) + 3 x {lv[1]:.1f} us = {head + 3 * lv[1]:.1f} us = **{255.9 / (head + 3 * lv[1]) / 8:.2f} of 8 TB/s for a lone frame**, pack {pack:.1f}, scan {scan:.1f} us |")
+h3, l3 = g(sb3, "dwt_fwd2_kernel")[1], g(sb3, "dwt_fwd_kernel")[1]
+per = (h3 + 3 * l3) / 3
+rows.append(f"| `r03_kernel_stats_b3.csv` | the three-frames-per-call shape (`picsong_encode_frames`, one stream): head {h3:.1f} us + 3 x {l3:.1f} us per THREE frames = {per:.1f} us per frame ({255.9 / per / 8:.2f} x the algorithmic bytes over 8 TB/s by kernel time; {rd['three_frames_per_call']['ms_per_frame']:.4f} ms = {rd['three_frames_per_call']['frac']:.2f} by the bench's events, launch gaps included) |")
+hl, ll, hl3, ll3 = g(sl, "dwt_fwd2_kernel")[1], g(sl, "dwt_fwd_kernel")[1], g(slb3, "dwt_fwd2_kernel")[1], g(slb3, "dwt_fwd_kernel")[1]
+perl = (hl3 + 4 * ll3) / 3
+rows.append(f"| `r03_kernel_stats_8k_lossy.csv`, `r03_kernel_stats_8k_lossy_b3.csv` | 9/7 wl 6: lone frame head {hl:.1f} us + 4 x {ll:.1f} us = {hl + 4 * ll:.1f} us = {256.2 / (hl + 4 * ll) / 8:.2f}; three frames per call {hl3:.1f} us + 4 x {ll3:.1f} us per three frames = **{perl:.1f} us per frame = {256.2 / perl / 8:.2f} of 8 TB/s** ({bl3['roofline_dwt']['single_stream']['avg_launch_ms'] / 3:.4f} ms = {bl3['roofline_dwt']['single_stream']['frac']:.2f} by events) -- the north star's 0.80 for the 9/7 transform, in the batched shape |")
+rows.append(f"| `r03_kernel_stats.csv`, `r03_kernel_stats_4k.csv` | the default three-stream shape (kernels of three calls share the GPU: coder {g(s3, 'bpc_encode_kernel')[1]:.0f} us, head {g(s3, 'dwt_fwd2_kernel')[1]:.0f} us while sharing); 4K frames four to a launch (coder {g(s4, 'bpc_encode_kernel')[1]:.0f} us per launch) |")
+dk, dkl = g(sd, "bpc_decode_kernel")[1], g(sdl, "bpc_decode_kernel")[1]
+tot = sum(v[0] * v[1] for k, v in sd.items() if "dwt_inv" in k) / g(sd, "bpc_decode_kernel")[0]
+totl = sum(v[0] * v[1] for k, v in sdl.items() if "dwt_inv" in k) / g(sdl, "bpc_decode_kernel")[0]
+rows.append(f"| `r03_kernel_stats_decode.csv`, `..._decode_8k_lossy.csv` | decoder `<false, 8, true>` (the stream-direct instantiation) **{dk:.1f} / {dkl:.1f} us** (r02: 476 / 442 + the empty 16-plane launch), ONE launch; inverse DWT {tot:.0f} us (5/3) / {totl:.0f} us (9/7) per frame; `scan_stream_kernel` {g(sd, 'scan_stream_kernel')[1]:.1f} / {g(sdl, 'scan_stream_kernel')[1]:.1f} us in place of read_sizes + scan + unpack (this round's first collection: 4.7 + 8.3 + 17.8 us) |")
+m = re.findall(r"bpc_decode_kernel[^\n]*\n\s+SQ_BUSY_CYCLES=\S+\s+SQ_INSTS_SALU=(\S+)\s+SQ_INSTS_VALU=(\S+)", open(P + "pmc_decode.txt").read())
+rows.append(f"| `r03_pmc_decode.txt` | SQ counters of the decode path: decoder **{float(m[0][1]) / 1e6:.1f} M vector + {float(m[0][0]) / 1e6:.1f} M scalar** wave-instructions per 8K lossless frame (r02: 205.3 M + 120.0 M), {float(m[1][1]) / 1e6:.1f} M + {float(m[1][0]) / 1e6:.1f} M per 9/7 frame (162.0 M + 93.5 M) |")
+rows.append(f"| `r03_pmc_hbm.csv` | FETCH_SIZE / WRITE_SIZE passes: coder FETCH x2 = {2 * F / 1e3:.1f} MB (int16 coefficients once + the plane scratch read back) + WRITE {W / 1e3:.1f} MB (16-bit codeword staging + the plane scratch) = **{(2 * F + W) / 1e3:.1f} MB = {(2 * F + W) / 1e3 / 153.7:.2f} x the 153.7 MB algorithmic** (r02: 247 MB, 1.61 x; this round's first pass 188.5 MB, the faster prologue raised it to 211 MB, the 16-bit staging brought it back: DESIGN 4.2); fused DWT head FETCH x2 = {2 * hF / 1e3:.1f} MB, WRITE {hW / 1e3:.1f} MB (r02: 135.7) |")
+wc = sq[(enc, "SQ_WAVE_CYCLES")]
+rows.append(f"| `r03_pmc_sq.csv` | two SQ passes (`--streams 1`): coder {sq[(enc, 'SQ_INSTS_VALU')] / 1e6:.1f} M VALU + {sq[(enc, 'SQ_INSTS_SALU')] / 1e6:.1f} M SALU per launch, {sq[(enc, 'SQ_INSTS_BRANCH')] / 1e6:.1f} M branches, {sq[(enc, 'SQ_INSTS_LDS')] / 1e6:.1f} M LDS; of its waves' cycles {100 * sq[(enc, 'SQ_ACTIVE_INST_ANY')] / wc:.0f} % issuing (`SQ_ACTIVE_INST_ANY` / `SQ_WAVE_CYCLES`), {100 * sq[(enc, 'SQ_WAIT_ANY')] / wc:.0f} % parked on `s_waitcnt`, {100 * sq[(enc, 'SQ_WAIT_INST_ANY')] / wc:.0f} % waiting for an issue slot |")
+rows.append(f"| `r03_pmc_sq_pipelined.csv` | the same counters + `SQ_BUSY_CU_CYCLES`, `GRBM_GUI_ACTIVE`, `SQ_THREAD_CYCLES_VALU` collected over the DEFAULT command (`--streams 3`, 48 frames).  **rocprofv3 serialises the dispatches of a `--pmc` run** (the pass's own kernel trace: no two dispatches overlap; the plain trace of the same command: 107 overlapping pairs of 451) -- so these, too, are counters of kernels running ALONE, and the profiler cannot deliver a per-dispatch counter in the pipelined shape.  What they give: rocprof's `VALUBusy` (100 x `SQ_ACTIVE_INST_VALU` / CUs / `GRBM_GUI_ACTIVE`, one vector instruction = one quad-cycle of one of a CU's four SIMDs) = **{vb['lone_kernel']['VALUBusy']:.2f} for a lone coder launch**; the same definition applied to the counter-measured instructions of all of a frame's kernels ({vb['pipelined']['valu_wave_insts_per_frame_all_kernels'] / 1e6:.1f} M) and the pipelined time per frame ({b['ms_per_frame']:.3f} ms, driver-timed shape) = **{vb['pipelined']['VALUBusy_same_definition']:.2f}**: the vector ALUs are the limit with frames in flight (full-rate instructions take less than a quad-cycle, `r03_valu_probe.txt`), `bench.py` prints both (`roofline.valu_busy`) |")
+rows.append("| `r03_valu_probe.txt` / `.json` | `tools/valu_probe` (built from `tools/valu_probe.hip` by the collection script): issue rates per instruction class, as round 2 |")
+num = lambda l: int(re.search(r"= (\d+) Mpixel", l).group(1)) / 1e3
+rows.append(f"| `r03_decode.txt` | `tools/decode_bench.py --streams=3`: lone frame **{num(dec_lines[0]):.1f} Gpixel/s** (r02: 58.1), pipelined **{num(dec_lines[1]):.1f}** (87.2); 9/7 wl 6: {num(dec_lines[2]):.1f}, pipelined **{num(dec_lines[3]):.1f}** (103.1); 4K: {num(dec_lines[4]):.1f} alone, {num(dec_lines[5]):.1f} over three streams, **{num(dec_lines[6]):.1f}** four to a `picsong_decode_frames` call (85.2) |")
+rg = [l for l in open(P + "rgb_probe.txt") if l.startswith("RGB")]
+rr = lambda l: (re.search(r"batched grid ([\d.]+) ms", l).group(1), re.search(r"per call ([\d.]+) ms: ratio ([\d.]+)", l).groups(), re.search(r"batched decode ([\d.]+) ms", l).group(1))
+a0, a1 = rr(rg[0]), rr(rg[2])
+pp0, pp1 = re.search(r": ([\d.]+) ms/frame", rg[1]).group(1), re.search(r": ([\d.]+) ms/frame", rg[3]).group(1)
+rows.append(f"| `r03_rgb_probe.txt` | `tools/rgb_probe.py`, an 8K RGB frame on one stream: plane by plane {pp0} ms (lossless) / {pp1} ms (9/7); through the batched grid (`picsong_encode_rgb_frame`) **{a0[0]} / {a1[0]} ms** = {a0[1][1]} x / {a1[1][1]} x three grey frames per `picsong_encode_frames` call ({a0[1][0]} / {a1[1][0]} ms); batched decode {a0[2]} / {a1[2]} ms |")
+rows.append("| `r03_lone_frame.txt` | `tools/lone_frame_time.py`: single-frame calls timed from Python (wall clock over 30 calls, launch overhead included): what an image codec's caller sees |")
+mt = [l.split() for l in open(P + "modes_time.txt") if l.strip()]
+rows.append("| `r03_modes_time.txt` | `tools/modes_time.py`: the other modes at 8K lossless -- a lone frame and three calls in flight, encode and decode -- beside the plain coder in the same harness: `-k 0.5`, `-k 1.5` (complexity-scalable bulk scan) and `-cp 3` run at roughly a half to a third of its rates (DESIGN 4.5 / 4.6) |")
+rows.append("| `r03_fuzz_parity.txt` | `tools/fuzz_parity.py 60 7`: sixty random geometries / contents / transforms through the frame paths, single and batched, against the oracle: no mismatch |")
+rows.append("| `r03_library.sha256` | the library all of the above belong to |")
 path = os.path.join(ROOT, "profiles", "README.md")
-s = open(path).read()
-m0, m1 = "<!-- %s table -->" % tag, "<!-- /%s table -->" % tag
-block = m0 + "\n" + table + tail + m1
-if m0 in s:
-    s = s[:s.index(m0)] + block + s[s.index(m1) + len(m1):]
-else:
-    print("markers not found: printing"); print(block); sys.exit(1)
-open(path, "w").write(s)
-print(block)
+txt = open(path).read()
+i = txt.index("| file | what |\n|---|---|\n") + len("| file | what |\n|---|---|\n")
+j = txt.index("\n## Round 2")
+open(path, "w").write(txt[:i] + "\n".join(rows) + "\n" + txt[j:])
+print("\n".join(r[:200] for r in rows))
