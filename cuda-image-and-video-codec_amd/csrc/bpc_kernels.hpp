@@ -1014,16 +1014,21 @@ __device__ __forceinline__ void bulk_row(CT &c, uint32_t t, uint32_t uL, uint32_
 
 // Per-half set-up shared by both kernels: consecutive planes, table choice, LDS copy of the table.
 // Returns cbp; fills b (Bh, LDS indices) and loff (int offset of table s inside a.lut).
+// consecutiveBitplanes of the lane's codeblock (level / subband of the codeblock's lane 0: see the oracle's note -- per-lane
+// values would diverge); 0 for a codeblock that codes nothing
+__device__ __forceinline__ int bulk_cbp(const BpcArgs &a, bool coded, int msb, int cbx, int cby)
+{
+    int lv0, sb0;
+    find_subband(cbx * 64, cby * 64, a.AW, a.AH, a.wl, lv0, sb0);
+    return coded ? consecutive_bitplanes(msb, a.k, lv0, sb0, a.wl) : 0;
+}
 __device__ __forceinline__ int bulk_setup(const BpcArgs &a, bool coded, int msb, int cbx, int cby, int grp,
                                           uint32_t t, uint8_t *lds_half, BulkLane &b, int &loff)
 {
     const int total = a.g.nRef + a.g.nSig + a.g.nSign;
-    // level / subband of the codeblock's lane 0 (see oracle note: per-lane values would diverge)
-    int lv0, sb0;
-    find_subband(cbx * 64, cby * 64, a.AW, a.AH, a.wl, lv0, sb0);
-    int cbp = 0, s = 0;
+    const int cbp = bulk_cbp(a, coded, msb, cbx, cby);
+    int s = 0;
     if (coded) {
-        cbp = consecutive_bitplanes(msb, a.k, lv0, sb0, a.wl);
         s = cbp < msb ? cbp : msb;
         if (s > a.n_tables - 1) s = a.n_tables - 1;
     }
@@ -1863,7 +1868,7 @@ __device__ __forceinline__ void write_rows(const uint32_t (&PL)[NA], const uint3
 // NP = 16 (4 waves / SIMD) takes the rest; the host launches both, a wave of the other class returns
 // at once.
 constexpr int kDecSmallPlanes = 8;
-// S16 (k = 0 only): the frame paths' instantiation, codewords read from the packed stream (BpcArgs::cw16)
+// S16: the frame paths' instantiation, codewords read from the packed stream (BpcArgs::cw16)
 // C16 (with S16): the coefficients leave as an int16 Mallat array (row stride AW) at coeffs_out, for the synthesis
 // kernels' C16 instantiations -- half the bytes the decoder writes and the transform reads.  Only in contexts whose
 // magnitudes are bounded below 2^15 (coef16_ok: an honest stream's codeblocks have MSB <= 14 there; a damaged table
@@ -1874,7 +1879,6 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcDecWgWaves,
 void bpc_decode_kernel(BpcArgs a)
 {
     static_assert(NP == kDecSmallPlanes || NP == kMaxPlanes, "two classes");
-    static_assert(!(BULK && S16), "-k > 0 decodes from the staging");
     static_assert(!C16 || S16, "the 16-bit coefficient form belongs to the frame paths");
     __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
     __shared__ uint8_t sign_tab[256];
@@ -1936,6 +1940,14 @@ void bpc_decode_kernel(BpcArgs a)
     }
     if (C16 && valid && sz != 4096 && msb == kMaxPlanes - 1) atomicOr(a.range_flag, 1);     // magnitudes of 16 bits: not in an int16
     const bool coded = valid && msb != 32 && sz != 4096;
+    if constexpr (BULK) {
+        // the wave's class -- which of the two instantiations over this grid decodes it -- before the codeword ring is
+        // filled and the table copied: the other class's launch was 30 us of loads for nothing
+        int npc = bulk_cbp(a, coded, msb, cbx, cby);
+        npc = coded ? (msb + 1 - npc > 0 ? msb + 1 - npc : 0) : 0;
+        { int o = __shfl_xor(npc, 32); npc = npc > o ? npc : o; }
+        if ((NP == kDecSmallPlanes) != ((int)__builtin_amdgcn_readfirstlane((uint32_t)npc) <= kDecSmallPlanes)) return;
+    }
 
     int level, sb;
     find_subband(cbx * 64 + 2 * (int)t, cby * 64, a.AW, a.AH, a.wl, level, sb);
@@ -2090,7 +2102,17 @@ void bpc_decode_kernel(BpcArgs a)
             if (!valid) continue;
             int32_t v0, v1;
             if (sz == 4096) {
-                int2 w = *reinterpret_cast<const int2 *>(stage + t * 128u + 2u * (uint32_t)i);
+                int2 w;
+                if constexpr (S16) {
+                    // the packed stream: words 1 .. 4095 are the codeblock's 4095 shorts, word 0 sits in the MSB's place
+                    // (as write_rows; loads kept inside the stream's shorts)
+                    const uint32_t kk = t * 128u + 2u * (uint32_t)i, rawlast = c.srclim + 1u;
+                    const uint32_t i0 = c.srcoff + kk - 1u, i1 = c.srcoff + kk;
+                    w.x = kk == 0u ? word0 : (int32_t)a.cw16[i0 < rawlast ? i0 : rawlast];
+                    w.y = (int32_t)a.cw16[i1 < rawlast ? i1 : rawlast];
+                } else {
+                    w = *reinterpret_cast<const int2 *>(stage + t * 128u + 2u * (uint32_t)i);
+                }
                 v0 = (int32_t)(((uint32_t)w.x & 0xFFFFFFu) >> 1); if (w.x & 1) v0 = -v0;
                 v1 = (int32_t)(((uint32_t)w.y & 0xFFFFFFu) >> 1); if (w.y & 1) v1 = -v1;
             } else {

@@ -812,7 +812,7 @@ int picsong_bpc_encode(picsong_ctx *c, const void *d_coeffs, int32_t *d_staging,
 static bool dec_from_stream(const picsong_ctx *c)
 {
     static const bool staged = [] { const char *e = getenv("PICSONG_DEC_STAGING"); return e && atoi(e) != 0; }();
-    return !staged && c->p.k <= 0.0f && c->p.cp != 3;
+    return !staged && c->p.cp != 3;
 }
 
 // d_stream16 != nullptr (k = 0, -cp 2): the codewords come from the packed stream, d_offsets the scan of its lengths
@@ -838,8 +838,16 @@ static int bpc_decode_impl(picsong_ctx *c, const int32_t *d_staging, const int32
     }
     if (a.k > 0.0f) {
         // -k > 0: both plane-count classes over the same grid, each wave is taken by exactly one of them
-        bpc_decode_kernel<true, kDecSmallPlanes><<<waves, 64, 0, s>>>(a);
-        bpc_decode_kernel<true, kMaxPlanes><<<waves, 64, 0, s>>>(a);
+        if (c16) return fail(PICSONG_ERR_ARG, "-k > 0 decodes into the 32-bit coefficient array");
+        if (d_stream16) {
+            a.cw16 = d_stream16; a.cw16_offsets = d_offsets; a.cw16_total = c->d_total;
+            a.cw16_max = (uint32_t)picsong_max_stream_shorts(c->aw, c->ah);
+            bpc_decode_kernel<true, kDecSmallPlanes, true><<<waves, 64, 0, s>>>(a);
+            bpc_decode_kernel<true, kMaxPlanes, true><<<waves, 64, 0, s>>>(a);
+        } else {
+            bpc_decode_kernel<true, kDecSmallPlanes><<<waves, 64, 0, s>>>(a);
+            bpc_decode_kernel<true, kMaxPlanes><<<waves, 64, 0, s>>>(a);
+        }
     } else {
         const unsigned wgs = (waves + kBpcDecWgWaves - 1) / kBpcDecWgWaves;
         if (d_stream16) {

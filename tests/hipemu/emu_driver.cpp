@@ -391,6 +391,25 @@ int emu_bpc_decode_stream(const uint16_t *stream, unsigned stream_shorts, int aw
     return bad;
 }
 
+// -k > 0 from the packed stream (bpc_decode_kernel<true, NP, true>: both plane-count classes over the grid)
+int emu_bpc_decode_stream_k(const uint16_t *stream, unsigned stream_shorts, int aw, int ah, int wl, const int32_t *lut,
+                            const int *geo, int32_t *coeffs, int *flag, float k, int n_tables)
+{
+    const int ncb = (aw / 64) * (ah / 64);
+    std::vector<int32_t> sizes(ncb), offsets(ncb);
+    int32_t total = 0;
+    int bad = 0;
+    emu::launch(dim3(1), dim3(scan_threads(ncb)), [&] { scan_stream_kernel(stream, ncb, sizes.data(), offsets.data(), &total, &bad, 0); });
+    BpcArgs a = mk(aw, ah, wl, lut, geo, nullptr, sizes.data(), flag);
+    a.coeffs_out = coeffs;
+    a.k = k; a.n_tables = n_tables;
+    a.cw16 = stream; a.cw16_offsets = offsets.data(); a.cw16_total = &total; a.cw16_max = stream_shorts;
+    const dim3 grid((unsigned)((a.nCB + 1) / 2));
+    emu::launch(grid, dim3(64), [&] { bpc_decode_kernel<true, kDecSmallPlanes, true>(a); });
+    emu::launch(grid, dim3(64), [&] { bpc_decode_kernel<true, kMaxPlanes, true>(a); });
+    return bad;
+}
+
 // the same, the coefficients leaving as an int16 Mallat array (bpc_decode_kernel's C16 form)
 int emu_bpc_decode_stream16(const uint16_t *stream, unsigned stream_shorts, int aw, int ah, int wl, const int32_t *lut,
                             const int *geo, int16_t *coeffs16, int *flag)

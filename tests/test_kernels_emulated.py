@@ -396,6 +396,22 @@ def test_bulk_mode_kernels_bit_exact(oracle, E, W, H, wl, k):
         assert np.array_equal(st_e[cb * 4096:cb * 4096 + n], st_o[cb * 4096:cb * 4096 + n]), cb
     back = E.bpc_decode(st_o, sz_o, W, H, wl, lut, k=k)
     assert np.array_equal(back, coef)
+    # ... and straight from the packed stream, as the frame paths of a -k > 0 context decode (round 4; a raw codeblock,
+    # whose word 0 travels in the MSB's place, included when the data makes one)
+    stream = oracle.bitstream_pack(st_o, sz_o, None)
+    assert np.array_equal(E.bpc_decode_stream_k(stream, W, H, wl, lut, k), coef)
+
+
+def test_bulk_mode_stream_decode_with_a_raw_codeblock(oracle, E):
+    rng = np.random.default_rng(31)
+    W, H, wl, k = 256, 64, 1, 0.8
+    coef = _bulk_coeffs(oracle, W, H, wl, False, 5).copy()
+    coef[:, 64:128] = rng.integers(-30000, 30000, (64, 64))       # no model fits noise: the expansion fallback
+    lut = oracle.lut_for_k(False, wl)
+    st_o, sz_o = oracle.bpc_encode(coef, wl, lut, k=k)
+    assert (sz_o == 4096).any() and (sz_o < 4096).any()
+    stream = oracle.bitstream_pack(st_o, sz_o, None)
+    assert np.array_equal(E.bpc_decode_stream_k(stream, W, H, wl, lut, k), oracle.bpc_decode(st_o, sz_o, W, H, wl, lut, k=k))
 
 
 def test_bulk_mode_kernels_float_input_and_odd_block_count(oracle, E):
