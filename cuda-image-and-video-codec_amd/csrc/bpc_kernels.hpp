@@ -1022,8 +1022,27 @@ __device__ __forceinline__ int bulk_cbp(const BpcArgs &a, bool coded, int msb, i
     find_subband(cbx * 64, cby * 64, a.AW, a.AH, a.wl, lv0, sb0);
     return coded ? consecutive_bitplanes(msb, a.k, lv0, sb0, a.wl) : 0;
 }
+// COMPACT (round 4): the LDS copy holds only the table's GROUPS the codeblock's lanes use -- groups g0 .. g1 of each of
+// the three sections, section after section, each with one plane's worth of slack (lut_get) -- instead of the whole
+// table: 210 bytes a group at the shipped geometry against 3360 for a whole wl = 5 table, so that a wave's two copies
+// stop being what bounds the -k > 0 kernels' occupancy (two whole tables + the decoder's ring: 11.7 KB a wave, 3 waves a
+// SIMD).  The host takes the COMPACT instantiations when every codeblock of the frame spans at most what
+// kBulkCompactBytes holds (bulk_max_span_bytes: a function of the geometry alone), the whole-table ones otherwise.
+// `gl`: the LUT geometry with the compact section sizes in nRef / nSig, `grpc`: the lane's group inside the copy -- what
+// plane_lut takes for the two-pass planes.
+constexpr int kBulkCompactBytes = 2048;
+__device__ __forceinline__ int half_min32(int v)
+{
+    { int o = __shfl_xor(v, 16); v = v < o ? v : o; }
+    { int o = __shfl_xor(v, 8); v = v < o ? v : o; }
+    { int o = __shfl_xor(v, 4); v = v < o ? v : o; }
+    { int o = __shfl_xor(v, 2); v = v < o ? v : o; }
+    { int o = __shfl_xor(v, 1); v = v < o ? v : o; }
+    return v;
+}
+template <bool COMPACT>
 __device__ __forceinline__ int bulk_setup(const BpcArgs &a, bool coded, int msb, int cbx, int cby, int grp,
-                                          uint32_t t, uint8_t *lds_half, BulkLane &b, int &loff)
+                                          uint32_t t, uint8_t *lds_half, BulkLane &b, int &loff, LutGeo &gl, int &grpc)
 {
     const int total = a.g.nRef + a.g.nSig + a.g.nSign;
     const int cbp = bulk_cbp(a, coded, msb, cbx, cby);
@@ -1033,23 +1052,49 @@ __device__ __forceinline__ int bulk_setup(const BpcArgs &a, bool coded, int msb,
         if (s > a.n_tables - 1) s = a.n_tables - 1;
     }
     loff = s * total;
-    // (eight loads in flight a lane, as lut_to_lds; the kLutSlack entries behind the table as lut_at delivers them: the
-    // next table's, or the array's last entry past its end)
-    const int ncopy = total + kLutSlack, glast = total * a.n_tables - 1;
+    const int glast = total * a.n_tables - 1;
+    gl = a.g;
+    grpc = grp;
+    if constexpr (COMPACT) {
+        const int g0 = half_min32(grp), g1 = -half_min32(-grp), span = g1 - g0 + 1;
+        const int sl = a.g.nBp < 15 ? 16 - a.g.nBp : 1;      // planes of slack behind a section's groups (bit-plane 15)
+        const int RB = (span * a.g.nBp + sl) * a.g.cRef, SB = (span * a.g.nBp + sl) * a.g.cSig, GB = (span * a.g.nBp + sl) * a.g.cSign;
+        const int br = loff + g0 * a.g.nBp * a.g.cRef, bs = loff + a.g.nRef + g0 * a.g.nBp * a.g.cSig - RB,
+                  bg = loff + a.g.nRef + a.g.nSig + g0 * a.g.nBp * a.g.cSign - RB - SB;
+        const int ncopy = RB + SB + GB;                      // (<= kBulkCompactBytes: the host chose this instantiation)
 #pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
-    for (int base = (int)t; base < ncopy; base += 8 * 32) {
-        int32_t v[8];
+        for (int base = (int)t; base < ncopy; base += 8 * 32) {
+            int32_t v[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) { const int j = loff + base + q * 32; v[q] = a.lut[j < glast ? j : glast]; }
+            for (int q = 0; q < 8; q++) {
+                const int jj = base + q * 32, j = jj < ncopy ? jj : ncopy - 1;
+                const int src = j + (j < RB ? br : (j < RB + SB ? bs : bg));
+                v[q] = a.lut[src < glast ? src : glast];
+            }
 #pragma unroll
-        for (int q = 0; q < 8; q++) { const int j = base + q * 32; if (j < ncopy) lds_half[j] = (uint8_t)((uint32_t)v[q] & 0xFFu); }
+            for (int q = 0; q < 8; q++) { const int j = base + q * 32; if (j < ncopy) lds_half[j] = (uint8_t)((uint32_t)v[q] & 0xFFu); }
+        }
+        gl.nRef = RB; gl.nSig = SB; gl.nSign = GB;
+        grpc = grp - g0;
+    } else {
+        // (eight loads in flight a lane, as lut_to_lds; the kLutSlack entries behind the table as lut_at delivers them: the
+        // next table's, or the array's last entry past its end)
+        const int ncopy = total + kLutSlack;
+#pragma clang loop unroll(disable) vectorize(disable) interleave(disable)
+        for (int base = (int)t; base < ncopy; base += 8 * 32) {
+            int32_t v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { const int j = loff + base + q * 32; v[q] = a.lut[j < glast ? j : glast]; }
+#pragma unroll
+            for (int q = 0; q < 8; q++) { const int j = base + q * 32; if (j < ncopy) lds_half[j] = (uint8_t)((uint32_t)v[q] & 0xFFu); }
+        }
     }
     __syncthreads();
     b.Bh = coded ? (msb < cbp - 1 ? msb : cbp - 1) : -1;
     b.cRef = (uint32_t)a.g.cRef; b.cSig = (uint32_t)a.g.cSig; b.cSign = (uint32_t)a.g.cSign;
-    b.ref0 = (uint32_t)(grp * a.g.nBp * a.g.cRef);
-    b.sig0 = (uint32_t)(grp * a.g.nBp * a.g.cSig + a.g.nRef);
-    b.sign0 = (uint32_t)(grp * a.g.nBp * a.g.cSign + a.g.nRef + a.g.nSig);
+    b.ref0 = (uint32_t)(grpc * a.g.nBp * a.g.cRef);
+    b.sig0 = (uint32_t)(grpc * a.g.nBp * a.g.cSig + gl.nRef);
+    b.sign0 = (uint32_t)(grpc * a.g.nBp * a.g.cSign + gl.nRef + gl.nSig);
     b.v.lds = lds_half; b.v.glob = a.lut; b.v.total = total; b.v.glob_total = total * a.n_tables; b.v.loff = loff;
     b.sgt = nullptr;
     return cbp;
@@ -1064,6 +1109,11 @@ __device__ __forceinline__ int bulk_setup(const BpcArgs &a, bool coded, int msb,
 // the request alone takes a lone frame from 0.536 to 0.465 ms at k = 0.5).
 #ifndef PICSONG_BPC_ENC_WAVES
 #define PICSONG_BPC_ENC_WAVES 7
+#endif
+// the -k > 0 instantiations (one wave a workgroup): resident waves per SIMD asked for -- what they get is also bounded by
+// their LDS (two table copies a wave: whole tables 4, compact copies 6 and more)
+#ifndef PICSONG_BPC_BULK_WAVES
+#define PICSONG_BPC_BULK_WAVES 6
 #endif
 
 // one row (two coefficients of the lane) of the coefficient array as magnitudes and sign bits
@@ -1227,10 +1277,12 @@ __device__ __forceinline__ void prio_by_planes(int np)
 
 // BULK = the -k > 0 instantiation (bulk scan after the ordinary planes, table s of the bit-plane
 // LUT files, LDS copy of that table); the k = 0 instantiation compiles to the plain coder.
-template <bool BULK>
-__global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, BULK ? 6 : PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(BpcArgs a)
+template <bool BULK, bool COMPACT = false>
+__global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, BULK ? PICSONG_BPC_BULK_WAVES : PICSONG_BPC_ENC_WAVES) void bpc_encode_kernel(BpcArgs a)
 {
-    __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
+    static_assert(BULK || !COMPACT, "compact table copies belong to the -k > 0 instantiations");
+    constexpr int kTab = COMPACT ? kBulkCompactBytes : kLutLdsMax;       // bytes of one LDS table copy
+    __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kTab];
     __shared__ uint32_t lds_cnt[2 * (BULK ? 1 : kBpcEncWgWaves)];      // codeword counters of the workgroup's codeblocks
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
     if (t == 0u) lds_cnt[(threadIdx.x >> 6) * 2u + half] = half * kStageCb + kStageBytes;   // bytes of the staging (enc_reserve); (the table copy below ends with a barrier)
@@ -1301,9 +1353,11 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, BULK ? 6 : PICSONG
     const int grp = level * a.g.nSub + sb;
     int cbp = 0, loff = 0;                                   // planes >= cbp take the two passes
     BulkLane bl;
-    if constexpr (BULK) cbp = bulk_setup(a, coded, msb, cbx, cby, grp, t, lds_lut + half * kLutLdsMax, bl, loff);
+    LutGeo gl = a.g;                                         // (COMPACT: the copy's own section sizes and the lane's group in it)
+    int grpc = grp;
+    if constexpr (BULK) cbp = bulk_setup<COMPACT>(a, coded, msb, cbx, cby, grp, t, lds_lut + half * kTab, bl, loff, gl, grpc);
     else lut_to_lds(a.lut, a.g.nRef + a.g.nSig + a.g.nSign, lds_lut);
-    const LutView lv = { lds_lut + (BULK ? half * kLutLdsMax : 0u), a.lut, a.g.nRef + a.g.nSig + a.g.nSign,
+    const LutView lv = { lds_lut + (BULK ? half * kTab : 0u), a.lut, a.g.nRef + a.g.nSig + a.g.nSign,
                          (a.g.nRef + a.g.nSig + a.g.nSign) * (BULK ? a.n_tables : 1), loff };
 
     int np = coded ? (msb + 1 - cbp > 0 ? msb + 1 - cbp : 0) : 0;
@@ -1354,7 +1408,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, BULK ? 6 : PICSONG
         const bool act = live && bp >= cbp;
 
         PlaneLut pl = { 0u, 0u, 0u, 0u, 0u, 0u };
-        if (act) pl = plane_lut<!BULK>(lv, a.g, grp, bp);
+        if (act) pl = plane_lut<!BULK>(lv, gl, grpc, bp);
 
         const U64 BL = BLn, BR = BRn;
         const U64 AL2 = u_or(AL, BL), AR2 = u_or(AR, BR);            // state after this plane's SPP
@@ -1873,14 +1927,16 @@ constexpr int kDecSmallPlanes = 8;
 // kernels' C16 instantiations -- half the bytes the decoder writes and the transform reads.  Only in contexts whose
 // magnitudes are bounded below 2^15 (coef16_ok: an honest stream's codeblocks have MSB <= 14 there; a damaged table
 // that claims more raises the range flag and decodes to wrapped values -- "something", as every damaged stream does)
-template <bool BULK, int NP, bool S16 = false, bool C16 = false>
-__global__ __launch_bounds__(BULK ? 64 : 64 * kBpcDecWgWaves,
-                             !BULK ? PICSONG_BPC_DEC_WAVES8 : (NP == kDecSmallPlanes ? 5 : PICSONG_BPC_DEC_WAVES))
+template <bool BULK, int NP, bool S16 = false, bool C16 = false, bool COMPACT = false>
+__global__ __launch_bounds__(BULK ? 64 : 64 * kBpcDecWgWaves, !BULK ? PICSONG_BPC_DEC_WAVES8 : PICSONG_BPC_BULK_WAVES)
 void bpc_decode_kernel(BpcArgs a)
 {
-    static_assert(NP == kDecSmallPlanes || NP == kMaxPlanes, "two classes");
+    static_assert(NP == kDecSmallPlanes, "one instantiation for every plane count (the planes are parked in the scratch)");
     static_assert(!C16 || S16, "the 16-bit coefficient form belongs to the frame paths");
-    __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kLutLdsMax];
+    static_assert(BULK || !COMPACT, "compact table copies belong to the -k > 0 instantiations");
+    static_assert(!(BULK && C16), "-k > 0 decodes into the 32-bit coefficient array");
+    constexpr int kTab = COMPACT ? kBulkCompactBytes : kLutLdsMax;       // bytes of one LDS table copy
+    __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kTab];
     __shared__ uint8_t sign_tab[256];
     __shared__ __attribute__((aligned(1024))) uint16_t cw_ring[(BULK ? 1 : kBpcDecWgWaves) * 2 * kDecRing];
     __shared__ uint32_t lds_cnt[(BULK ? 1 : kBpcDecWgWaves) * 2];
@@ -1915,17 +1971,19 @@ void bpc_decode_kernel(BpcArgs a)
     const uint32_t prec = (uint32_t)a.g.prec;
     const uint32_t upper_mask = opaque_mask(half ? 0xFFFFFFFFu : 0u);
 
-    // k = 0: ONE plane in registers, the one being decoded; a finished plane is parked in the wave's scratch (the
+    // ONE plane in registers, the one being decoded; a finished plane is parked in the wave's scratch (the
     // encoder's layout: [plane][L rows 0-31, L rows 32-63, R rows 0-31, R rows 32-63][lane], every access a 256-byte
     // row) and the epilogue reads the planes back eight at a time for the transposition -- 28 registers fewer than
     // eight resident planes, none of the 28 moves a plane that rotated them upward, and one kernel for every plane
     // count (round 2: two instantiations over the same grid, NP = 8 and NP = 16, a launch of nothing for most frames).
-    // -k > 0 keeps its planes in registers (the bulk scan reads them row by row).
-    constexpr int NPR = BULK ? NP : 1;
+    // -k > 0 (round 4) parks its two-pass planes the same way: the epilogue writes the coefficients they make, and the
+    // bulk scan that follows ORs its low bits into them row by row (until round 4 it kept eight planes in registers
+    // and assembled every row from them bit by bit: 32 registers and ~50 vector instructions a row).
+    constexpr int NPR = 1;
     uint32_t PLlo[NPR], PLhi[NPR], PRlo[NPR], PRhi[NPR];
 #pragma unroll
     for (int k = 0; k < NPR; k++) { PLlo[k] = PLhi[k] = PRlo[k] = PRhi[k] = 0u; }
-    uint32_t *const pscr = BULK ? nullptr : a.plane_scratch + (size_t)gwave * (size_t)kEncScratchDwordsPerWave + lane;
+    uint32_t *const pscr = a.plane_scratch + (size_t)gwave * (size_t)kEncScratchDwordsPerWave + lane;
     // significance + sign of the lane's two columns, interleaved (C-form, see dec_spp_block)
     // (ten scalars, not two arrays: an array lives in a register tuple, and a masked update of one element copies it)
     uint32_t CL0 = 0u, CL1 = 0u, CL2 = 0u, CL3 = 0u, CL4 = 0u, CR0 = 0u, CR1 = 0u, CR2 = 0u, CR3 = 0u, CR4 = 0u;
@@ -1940,14 +1998,6 @@ void bpc_decode_kernel(BpcArgs a)
     }
     if (C16 && valid && sz != 4096 && msb == kMaxPlanes - 1) atomicOr(a.range_flag, 1);     // magnitudes of 16 bits: not in an int16
     const bool coded = valid && msb != 32 && sz != 4096;
-    if constexpr (BULK) {
-        // the wave's class -- which of the two instantiations over this grid decodes it -- before the codeword ring is
-        // filled and the table copied: the other class's launch was 30 us of loads for nothing
-        int npc = bulk_cbp(a, coded, msb, cbx, cby);
-        npc = coded ? (msb + 1 - npc > 0 ? msb + 1 - npc : 0) : 0;
-        { int o = __shfl_xor(npc, 32); npc = npc > o ? npc : o; }
-        if ((NP == kDecSmallPlanes) != ((int)__builtin_amdgcn_readfirstlane((uint32_t)npc) <= kDecSmallPlanes)) return;
-    }
 
     int level, sb;
     find_subband(cbx * 64 + 2 * (int)t, cby * 64, a.AW, a.AH, a.wl, level, sb);
@@ -1972,37 +2022,30 @@ void bpc_decode_kernel(BpcArgs a)
 
     int cbp = 0, loff = 0;
     BulkLane bl;
-    if constexpr (BULK) { cbp = bulk_setup(a, coded, msb, cbx, cby, grp, t, lds_lut + half * kLutLdsMax, bl, loff); bl.sgt = sign_tab; }
+    LutGeo gl = a.g;                                         // (COMPACT: the copy's own section sizes and the lane's group in it)
+    int grpc = grp;
+    if constexpr (BULK) { cbp = bulk_setup<COMPACT>(a, coded, msb, cbx, cby, grp, t, lds_lut + half * kTab, bl, loff, gl, grpc); bl.sgt = sign_tab; }
     else lut_to_lds(a.lut, a.g.nRef + a.g.nSig + a.g.nSign, lds_lut);
-    const LutView lv = { lds_lut + (BULK ? half * kLutLdsMax : 0u), a.lut, a.g.nRef + a.g.nSig + a.g.nSign,
+    const LutView lv = { lds_lut + (BULK ? half * kTab : 0u), a.lut, a.g.nRef + a.g.nSig + a.g.nSign,
                          (a.g.nRef + a.g.nSig + a.g.nSign) * (BULK ? a.n_tables : 1), loff };
 
     int np = coded ? (msb + 1 - cbp > 0 ? msb + 1 - cbp : 0) : 0;
     { int o = __shfl_xor(np, 32); np = np > o ? np : o; }
     np = (int)__builtin_amdgcn_readfirstlane((uint32_t)np);
-    if (BULK && (NP == kDecSmallPlanes) != (np <= kDecSmallPlanes)) return;      // (-k > 0) the other instantiation's wave
+    // (does a codeblock of the wave hold a plane above 7?  then the epilogue transposes sixteen planes)
+    int msbw = coded ? msb : -1;
+    { int o = __shfl_xor(msbw, 32); msbw = msbw > o ? msbw : o; }
+    msbw = (int)__builtin_amdgcn_readfirstlane((uint32_t)msbw);
     prio_by_planes(np);
 
     for (int p = 0; p < np; p++) {
         const int bp = msb - p;
         const bool act = coded && bp >= cbp;
 
-        // make room: plane registers move up so that after the last plane index k = plane k
-        if constexpr (BULK) {
-            if (act && p > 0) {
-#pragma unroll
-                for (int k = NPR - 1; k > 0; k--) {
-                    PLlo[k] = PLlo[k - 1]; PLhi[k] = PLhi[k - 1];
-                    PRlo[k] = PRlo[k - 1]; PRhi[k] = PRhi[k - 1];
-                }
-                PLlo[0] = PLhi[0] = PRlo[0] = PRhi[0] = 0u;
-            }
-        } else {
-            PLlo[0] = PLhi[0] = PRlo[0] = PRhi[0] = 0u;
-        }
+        PLlo[0] = PLhi[0] = PRlo[0] = PRhi[0] = 0u;
 
         PlaneLut pl = { 0u, 0u, 0u, 0u, 0u, 0u };
-        if (act) pl = plane_lut<!BULK>(lv, a.g, grp, bp);
+        if (act) pl = plane_lut<!BULK>(lv, gl, grpc, bp);
 
         // ---- significance propagation pass (SPPDecoderLauncher), rows with an insignificant coeff.  A half that
         // codes nothing in this plane (its codeblock is done, all zero, raw or beyond the last one) shows every
@@ -2069,86 +2112,33 @@ void bpc_decode_kernel(BpcArgs a)
             if (hw == 0) { PLlo[0] = curL; PRlo[0] = curR; } else { PLhi[0] = curL; PRhi[0] = curR; }
         }
         refL = sigL; refR = sigR;
-        if constexpr (!BULK) {
-            if (act) {                                         // plane bp of this lane's codeblock is complete
-                uint32_t *q = pscr + (size_t)bp * kEncPlaneDwords;
-                q[0] = PLlo[0]; q[64] = PLhi[0]; q[128] = PRlo[0]; q[192] = PRhi[0];
-            }
+        if (act) {                                             // plane bp of this lane's codeblock is complete
+            uint32_t *q = pscr + (size_t)bp * kEncPlaneDwords;
+            q[0] = PLlo[0]; q[64] = PLhi[0]; q[128] = PRlo[0]; q[192] = PRhi[0];
         }
     }
     // the signs back as X-form row masks (the all-significant marks of an idle half sit on the even bits)
     const M64 sgnL = { cform_signs(CL0, CL1, CL2), cform_signs(CL2, CL3, CL4) };
     const M64 sgnR = { cform_signs(CR0, CR1, CR2), cform_signs(CR2, CR3, CR4) };
 
-    if constexpr (BULK) {
-        // ---- bulk scan (decodeBulkMode :1653-1662) fused with writeCoefficients: plane register k
-        // holds plane Bh+1+k here, the scan delivers the Bh+1 low bits and the missing signs row by row
-        // (the scan's sites look after the codeword window once per plane of a coefficient: dec_ring_row in bulk_coeff)
-        int Bmax = bl.Bh;
-        { int o = __shfl_xor(Bmax, 32); Bmax = Bmax > o ? Bmax : o; }
-        Bmax = (int)__builtin_amdgcn_readfirstlane((uint32_t)Bmax);
-        auto unp = [&](const M64 &sg, const M64 &sn, int r) -> uint32_t {
-            if (r > 63) return 0u;
-            const uint32_t g = ((r < 32 ? sg.lo : sg.hi) >> (r & 31)) & 1u, n = ((r < 32 ? sn.lo : sn.hi) >> (r & 31)) & 1u;
-            return (g << 1) | (g & n);
-        };
-        uint32_t pUL = 0u, pUR = 0u;
-        for (int i = 0; i < 64; i++) {
-            const uint32_t uL = unp(sigL, sgnL, i), uR = unp(sigR, sgnR, i);
-            if (Bmax >= 0)
-                bulk_row<true>(c, t, uL, uR, 0u, 0u, unp(sigL, sgnL, i + 1), unp(sigR, sgnR, i + 1), pUL, pUR, bl,
-                               Bmax, prec, upper_mask, const_cast<int32_t *>(cw));
-            else { pUL = uL; pUR = uR; }
-            if (!valid) continue;
-            int32_t v0, v1;
-            if (sz == 4096) {
-                int2 w;
-                if constexpr (S16) {
-                    // the packed stream: words 1 .. 4095 are the codeblock's 4095 shorts, word 0 sits in the MSB's place
-                    // (as write_rows; loads kept inside the stream's shorts)
-                    const uint32_t kk = t * 128u + 2u * (uint32_t)i, rawlast = c.srclim + 1u;
-                    const uint32_t i0 = c.srcoff + kk - 1u, i1 = c.srcoff + kk;
-                    w.x = kk == 0u ? word0 : (int32_t)a.cw16[i0 < rawlast ? i0 : rawlast];
-                    w.y = (int32_t)a.cw16[i1 < rawlast ? i1 : rawlast];
-                } else {
-                    w = *reinterpret_cast<const int2 *>(stage + t * 128u + 2u * (uint32_t)i);
-                }
-                v0 = (int32_t)(((uint32_t)w.x & 0xFFFFFFu) >> 1); if (w.x & 1) v0 = -v0;
-                v1 = (int32_t)(((uint32_t)w.y & 0xFFFFFFu) >> 1); if (w.y & 1) v1 = -v1;
-            } else {
-                const uint32_t ii = (uint32_t)i & 31u, hs = (uint32_t)(bl.Bh + 1);
-                uint32_t m0 = 0u, m1 = 0u;
-#pragma unroll
-                for (int k = 0; k < NP; k++) {
-                    uint32_t l = i < 32 ? PLlo[k] : PLhi[k], r = i < 32 ? PRlo[k] : PRhi[k];
-                    m0 |= ((l >> ii) & 1u) << k;
-                    m1 |= ((r >> ii) & 1u) << k;
-                }
-                m0 = (m0 << hs) | (pUL >> 2);
-                m1 = (m1 << hs) | (pUR >> 2);
-                v0 = (pUL & 1u) ? -(int32_t)m0 : (int32_t)m0;
-                v1 = (pUR & 1u) ? -(int32_t)m1 : (int32_t)m1;
-            }
-            *reinterpret_cast<int2 *>(a.coeffs_out + cbase + (size_t)i * (size_t)a.AW) = make_int2(v0, v1);
-        }
-    } else {
-        // writeCoefficients BPCEngine.cu:94-111 / copyEntireCodeblock :1915-1922.  Plane registers
-        // NP.. do not exist in this instantiation (its waves have at most NP coded planes).
-        // The planes come back from the scratch, eight (sixteen for a wave with a codeblock of MSB >= 8) of one
-        // 32-row half at a time; planes above a codeblock's MSB were never written and read as zero.
+    // writeCoefficients BPCEngine.cu:94-111 / copyEntireCodeblock :1915-1922.
+    // The planes come back from the scratch, eight (sixteen for a wave with a codeblock of MSB >= 8) of one
+    // 32-row half at a time; planes a codeblock never decoded in its two passes -- above its MSB, and (-k > 0) below
+    // its cbp: the bulk scan's -- were never written and read as zero.
+    {
         const bool have = coded;
         auto planes_of = [&](auto &A, auto &B, int hw, int n) {
 #pragma unroll
             for (int k = 0; k < (int)(sizeof(A) / sizeof(A[0])); k++) {
                 A[k] = 0u; B[k] = 0u;
-                if (k < n && have && k <= msb) {
+                if (k < n && have && k <= msb && k >= cbp) {
                     const uint32_t *q = pscr + (size_t)k * kEncPlaneDwords + hw * 64;
                     A[k] = q[0]; B[k] = q[128];
                 }
             }
         };
         const uint16_t *const raw16 = s16 ? a.cw16 : nullptr;
-        if (np > kDecSmallPlanes) {
+        if (msbw >= kDecSmallPlanes) {
 #pragma unroll 1
             for (int hw = 0; hw < 2; hw++) {
                 uint32_t A[kMaxPlanes], B[kMaxPlanes];
@@ -2163,6 +2153,39 @@ void bpc_decode_kernel(BpcArgs a)
                 planes_of(A, B, hw, kDecSmallPlanes);
                 write_rows<kDecSmallPlanes, kDecSmallPlanes, C16>(A, B, hw ? sgnL.hi : sgnL.lo, hw ? sgnR.hi : sgnR.lo, 32 * hw, valid, sz, stage, t,
                                                                   obase, a.AW, raw16, c.srcoff, c.srclim + 1u, word0);
+            }
+        }
+    }
+    if constexpr (BULK) {
+        // ---- bulk scan (decodeBulkMode :1653-1662): the planes below cbp, row by row; a row's two coefficients as the
+        // epilogue left them (magnitude bits of the two-pass planes, sign) are read back two rows ahead, the scan's low bits
+        // and the signs it decoded go in, the row is stored (L2-resident: the wave has just written it)
+        int Bmax = bl.Bh;
+        { int o = __shfl_xor(Bmax, 32); Bmax = Bmax > o ? Bmax : o; }
+        Bmax = (int)__builtin_amdgcn_readfirstlane((uint32_t)Bmax);
+        if (Bmax >= 0) {
+            wave_stores_issued();                            // (the epilogue's stores of this lane's rows have landed)
+            auto unp = [&](const M64 &sg, const M64 &sn, int r) -> uint32_t {
+                if (r > 63) return 0u;
+                const uint32_t g = ((r < 32 ? sg.lo : sg.hi) >> (r & 31)) & 1u, n = ((r < 32 ? sn.lo : sn.hi) >> (r & 31)) & 1u;
+                return (g << 1) | (g & n);
+            };
+            const bool mine = valid && sz != 4096 && bl.Bh >= 0;        // this lane's codeblock has bulk planes
+            int32_t *const orow = a.coeffs_out + cbase;
+            auto row_at = [&](int i) -> int2 { return mine && i < 64 ? *reinterpret_cast<const int2 *>(orow + (size_t)i * (size_t)a.AW) : make_int2(0, 0); };
+            uint32_t pUL = 0u, pUR = 0u;
+            int2 w0 = row_at(0), w1 = row_at(1);
+            for (int i = 0; i < 64; i++) {
+                const int2 w2 = row_at(i + 2);
+                const uint32_t uL = unp(sigL, sgnL, i), uR = unp(sigR, sgnR, i);
+                bulk_row<true>(c, t, uL, uR, 0u, 0u, unp(sigL, sgnL, i + 1), unp(sigR, sgnR, i + 1), pUL, pUR, bl,
+                               Bmax, prec, upper_mask, const_cast<int32_t *>(cw));
+                if (mine) {
+                    const uint32_t m0 = (uint32_t)(w0.x < 0 ? -w0.x : w0.x) | (pUL >> 2), m1 = (uint32_t)(w0.y < 0 ? -w0.y : w0.y) | (pUR >> 2);
+                    const int32_t v0 = (pUL & 1u) ? -(int32_t)m0 : (int32_t)m0, v1 = (pUR & 1u) ? -(int32_t)m1 : (int32_t)m1;
+                    *reinterpret_cast<int2 *>(orow + (size_t)i * (size_t)a.AW) = make_int2(v0, v1);
+                }
+                w0 = w1; w1 = w2;
             }
         }
     }

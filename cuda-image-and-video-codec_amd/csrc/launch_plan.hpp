@@ -73,6 +73,30 @@ inline int inv97_band_rows(int level, int strips, int H)
     return n >= (16L << 20) ? 32 : (n >= (4L << 20) ? 16 : (n >= (1L << 20) ? 8 : 4));
 }
 
+// -k > 0: bytes the COMPACT table copy of the frame's widest codeblock needs (bulk_setup<true>, bpc_kernels.hpp): the
+// groups g0 .. g1 its 32 lanes' subbands span (findSubband BPC/BPCEngine.cu:143-170 at x = 64 cbx + 2 t, y = 64 cby), of
+// the three sections, each with its slack planes.  A function of the geometry alone; the host takes the COMPACT
+// instantiations of the -k > 0 kernels when it is at most kBulkCompactBytes.
+inline int bulk_max_span_bytes(int aw, int ah, int wl, int nBp, int nSub, int cRef, int cSig, int cSign)
+{
+    auto group = [&](int x, int y) {
+        for (int a = 1; a <= wl; a++) {
+            const bool cx = x >= (aw >> a), cy = y >= (ah >> a);
+            if (cx || cy) return (a - 1) * nSub + (cx ? (cy ? 2 : 0) : 1);
+        }
+        return wl * nSub;
+    };
+    int worst = 1;
+    for (int cby = 0; cby < ah / 64; cby++)
+        for (int cbx = 0; cbx < aw / 64; cbx++) {
+            int g0 = 1 << 30, g1 = -1;
+            for (int t = 0; t < 32; t++) { const int g = group(cbx * 64 + 2 * t, cby * 64); g0 = g < g0 ? g : g0; g1 = g > g1 ? g : g1; }
+            worst = g1 - g0 + 1 > worst ? g1 - g0 + 1 : worst;
+        }
+    const int sl = nBp < 15 ? 16 - nBp : 1;
+    return (worst * nBp + sl) * (cRef + cSig + cSign);
+}
+
 // May the frame paths carry their coded coefficients as 16-bit integers (DwtFwdArgs::c16)?  The largest magnitude a
 // subband sample can take is  max|sample| x G_x x G_y  x (9/7: the quantisation weight QSTEP[l][sb] x qs), G = the L1
 // gain of the multi-level 1-D analysis from the input to a level's low / high output: at most 1.3803 / 2.6253 for the

@@ -52,6 +52,7 @@ struct picsong_ctx {
     bool fast_div;        // 9/7 synthesis: reciprocal form of the divisions verified for this qs
     bool c16;             // frame paths: coded coefficients travel as int16 between transform and coder (coef16_ok)
     bool c16_dec;         // decode frame paths: ... and between decoder and synthesis (dec_c16_ok)
+    int bulk_compact[3];  // -k > 0: the component's table geometry lets every codeblock use the compact LDS copy (-1: not looked at yet)
     bool pipelined;       // picsong_ctx_set_pipelined: other frames share the GPU (throughput over latency)
     // LUT
     picsong_lut_info li[3];
@@ -419,6 +420,7 @@ int picsong_ctx_create(const picsong_params *p, int device, picsong_ctx **out)
     // 8-bit samples: 128 after the level shift; 255 covers the chroma differences of the RGB path's RCT
     c->c16 = p->cp != 3 && p->bit_depth == 8 && dwt_c16_geometry_ok(c->aw, c->ah, p->wl) &&
              coef16_ok(p->lossy != 0, p->wl, p->qs, p->is_rgb ? 255 : 128);
+    c->bulk_compact[0] = c->bulk_compact[1] = c->bulk_compact[2] = -1;
     c->c16_dec = p->k <= 0.0f && p->cp != 3 && p->bit_depth == 8 && !p->is_rgb &&
                  dec_c16_ok(p->lossy != 0, p->wl, p->qs, 128, c->aw, c->ah, c->fast_div);
     hipError_t e = hipMalloc(&c->d_offsets, sizeof(int32_t) * (size_t)c->ncb);
@@ -497,6 +499,7 @@ int picsong_ctx_set_lut_component(picsong_ctx *c, int comp, const picsong_lut_in
     c->li[comp] = *info;
     c->li[comp].n_tables = n_tables;
     c->has_lut[comp] = true;
+    c->bulk_compact[comp] = -1;
     return PICSONG_OK;
 }
 
@@ -532,6 +535,7 @@ int picsong_ctx_set_lut_device(picsong_ctx *c, int comp, const picsong_lut_info 
     c->lut_borrowed[comp] = true;
     c->li[comp] = li;
     c->has_lut[comp] = true;
+    c->bulk_compact[comp] = -1;
     return PICSONG_OK;
 }
 
@@ -745,6 +749,19 @@ static int bpc_args(picsong_ctx *c, BpcArgs &a, int comp = 0)
     return PICSONG_OK;
 }
 
+// -k > 0: may the launch take the kernels' COMPACT table copies (bulk_max_span_bytes: the geometry's widest codeblock)?
+// PICSONG_BULK_FULLTAB=1 keeps the whole-table instantiations (the tests cross-check both)
+static bool bulk_compact(picsong_ctx *c, int comp)
+{
+    if (const char *e = getenv("PICSONG_BULK_FULLTAB")) if (atoi(e) != 0) return false;
+    if (c->bulk_compact[comp] < 0) {
+        const picsong_lut_info &li = c->li[comp];
+        c->bulk_compact[comp] = bulk_max_span_bytes(c->aw, c->ah, c->p.wl, li.n_bitplanes, li.n_subbands, li.ctx_ref, li.ctx_sig,
+                                                    li.ctx_sign) <= kBulkCompactBytes ? 1 : 0;
+    }
+    return c->bulk_compact[comp] == 1;
+}
+
 // the coders' bit-plane scratch: kEncScratchDwordsPerWave per wave of a frame's launch (whole workgroups), allocated
 // at the first use
 static int ensure_plane_scratch(picsong_ctx *c)
@@ -778,7 +795,15 @@ static int bpc_encode_impl(picsong_ctx *c, const void *d_coeffs, uint16_t *d_sta
         return PICSONG_OK;
     }
     // -k > 0: the BULK instantiation (bulk scan below the consecutive bit-planes, table s in LDS)
-    if (a.k > 0.0f) bpc_encode_kernel<true><<<(unsigned)((cb_count + 1) / 2), 64, 0, s>>>(a);
+    if (a.k > 0.0f) {
+        // Two instantiations of the -k > 0 encoder: with compact table copies it is asked for six waves a SIMD (80
+        // registers, some of its prologue spilled) -- what frames in flight want: 133 -> 142 Gpixel/s at k = 0.5; with
+        // whole tables its LDS bounds it to four waves anyway, it takes 102 registers and spills nothing -- what a lone
+        // frame wants, whose 4080 waves are four to a SIMD whatever the kernel allows: 0.376 against 0.411 ms.  The
+        // context's hint (picsong_ctx_set_pipelined) chooses.
+        if (bulk_compact(c, comp) && c->pipelined) bpc_encode_kernel<true, true><<<(unsigned)((cb_count + 1) / 2), 64, 0, s>>>(a);
+        else bpc_encode_kernel<true><<<(unsigned)((cb_count + 1) / 2), 64, 0, s>>>(a);
+    }
     else bpc_encode_kernel<false><<<(unsigned)(((cb_count + 1) / 2 + kBpcEncWgWaves - 1) / kBpcEncWgWaves), 64 * kBpcEncWgWaves, 0, s>>>(a);
     HIP_TRY(hipGetLastError());
     return PICSONG_OK;
@@ -837,16 +862,17 @@ static int bpc_decode_impl(picsong_ctx *c, const int32_t *d_staging, const int32
         return PICSONG_OK;
     }
     if (a.k > 0.0f) {
-        // -k > 0: both plane-count classes over the same grid, each wave is taken by exactly one of them
         if (c16) return fail(PICSONG_ERR_ARG, "-k > 0 decodes into the 32-bit coefficient array");
+        // (one launch: the two-pass planes are parked in the scratch whatever their number)
+        const bool cmp = bulk_compact(c, comp);
         if (d_stream16) {
             a.cw16 = d_stream16; a.cw16_offsets = d_offsets; a.cw16_total = c->d_total;
             a.cw16_max = (uint32_t)picsong_max_stream_shorts(c->aw, c->ah);
-            bpc_decode_kernel<true, kDecSmallPlanes, true><<<waves, 64, 0, s>>>(a);
-            bpc_decode_kernel<true, kMaxPlanes, true><<<waves, 64, 0, s>>>(a);
+            if (cmp) bpc_decode_kernel<true, kDecSmallPlanes, true, false, true><<<waves, 64, 0, s>>>(a);
+            else bpc_decode_kernel<true, kDecSmallPlanes, true><<<waves, 64, 0, s>>>(a);
         } else {
-            bpc_decode_kernel<true, kDecSmallPlanes><<<waves, 64, 0, s>>>(a);
-            bpc_decode_kernel<true, kMaxPlanes><<<waves, 64, 0, s>>>(a);
+            if (cmp) bpc_decode_kernel<true, kDecSmallPlanes, false, false, true><<<waves, 64, 0, s>>>(a);
+            else bpc_decode_kernel<true, kDecSmallPlanes><<<waves, 64, 0, s>>>(a);
         }
     } else {
         const unsigned wgs = (waves + kBpcDecWgWaves - 1) / kBpcDecWgWaves;

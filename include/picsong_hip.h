@@ -109,10 +109,10 @@ int  picsong_ctx_set_lut(picsong_ctx *ctx, const picsong_lut_info *info, const i
 int  picsong_ctx_padded_dims(const picsong_ctx *ctx, int *aw, int *ah, int *n_codeblocks);
 /* Hint, no effect on results: on != 0 says that frames of OTHER contexts / streams are in flight on
  * this GPU while this context's frames run (the reference's -numberOfStreams > 1 video engine,
- * Engines/CodingEngine.cu:758-1069).  Recorded; the frame path currently takes the same launches either
- * way (until round 2 it ran DWT levels 0 and 1 as two launches when hinted: the fused kernel's recomputed
- * run-in rows then cost 3.5 % of the pipelined throughput; in its lean form the fused kernel is the
- * faster one there too, 153.6 against 148.5 Gpixel/s).  Default: off. */
+ * Engines/CodingEngine.cu:758-1069): throughput over latency.  What it selects today: the -k > 0 encoder's
+ * instantiation (six waves a SIMD with compact table copies when hinted, the register-rich four-wave one for a
+ * lone frame).  The k = 0 kernels take the same launches either way -- their waves ask for issue priority by
+ * plane count instead, which serves a lone frame and costs frames in flight nothing.  Default: off. */
 int  picsong_ctx_set_pipelined(picsong_ctx *ctx, int on);
 /* RGB: component c (0,1,2) uses its own table, files {ref,sig,sign}{R,G,B}.txt_0
  * (Engine::initLUT Engines/Engine.cu:124-136: _LUTInformation[i]); picsong_ctx_set_lut == component 0 */

@@ -300,6 +300,13 @@ void emu_level_shift_fwd(const uint8_t *in, void *out, size_t n, int lossy)
     else emu::launch(dim3(4), dim3(256), [&] { level_shift_fwd_kernel<int32_t>(in, (int32_t *)out, n / 4, 128); });
 }
 
+// mirrors bulk_compact (picsong_hip.hip)
+static bool emu_bulk_compact(int aw, int ah, int wl, const int *geo)
+{
+    if (const char *e = getenv("PICSONG_BULK_FULLTAB")) if (atoi(e) != 0) return false;
+    return bulk_max_span_bytes(aw, ah, wl, geo[0], geo[1], geo[2], geo[4], geo[3]) <= kBulkCompactBytes;
+}
+
 static BpcArgs mk(int aw, int ah, int wl, const int32_t *lut, const int *geo, int32_t *staging, int32_t *sizes,
                   int *flag)
 {
@@ -345,7 +352,8 @@ void emu_bpc_encode(const void *coeffs, int is_float, int aw, int ah, int wl, co
     std::vector<uint32_t> plane_scratch((size_t)(((a.nCB + 1) / 2 + kBpcEncWgWaves - 1) / kBpcEncWgWaves * kBpcEncWgWaves) * kEncScratchDwordsPerWave, 0xDEADBEEFu);
     a.plane_scratch = plane_scratch.data();
     memset(staging, 0xFF, (size_t)aw * ah * 4);
-    if (k > 0.0f) emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_encode_kernel<true>(a); });
+    if (k > 0.0f && emu_bulk_compact(aw, ah, wl, geo)) emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_encode_kernel<true, true>(a); });
+    else if (k > 0.0f) emu::launch(dim3((unsigned)((a.nCB + 1) / 2)), dim3(64), [&] { bpc_encode_kernel<true>(a); });
     else emu::launch(dim3((unsigned)(((a.nCB + 1) / 2 + kBpcEncWgWaves - 1) / kBpcEncWgWaves)), dim3(64 * kBpcEncWgWaves), [&] { bpc_encode_kernel<false>(a); });
     emu::launch(dim3((unsigned)a.nCB), dim3(256), [&] { widen_staging_kernel(st16.data(), sizes, 0, staging); });
 }
@@ -358,8 +366,10 @@ void emu_bpc_decode(const int32_t *staging, const int32_t *sizes, int aw, int ah
     a.k = k; a.n_tables = n_tables;
     const dim3 grid((unsigned)((a.nCB + 1) / 2));
     if (k > 0.0f) {
-        emu::launch(grid, dim3(64), [&] { bpc_decode_kernel<true, kDecSmallPlanes>(a); });
-        emu::launch(grid, dim3(64), [&] { bpc_decode_kernel<true, kMaxPlanes>(a); });
+        std::vector<uint32_t> plane_scratch((size_t)grid.x * kEncScratchDwordsPerWave, 0xDEADBEEFu);
+        a.plane_scratch = plane_scratch.data();
+        if (emu_bulk_compact(aw, ah, wl, geo)) emu::launch(grid, dim3(64), [&] { bpc_decode_kernel<true, kDecSmallPlanes, false, false, true>(a); });
+        else emu::launch(grid, dim3(64), [&] { bpc_decode_kernel<true, kDecSmallPlanes>(a); });
     } else {
         const dim3 wgs((grid.x + kBpcDecWgWaves - 1) / kBpcDecWgWaves);
         // (the decoder parks its finished planes in the scratch; poisoned: planes above a codeblock's MSB are never written)
@@ -405,8 +415,10 @@ int emu_bpc_decode_stream_k(const uint16_t *stream, unsigned stream_shorts, int 
     a.k = k; a.n_tables = n_tables;
     a.cw16 = stream; a.cw16_offsets = offsets.data(); a.cw16_total = &total; a.cw16_max = stream_shorts;
     const dim3 grid((unsigned)((a.nCB + 1) / 2));
-    emu::launch(grid, dim3(64), [&] { bpc_decode_kernel<true, kDecSmallPlanes, true>(a); });
-    emu::launch(grid, dim3(64), [&] { bpc_decode_kernel<true, kMaxPlanes, true>(a); });
+    std::vector<uint32_t> plane_scratch((size_t)grid.x * kEncScratchDwordsPerWave, 0xDEADBEEFu);
+    a.plane_scratch = plane_scratch.data();
+    if (emu_bulk_compact(aw, ah, wl, geo)) emu::launch(grid, dim3(64), [&] { bpc_decode_kernel<true, kDecSmallPlanes, true, false, true>(a); });
+    else emu::launch(grid, dim3(64), [&] { bpc_decode_kernel<true, kDecSmallPlanes, true>(a); });
     return bad;
 }
 

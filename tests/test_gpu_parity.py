@@ -814,6 +814,29 @@ def test_pipelined_hint_changes_launches_not_results(oracle, pa, torch):
         assert np.array_equal(got[0], ref) and np.array_equal(got[1], ref)
 
 
+@pytest.mark.parametrize("W,H,wl,k", [(1920, 1080, 5, 0.5), (512, 512, 5, 1.5)])
+def test_complexity_scalable_instantiations_agree(oracle, pa, torch, monkeypatch, W, H, wl, k):
+    """-k > 0: the encoder's two instantiations (the hint picks: compact table copies and six waves a SIMD for frames in
+    flight, whole tables and more registers for a lone frame), the whole-table forms of both coders
+    (PICSONG_BULK_FULLTAB=1; the 512 x 512 wl 5 geometry has a codeblock that spans 13 table groups and takes them by
+    itself) -- one codestream, the oracle's, and its decode the frame."""
+    img = oracle.gen_frame(W, H, 33)
+    lut = oracle.lut_for_k(False, wl)
+    ref = oracle.encode_frame(img, wl, False, 1.0, lut, 0, 0, k=k)
+    frame = _dev(torch, oracle.pad_frame(img))
+    for hint, fulltab in ((False, False), (True, False), (True, True)):
+        if fulltab:
+            monkeypatch.setenv("PICSONG_BULK_FULLTAB", "1")
+        c = pa.Codec(W, H, wl=wl, lut_folder=_lutdir(oracle, False), k=k, pipelined=hint)
+        s = c.encode_frame(frame, 0)
+        assert np.array_equal(s.cpu().numpy().view(np.uint16), ref), (hint, fulltab)
+        assert np.array_equal(c.decode_frame(s.clone()).cpu().numpy()[:H, :W], img), (hint, fulltab)
+        assert c.range_flag() == 0
+        c.close()
+        if fulltab:
+            monkeypatch.delenv("PICSONG_BULK_FULLTAB")
+
+
 def test_random_geometries_through_the_frame_paths(oracle, pa, torch):
     """Seeded random W x H, wl, transform and content (synthetic, noise = raw blocks, flat = empty blocks, mixed) through
     the frame paths: the codestream is the oracle's, the decode -- which reads it straight from an EXACT-length buffer --

@@ -382,9 +382,15 @@ def _bulk_coeffs(oracle, W, H, wl, lossy, seed):
     return f[:W * H].reshape(H, W)
 
 
-@pytest.mark.parametrize("W,H,wl,k", [(256, 128, 2, 0.3), (256, 128, 2, 1.0), (128, 192, 1, 4.0),
-                                      (192, 128, 2, 65.0), (128, 128, 3, 0.7)])
-def test_bulk_mode_kernels_bit_exact(oracle, E, W, H, wl, k):
+@pytest.mark.parametrize("W,H,wl,k,fulltab", [(256, 128, 2, 0.3, False), (256, 128, 2, 1.0, True), (128, 192, 1, 4.0, False),
+                                              (192, 128, 2, 65.0, False), (128, 128, 3, 0.7, False),
+                                              (128, 128, 5, 0.7, False)])      # (wl 5 at 128 x 128: a codeblock spans 13 table groups)
+def test_bulk_mode_kernels_bit_exact(oracle, E, monkeypatch, W, H, wl, k, fulltab):
+    """-k > 0 on the emulator against the oracle.  The kernels keep only the table GROUPS a codeblock's lanes use in LDS
+    (COMPACT) where the geometry's widest codeblock fits, whole tables otherwise (the last case) or when told to
+    (PICSONG_BULK_FULLTAB=1: the second)."""
+    if fulltab:
+        monkeypatch.setenv("PICSONG_BULK_FULLTAB", "1")
     coef = _bulk_coeffs(oracle, W, H, wl, False, 11)
     lut = oracle.lut_for_k(False, wl)
     st_o, sz_o = oracle.bpc_encode(coef, wl, lut, k=k)
