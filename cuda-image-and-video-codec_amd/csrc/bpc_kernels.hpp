@@ -253,8 +253,8 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void *p)
 // counter.  A reservation then reads its codeword with LDS latency.  The plane loops look after the window
 // once per ROW (a row's call sites reserve at most 4 x 32 slots of a codeblock: two columns, bit and sign),
 // not per call site: seven scalar instructions and a branch fewer at every site that starts a codeword, which
-// nearly every site does for some lane.  (-k's row scan, with up to 34 sites a row, and -cp 3 keep the check
-// in the call site.)
+// nearly every site does for some lane.  (-k's row scan looks once per plane of a coefficient -- three sites --, -cp 3
+// keeps the check in the call site.)
 constexpr int kDecRing = 512;                 // 16-bit entries per codeblock: 1 KB
 constexpr uint32_t kDecRingAhead = 192u;      // per-site check (dec_site_m<true>): exact counters
 constexpr uint32_t kDecRingAheadRow = 256u;   // per-row check (dec_ring_row): counters one row old
@@ -338,19 +338,6 @@ __device__ __forceinline__ void dec_ring_row(Coder &c, uint32_t upper_mask)
     if ((a < b ? a : b) < kDecRingAheadRow) dec_ring_refill(c, upper_mask, c.cnt_lo, c.cnt_hi, kDecRingAheadRow);
 #endif
 }
-// the exact counters for the per-site form that follows the plane loops (-k's row scan)
-__device__ __forceinline__ void dec_ring_sync(Coder &c)
-{
-#if PS_ENC_LDS
-    wave_lds_done();
-    const uint32_t v = __hip_atomic_load(c.ldscnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    c.cnt_lo = __builtin_amdgcn_readlane(v, 0) / kDecCntUnit;
-    c.cnt_hi = __builtin_amdgcn_readlane(v, 32) / kDecCntUnit;
-#else
-    (void)c;
-#endif
-}
-
 // significance probabilities for contexts 0..8 packed as bytes: w0 = ctx 0-3, w1 = ctx 4-7, p8.
 struct PlaneLut { uint32_t sig0, sig1, sig8, sign, ref, sig8x4; };
 

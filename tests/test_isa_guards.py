@@ -98,10 +98,15 @@ def test_coder_kernels_keep_their_plane_loops_free_of_scratch(device_asm):
     of an argument in the plane loops becomes a scratch load -- 15 % of the encoder's rate, with every test still green.
     So: no more than a handful of scratch instructions from the first interval update (v_mul_u32_u24) on, and a bounded
     frame."""
-    # (the decoder twice: from the 32-bit staging, and the frame paths' instantiation that reads the packed stream)
+    # (the decoder three times: from the 32-bit staging, the frame paths' instantiation that reads the packed stream, and
+    # that one writing 16-bit coefficients; round 4: the -k > 0 instantiations with compact table copies, which are asked
+    # for six waves a SIMD and spill part of their prologues / epilogues -- not their plane loops)
     for key, first, most, frame in (("17bpc_encode_kernelILb0E", "v_mul_u32_u24", 8, 320),
                                     ("17bpc_decode_kernelILb0ELi8ELb0E", "v_bcnt_u32_b32", 80, 192),
-                                    ("17bpc_decode_kernelILb0ELi8ELb1E", "v_bcnt_u32_b32", 80, 192)):
+                                    ("17bpc_decode_kernelILb0ELi8ELb1ELb0E", "v_bcnt_u32_b32", 80, 192),
+                                    ("17bpc_decode_kernelILb0ELi8ELb1ELb1E", "v_bcnt_u32_b32", 80, 192),
+                                    ("17bpc_encode_kernelILb1ELb1E", "v_mul_u32_u24", 16, 320),
+                                    ("17bpc_decode_kernelILb1ELi8ELb1ELb0ELb1E", "v_bcnt_u32_b32", 80, 320)):
         body = _kernel_body(device_asm, key)
         i0 = next(i for i, ln in enumerate(body) if first in ln)
         tail = [ln for ln in body[i0:] if re.match(r"^\s*scratch_", ln)]
@@ -116,4 +121,4 @@ def test_coder_kernels_keep_their_plane_loops_free_of_scratch(device_asm):
             sizes[name] = int(m.group(1))
     enc = [v for k, v in sizes.items() if "bpc_encode_kernelILb0E" in k]
     dec = [v for k, v in sizes.items() if "bpc_decode_kernelILb0ELi8" in k]
-    assert enc and len(dec) == 2 and enc[0] <= 320 and max(dec) <= 192, (enc, dec)
+    assert enc and len(dec) == 3 and enc[0] <= 320 and max(dec) <= 192, (enc, dec)
