@@ -836,6 +836,7 @@ __device__ __forceinline__ uint32_t dec_site(Coder &c, uint32_t inact, uint32_t 
 template <bool KEEP>
 __device__ __forceinline__ uint64_t dec_site_m(Coder &c, bool on, uint64_t onm, uint32_t p, uint32_t prec,
                                                uint32_t upper_mask, const int32_t *stage, bool &one);
+__device__ __forceinline__ void sign_table2_fill(uint8_t *tab, uint32_t lane);
 
 // =============================================================================================
 // Complexity-scalable mode, -k > 0 (Encode BPCEngine.cu:1684-1716, Decode :1794-1835,
@@ -885,7 +886,8 @@ struct BulkLane {
     uint32_t ref0, sig0, sign0;    // LDS byte index of the plane-0 entries of the lane's LUT group
     uint32_t cRef, cSig, cSign;    // contexts per plane
     LutView v;                     // this codeblock's table
-    const uint8_t *sgt;            // decoder: the sign table (sign_table2_fill)
+    const uint8_t *sgt;            // the sign table (sign_table2_fill)
+    int bh_lo, bh_hi;              // Bh of the codeblocks in lanes 0-31 / 32-63 (wave-uniform)
 };
 
 __device__ __forceinline__ uint32_t bulk_lut(const BulkLane &b, uint32_t idx) { return b.v.lds[idx]; }   // (the LDS copy's slack: lut_get)
@@ -919,10 +921,14 @@ __device__ __forceinline__ uint32_t bulk_coeff(CT &c, uint32_t u, uint32_t low, 
     uint64_t ssymm = 0ull;
     if constexpr (!DEC) {
         lowx = low << (31 - Bmax);                          // plane Bmax at bit 31: a plane's bit is the next carry
-        const uint32_t qs = low ? 31u - (uint32_t)__builtin_clz(low) : 0u;      // (a lane that never becomes significant: unused)
-        const uint32_t sc = sign_ctx(bulk_sc(lf, qs) + bulk_sc(rt, qs), bulk_sc(up, qs) + bulk_sc(dn, qs));
-        saddr = b.sign0 + (sc >> 1);
-        ssymm = __builtin_amdgcn_ballot_w64(((neg ^ sc) & 1u) != 0u);           // :1308
+        // computeSignContextBulk :311-323 at the plane where THIS lane's coefficient becomes significant (its top low bit),
+        // by the decoders' table (sign_table2_fill: index = up | left << 2 | down << 4 | right << 6, a neighbour's field
+        // (significant, sign) once it counts at that plane; entry = 8 * (c >> 1) | (c & 1) << 6)
+        const uint32_t sq = 2u + (low ? 31u - (uint32_t)__builtin_clz(low) : 0u);   // (a lane that never becomes significant: unused)
+        auto field = [&](uint32_t w) -> uint32_t { return ((w >> sq) | (w & 2u)) != 0u ? (((w & 1u) << 1) | 1u) : 0u; };
+        const uint32_t tv = b.sgt[field(up) | (field(lf) << 2) | (field(dn) << 4) | (field(rt) << 6)];
+        saddr = b.sign0 + ((tv >> 3) & 3u);
+        ssymm = __builtin_amdgcn_ballot_w64(((neg ^ (tv >> 6)) & 1u) != 0u);    // :1308
     }
     const uint32_t sgaddr = b.sig0 + ctx;
     // decoder: a neighbour's field of the sign table's index once it counts -- significant | sign << 1 (sign_table2_fill)
@@ -932,7 +938,8 @@ __device__ __forceinline__ uint32_t bulk_coeff(CT &c, uint32_t u, uint32_t low, 
         // (decoder: the codeword window once per plane of a coefficient -- its three sites reserve at most 64 slots of a
         // codeblock -- from the LDS counters, one iteration late, as the plane loops do once per row: dec_ring_row)
         if constexpr (DEC) dec_ring_row(c, upper_mask);
-        const uint64_t onq = __builtin_amdgcn_ballot_w64(q <= b.Bh);
+        // (the lanes whose codeblock scans plane q: a function of the halves' Bh alone -- scalar work, not a compare)
+        const uint64_t onq = (q <= b.bh_lo ? 0xFFFFFFFFull : 0ull) | (q <= b.bh_hi ? 0xFFFFFFFF00000000ull : 0ull);
         uint64_t bitm = 0ull, dm = 0ull, nsm = 0ull;
         if constexpr (!DEC) bitm = shl_carry(lowx);
         // refinement call site: coefficients that are significant by now
@@ -984,17 +991,20 @@ __device__ __forceinline__ void bulk_row(CT &c, uint32_t t, uint32_t uL, uint32_
                                          int32_t *st)
 {
     const uint32_t sh = 2u + (uint32_t)(b.Bh < 0 ? 0 : b.Bh);
-    // lane-1's right column (rows above / this / below) and lane+1's left column (above, below)
-    const uint32_t P_ur = from_prev32(pUR, t), P_r = from_prev32(uR, t), P_dr = from_prev32(dR, t);
-    const uint32_t N_ul = from_next32(pUL, t), N_dl = from_next32(dL, t);
+    // computeContextBulk's term of every word the two contexts count, formed ONCE where the word lives: a neighbour lane's
+    // terms travel as bits (lanes of one codeblock share Bh) -- lane-1's right column of the rows above / this / below
+    // in one DPP move, lane+1's left column above / below in another -- where round 3 moved five words and formed
+    // sixteen terms a row
+    const uint32_t ca = bulk_cc(pUL, sh), cb = bulk_cc(pUR, sh), cr = bulk_cc(uR, sh), ce = bulk_cc(dL, sh), cf = bulk_cc(dR, sh);
+    const uint32_t Pb = from_prev32(cb | (cr << 1) | (cf << 2), t), Nb = from_next32(ca | (ce << 1), t);
+    const uint32_t P_r = from_prev32(uR, t);                 // (words only where a sign context needs them)
+    const uint32_t own = ca + cb + ce + cf;
     // left coefficients of all lanes (encodeLeftCoefficients :1320-1381)
-    const uint32_t ctxL = bulk_cc(P_ur, sh) + bulk_cc(pUL, sh) + bulk_cc(pUR, sh) + bulk_cc(P_r, sh) +
-                          bulk_cc(uR, sh) + bulk_cc(P_dr, sh) + bulk_cc(dL, sh) + bulk_cc(dR, sh);
+    const uint32_t ctxL = (uint32_t)__builtin_popcount(Pb) + own + cr;
     const uint32_t nL = bulk_coeff<DEC, CT>(c, uL, lowL, ctxL, pUL, P_r, uR, dL, b, Bmax, prec, upper_mask, st);
     // right coefficients (encodeRightCoefficients :1387-1448): the left ones of this row are done
     const uint32_t N_l = from_next32(nL, t);
-    const uint32_t ctxR = bulk_cc(pUL, sh) + bulk_cc(pUR, sh) + bulk_cc(N_ul, sh) + bulk_cc(nL, sh) +
-                          bulk_cc(N_l, sh) + bulk_cc(dL, sh) + bulk_cc(dR, sh) + bulk_cc(N_dl, sh);
+    const uint32_t ctxR = (uint32_t)__builtin_popcount(Nb) + own + bulk_cc(nL, sh) + bulk_cc(N_l, sh);
     const uint32_t nR = bulk_coeff<DEC, CT>(c, uR, lowR, ctxR, pUR, nL, N_l, dR, b, Bmax, prec, upper_mask, st);
     pUL = nL; pUR = nR;
 }
@@ -1084,6 +1094,8 @@ __device__ __forceinline__ int bulk_setup(const BpcArgs &a, bool coded, int msb,
     b.sign0 = (uint32_t)(grpc * a.g.nBp * a.g.cSign + gl.nRef + gl.nSig);
     b.v.lds = lds_half; b.v.glob = a.lut; b.v.total = total; b.v.glob_total = total * a.n_tables; b.v.loff = loff;
     b.sgt = nullptr;
+    b.bh_lo = (int)__builtin_amdgcn_readfirstlane((uint32_t)b.Bh);
+    b.bh_hi = (int)__builtin_amdgcn_readfirstlane((uint32_t)__shfl_xor(b.Bh, 32));
     return cbp;
 }
 
@@ -1271,7 +1283,9 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, BULK ? PICSONG_BPC
     constexpr int kTab = COMPACT ? kBulkCompactBytes : kLutLdsMax;       // bytes of one LDS table copy
     __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kTab];
     __shared__ uint32_t lds_cnt[2 * (BULK ? 1 : kBpcEncWgWaves)];      // codeword counters of the workgroup's codeblocks
+    __shared__ uint8_t sign_tab[BULK ? 256 : 4];             // -k > 0: the bulk scan's sign contexts (sign_table2_fill)
     const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, t = lane & 31u;
+    if constexpr (BULK) sign_table2_fill(sign_tab, lane);   // (the table copy ends with the barrier)
     if (t == 0u) lds_cnt[(threadIdx.x >> 6) * 2u + half] = half * kStageCb + kStageBytes;   // bytes of the staging (enc_reserve); (the table copy below ends with a barrier)
     const int gwave = BULK ? (int)blockIdx.x
                            : (int)blockIdx.x * kBpcEncWgWaves + (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1342,7 +1356,7 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, BULK ? PICSONG_BPC
     BulkLane bl;
     LutGeo gl = a.g;                                         // (COMPACT: the copy's own section sizes and the lane's group in it)
     int grpc = grp;
-    if constexpr (BULK) cbp = bulk_setup<COMPACT>(a, coded, msb, cbx, cby, grp, t, lds_lut + half * kTab, bl, loff, gl, grpc);
+    if constexpr (BULK) { cbp = bulk_setup<COMPACT>(a, coded, msb, cbx, cby, grp, t, lds_lut + half * kTab, bl, loff, gl, grpc); bl.sgt = sign_tab; }
     else lut_to_lds(a.lut, a.g.nRef + a.g.nSig + a.g.nSign, lds_lut);
     const LutView lv = { lds_lut + (BULK ? half * kTab : 0u), a.lut, a.g.nRef + a.g.nSig + a.g.nSign,
                          (a.g.nRef + a.g.nSig + a.g.nSign) * (BULK ? a.n_tables : 1), loff };
@@ -1500,12 +1514,13 @@ __global__ __launch_bounds__(BULK ? 64 : 64 * kBpcEncWgWaves, BULK ? PICSONG_BPC
             uint32_t pUL = 0u, pUR = 0u, c0, c1, n0 = 0u, n1 = 0u, m0 = 0u, m1 = 0u;
             row_words(0, c0, c1);
             row_words(1, n0, n1);
+            uint32_t uc0 = unp(c0), uc1 = unp(c1);           // (a row's unprocessed words are formed once: as the row below, then reused)
             for (int i = 0; i < 64; i++) {
                 if (i < 62) row_words(i + 2, m0, m1); else { m0 = 0u; m1 = 0u; }
-                bulk_row<false>(c, t, unp(c0), unp(c1), (c0 >> 1) & lowmask, (c1 >> 1) & lowmask,
-                                i < 63 ? unp(n0) : 0u, i < 63 ? unp(n1) : 0u, pUL, pUR, bl, Bmax, prec,
+                const uint32_t un0 = i < 63 ? unp(n0) : 0u, un1 = i < 63 ? unp(n1) : 0u;
+                bulk_row<false>(c, t, uc0, uc1, (c0 >> 1) & lowmask, (c1 >> 1) & lowmask, un0, un1, pUL, pUR, bl, Bmax, prec,
                                 upper_mask, (int32_t *)nullptr);
-                c0 = n0; c1 = n1; n0 = m0; n1 = m1;
+                c0 = n0; c1 = n1; n0 = m0; n1 = m1; uc0 = un0; uc1 = un1;
             }
         }
     }
@@ -2162,11 +2177,13 @@ void bpc_decode_kernel(BpcArgs a)
             auto row_at = [&](int i) -> int2 { return mine && i < 64 ? *reinterpret_cast<const int2 *>(orow + (size_t)i * (size_t)a.AW) : make_int2(0, 0); };
             uint32_t pUL = 0u, pUR = 0u;
             int2 w0 = row_at(0), w1 = row_at(1);
+            uint32_t uL = unp(sigL, sgnL, 0), uR = unp(sigR, sgnR, 0);
             for (int i = 0; i < 64; i++) {
                 const int2 w2 = row_at(i + 2);
-                const uint32_t uL = unp(sigL, sgnL, i), uR = unp(sigR, sgnR, i);
-                bulk_row<true>(c, t, uL, uR, 0u, 0u, unp(sigL, sgnL, i + 1), unp(sigR, sgnR, i + 1), pUL, pUR, bl,
+                const uint32_t dL = unp(sigL, sgnL, i + 1), dR = unp(sigR, sgnR, i + 1);
+                bulk_row<true>(c, t, uL, uR, 0u, 0u, dL, dR, pUL, pUR, bl,
                                Bmax, prec, upper_mask, const_cast<int32_t *>(cw));
+                uL = dL; uR = dR;
                 if (mine) {
                     const uint32_t m0 = (uint32_t)(w0.x < 0 ? -w0.x : w0.x) | (pUL >> 2), m1 = (uint32_t)(w0.y < 0 ? -w0.y : w0.y) | (pUR >> 2);
                     const int32_t v0 = (pUL & 1u) ? -(int32_t)m0 : (int32_t)m0, v1 = (pUR & 1u) ? -(int32_t)m1 : (int32_t)m1;
