@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Random geometries through the frame paths against the oracle (GPU box): encode == the oracle's codestream, decode ==
-the oracle's pixels, for random W x H (ragged, padded by the caller as the CLI does), wl, 5/3 and 9/7, single frames and
-batched calls.  A last safety net after changes to the coders' boundaries; not part of the test suite.
+the oracle's pixels, for random W x H (ragged, padded by the caller as the CLI does), wl, 5/3 and 9/7, the coder's modes
+(two passes; -k > 0 with and without the pipelined hint; -cp 3), single frames and batched calls.  A last safety net after changes to the coders' boundaries; not part of the test suite.
 usage: tools/fuzz_parity.py [n_cases] [seed]"""
 import os
 import sys
@@ -35,21 +35,28 @@ for case in range(n_cases):
         img = np.full((H, W), int(rng.integers(0, 256)), np.uint8)   # flat: empty codeblocks
     else:
         img = orc.gen_frame(W, H, 3); img[: H // 2] = rng.integers(0, 256, (H // 2, W), dtype=np.uint8)
-    lut = orc.lut_for(lossy, wl)
-    lutdir = os.path.join(orc.LUT_DIR, "n1_lossy" if lossy else "n1_lossless")
+    mode = int(rng.integers(0, 10))                # 0-4 two passes, 5-7 -k > 0, 8-9 -cp 3
+    k, cp, hint = 0.0, 2, False
+    sub = "n1_lossy" if lossy else "n1_lossless"
+    lut, lutdir = orc.lut_for(lossy, wl), os.path.join(orc.LUT_DIR, sub)
+    if 5 <= mode <= 7:
+        k, hint = float(rng.choice([0.3, 0.5, 0.7, 0.9])), bool(rng.integers(0, 2))
+        lut = orc.lut_for_k(lossy, wl)
+    elif mode >= 8:
+        cp, lut, lutdir = 3, orc.lut_for_cp3(lossy, wl), os.path.join(orc.LUT_CP3_DIR, sub)
     try:
-        ref = orc.encode_frame(img, wl, lossy, qs, lut)
-        c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=lutdir)
+        ref = orc.encode_frame(img, wl, lossy, qs, lut, 0, 0, k=k)
+        c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=lutdir, k=k, cp=cp, pipelined=hint)
         frame = torch.from_numpy(orc.pad_frame(img)).cuda()
         s = c.encode_frame(frame)
         ok_enc = s.numel() == ref.size and np.array_equal(s.cpu().numpy().view(np.uint16), ref)
         d = c.decode_frame(s.clone())
-        refpix = orc.decode_frame(ref, W, H, wl, lossy, qs, lut) if hasattr(orc, "decode_frame") else None
+        refpix = orc.decode_frame(ref, W, H, wl, lossy, qs, lut, k=k)
         got = d.cpu().numpy()[:H, :W]
-        ok_dec = np.array_equal(got, img) if not lossy else (refpix is None or np.array_equal(got, refpix[:H, :W]))
+        ok_dec = np.array_equal(got, refpix[:H, :W]) and (lossy or np.array_equal(got, img))
         # batched: three copies of the frame through encode_frames / decode_frames
         ok_b = True
-        if c.ncb <= 4096:
+        if c.ncb <= 4096 and k == 0.0 and cp == 2:     # (the batched call is the two-pass k = 0 path only)
             frames = torch.stack([frame.view(-1)] * 3)
             out = torch.empty((3, c.max_stream_shorts()), dtype=torch.int16, device="cuda")
             c.encode_frames_async(frames, out, 1)
@@ -57,11 +64,11 @@ for case in range(n_cases):
             ok_b = bool(torch.equal(out[1, 9:s.numel()], s[9:]))      # (frames 1.. of a video carry no header)
         c.close()
     except Exception as e:                                      # noqa: BLE001
-        print(f"case {case}: {W}x{H} wl {wl} lossy {lossy} qs {qs} kind {kind}: EXCEPTION {e!r}")
+        print(f"case {case}: {W}x{H} wl {wl} lossy {lossy} qs {qs} kind {kind} k {k} cp {cp} hint {hint}: EXCEPTION {e!r}")
         bad += 1
         continue
     flag = "" if (ok_enc and ok_dec and ok_b) else "   <-- MISMATCH"
     bad += 0 if not flag else 1
-    print(f"case {case}: {W}x{H} wl {wl} lossy {lossy} qs {qs} kind {kind}: enc {ok_enc} dec {ok_dec} batched {ok_b}{flag}")
+    print(f"case {case}: {W}x{H} wl {wl} lossy {lossy} qs {qs} kind {kind} k {k} cp {cp} hint {hint}: enc {ok_enc} dec {ok_dec} batched {ok_b}{flag}")
 print("mismatches:", bad)
 sys.exit(1 if bad else 0)
