@@ -2200,7 +2200,7 @@ void bpc_decode_kernel(BpcArgs a)
 // -cp 3: three coding passes (kernelBPCCoder3CP / kernelBPCDecoder3CP BPC/BPCEngine.cu:2029-2121,
 // 2221-2299; Encode3CP :1727-1776, Decode3CP :1844-1900; SPPEncoder3CP :521-553, SPPDecoder3CP :599-640,
 // CPEncoder :645-680, CPDecoder :686-719 and their launchers :850-925, :1010-1243).  Deprecated in the
-// reference (IO/CommandLineParser.cpp:34) and not tuned here: one kernel for both directions over LIVE
+// reference (IO/CommandLineParser.cpp:34) and tuned only as far as its registers go: one kernel for both directions over LIVE
 // row masks, as the 2-pass decoder keeps them -- in this mode even the encoder cannot form its contexts
 // ahead of the scan, because whether the significance pass codes a coefficient at all (one of its eight
 // neighbours is significant when the scan reaches it) depends on what the pass did to the coefficients
@@ -2275,15 +2275,23 @@ __device__ __forceinline__ uint64_t cp3_coeff(CT &c, bool idle, uint32_t ii, M64
 }
 
 #ifndef PICSONG_BPC3_WG
-#define PICSONG_BPC3_WG 2
+#define PICSONG_BPC3_WG 4
 #endif
 constexpr int kBpc3WgWaves = PICSONG_BPC3_WG;
+// (round 4) The planes live in the wave's scratch as in the two-pass kernels -- the encoder's prologue is theirs
+// (enc_transpose_pass: until then a bit at a time, ~6 K instructions a wave, into 64 plane registers), the decoder parks
+// a finished plane and its epilogue reads them back eight at a time -- and ONE plane is in registers: 125 / 160
+// registers (4 / 3 waves a SIMD) become 80, six waves.  8K lossless, lone frame / three calls in flight: encode 0.651 ms /
+// 71 Gpixel/s -> 0.60 ms / 90, decode 0.925 ms / 55 -> 0.69 ms / 76 (5 / 6 / 7 / 8 waves asked for: the same within
+// 2 %; four waves to a workgroup -- one table copy in LDS for four -- over two: lone decode 0.77 -> 0.69 ms).
+#ifndef PICSONG_BPC3_WAVES
+#define PICSONG_BPC3_WAVES 6
+#endif
 
 template <bool DEC>
-__global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
+__global__ __launch_bounds__(64 * kBpc3WgWaves, PICSONG_BPC3_WAVES) void bpc3_kernel(BpcArgs a)
 {
     using CT = typename std::conditional<DEC, Coder, EncCoder>::type;
-    constexpr int NP = kMaxPlanes;
     __shared__ uint8_t lds_lut[kLutLdsMax3];
     __shared__ uint8_t sign_tab[256];
     __shared__ __attribute__((aligned(1024))) uint16_t cw_ring[kBpc3WgWaves * 2 * kDecRing];
@@ -2296,7 +2304,8 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
     const bool valid = cb < a.nCB;
     const int cbx = valid ? cb % a.ncx : 0, cby = valid ? cb / a.ncx : 0;
     const size_t cbase = (size_t)(cby * 64) * (size_t)a.AW + (size_t)(cbx * 64) + 2u * t;
-    const uint32_t cbyte = (uint32_t)cbase * 4u, rstride = (uint32_t)a.AW * 4u;
+    const uint32_t esz = a.c16 ? 2u : 4u;                    // bytes of a coefficient (encoder input)
+    const uint32_t cbyte = (uint32_t)cbase * esz, rstride = (uint32_t)a.AW * esz;
     // the decoder's staging (32-bit, the reference's array) / the encoder's (16-bit words, BpcArgs::staging16)
     int32_t *const st = DEC ? a.staging + (size_t)(a.cb_base + 2 * wave + (int)half) * 4096u : nullptr;
     uint16_t *const stw16 = DEC ? nullptr : a.staging16 + (size_t)(a.cb_base + 2 * wave) * 4096u;
@@ -2307,9 +2316,10 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
     const uint32_t upper_mask = opaque_mask(half ? 0xFFFFFFFFu : 0u);
     const int total = a.g.nRef + 2 * (a.g.nSig + a.g.nSign), aux = a.g.nSig + a.g.nSign;
 
-    uint32_t PLlo[NP], PLhi[NP], PRlo[NP], PRhi[NP];
-#pragma unroll
-    for (int k = 0; k < NP; k++) { PLlo[k] = PLhi[k] = PRlo[k] = PRhi[k] = 0u; }
+    // the plane being coded: rows 0-31 / 32-63 of the left and of the right column
+    uint32_t PLlo = 0u, PLhi = 0u, PRlo = 0u, PRhi = 0u;
+    const int gwave = (int)blockIdx.x * kBpc3WgWaves + (int)(threadIdx.x >> 6);
+    uint32_t *const pscr = a.plane_scratch + (size_t)gwave * (size_t)kEncScratchDwordsPerWave + lane;
     M64 sgnL = { 0u, 0u }, sgnR = { 0u, 0u };              // X-form here: lo = rows 0-31, hi = rows 32-63
     int msb = 32;
     int32_t sz = 0;
@@ -2317,35 +2327,29 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
         if (valid) { msb = st[0]; sz = a.sizes[cb]; }
         if (valid && sz != 4096 && msb != 32 && (msb < 0 || msb > kMaxPlanes - 1)) { atomicOr(a.range_flag, 1); msb = kMaxPlanes - 1; }
     } else {
-        // findMSB3CP :198-216 (the cleanup flag does not count) and the planes, plane msb - k in register k
+        // findMSB3CP :198-216 (the cleanup flag does not count) and the planes as row masks into the scratch: the
+        // two-pass encoder's prologue (planes 8-15 only for a wave with a codeblock of MSB >= 8)
+        U64 sgL = { 0u, 0u }, sgR = { 0u, 0u };
         uint32_t ormag = 0u;
-        if (valid)
-            for (int i = 0; i < 64; i++) {
-                uint32_t m0, m1, n0, n1;
-                load_row(a, cbyte + (uint32_t)i * rstride, m0, m1, n0, n1);
-                ormag |= m0 | m1;
+        int msbmax = -1;
+#pragma unroll 1
+        for (int pass = 0; pass < kMaxPlanes / kEncPassPlanes; pass++) {
+            if (valid) {
+                if (a.c16) enc_transpose_pass<2>(a, pass, cbyte, rstride, pscr, ormag, sgL, sgR);
+                else if (a.is_float) enc_transpose_pass<1>(a, pass, cbyte, rstride, pscr, ormag, sgL, sgR);
+                else enc_transpose_pass<0>(a, pass, cbyte, rstride, pscr, ormag, sgL, sgR);
             }
-        ormag = half_or_dpp(ormag, upper_mask);
-        msb = ormag ? 31 - __builtin_clz(ormag) : 32;
-        if (valid && msb != 32 && msb > kMaxPlanes - 1) { atomicOr(a.range_flag, 1); msb = kMaxPlanes - 1; }
-        if (valid && msb != 32) {
-            const uint32_t up = (uint32_t)(kMaxPlanes - 1 - msb);
-#pragma unroll
-            for (int hw = 0; hw < 2; hw++)
-                for (int ii = 0; ii < 32; ii++) {
-                    uint32_t m0, m1, n0, n1;
-                    load_row(a, cbyte + (uint32_t)(hw * 32 + ii) * rstride, m0, m1, n0, n1);
-                    m0 = (m0 << up) & 0xFFFFu; m1 = (m1 << up) & 0xFFFFu;
-                    if (hw == 0) { sgnL.lo |= n0 << ii; sgnR.lo |= n1 << ii; }
-                    else         { sgnL.hi |= n0 << ii; sgnR.hi |= n1 << ii; }
-#pragma unroll
-                    for (int k = 0; k < NP; k++) {
-                        const uint32_t b0 = (m0 >> (kMaxPlanes - 1 - k)) & 1u, b1 = (m1 >> (kMaxPlanes - 1 - k)) & 1u;
-                        if (hw == 0) { PLlo[k] |= b0 << ii; PRlo[k] |= b1 << ii; }
-                        else         { PLhi[k] |= b0 << ii; PRhi[k] |= b1 << ii; }
-                    }
-                }
+            if (pass == 0) {
+                ormag = half_or_dpp(ormag, upper_mask);
+                msb = ormag ? 31 - __builtin_clz(ormag) : 32;
+                if (valid && msb != 32 && msb > kMaxPlanes - 1) { atomicOr(a.range_flag, 1); msb = kMaxPlanes - 1; }
+                int mm = valid && msb != 32 ? msb : -1;
+                { int o = __shfl_xor(mm, 32); mm = mm > o ? mm : o; }
+                msbmax = (int)__builtin_amdgcn_readfirstlane((uint32_t)mm);
+            }
+            if (msbmax < (pass + 1) * kEncPassPlanes) break;
         }
+        sgnL = M64{ sgL.lo, sgL.hi }; sgnR = M64{ sgR.lo, sgR.hi };
     }
     const bool coded = valid && msb != 32 && sz != 4096;
 
@@ -2379,6 +2383,7 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
     int np = coded ? msb + 1 : 0;
     { int o = __shfl_xor(np, 32); np = np > o ? np : o; }
     np = (int)__builtin_amdgcn_readfirstlane((uint32_t)np);
+    prio_by_planes(np);
 
     M64 sigL = { 0u, 0u }, sigR = { 0u, 0u }, refL = { 0u, 0u }, refR = { 0u, 0u };
     M64 flgL = { ~0u, ~0u }, flgR = { ~0u, ~0u };          // readCoefficients3CP :84-86: every coefficient flagged
@@ -2387,11 +2392,11 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
         const int bp = msb - p;
         const bool act = coded && bp >= 0;
         const bool idle = !act;
-        if constexpr (DEC) {
-            if (act && p > 0) {                            // make room: index 0 = the plane being decoded
-#pragma unroll
-                for (int k = NP - 1; k > 0; k--) { PLlo[k] = PLlo[k - 1]; PLhi[k] = PLhi[k - 1]; PRlo[k] = PRlo[k - 1]; PRhi[k] = PRhi[k - 1]; }
-                PLlo[0] = PLhi[0] = PRlo[0] = PRhi[0] = 0u;
+        PLlo = PLhi = PRlo = PRhi = 0u;
+        if constexpr (!DEC) {
+            if (act) {                                     // the plane's row masks, as the prologue parked them
+                const uint32_t *q = pscr + (size_t)bp * kEncPlaneDwords;
+                PLlo = q[0]; PLhi = q[64]; PRlo = q[128]; PRhi = q[192];
             }
         }
         PlaneLut pl = { 0u, 0u, 0u, 0u, 0u, 0u }, plc = pl;
@@ -2407,7 +2412,7 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
                 // refinement pass: coefficients significant before this plane (bit 29), :726-736 / :743-762
 #pragma unroll
                 for (int hw = 0; hw < 2; hw++) {
-                    uint32_t curL = hw ? PLhi[0] : PLlo[0], curR = hw ? PRhi[0] : PRlo[0];
+                    uint32_t curL = hw ? PLhi : PLlo, curR = hw ? PRhi : PRlo;
                     const uint32_t rL = spp_idle ? 0u : (hw ? refL.hi : refL.lo), rR = spp_idle ? 0u : (hw ? refR.hi : refR.lo);
                     uint32_t rows = wave_or32(rL | rR);
                     while (rows) {
@@ -2423,7 +2428,7 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
                             if (mR != 0ull) enc_site2(c, mR, mR & __builtin_amdgcn_ballot_w64(((curR >> ii) & 1u) != 0u), pl.ref, prec, upper_mask);
                         }
                     }
-                    if constexpr (DEC) { if (hw == 0) { PLlo[0] = curL; PRlo[0] = curR; } else { PLhi[0] = curL; PRhi[0] = curR; } }
+                    if constexpr (DEC) { if (hw == 0) { PLlo = curL; PRlo = curR; } else { PLhi = curL; PRhi = curR; } }
                 }
                 // coefficients the significance pass made significant become eligible now (MRP's else branch)
                 if (!spp_idle) { refL.lo |= sigL.lo; refL.hi |= sigL.hi; refR.lo |= sigR.lo; refR.hi |= sigR.hi; }
@@ -2438,7 +2443,7 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
                 M64 wNL = { from_next32(wL.lo, t), from_next32(wL.hi, t) };
                 M64 sPR = { from_prev32(sR.lo, t), from_prev32(sR.hi, t) };
                 M64 sNL = { from_next32(sL.lo, t), from_next32(sL.hi, t) };
-                uint32_t curL = hw ? PLhi[0] : PLlo[0], curR = hw ? PRhi[0] : PRlo[0];
+                uint32_t curL = hw ? PLhi : PLlo, curR = hw ? PRhi : PRlo;
                 uint32_t fL = hw ? flgL.hi : flgL.lo, fR = hw ? flgR.hi : flgR.lo;
                 uint32_t eL = 0u, eR = 0u;
                 const uint32_t xl = hw ? sigL.hi : sigL.lo, xr = hw ? sigR.hi : sigR.lo;
@@ -2463,21 +2468,50 @@ __global__ __launch_bounds__(64 * kBpc3WgWaves) void bpc3_kernel(BpcArgs a)
                 if (hw == 0) { sigL.lo = w_rows(wL); sigR.lo = w_rows(wR); flgL.lo = fL; flgR.lo = fR; refL.lo |= eL; refR.lo |= eR; }
                 else         { sigL.hi = w_rows(wL); sigR.hi = w_rows(wR); flgL.hi = fL; flgR.hi = fR; refL.hi |= eL; refR.hi |= eR; }
                 if constexpr (DEC) {
-                    if (hw == 0) { sgnL.lo = w_rows(sL); sgnR.lo = w_rows(sR); PLlo[0] = curL; PRlo[0] = curR; }
-                    else         { sgnL.hi = w_rows(sL); sgnR.hi = w_rows(sR); PLhi[0] = curL; PRhi[0] = curR; }
+                    if (hw == 0) { sgnL.lo = w_rows(sL); sgnR.lo = w_rows(sR); PLlo = curL; PRlo = curR; }
+                    else         { sgnL.hi = w_rows(sL); sgnR.hi = w_rows(sR); PLhi = curL; PRhi = curR; }
                 }
             }
         }
-        if constexpr (!DEC) {                              // the next plane moves into register 0
-#pragma unroll
-            for (int k = 0; k < NP - 1; k++) { PLlo[k] = PLlo[k + 1]; PLhi[k] = PLhi[k + 1]; PRlo[k] = PRlo[k + 1]; PRhi[k] = PRhi[k + 1]; }
-            PLlo[NP - 1] = PLhi[NP - 1] = PRlo[NP - 1] = PRhi[NP - 1] = 0u;
+        if constexpr (DEC) {
+            if (act) {                                     // plane bp of this lane's codeblock is complete
+                uint32_t *q = pscr + (size_t)bp * kEncPlaneDwords;
+                q[0] = PLlo; q[64] = PLhi; q[128] = PRlo; q[192] = PRhi;
+            }
         }
     }
 
     if constexpr (DEC) {
-        write_rows<NP>(PLlo, PRlo, sgnL.lo, sgnR.lo, 0, valid, sz, st, t, a.coeffs_out + cbase, a.AW);
-        write_rows<NP>(PLhi, PRhi, sgnL.hi, sgnR.hi, 32, valid, sz, st, t, a.coeffs_out + cbase, a.AW);
+        // the planes back from the scratch, eight (sixteen for a wave with a codeblock of MSB >= 8) of one 32-row half
+        // at a time, as in bpc_decode_kernel; planes above a codeblock's MSB were never written and read as zero
+        int msbw = coded ? msb : -1;
+        { int o = __shfl_xor(msbw, 32); msbw = msbw > o ? msbw : o; }
+        msbw = (int)__builtin_amdgcn_readfirstlane((uint32_t)msbw);
+        auto planes_of = [&](auto &A, auto &B, int hw) {
+#pragma unroll
+            for (int k = 0; k < (int)(sizeof(A) / sizeof(A[0])); k++) {
+                A[k] = 0u; B[k] = 0u;
+                if (coded && k <= msb) {
+                    const uint32_t *q = pscr + (size_t)k * kEncPlaneDwords + hw * 64;
+                    A[k] = q[0]; B[k] = q[128];
+                }
+            }
+        };
+        if (msbw >= kDecSmallPlanes) {
+#pragma unroll 1
+            for (int hw = 0; hw < 2; hw++) {
+                uint32_t A[kMaxPlanes], B[kMaxPlanes];
+                planes_of(A, B, hw);
+                write_rows<kMaxPlanes, kMaxPlanes>(A, B, hw ? sgnL.hi : sgnL.lo, hw ? sgnR.hi : sgnR.lo, 32 * hw, valid, sz, st, t, a.coeffs_out + cbase, a.AW);
+            }
+        } else {
+#pragma unroll 1
+            for (int hw = 0; hw < 2; hw++) {
+                uint32_t A[kDecSmallPlanes], B[kDecSmallPlanes];
+                planes_of(A, B, hw);
+                write_rows<kDecSmallPlanes, kDecSmallPlanes>(A, B, hw ? sgnL.hi : sgnL.lo, hw ? sgnR.hi : sgnR.lo, 32 * hw, valid, sz, st, t, a.coeffs_out + cbase, a.AW);
+            }
+        }
     } else {
         // flush + sizeArray + MSB word + expansion fallback, as bpc_encode_kernel
 #if PS_ENC_LDS

@@ -418,7 +418,7 @@ int picsong_ctx_create(const picsong_params *p, int device, picsong_ctx **out)
     c->extra = picsong_dwt_extra(aw, ah, p->wl);
     c->fast_div = p->lossy != 0 && dequant_fast_ok(p->qs, p->wl);
     // 8-bit samples: 128 after the level shift; 255 covers the chroma differences of the RGB path's RCT
-    c->c16 = p->cp != 3 && p->bit_depth == 8 && dwt_c16_geometry_ok(c->aw, c->ah, p->wl) &&
+    c->c16 = p->bit_depth == 8 && dwt_c16_geometry_ok(c->aw, c->ah, p->wl) &&
              coef16_ok(p->lossy != 0, p->wl, p->qs, p->is_rgb ? 255 : 128);
     c->bulk_compact[0] = c->bulk_compact[1] = c->bulk_compact[2] = -1;
     c->c16_dec = p->k <= 0.0f && p->cp != 3 && p->bit_depth == 8 && !p->is_rgb &&
@@ -767,6 +767,7 @@ static bool bulk_compact(picsong_ctx *c, int comp)
 static int ensure_plane_scratch(picsong_ctx *c)
 {
     static_assert(kBpcEncWgWaves == kBpcDecWgWaves, "one scratch serves the launches of both directions");
+    static_assert(kBpcEncWgWaves % kBpc3WgWaves == 0, "-cp 3 launches fit the same allocation");
     if (c->d_plane_scratch) return PICSONG_OK;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMalloc(&c->d_plane_scratch, (size_t)(((c->ncb + 1) / 2 + kBpcEncWgWaves - 1) / kBpcEncWgWaves * kBpcEncWgWaves) * kEncScratchDwordsPerWave * sizeof(uint32_t)));

@@ -451,7 +451,10 @@ void emu_bpc3_encode(const void *coeffs, int is_float, int aw, int ah, int wl, c
     std::vector<uint16_t> st16((size_t)a.nCB * 4096, 0xDEADu);
     a.staging16 = st16.data();
     memset(staging, 0xFF, (size_t)aw * ah * 4);
-    emu::launch(dim3((unsigned)(((a.nCB + 1) / 2 + kBpc3WgWaves - 1) / kBpc3WgWaves)), dim3(64 * kBpc3WgWaves), [&] { bpc3_kernel<false>(a); });
+    const unsigned wgs3 = (unsigned)(((a.nCB + 1) / 2 + kBpc3WgWaves - 1) / kBpc3WgWaves);
+    std::vector<uint32_t> plane_scratch((size_t)wgs3 * kBpc3WgWaves * kEncScratchDwordsPerWave, 0xDEADBEEFu);
+    a.plane_scratch = plane_scratch.data();
+    emu::launch(dim3(wgs3), dim3(64 * kBpc3WgWaves), [&] { bpc3_kernel<false>(a); });
     emu::launch(dim3((unsigned)a.nCB), dim3(256), [&] { widen_staging_kernel(st16.data(), sizes, 0, staging); });
 }
 
@@ -460,7 +463,10 @@ void emu_bpc3_decode(const int32_t *staging, const int32_t *sizes, int aw, int a
 {
     BpcArgs a = mk(aw, ah, wl, lut, geo, const_cast<int32_t *>(staging), const_cast<int32_t *>(sizes), flag);
     a.coeffs_out = coeffs; a.n_tables = 1;
-    emu::launch(dim3((unsigned)(((a.nCB + 1) / 2 + kBpc3WgWaves - 1) / kBpc3WgWaves)), dim3(64 * kBpc3WgWaves), [&] { bpc3_kernel<true>(a); });
+    const unsigned wgs3 = (unsigned)(((a.nCB + 1) / 2 + kBpc3WgWaves - 1) / kBpc3WgWaves);
+    std::vector<uint32_t> plane_scratch((size_t)wgs3 * kBpc3WgWaves * kEncScratchDwordsPerWave, 0xDEADBEEFu);
+    a.plane_scratch = plane_scratch.data();
+    emu::launch(dim3(wgs3), dim3(64 * kBpc3WgWaves), [&] { bpc3_kernel<true>(a); });
 }
 
 int emu_pack(const int32_t *staging, const int32_t *sizes, int ncb, const uint16_t *header, uint16_t *out)

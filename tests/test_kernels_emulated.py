@@ -656,20 +656,29 @@ def test_three_coding_passes_bit_exact(oracle, E, W, H, wl, lossy):
 
 
 def test_three_coding_passes_stress_blocks(oracle, E):
-    """-cp 3 corner cases: an all-zero codeblock, an impulse, noise that takes the raw fallback."""
+    """-cp 3 corner cases: an all-zero codeblock, an impulse, noise that takes the raw fallback, and a codeblock of
+    twelve planes (sparse large coefficients: the planes above the eighth come from the prologue's second pass and go
+    through the decoder's sixteen-plane epilogue)."""
     lut = oracle.lut_for_cp3(False, 1)
     rng = np.random.default_rng(7)
-    coef = np.zeros((64, 256), np.int32)
+    coef = np.zeros((64, 384), np.int32)
     coef[10, 64 + 20] = -37                                      # impulse in codeblock 1
     coef[:, 128:192] = rng.integers(-255, 256, (64, 64))         # noise: expands -> raw fallback (size 4096)
     coef[:, 192:256] = rng.integers(-3, 4, (64, 64))
+    ys, xs = rng.integers(0, 64, 40), rng.integers(0, 64, 40)
+    coef[ys, 256 + xs] = rng.integers(-3000, 3001, 40)           # codeblock 4: MSB 11, mostly zeros
+    coef[:, 320:384] = rng.integers(-1, 2, (64, 64)) * (rng.integers(0, 8, (64, 64)) == 0)
+    coef[5, 330] = 20000                                         # codeblock 5: MSB 14
     st_ref, sz_ref = oracle.bpc_encode(coef, 1, lut)
     st, sz, flag = E.bpc3_encode(coef, 1, lut)
     assert flag == 0 and np.array_equal(sz, sz_ref) and sz_ref[0] == 1
+    assert sz_ref[4] < 4096 and sz_ref[5] < 4096 and st_ref[4 * 4096] == 11 and st_ref[5 * 4096] == 14
     for cb in range(sz.size):
         n = int(sz[cb])
         assert np.array_equal(st[cb * 4096:cb * 4096 + n], st_ref[cb * 4096:cb * 4096 + n]), f"codeblock {cb}"
-    assert np.array_equal(E.bpc3_decode(st_ref, sz_ref, 256, 64, 1, lut), oracle.bpc_decode(st_ref, sz_ref, 256, 64, 1, lut))
+    dec = E.bpc3_decode(st_ref, sz_ref, 384, 64, 1, lut)
+    assert np.array_equal(dec, oracle.bpc_decode(st_ref, sz_ref, 384, 64, 1, lut))
+    assert np.array_equal(dec[:, 256:], coef[:, 256:])
 
 
 @pytest.mark.parametrize("W,H,wl,lossy,qs", [(320, 192, 3, False, 1.0), (512, 128, 4, False, 1.0), (256, 64, 3, True, 0.5),

@@ -16,7 +16,10 @@ import picsong_amd as pa
 W, H, wl = 7680, 4320, 5
 frame = torch.from_numpy(orc.pad_frame(orc.gen_frame(W, H, 0))).cuda()
 sts = [torch.cuda.Stream() for _ in range(3)]
+only = sys.argv[1] if len(sys.argv) > 1 else ""             # e.g. "cp 3": that mode's line alone
 for name, kw in (("-cp 2, k = 0", {}), ("-k 0.5", {"k": 0.5}), ("-k 1.5", {"k": 1.5}), ("-cp 3", {"cp": 3})):
+    if only not in name:
+        continue
     lut = orc.LUT_CP3_DIR + "/n1_lossless" if kw.get("cp") == 3 else os.path.join(orc.LUT_DIR, "n1_lossless")
     if not os.path.isdir(lut):
         lut = orc.LUT_CP3_DIR
