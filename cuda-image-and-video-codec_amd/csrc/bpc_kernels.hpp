@@ -1936,7 +1936,6 @@ void bpc_decode_kernel(BpcArgs a)
     static_assert(NP == kDecSmallPlanes, "one instantiation for every plane count (the planes are parked in the scratch)");
     static_assert(!C16 || S16, "the 16-bit coefficient form belongs to the frame paths");
     static_assert(BULK || !COMPACT, "compact table copies belong to the -k > 0 instantiations");
-    static_assert(!(BULK && C16), "-k > 0 decodes into the 32-bit coefficient array");
     constexpr int kTab = COMPACT ? kBulkCompactBytes : kLutLdsMax;       // bytes of one LDS table copy
     __shared__ uint8_t lds_lut[(BULK ? 2 : 1) * kTab];
     __shared__ uint8_t sign_tab[256];
@@ -2173,8 +2172,16 @@ void bpc_decode_kernel(BpcArgs a)
                 return (g << 1) | (g & n);
             };
             const bool mine = valid && sz != 4096 && bl.Bh >= 0;        // this lane's codeblock has bulk planes
-            int32_t *const orow = a.coeffs_out + cbase;
-            auto row_at = [&](int i) -> int2 { return mine && i < 64 ? *reinterpret_cast<const int2 *>(orow + (size_t)i * (size_t)a.AW) : make_int2(0, 0); };
+            // (C16: a row's two coefficients are one dword of the int16 array)
+            auto row_at = [&](int i) -> int2 {
+                if (!(mine && i < 64)) return make_int2(0, 0);
+                if constexpr (C16) {
+                    const uint32_t w = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const int16_t *>(obase) + (size_t)i * (size_t)a.AW);
+                    return make_int2((int32_t)(int16_t)(w & 0xFFFFu), (int32_t)w >> 16);
+                } else {
+                    return *reinterpret_cast<const int2 *>(obase + (size_t)i * (size_t)a.AW);
+                }
+            };
             uint32_t pUL = 0u, pUR = 0u;
             int2 w0 = row_at(0), w1 = row_at(1);
             uint32_t uL = unp(sigL, sgnL, 0), uR = unp(sigR, sgnR, 0);
@@ -2187,7 +2194,7 @@ void bpc_decode_kernel(BpcArgs a)
                 if (mine) {
                     const uint32_t m0 = (uint32_t)(w0.x < 0 ? -w0.x : w0.x) | (pUL >> 2), m1 = (uint32_t)(w0.y < 0 ? -w0.y : w0.y) | (pUR >> 2);
                     const int32_t v0 = (pUL & 1u) ? -(int32_t)m0 : (int32_t)m0, v1 = (pUR & 1u) ? -(int32_t)m1 : (int32_t)m1;
-                    *reinterpret_cast<int2 *>(orow + (size_t)i * (size_t)a.AW) = make_int2(v0, v1);
+                    store_coef_pair<C16>(obase, (size_t)i, a.AW, v0, v1);
                 }
                 w0 = w1; w1 = w2;
             }

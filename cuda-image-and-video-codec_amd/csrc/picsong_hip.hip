@@ -421,7 +421,7 @@ int picsong_ctx_create(const picsong_params *p, int device, picsong_ctx **out)
     c->c16 = p->bit_depth == 8 && dwt_c16_geometry_ok(c->aw, c->ah, p->wl) &&
              coef16_ok(p->lossy != 0, p->wl, p->qs, p->is_rgb ? 255 : 128);
     c->bulk_compact[0] = c->bulk_compact[1] = c->bulk_compact[2] = -1;
-    c->c16_dec = p->k <= 0.0f && p->cp != 3 && p->bit_depth == 8 && !p->is_rgb &&
+    c->c16_dec = p->cp != 3 && p->bit_depth == 8 && !p->is_rgb &&
                  dec_c16_ok(p->lossy != 0, p->wl, p->qs, 128, c->aw, c->ah, c->fast_div);
     hipError_t e = hipMalloc(&c->d_offsets, sizeof(int32_t) * (size_t)c->ncb);
     if (e == hipSuccess) e = hipMalloc(&c->d_total, sizeof(int32_t));
@@ -863,15 +863,20 @@ static int bpc_decode_impl(picsong_ctx *c, const int32_t *d_staging, const int32
         return PICSONG_OK;
     }
     if (a.k > 0.0f) {
-        if (c16) return fail(PICSONG_ERR_ARG, "-k > 0 decodes into the 32-bit coefficient array");
         // (one launch: the two-pass planes are parked in the scratch whatever their number)
         const bool cmp = bulk_compact(c, comp);
         if (d_stream16) {
             a.cw16 = d_stream16; a.cw16_offsets = d_offsets; a.cw16_total = c->d_total;
             a.cw16_max = (uint32_t)picsong_max_stream_shorts(c->aw, c->ah);
-            if (cmp) bpc_decode_kernel<true, kDecSmallPlanes, true, false, true><<<waves, 64, 0, s>>>(a);
-            else bpc_decode_kernel<true, kDecSmallPlanes, true><<<waves, 64, 0, s>>>(a);
+            if (c16) {
+                if (cmp) bpc_decode_kernel<true, kDecSmallPlanes, true, true, true><<<waves, 64, 0, s>>>(a);
+                else bpc_decode_kernel<true, kDecSmallPlanes, true, true><<<waves, 64, 0, s>>>(a);
+            } else {
+                if (cmp) bpc_decode_kernel<true, kDecSmallPlanes, true, false, true><<<waves, 64, 0, s>>>(a);
+                else bpc_decode_kernel<true, kDecSmallPlanes, true><<<waves, 64, 0, s>>>(a);
+            }
         } else {
+            if (c16) return fail(PICSONG_ERR_ARG, "the 16-bit coefficient form decodes from the stream itself");
             if (cmp) bpc_decode_kernel<true, kDecSmallPlanes, false, false, true><<<waves, 64, 0, s>>>(a);
             else bpc_decode_kernel<true, kDecSmallPlanes><<<waves, 64, 0, s>>>(a);
         }

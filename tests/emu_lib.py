@@ -267,15 +267,16 @@ def bpc_decode_stream(stream, AW, AH, wl, lut):
     return coef
 
 
-def bpc_decode_stream_k(stream, AW, AH, wl, lut, k):
-    """-k > 0 straight from the packed stream (the frame paths' decoder of a complexity-scalable context)."""
+def bpc_decode_stream_k(stream, AW, AH, wl, lut, k, c16=False):
+    """-k > 0 straight from the packed stream (the frame paths' decoder of a complexity-scalable context); c16: into an
+    int16 Mallat array (the C16 instantiations)."""
     stream = np.ascontiguousarray(stream, np.uint16)
-    coef = np.empty((AH, AW), np.int32)
+    coef = np.empty((AH, AW), np.int16 if c16 else np.int32)
     flag = np.zeros(1, np.int32)
     tab = np.ascontiguousarray(lut.table, np.int32)
     geo = _geo(lut)
     bad = lib().emu_bpc_decode_stream_k(_p(stream), int(stream.size), AW, AH, wl, _p(tab), _p(geo), _p(coef), _p(flag),
-                                        C.c_float(k), int(getattr(lut, "n_tables", 1)))
+                                        C.c_float(k), int(getattr(lut, "n_tables", 1)), int(c16))
     assert int(bad) == 0
     return coef
 

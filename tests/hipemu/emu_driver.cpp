@@ -403,7 +403,7 @@ int emu_bpc_decode_stream(const uint16_t *stream, unsigned stream_shorts, int aw
 
 // -k > 0 from the packed stream (bpc_decode_kernel<true, NP, true>: both plane-count classes over the grid)
 int emu_bpc_decode_stream_k(const uint16_t *stream, unsigned stream_shorts, int aw, int ah, int wl, const int32_t *lut,
-                            const int *geo, int32_t *coeffs, int *flag, float k, int n_tables)
+                            const int *geo, int32_t *coeffs, int *flag, float k, int n_tables, int c16)
 {
     const int ncb = (aw / 64) * (ah / 64);
     std::vector<int32_t> sizes(ncb), offsets(ncb);
@@ -417,8 +417,14 @@ int emu_bpc_decode_stream_k(const uint16_t *stream, unsigned stream_shorts, int 
     const dim3 grid((unsigned)((a.nCB + 1) / 2));
     std::vector<uint32_t> plane_scratch((size_t)grid.x * kEncScratchDwordsPerWave, 0xDEADBEEFu);
     a.plane_scratch = plane_scratch.data();
-    if (emu_bulk_compact(aw, ah, wl, geo)) emu::launch(grid, dim3(64), [&] { bpc_decode_kernel<true, kDecSmallPlanes, true, false, true>(a); });
-    else emu::launch(grid, dim3(64), [&] { bpc_decode_kernel<true, kDecSmallPlanes, true>(a); });
+    // c16: `coeffs` is an int16 Mallat array (the C16 instantiations)
+    if (c16) {
+        if (emu_bulk_compact(aw, ah, wl, geo)) emu::launch(grid, dim3(64), [&] { bpc_decode_kernel<true, kDecSmallPlanes, true, true, true>(a); });
+        else emu::launch(grid, dim3(64), [&] { bpc_decode_kernel<true, kDecSmallPlanes, true, true>(a); });
+    } else {
+        if (emu_bulk_compact(aw, ah, wl, geo)) emu::launch(grid, dim3(64), [&] { bpc_decode_kernel<true, kDecSmallPlanes, true, false, true>(a); });
+        else emu::launch(grid, dim3(64), [&] { bpc_decode_kernel<true, kDecSmallPlanes, true>(a); });
+    }
     return bad;
 }
 

@@ -819,22 +819,27 @@ def test_complexity_scalable_instantiations_agree(oracle, pa, torch, monkeypatch
     """-k > 0: the encoder's two instantiations (the hint picks: compact table copies and six waves a SIMD for frames in
     flight, whole tables and more registers for a lone frame), the whole-table forms of both coders
     (PICSONG_BULK_FULLTAB=1; the 512 x 512 wl 5 geometry has a codeblock that spans 13 table groups and takes them by
-    itself) -- one codestream, the oracle's, and its decode the frame."""
+    itself), the decoder's int16 and 32-bit coefficient forms -- one codestream, the oracle's, and its decode the frame."""
     img = oracle.gen_frame(W, H, 33)
     lut = oracle.lut_for_k(False, wl)
     ref = oracle.encode_frame(img, wl, False, 1.0, lut, 0, 0, k=k)
     frame = _dev(torch, oracle.pad_frame(img))
-    for hint, fulltab in ((False, False), (True, False), (True, True)):
+    for hint, fulltab, dec32 in ((False, False, False), (True, False, False), (True, True, False), (False, False, True),
+                                 (False, True, True)):
         if fulltab:
             monkeypatch.setenv("PICSONG_BULK_FULLTAB", "1")
+        if dec32:                      # the decoder's 32-bit coefficient form (the default is int16 where the geometry allows)
+            monkeypatch.setenv("PICSONG_DEC_C16", "0")
         c = pa.Codec(W, H, wl=wl, lut_folder=_lutdir(oracle, False), k=k, pipelined=hint)
         s = c.encode_frame(frame, 0)
-        assert np.array_equal(s.cpu().numpy().view(np.uint16), ref), (hint, fulltab)
-        assert np.array_equal(c.decode_frame(s.clone()).cpu().numpy()[:H, :W], img), (hint, fulltab)
+        assert np.array_equal(s.cpu().numpy().view(np.uint16), ref), (hint, fulltab, dec32)
+        assert np.array_equal(c.decode_frame(s.clone()).cpu().numpy()[:H, :W], img), (hint, fulltab, dec32)
         assert c.range_flag() == 0
         c.close()
         if fulltab:
             monkeypatch.delenv("PICSONG_BULK_FULLTAB")
+        if dec32:
+            monkeypatch.delenv("PICSONG_DEC_C16")
 
 
 def test_random_geometries_through_the_frame_paths(oracle, pa, torch):

@@ -406,6 +406,9 @@ def test_bulk_mode_kernels_bit_exact(oracle, E, monkeypatch, W, H, wl, k, fullta
     # whose word 0 travels in the MSB's place, included when the data makes one)
     stream = oracle.bitstream_pack(st_o, sz_o, None)
     assert np.array_equal(E.bpc_decode_stream_k(stream, W, H, wl, lut, k), coef)
+    # ... and into an int16 Mallat array (the decode frame paths' 16-bit form: the bulk scan reads a row's two
+    # coefficients back as one dword)
+    assert np.array_equal(E.bpc_decode_stream_k(stream, W, H, wl, lut, k, c16=True).astype(np.int32), coef)
 
 
 def test_bulk_mode_stream_decode_with_a_raw_codeblock(oracle, E):
@@ -417,7 +420,9 @@ def test_bulk_mode_stream_decode_with_a_raw_codeblock(oracle, E):
     st_o, sz_o = oracle.bpc_encode(coef, wl, lut, k=k)
     assert (sz_o == 4096).any() and (sz_o < 4096).any()
     stream = oracle.bitstream_pack(st_o, sz_o, None)
-    assert np.array_equal(E.bpc_decode_stream_k(stream, W, H, wl, lut, k), oracle.bpc_decode(st_o, sz_o, W, H, wl, lut, k=k))
+    ref = oracle.bpc_decode(st_o, sz_o, W, H, wl, lut, k=k)
+    assert np.array_equal(E.bpc_decode_stream_k(stream, W, H, wl, lut, k), ref)
+    assert np.array_equal(E.bpc_decode_stream_k(stream, W, H, wl, lut, k, c16=True), ref.astype(np.int16))
 
 
 def test_bulk_mode_kernels_float_input_and_odd_block_count(oracle, E):
