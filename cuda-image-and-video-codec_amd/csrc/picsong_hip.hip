@@ -421,8 +421,9 @@ int picsong_ctx_create(const picsong_params *p, int device, picsong_ctx **out)
     c->c16 = p->bit_depth == 8 && dwt_c16_geometry_ok(c->aw, c->ah, p->wl) &&
              coef16_ok(p->lossy != 0, p->wl, p->qs, p->is_rgb ? 255 : 128);
     c->bulk_compact[0] = c->bulk_compact[1] = c->bulk_compact[2] = -1;
-    c->c16_dec = p->cp != 3 && p->bit_depth == 8 && !p->is_rgb &&
-                 dec_c16_ok(p->lossy != 0, p->wl, p->qs, 128, c->aw, c->ah, c->fast_div);
+    // (an RGB context: picsong_decode_rgb_frame's three components; the plane-by-plane calls keep the 32-bit arrays)
+    c->c16_dec = p->cp != 3 && p->bit_depth == 8 &&
+                 dec_c16_ok(p->lossy != 0, p->wl, p->qs, p->is_rgb ? 255 : 128, c->aw, c->ah, c->fast_div);
     hipError_t e = hipMalloc(&c->d_offsets, sizeof(int32_t) * (size_t)c->ncb);
     if (e == hipSuccess) e = hipMalloc(&c->d_total, sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc(&c->d_flag, sizeof(int));
@@ -658,12 +659,15 @@ int picsong_dwt_forward_tail(picsong_ctx *c, void *d_out, void *stream)
 // work buffer at d_out + z * (P + extra) elements, its pixels at d_pixels + z * pix_stride bytes.
 // want_c16: the decoder may write 16-bit coefficients (picsong_ctx::c16_dec) -- the plan says whether this call's
 // pointers allow it (plan_inv_is_c16), BEFORE the decoder is launched: inverse_plan, then the decoder, then run_inverse.
+// (the grey frame paths take the 16-bit form only with the fused pixel store; planes_out: an RGB frame's components,
+// whose finest level writes T samples for the inverse colour transform, take it too)
 static std::vector<InvLaunch> inverse_plan(picsong_ctx *c, const int32_t *d_in, void *d_out, uint8_t *d_pixels, bool *fused,
-                                           unsigned frames, size_t pix_stride, bool want_c16)
+                                           unsigned frames, size_t pix_stride, bool want_c16, bool planes_out = false)
 {
     if (fused) *fused = false;
     const bool px = d_pixels && (((uintptr_t)d_pixels) & 3u) == 0 && (pix_stride & 3u) == 0;
-    std::vector<InvLaunch> plan = plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs, c->fast_div, want_c16 && px);
+    std::vector<InvLaunch> plan = plan_dwt_inverse(d_in, d_out, c->aw, c->ah, c->p.wl, c->p.qs, c->fast_div,
+                                                   want_c16 && (px || planes_out));
     if (px && !plan.empty() && plan.back().vec) {
         plan.back().a.dst_u8 = d_pixels;
         plan.back().a.off = 1 << (c->p.bit_depth - 1);
@@ -1554,18 +1558,23 @@ int picsong_decode_rgb_frame(picsong_ctx *c, const uint16_t *d_streams, size_t s
         unpack_kernel<<<dim3((unsigned)c->ncb, 3u), 256, 0, s>>>(d_streams, c->b_sizes, c->b_offsets, c->ncb, c->b_staging, stream_stride, c->P);
         HIP_TRY(hipGetLastError());
     }
+    // (16-bit coefficients between the decoder and the synthesis where the context's magnitudes are bounded: the
+    // plan says whether this call's arrays take the vector kernels)
+    const std::vector<InvLaunch> plan = inverse_plan(c, c->b_coef_i, c->b_coef, nullptr, nullptr, 3u, 0, c->c16_dec && direct, true);
+    const bool c16 = plan_inv_is_c16(plan);
     a.coeffs_out = c->b_coef_i; a.staging = c->b_staging; a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch;
-    a.coef_z = (unsigned long long)c->P * 4ull;
+    a.coef_z = (unsigned long long)c->P * (c16 ? 2ull : 4ull);
     const unsigned wgs3 = (unsigned)(3 * a.waves_per_frame / kBpcDecWgWaves);
     if (direct) {
         a.cw16 = d_streams; a.cw16_offsets = c->b_offsets; a.cw16_total = c->b_total; a.cw16_stride = stream_stride;
         a.cw16_max = (uint32_t)picsong_max_stream_shorts(c->aw, c->ah);
-        bpc_decode_kernel<false, kDecSmallPlanes, true><<<wgs3, 64 * kBpcDecWgWaves, 0, s>>>(a);
+        if (c16) bpc_decode_kernel<false, kDecSmallPlanes, true, true><<<wgs3, 64 * kBpcDecWgWaves, 0, s>>>(a);
+        else bpc_decode_kernel<false, kDecSmallPlanes, true><<<wgs3, 64 * kBpcDecWgWaves, 0, s>>>(a);
     } else {
         bpc_decode_kernel<false, kDecSmallPlanes><<<wgs3, 64 * kBpcDecWgWaves, 0, s>>>(a);
     }
     HIP_TRY(hipGetLastError());
-    if ((rc = dwt_inverse_impl(c, c->b_coef_i, c->b_coef, nullptr, nullptr, s, 3u, 0))) return rc;
+    if ((rc = run_inverse(c, plan, s, 3u))) return rc;
     const char *img = (const char *)c->b_coef + c->extra * 4;
     const size_t z = (c->P + c->extra) * 4;
     return picsong_rgb_inverse(c, img, img + z, img + 2 * z, d_r, d_g, d_b, stream);
