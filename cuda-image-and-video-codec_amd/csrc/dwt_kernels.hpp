@@ -113,13 +113,14 @@ __device__ __forceinline__ int c16_lo(uint32_t w) { return (int)(int16_t)(w & 0x
 __device__ __forceinline__ int c16_hi(uint32_t w) { return (int)w >> 16; }
 
 // frame blockIdx.z of a batched launch
-__device__ __forceinline__ void dwt_fwd_select_frame(DwtFwdArgs &a)
+__device__ __forceinline__ void dwt_fwd_select_frame(DwtFwdArgs &a, unsigned bz)
 {
-    const unsigned long long z = blockIdx.z;
+    const unsigned long long z = bz;
     a.src = (const char *)a.src + z * a.src_z;
     a.ll = (char *)a.ll + z * a.dst_z;
     a.mallat = (char *)a.mallat + z * a.dst_z;
 }
+__device__ __forceinline__ void dwt_fwd_select_frame(DwtFwdArgs &a) { dwt_fwd_select_frame(a, blockIdx.z); }
 
 struct DwtInvArgs {
     const int32_t *mallat;  // coded coefficients, int32, row stride AW
@@ -824,7 +825,7 @@ __device__ __forceinline__ void unpack_rct(uint32_t wr, uint32_t wg, uint32_t wb
 }
 
 template <typename T, bool LOSSY, int NB, bool EDGE, bool C16, bool RGB = false>
-__device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdArgs &a1, int strip, int lane)
+__device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdArgs &a1, int strip, int lane, unsigned by, unsigned bz)
 {
     static_assert(!RGB || (!LOSSY && std::is_same<T, int>::value), "the colour transform in the head's load stage: RCT only");
     constexpr uint32_t kCB = C16 ? 2u : 4u;                  // bytes of a coded coefficient
@@ -833,7 +834,7 @@ __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdA
     constexpr int kLag1 = LOSSY ? 5 : 2;                     // ... and the level-1 pair n0 + i - kLag1
     constexpr int kHist = LOSSY ? 6 : 2;                     // LL rows kept for level 1's bottom mirror
     const int c0 = strip * kF2Useful - 4 * kF2Edge + 4 * lane;
-    const int n0 = blockIdx.y * NB;
+    const int n0 = (int)by * NB;
     const bool wr = lane >= kF2Edge && lane <= 63 - kF2Edge && c0 >= 0 && c0 < a.W;
     const bool le = EDGE && c0 == 0, re = EDGE && c0 + 4 == a.W;
     const int cl = c0 < 0 ? 0 : (c0 > a.W - 4 ? a.W - 4 : c0);
@@ -868,7 +869,7 @@ __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdA
     RawRow<true> r0, raw[kIters][4];
     uint32_t g0 = 0u, b0 = 0u, rawG[RGB ? kIters : 1][4], rawB[RGB ? kIters : 1][4];
     const RowBuf ing = rowbuf(RGB ? a.src_g : a.src), inb = rowbuf(RGB ? a.src_b : a.src);
-    const RctCoef rct = rct_coef(RGB ? (int)blockIdx.z : 0);
+    const RctCoef rct = rct_coef(RGB ? (int)bz : 0);
     PS_TRACE(0);
     __builtin_amdgcn_s_setprio(3);
     r0.w = rb_load32(in, vin, (uint32_t)reflect(y0, a.H) * (uint32_t)a.src_stride);
@@ -975,17 +976,32 @@ template <typename T, bool LOSSY, bool U8IN, int NB, bool C16 = false, bool RGB 
 __global__ __launch_bounds__(256, RGB ? 4 : (LOSSY ? PICSONG_DWT_F2_WAVES_LOSSY : PICSONG_DWT_F2_WAVES)) void dwt_fwd2_kernel(DwtFwd2Args a2)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int strip = blockIdx.x * 4 + wave;
-    dwt_fwd_select_frame(a2.l0);
-    dwt_fwd_select_frame(a2.l1);
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if constexpr (RGB) {
+        // The three components of a tile read the same rows of the same three planes.  Workgroups go to the eight XCDs
+        // round robin by their linear index, each XCD with an L2 of its own: in launch order (component = blockIdx.z,
+        // the slowest) a tile's three workgroups run a third of the launch apart, wherever their indices fall, and
+        // every plane comes from the memory side three times.  Re-indexed so that they are 8 apart -- same XCD, in
+        // flight together -- the second and third read hit that XCD's L2 (8K: head 118.6 -> see profiles/NOTES.md).
+        const unsigned tiles = gridDim.x * gridDim.y;
+        if ((tiles & 7u) == 0u && gridDim.z == 3u) {
+            const unsigned L = bx + gridDim.x * (by + gridDim.y * bz);
+            const unsigned tile = (L / 24u) * 8u + (L & 7u);
+            bz = (L >> 3) % 3u;
+            bx = tile % gridDim.x; by = tile / gridDim.x;
+        }
+    }
+    const int strip = (int)bx * 4 + wave;
+    dwt_fwd_select_frame(a2.l0, bz);
+    dwt_fwd_select_frame(a2.l1, bz);
     // the wave's 256 columns start at strip * kF2Useful - 4 * kF2Edge: does it hold column 0 or W - 4?
     const int first = strip * kF2Useful - 4 * kF2Edge;
     // (only the 9/7 kernel, which is bound by vector instructions, gets the second instantiation)
     static_assert(U8IN, "the fused head ingests u8 frames");
     if (strip * kF2Useful >= a2.l0.W) return;               // whole wave idle (no cross-lane use)
     if (!LOSSY || first <= 0 || first + kStripCols >= a2.l0.W)
-        dwt_fwd2_band<T, LOSSY, NB, true, C16, RGB>(a2.l0, a2.l1, strip, lane);
-    else dwt_fwd2_band<T, LOSSY, NB, LOSSY ? false : true, C16, RGB>(a2.l0, a2.l1, strip, lane);
+        dwt_fwd2_band<T, LOSSY, NB, true, C16, RGB>(a2.l0, a2.l1, strip, lane, by, bz);
+    else dwt_fwd2_band<T, LOSSY, NB, LOSSY ? false : true, C16, RGB>(a2.l0, a2.l1, strip, lane, by, bz);
 }
 
 // ---- the small levels of the forward transform ---------------------------------------------------------
