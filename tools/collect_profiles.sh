@@ -55,5 +55,5 @@ echo "decode done"
 python3 tools/modes_time.py > $out/modes_time.txt 2>&1 || true
 python3 tools/lone_frame_time.py > $out/lone_frame.txt 2>&1 || true
 python3 tools/rgb_probe.py > $out/rgb_probe.txt 2>&1 || true
-python3 tools/fuzz_parity.py 40 7 > $out/fuzz_parity.txt 2>&1 || true
+python3 tools/fuzz_parity.py 120 4 > $out/fuzz_parity.txt 2>&1 || true
 echo "modes done"
