@@ -793,6 +793,10 @@ __device__ __forceinline__ void ll_row_or_mirror(T (&row)[2], T (&hist)[NH][2], 
 }
 
 template <bool LOSSY, int NB> constexpr int f2_iters() { return NB + (LOSSY ? 5 : 2); }
+#ifndef PICSONG_DWT_F2_RGB_AHEAD
+#define PICSONG_DWT_F2_RGB_AHEAD 3
+#endif
+constexpr int kF2RgbAhead = PICSONG_DWT_F2_RGB_AHEAD;        // RGB head: iterations whose raw rows are in flight
 
 // The same band, lean (round 2): the whole band unrolled, every row address a scalar offset into a buffer
 // resource (RowBuf), store conditions resolved at compile time (bands are whole: plan_dwt_fwd2 takes the fused
@@ -823,11 +827,34 @@ __device__ __forceinline__ void unpack_rct(uint32_t wr, uint32_t wg, uint32_t wb
         v[i] = (r * k.cr + g * k.cg + b * k.cb) >> k.sh;
     }
 }
+// ... and of the irreversible one (RGBTransformLossy Engines/CodingEngine.cu:384-449, level shift fused): row `comp` of
+// the matrix rgb_forward_kernel<float> applies, in its operation order -- m2 b + (m1 g + (m0 r)), each step one fmaf --
+// so the component planes the separate launch would have written never exist.  (The coefficients sit in vector
+// registers: a multiply with a scalar operand issues at half rate.)
+struct IctCoef { float m0, m1, m2; };
+__device__ __forceinline__ IctCoef ict_coef(int comp)
+{
+    IctCoef k;
+    k.m0 = comp == 0 ? 0.299f : (comp == 1 ? -0.168736f : 0.5f);
+    k.m1 = comp == 0 ? 0.587f : (comp == 1 ? -0.331264f : -0.418688f);
+    k.m2 = comp == 0 ? 0.114f : (comp == 1 ? 0.5f : -0.081312f);
+    return k;
+}
+__device__ __forceinline__ void unpack_ict(uint32_t wr, uint32_t wg, uint32_t wb, const IctCoef &k, float v[4])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        // (small integers: (float)(x - 128) and (float)x - 128.0f are the same value)
+        const float r = (float)((wr >> (8 * i)) & 0xFFu) - 128.0f, g = (float)((wg >> (8 * i)) & 0xFFu) - 128.0f,
+                    b = (float)((wb >> (8 * i)) & 0xFFu) - 128.0f;
+        v[i] = fmaf(k.m2, b, fmaf(k.m1, g, k.m0 * r));
+    }
+}
 
 template <typename T, bool LOSSY, int NB, bool EDGE, bool C16, bool RGB = false>
 __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdArgs &a1, int strip, int lane, unsigned by, unsigned bz)
 {
-    static_assert(!RGB || (!LOSSY && std::is_same<T, int>::value), "the colour transform in the head's load stage: RCT only");
+    static_assert(!RGB || (LOSSY ? std::is_same<T, float>::value : std::is_same<T, int>::value), "the colour transform in the head's load stage: RCT on integers, ICT on floats");
     constexpr uint32_t kCB = C16 ? 2u : 4u;                  // bytes of a coded coefficient
     constexpr int kIters = f2_iters<LOSSY, NB>();
     constexpr int kRel0 = LOSSY ? 7 : 3;                     // iteration i delivers the level-0 pairs 2 n0 + 2 i - kRel0, + 1
@@ -864,12 +891,29 @@ __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdA
 #pragma unroll
     for (int k = 0; k < 2; k++) { xe1[k] = st1[0][k] = st1[1][k] = st1[2][k] = (T)0; }
 
-    // all of the band's input rows go out before the first store (one in-order memory pipe), at raised priority
-    // (RGB: the rows of all three planes -- three times the registers, which is why that form runs 16-row bands)
-    RawRow<true> r0, raw[kIters][4];
-    uint32_t g0 = 0u, b0 = 0u, rawG[RGB ? kIters : 1][4], rawB[RGB ? kIters : 1][4];
+    // all of the band's input rows go out before the first store (one in-order memory pipe), at raised priority.
+    // RGB: the rows of all three planes -- three times the registers -- so only kF2RgbAhead iterations' rows are in
+    // flight, the rows of iteration i + kF2RgbAhead going out in iteration i BEFORE its stores (the synthesis kernels'
+    // scheme): 36 raw registers instead of 3 x 4 x kIters, which is what lets that form run whole 32-row bands too.
+    constexpr int kRing = RGB ? (kF2RgbAhead < kIters ? kF2RgbAhead : kIters) : kIters;
+    RawRow<true> r0, raw[kRing][4];
+    uint32_t g0 = 0u, b0 = 0u, rawG[RGB ? kRing : 1][4], rawB[RGB ? kRing : 1][4];
     const RowBuf ing = rowbuf(RGB ? a.src_g : a.src), inb = rowbuf(RGB ? a.src_b : a.src);
     const RctCoef rct = rct_coef(RGB ? (int)bz : 0);
+    IctCoef ict = ict_coef(RGB ? (int)bz : 0);
+    ict.m0 = in_vgpr(ict.m0); ict.m1 = in_vgpr(ict.m1); ict.m2 = in_vgpr(ict.m2);
+    auto load_iter = [&](int p) {                            // (p: a compile-time value after unrolling)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t ro = (uint32_t)reflect(y0 + 1 + 4 * p + q, a.H) * (uint32_t)a.src_stride;
+            raw[p % kRing][q].w = rb_load32(in, vin, ro);
+            if constexpr (RGB) { rawG[p % kRing][q] = rb_load32(ing, vin, ro); rawB[p % kRing][q] = rb_load32(inb, vin, ro); }
+        }
+    };
+    auto unpack_rgb = [&](uint32_t wr_, uint32_t wg_, uint32_t wb_, T v[4]) {
+        if constexpr (LOSSY) unpack_ict(wr_, wg_, wb_, ict, v);
+        else unpack_rct(wr_, wg_, wb_, rct, v);
+    };
     PS_TRACE(0);
     __builtin_amdgcn_s_setprio(3);
     r0.w = rb_load32(in, vin, (uint32_t)reflect(y0, a.H) * (uint32_t)a.src_stride);
@@ -878,16 +922,10 @@ __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdA
         b0 = rb_load32(inb, vin, (uint32_t)reflect(y0, a.H) * (uint32_t)a.src_stride);
     }
 #pragma unroll
-    for (int p = 0; p < kIters; p++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t ro = (uint32_t)reflect(y0 + 1 + 4 * p + q, a.H) * (uint32_t)a.src_stride;
-            raw[p][q].w = rb_load32(in, vin, ro);
-            if constexpr (RGB) { rawG[p][q] = rb_load32(ing, vin, ro); rawB[p][q] = rb_load32(inb, vin, ro); }
-        }
+    for (int p = 0; p < kRing; p++) load_iter(p);
     __builtin_amdgcn_s_setprio(0);
     PS_TRACE(1);
-    if constexpr (RGB) unpack_rct(r0.w, g0, b0, rct, xe);
+    if constexpr (RGB) unpack_rgb(r0.w, g0, b0, xe);
     else unpack_row<T, true>(r0, xe);
     PS_TRACE(2);
 
@@ -897,9 +935,10 @@ __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdA
         T x[4][4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            if constexpr (RGB) unpack_rct(raw[i][q].w, rawG[i][q], rawB[i][q], rct, x[q]);
-            else unpack_row<T, true>(raw[i][q], x[q]);
+            if constexpr (RGB) unpack_rgb(raw[i % kRing][q].w, rawG[i % kRing][q], rawB[i % kRing][q], x[q]);
+            else unpack_row<T, true>(raw[i % kRing][q], x[q]);
         }
+        if (i + kRing < kIters) load_iter(i + kRing);        // (RGB only: the ring's next rows, ahead of this iteration's stores)
         const int rel = 2 * i - kRel0;                       // (compile-time after unrolling)
         T LA[4], HA[4], LB[4], HB[4];
         vstep<T, LOSSY, 4>(xe, st0, x[0], x[1], LA, HA);
@@ -970,10 +1009,16 @@ __device__ __forceinline__ void dwt_fwd2_band(const DwtFwdArgs &a, const DwtFwdA
 #endif
 }
 
-// RGB: the RCT in the load stage (blockIdx.z = component; four waves per SIMD: a band holds three planes' rows)
-constexpr int kF2PairsRgb = 4;
+// RGB: the colour transform in the load stage (blockIdx.z = component)
+#ifndef PICSONG_DWT_F2_RGB_PAIRS
+#define PICSONG_DWT_F2_RGB_PAIRS 8
+#endif
+#ifndef PICSONG_DWT_F2_RGB_WAVES
+#define PICSONG_DWT_F2_RGB_WAVES 4
+#endif
+constexpr int kF2PairsRgb = PICSONG_DWT_F2_RGB_PAIRS;
 template <typename T, bool LOSSY, bool U8IN, int NB, bool C16 = false, bool RGB = false>
-__global__ __launch_bounds__(256, RGB ? 4 : (LOSSY ? PICSONG_DWT_F2_WAVES_LOSSY : PICSONG_DWT_F2_WAVES)) void dwt_fwd2_kernel(DwtFwd2Args a2)
+__global__ __launch_bounds__(256, RGB ? PICSONG_DWT_F2_RGB_WAVES : (LOSSY ? PICSONG_DWT_F2_WAVES_LOSSY : PICSONG_DWT_F2_WAVES)) void dwt_fwd2_kernel(DwtFwd2Args a2)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;

@@ -1479,17 +1479,19 @@ int picsong_encode_rgb_frame(picsong_ctx *c, const uint8_t *d_r, const uint8_t *
     // (the fused head's buffer loads want all three planes 16-byte aligned like a grey frame's; others take the
     // separate colour transform below)
     const bool planes_aligned = ((((uintptr_t)d_r) | ((uintptr_t)d_g) | ((uintptr_t)d_b)) & 15u) == 0;
-    if (!c->p.lossy && c->c16 && planes_aligned && !getenv("PICSONG_RGB_NOFUSE")) {
+    if (c->c16 && planes_aligned && !getenv("PICSONG_RGB_NOFUSE")) {
         std::vector<FwdLaunch> plan = plan_dwt_forward(d_r, true, c->b_coef, c->aw, c->ah, c->p.wl, c->p.qs, true);
         Fwd2Launch f2;
-        if (plan_is_c16(plan) && plan_dwt_fwd2(plan, f2, true, false, kF2PairsRgb)) {
+        if (plan_is_c16(plan) && plan_dwt_fwd2(plan, f2, true, c->p.lossy != 0, kF2PairsRgb)) {
             for (size_t l = 0; l < plan.size(); l++) {
                 plan[l].a.src_z = l == 0 ? 0ull : (unsigned long long)coef_z;      // level 0: every component reads the three planes
                 plan[l].a.dst_z = (unsigned long long)coef_z;
             }
             plan[0].a.src_g = d_g; plan[0].a.src_b = d_b;
             f2.a.l0 = plan[0].a; f2.a.l1 = plan[1].a;
-            dwt_fwd2_kernel<int, false, true, kF2PairsRgb, true, true><<<dim3(f2.gx, f2.gy, 3u), 256, 0, s>>>(f2.a);
+            // (RCT on the integer head, ICT on the 9/7 one: the component planes are never written)
+            if (c->p.lossy) dwt_fwd2_kernel<float, true, true, kF2PairsRgb, true, true><<<dim3(f2.gx, f2.gy, 3u), 256, 0, s>>>(f2.a);
+            else dwt_fwd2_kernel<int, false, true, kF2PairsRgb, true, true><<<dim3(f2.gx, f2.gy, 3u), 256, 0, s>>>(f2.a);
             HIP_TRY(hipGetLastError());
             if ((rc = launch_fwd_levels(c, plan, 2, s, 3u))) return rc;
             a.c16 = 1;

@@ -88,14 +88,14 @@ def dwt_forward(x, wl, lossy, qs=1.0, extra=0):
     return out
 
 
-def dwt_forward_rgb(r, g, b, wl, extra):
-    """The three components' int16 Mallat arrays of an RGB frame, RCT in the fused head's load stage (lossless);
-    None when that form does not apply to the geometry."""
+def dwt_forward_rgb(r, g, b, wl, extra, lossy=False, qs=1.0):
+    """The three components' int16 Mallat arrays of an RGB frame, the colour transform (RCT; lossy: ICT) in the fused
+    head's load stage; None when that form does not apply to the geometry."""
     AH, AW = r.shape
     r, g, b = (aligned_copy(np.ascontiguousarray(x, np.uint8)) for x in (r, g, b))
     stride = (AW * AH + extra) * 4
     out = aligned_zeros(3 * (AW * AH + extra), np.int32)
-    if not lib().emu_dwt_forward_rgb(_p(r), _p(g), _p(b), _p(out), C.c_size_t(stride), AW, AH, wl):
+    if not lib().emu_dwt_forward_rgb(_p(r), _p(g), _p(b), _p(out), C.c_size_t(stride), AW, AH, wl, int(lossy), C.c_float(qs)):
         return None
     return [mallat16(out[k * (AW * AH + extra):(k + 1) * (AW * AH + extra)], AW, AH).copy() for k in range(3)]
 

@@ -162,14 +162,15 @@ int emu_dwt_forward(const void *in, int u8in, void *out, int aw, int ah, int wl,
     return fused01 ? 1 : 0;
 }
 
-// mirrors picsong_encode_rgb_frame's lossless transform: the RCT in the fused head's load stage, one launch for the
+// mirrors picsong_encode_rgb_frame's transform: the colour transform (RCT / ICT) in the fused head's load stage, one launch for the
 // three components (out: three coefficient buffers of `stride` bytes, int16 Mallat arrays at their starts); returns 1
 // when the fused form applies
-int emu_dwt_forward_rgb(const uint8_t *r, const uint8_t *g, const uint8_t *b, void *out, size_t stride, int aw, int ah, int wl)
+int emu_dwt_forward_rgb(const uint8_t *r, const uint8_t *g, const uint8_t *b, void *out, size_t stride, int aw, int ah, int wl,
+                        int lossy, float qs)
 {
-    std::vector<FwdLaunch> plan = plan_dwt_forward(r, true, out, aw, ah, wl, 1.0f, true);
+    std::vector<FwdLaunch> plan = plan_dwt_forward(r, true, out, aw, ah, wl, qs, true);
     Fwd2Launch f2;
-    if (!plan_is_c16(plan) || !plan_dwt_fwd2(plan, f2, true, false, kF2PairsRgb)) return 0;
+    if (!plan_is_c16(plan) || !plan_dwt_fwd2(plan, f2, true, lossy != 0, kF2PairsRgb)) return 0;
     for (size_t l = 0; l < plan.size(); l++) {
         plan[l].a.src_z = l == 0 ? 0ull : (unsigned long long)stride;
         plan[l].a.dst_z = (unsigned long long)stride;
@@ -177,16 +178,26 @@ int emu_dwt_forward_rgb(const uint8_t *r, const uint8_t *g, const uint8_t *b, vo
     plan[0].a.src_g = g; plan[0].a.src_b = b;
     f2.a.l0 = plan[0].a; f2.a.l1 = plan[1].a;
     DwtFwd2Args a2 = f2.a;
-    emu::launch(dim3(f2.gx, f2.gy, 3), dim3(256), [&] { dwt_fwd2_kernel<int, false, true, kF2PairsRgb, true, true>(a2); });
+    if (lossy) emu::launch(dim3(f2.gx, f2.gy, 3), dim3(256), [&] { dwt_fwd2_kernel<float, true, true, kF2PairsRgb, true, true>(a2); });
+    else emu::launch(dim3(f2.gx, f2.gy, 3), dim3(256), [&] { dwt_fwd2_kernel<int, false, true, kF2PairsRgb, true, true>(a2); });
     for (size_t l = 2; l < plan.size(); l++) {
         const FwdLaunch &f = plan[l];
         DwtFwdArgs a = f.a;
         const dim3 grid(f.gx, f.gy, 3);
-        switch (f.band) {
-        case 32: emu::launch(grid, dim3(256), [&] { dwt_fwd_kernel<int, false, false, 32, true>(a); }); break;
-        case 16: emu::launch(grid, dim3(256), [&] { dwt_fwd_kernel<int, false, false, 16, true>(a); }); break;
-        case 8: emu::launch(grid, dim3(256), [&] { dwt_fwd_kernel<int, false, false, 8, true>(a); }); break;
-        default: emu::launch(grid, dim3(256), [&] { dwt_fwd_kernel<int, false, false, 4, true>(a); }); break;
+        if (lossy) {
+            switch (f.band) {
+            case 32: emu::launch(grid, dim3(256), [&] { dwt_fwd_kernel<float, true, false, 32, true>(a); }); break;
+            case 16: emu::launch(grid, dim3(256), [&] { dwt_fwd_kernel<float, true, false, 16, true>(a); }); break;
+            case 8: emu::launch(grid, dim3(256), [&] { dwt_fwd_kernel<float, true, false, 8, true>(a); }); break;
+            default: emu::launch(grid, dim3(256), [&] { dwt_fwd_kernel<float, true, false, 4, true>(a); }); break;
+            }
+        } else {
+            switch (f.band) {
+            case 32: emu::launch(grid, dim3(256), [&] { dwt_fwd_kernel<int, false, false, 32, true>(a); }); break;
+            case 16: emu::launch(grid, dim3(256), [&] { dwt_fwd_kernel<int, false, false, 16, true>(a); }); break;
+            case 8: emu::launch(grid, dim3(256), [&] { dwt_fwd_kernel<int, false, false, 8, true>(a); }); break;
+            default: emu::launch(grid, dim3(256), [&] { dwt_fwd_kernel<int, false, false, 4, true>(a); }); break;
+            }
         }
     }
     return 1;

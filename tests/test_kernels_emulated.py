@@ -324,17 +324,21 @@ def test_frame_path_with_16_bit_coefficients(oracle, E, monkeypatch, W, H, wl, l
     assert fused and np.array_equal(pix, ref_pix)
 
 
-@pytest.mark.parametrize("W,H,wl", [(320, 192, 3), (256, 128, 2), (512, 320, 5)])
-def test_rgb_colour_transform_in_the_fused_heads_load_stage(oracle, E, W, H, wl):
-    """dwt_fwd2_kernel<..., RGB>: the head reads the R, G, B planes and delivers component blockIdx.z of the RCT --
-    the three components' coefficients equal the oracle's colour transform + 5/3 transform of each component."""
+@pytest.mark.parametrize("W,H,wl,lossy,qs", [(320, 192, 3, False, 1.0), (256, 128, 2, False, 1.0), (512, 320, 5, False, 1.0),
+                                             (320, 192, 3, True, 0.5), (512, 320, 5, True, 1.0), (256, 64, 2, True, 0.3)])
+def test_rgb_colour_transform_in_the_fused_heads_load_stage(oracle, E, W, H, wl, lossy, qs):
+    """dwt_fwd2_kernel<..., RGB>: the head reads the R, G, B planes and delivers component blockIdx.z of the colour
+    transform (RCT on the 5/3 head, ICT on the 9/7 one; the rows of three iterations in flight, 32-row bands, the
+    three components of a tile re-indexed onto one XCD) -- the three components' coefficients equal the oracle's colour
+    transform + transform (+ quantisation, truncated as the coder reads them) of each component."""
     planes = [oracle.pad_frame(oracle.gen_frame(W, H, 80 + c)) for c in range(3)]
-    got = E.dwt_forward_rgb(*planes, wl, oracle.dwt_extra(W, H, wl))
+    planes[1][:9, :13] = 255; planes[2][-7:, -5:] = 0              # extremes of the chroma range at two corners
+    got = E.dwt_forward_rgb(*planes, wl, oracle.dwt_extra(W, H, wl), lossy, qs)
     assert got is not None
-    comps = oracle.rgb_forward(*planes, False)
+    comps = oracle.rgb_forward(*planes, lossy)
     for k in range(3):
-        ref = oracle.dwt_forward(comps[k], wl)[:W * H].reshape(H, W)
-        assert np.array_equal(got[k].astype(np.int32), ref), f"component {k}"
+        ref = (oracle.dwt_forward(comps[k], wl, qs) if lossy else oracle.dwt_forward(comps[k], wl))[:W * H].reshape(H, W)
+        assert np.array_equal(got[k].astype(np.int32), np.trunc(ref).astype(np.int32)), f"component {k}"
 
 
 def test_16_bit_coefficient_bound(E):
