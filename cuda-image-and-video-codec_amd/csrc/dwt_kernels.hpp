@@ -1332,6 +1332,104 @@ __global__ __launch_bounds__(256) void dwt_inv_kernel(DwtInvArgs a)
     }
 }
 
+// ---- RGB frames, 5/3: the finest synthesis level of all three components and the inverse colour transform -----
+// picsong_decode_rgb_frame's last two launches were the finest level of the three components (grid.z = component:
+// 3 x 67 MB of int16 coefficients in, 3 x 134 MB of 32-bit planes out) and rgb_inverse_kernel (those planes in, 100 MB
+// of pixels out).  Here ONE wave runs the level for the same columns of all three components -- three copies of the
+// streamed vertical state, the rows of kInvRgbAhead iterations in flight per component -- and a finished row pair
+// goes through the inverse RCT (RGBTransformLossless's inverse, Engines/DecodingEngine.cu:599-626: G = Y - ((Cb + Cr)
+// >> 2), R = Cr + G, B = Cb + G), the level shift and the clamp on its way out: the planes are never written.
+// a: the finest level's arguments as the plan made them for a three-frame launch (component c's coefficients at
+// mallat + c * mallat_z, its LL at ll + c * ll_z); dr / dg / db: the pixel planes, row stride W.
+#ifndef PICSONG_DWT_INV_RGB_AHEAD
+#define PICSONG_DWT_INV_RGB_AHEAD 3
+#endif
+__device__ __forceinline__ void store_rgb_row4(uint8_t *dr, uint8_t *dg, uint8_t *db, size_t at, int off, const int (&v)[3][4])
+{
+    uint32_t wr_ = 0u, wg_ = 0u, wb_ = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int G = v[0][k] - ((v[1][k] + v[2][k]) >> 2), R = v[2][k] + G, B = v[1][k] + G;
+        wr_ |= to_pixel(R, off) << (8 * k); wg_ |= to_pixel(G, off) << (8 * k); wb_ |= to_pixel(B, off) << (8 * k);
+    }
+    *reinterpret_cast<uint32_t *>(dr + at) = wr_;
+    *reinterpret_cast<uint32_t *>(dg + at) = wg_;
+    *reinterpret_cast<uint32_t *>(db + at) = wb_;
+}
+#ifndef PICSONG_DWT_INV_RGB_WAVES
+#define PICSONG_DWT_INV_RGB_WAVES 3
+#endif
+template <int BAND>
+__global__ __launch_bounds__(256, PICSONG_DWT_INV_RGB_WAVES) void dwt_inv_rgb_kernel(DwtInvArgs a, uint8_t *dr, uint8_t *dg, uint8_t *db)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int strip = blockIdx.x * 4 + wave;
+    if (strip * kStripUseful >= a.W) return;
+    const int c0 = strip * kStripUseful - 4 * kEdgeLanes + 4 * lane;
+    const int pc = c0 >> 1;
+    const int hW = a.W >> 1, hH = a.H >> 1;
+    const int m0 = blockIdx.y * (BAND / 2);
+    int m1 = m0 + BAND / 2;
+    if (m1 > hH) m1 = hH;
+    const bool inside = pc >= 0 && pc + 1 < hW;
+    const bool wr = lane >= kEdgeLanes && lane <= 63 - kEdgeLanes && c0 >= 0 && c0 < a.W;
+    const bool le = c0 == 0, re = c0 + 4 == a.W;
+    const int pl = pc < 0 ? 0 : (pc > hW - 2 ? hW - 2 : pc);
+    DwtInvArgs ac[3] = { a, a, a };
+#pragma unroll
+    for (int c = 1; c < 3; c++) {
+        ac[c].mallat = (const int32_t *)((const char *)a.mallat + (unsigned long long)c * a.mallat_z);
+        ac[c].ll = (const char *)a.ll + (unsigned long long)c * a.ll_z;
+    }
+    constexpr int kIters = BAND / 2 + 2;
+    constexpr int kAhead = kIters < PICSONG_DWT_INV_RGB_AHEAD ? kIters : PICSONG_DWT_INV_RGB_AHEAD;
+    const int j0 = m0 - 1;
+    SubRaw rawL[3][kAhead], rawH[3][kAhead];
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int p = 0; p < kAhead; p++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            rawL[c][p] = load_sub_raw<int, true, true>(ac[c], reflect_s(j0 + p, hH), false, pl, inside);
+            rawH[c][p] = load_sub_raw<int, true, true>(ac[c], reflect_d(j0 + p, hH), true, pl, inside);
+        }
+    __builtin_amdgcn_s_setprio(0);
+    int Hp[3][4], sp[3][4];
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) { Hp[c][k] = sp[c][k] = 0; }
+#pragma unroll
+    for (int it = 0; it < kIters; it++) {
+        const int j = j0 + it;
+        int ev[3][4], od[3][4];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            int Lr[4], Hr[4];
+            convert_sub<int, false, false, true>(ac[c], rawL[c][it % kAhead], false, Lr);
+            convert_sub<int, false, false, true>(ac[c], rawH[c][it % kAhead], true, Hr);
+            if (it + kAhead < kIters) {
+                rawL[c][it % kAhead] = load_sub_raw<int, true, true>(ac[c], reflect_s(j + kAhead, hH), false, pl, inside);
+                rawH[c][it % kAhead] = load_sub_raw<int, true, true>(ac[c], reflect_d(j + kAhead, hH), true, pl, inside);
+            }
+            hinv<false>(Lr, le, re);
+            hinv<false>(Hr, le, re);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {                    // vertical 5/3 synthesis, as dwt_inv_kernel
+                const int s_ = Lr[k] - ((Hp[c][k] + Hr[k] + 2) >> 2);
+                ev[c][k] = sp[c][k];
+                od[c][k] = Hp[c][k] + ((sp[c][k] + s_) >> 1);
+                sp[c][k] = s_; Hp[c][k] = Hr[k];
+            }
+        }
+        if (it >= 2 && j - 1 < m1 && wr) {
+            const size_t at = (size_t)(2 * (j - 1)) * (size_t)a.W + (size_t)(uint32_t)c0;
+            store_rgb_row4(dr, dg, db, at, a.off, ev);
+            store_rgb_row4(dr, dg, db, at + (size_t)a.W, a.off, od);
+        }
+    }
+}
+
 // ---- 9/7 synthesis of one level, lean (round 2) ---------------------------------------------------
 // The vector launches of a context whose reciprocal divisions verified (InvLaunch::fast).  Same strips, bands and
 // streamed vertical synthesis as dwt_inv_kernel, same arithmetic value for value; what is gone is everything that

@@ -1576,6 +1576,25 @@ int picsong_decode_rgb_frame(picsong_ctx *c, const uint16_t *d_streams, size_t s
         bpc_decode_kernel<false, kDecSmallPlanes><<<wgs3, 64 * kBpcDecWgWaves, 0, s>>>(a);
     }
     HIP_TRY(hipGetLastError());
+    // 5/3 with 16-bit coefficients: the finest level of the three components and the inverse colour transform as ONE
+    // launch (dwt_inv_rgb_kernel: the 32-bit planes are never written); PICSONG_RGB_NOFUSE=1 keeps the two
+    const bool px_aligned = ((((uintptr_t)d_r) | ((uintptr_t)d_g) | ((uintptr_t)d_b)) & 3u) == 0;
+    if (!c->p.lossy && c16 && plan.size() >= 2 && plan.back().vec && px_aligned && !getenv("PICSONG_RGB_NOFUSE")) {
+        std::vector<InvLaunch> head(plan.begin(), plan.end() - 1);
+        if ((rc = run_inverse(c, head, s, 3u))) return rc;
+        const InvLaunch &f = plan.back();
+        DwtInvArgs fa = f.a;
+        fa.off = 1 << (c->p.bit_depth - 1);
+        const dim3 grid(f.gx, f.gy, 1);
+        switch (f.band) {
+        case 32: dwt_inv_rgb_kernel<32><<<grid, 256, 0, s>>>(fa, d_r, d_g, d_b); break;
+        case 16: dwt_inv_rgb_kernel<16><<<grid, 256, 0, s>>>(fa, d_r, d_g, d_b); break;
+        case 8: dwt_inv_rgb_kernel<8><<<grid, 256, 0, s>>>(fa, d_r, d_g, d_b); break;
+        default: dwt_inv_rgb_kernel<4><<<grid, 256, 0, s>>>(fa, d_r, d_g, d_b); break;
+        }
+        HIP_TRY(hipGetLastError());
+        return PICSONG_OK;
+    }
     if ((rc = run_inverse(c, plan, s, 3u))) return rc;
     const char *img = (const char *)c->b_coef + c->extra * 4;
     const size_t z = (c->P + c->extra) * 4;

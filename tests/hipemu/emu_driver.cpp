@@ -281,6 +281,43 @@ int emu_dwt_inverse_u8_c16(const int16_t *in16, void *scratch, uint8_t *pixels, 
     return res;
 }
 
+// picsong_decode_rgb_frame's lossless synthesis with 16-bit coefficients: the levels above the finest per component,
+// then the finest level of all three components + the inverse colour transform as ONE launch (dwt_inv_rgb_kernel).
+// in16: three int16 Mallat arrays in_z BYTES apart; scratch: three work buffers wrk_z bytes apart.  Returns 1 when the
+// form applies.
+int emu_dwt_inverse_rgb(const int16_t *in16, size_t in_z, void *scratch, size_t wrk_z, uint8_t *r, uint8_t *g, uint8_t *b,
+                        int aw, int ah, int wl)
+{
+    if (!dec_c16_ok(false, wl, 1.0f, 255, aw, ah, false)) return 0;
+    std::vector<InvLaunch> plan0;
+    for (int c = 0; c < 3; c++) {
+        std::vector<InvLaunch> plan = plan_dwt_inverse((const int32_t *)((const char *)in16 + c * in_z), (char *)scratch + c * wrk_z,
+                                                       aw, ah, wl, 1.0f, false, true);
+        if (!plan_inv_is_c16(plan) || plan.size() < 2 || !plan.back().vec) return 0;
+        for (size_t l = 0; l + 1 < plan.size(); l++) {
+            const InvLaunch &f = plan[l];
+            switch (f.band) {
+            case 32: emu_inv<32>(f, 0); break;
+            case 16: emu_inv<16>(f, 0); break;
+            case 8: emu_inv<8>(f, 0); break;
+            default: emu_inv<4>(f, 0); break;
+            }
+        }
+        if (c == 0) plan0 = plan;
+    }
+    const InvLaunch &f = plan0.back();
+    DwtInvArgs fa = f.a;
+    fa.mallat_z = in_z; fa.ll_z = wrk_z; fa.off = 128;
+    const dim3 grid(f.gx, f.gy);
+    switch (f.band) {
+    case 32: emu::launch(grid, dim3(256), [&] { dwt_inv_rgb_kernel<32>(fa, r, g, b); }); break;
+    case 16: emu::launch(grid, dim3(256), [&] { dwt_inv_rgb_kernel<16>(fa, r, g, b); }); break;
+    case 8: emu::launch(grid, dim3(256), [&] { dwt_inv_rgb_kernel<8>(fa, r, g, b); }); break;
+    default: emu::launch(grid, dim3(256), [&] { dwt_inv_rgb_kernel<4>(fa, r, g, b); }); break;
+    }
+    return 1;
+}
+
 void emu_level_shift_inv(void *data, size_t n, int lossy)
 {
     if (lossy) emu::launch(dim3(4), dim3(256), [&] { level_shift_inv_f32_kernel((float *)data, n, 128.0f); });

@@ -341,6 +341,34 @@ def test_rgb_colour_transform_in_the_fused_heads_load_stage(oracle, E, W, H, wl,
         assert np.array_equal(got[k].astype(np.int32), np.trunc(ref).astype(np.int32)), f"component {k}"
 
 
+@pytest.mark.parametrize("W,H,wl", [(320, 192, 3), (256, 128, 2), (512, 320, 5), (200, 100, 2)])
+def test_rgb_inverse_colour_transform_in_the_finest_synthesis_level(oracle, E, W, H, wl):
+    """dwt_inv_rgb_kernel: the finest 5/3 synthesis level of the three components in one wave, the inverse RCT, the level
+    shift and the clamp at its stores -- the planes of the frame, from the coefficients the forward side makes of them
+    (extremes of the chroma range included), and the oracle's pixels for coefficients that overshoot (a coarse
+    perturbation: the clamp at both ends)."""
+    planes = [oracle.pad_frame(oracle.gen_frame(W, H, 90 + c)) for c in range(3)]
+    planes[0][:11, :7] = 255; planes[1][:11, :7] = 0; planes[2][-9:, -6:] = 255; planes[0][-9:, -6:] = 0
+    AH, AW = planes[0].shape
+    comps = oracle.rgb_forward(*planes, False)
+    coefs = [oracle.dwt_forward(comps[k], wl)[:AW * AH].reshape(AH, AW).astype(np.int16) for k in range(3)]
+    got = E.dwt_inverse_rgb(coefs, wl, oracle.dwt_extra(W, H, wl))
+    assert got is not None
+    for k in range(3):
+        assert np.array_equal(got[k], planes[k]), f"plane {k}"
+    rng = np.random.default_rng(3)
+    noisy = [c + (rng.integers(-40, 41, c.shape) * (rng.integers(0, 16, c.shape) == 0)).astype(np.int16) for c in coefs]
+    got = E.dwt_inverse_rgb(noisy, wl, oracle.dwt_extra(W, H, wl))
+    back = []
+    for k in range(3):
+        inv, extra = oracle.dwt_inverse(noisy[k].astype(np.int32), wl, False, 1.0)
+        back.append(inv[extra:].reshape(AH, AW))
+    ref = oracle.rgb_inverse(*back)
+    for k in range(3):
+        assert np.array_equal(got[k], ref[k]), f"plane {k} (perturbed)"
+    assert (got[0] == 0).any() and (got[0] == 255).any()
+
+
 def test_16_bit_coefficient_bound(E):
     """coef16_ok: the 16-bit form only where magnitudes are bounded below 2^15 (8-bit samples; 9/7: times the
     quantisation weights): BASELINE's configurations qualify, a fine qs or a geometry off the vector kernels does not."""
