@@ -1446,7 +1446,7 @@ static int bpc_args_rgb(picsong_ctx *c, BpcArgs &a)
         if (!c->has_lut[k]) return fail(PICSONG_ERR_ARG, "no LUT loaded for component %d", k);
         const picsong_lut_info &x = c->li[0], &y = c->li[k];
         if (x.n_bitplanes != y.n_bitplanes || x.n_subbands != y.n_subbands || x.precision != y.precision ||
-            x.n_ref != y.n_ref || x.n_sig != y.n_sig || x.n_sign != y.n_sign)
+            x.n_ref != y.n_ref || x.n_sig != y.n_sig || x.n_sign != y.n_sign || x.n_tables != y.n_tables)
             return fail(PICSONG_ERR_ARG, "the components' tables differ in geometry: code the planes one by one (picsong_encode_plane)");
     }
     for (int k = 0; k < 3; k++) a.lut_c[k] = c->d_lut[k];
@@ -1461,7 +1461,7 @@ int picsong_encode_rgb_frame(picsong_ctx *c, const uint8_t *d_r, const uint8_t *
 {
     if (!c || !d_r || !d_g || !d_b || !d_streams) return fail(PICSONG_ERR_ARG, "encode_rgb_frame: null argument");
     if (!c->p.is_rgb) return fail(PICSONG_ERR_ARG, "encode_rgb_frame: the context is not an RGB one");
-    if (c->p.k > 0.0f || c->p.cp == 3) return fail(PICSONG_ERR_ARG, "encode_rgb_frame: -k > 0 and -cp 3 code their planes one by one");
+    if (c->p.cp == 3) return fail(PICSONG_ERR_ARG, "encode_rgb_frame: -cp 3 codes its planes one by one (picsong_encode_plane)");
     if (stream_stride < picsong_max_stream_shorts(c->aw, c->ah)) return fail(PICSONG_ERR_ARG, "encode_rgb_frame: stream stride smaller than a worst-case codestream");
     HIP_TRY(hipSetDevice(c->device));
     BpcArgs a;
@@ -1513,7 +1513,16 @@ int picsong_encode_rgb_frame(picsong_ctx *c, const uint8_t *d_r, const uint8_t *
     a.coeffs_in = c->b_coef; a.is_float = c->p.lossy ? 1 : 0;
     a.staging16 = reinterpret_cast<uint16_t *>(c->b_staging);
     a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch; a.coef_z = coef_z;
-    bpc_encode_kernel<false><<<(unsigned)(3 * a.waves_per_frame / kBpcEncWgWaves), 64 * kBpcEncWgWaves, 0, s>>>(a);
+    if (a.k > 0.0f) {
+        // -k > 0: the BULK instantiations (one-wave workgroups: a frame is exactly its codeblock pairs), the hint's
+        // choice between them as in bpc_encode_impl
+        a.waves_per_frame = (c->ncb + 1) / 2;
+        const unsigned wgs = 3u * (unsigned)a.waves_per_frame;
+        if (bulk_compact(c, 0) && bulk_compact(c, 1) && bulk_compact(c, 2) && c->pipelined) bpc_encode_kernel<true, true><<<wgs, 64, 0, s>>>(a);
+        else bpc_encode_kernel<true><<<wgs, 64, 0, s>>>(a);
+    } else {
+        bpc_encode_kernel<false><<<(unsigned)(3 * a.waves_per_frame / kBpcEncWgWaves), 64 * kBpcEncWgWaves, 0, s>>>(a);
+    }
     HIP_TRY(hipGetLastError());
     // ---- pack: the populated header on the components of header_mask
     HeaderArg h;
@@ -1538,7 +1547,7 @@ int picsong_decode_rgb_frame(picsong_ctx *c, const uint16_t *d_streams, size_t s
 {
     if (!c || !d_streams || !d_r || !d_g || !d_b) return fail(PICSONG_ERR_ARG, "decode_rgb_frame: null argument");
     if (!c->p.is_rgb) return fail(PICSONG_ERR_ARG, "decode_rgb_frame: the context is not an RGB one");
-    if (c->p.k > 0.0f || c->p.cp == 3) return fail(PICSONG_ERR_ARG, "decode_rgb_frame: -k > 0 and -cp 3 decode their planes one by one");
+    if (c->p.cp == 3) return fail(PICSONG_ERR_ARG, "decode_rgb_frame: -cp 3 decodes its planes one by one (picsong_decode_plane)");
     if (stream_stride < picsong_max_stream_shorts(c->aw, c->ah)) return fail(PICSONG_ERR_ARG, "decode_rgb_frame: stream stride smaller than a worst-case codestream");
     HIP_TRY(hipSetDevice(c->device));
     BpcArgs a;
@@ -1570,6 +1579,23 @@ int picsong_decode_rgb_frame(picsong_ctx *c, const uint16_t *d_streams, size_t s
     if (direct) {
         a.cw16 = d_streams; a.cw16_offsets = c->b_offsets; a.cw16_total = c->b_total; a.cw16_stride = stream_stride;
         a.cw16_max = (uint32_t)picsong_max_stream_shorts(c->aw, c->ah);
+    }
+    if (a.k > 0.0f) {
+        // -k > 0: the BULK instantiations over the three components (one-wave workgroups), as bpc_decode_impl picks them
+        a.waves_per_frame = (c->ncb + 1) / 2;
+        const unsigned wgs = 3u * (unsigned)a.waves_per_frame;
+        const bool cmp = bulk_compact(c, 0) && bulk_compact(c, 1) && bulk_compact(c, 2);
+        if (direct && c16) {
+            if (cmp) bpc_decode_kernel<true, kDecSmallPlanes, true, true, true><<<wgs, 64, 0, s>>>(a);
+            else bpc_decode_kernel<true, kDecSmallPlanes, true, true><<<wgs, 64, 0, s>>>(a);
+        } else if (direct) {
+            if (cmp) bpc_decode_kernel<true, kDecSmallPlanes, true, false, true><<<wgs, 64, 0, s>>>(a);
+            else bpc_decode_kernel<true, kDecSmallPlanes, true><<<wgs, 64, 0, s>>>(a);
+        } else {
+            if (cmp) bpc_decode_kernel<true, kDecSmallPlanes, false, false, true><<<wgs, 64, 0, s>>>(a);
+            else bpc_decode_kernel<true, kDecSmallPlanes><<<wgs, 64, 0, s>>>(a);
+        }
+    } else if (direct) {
         if (c16) bpc_decode_kernel<false, kDecSmallPlanes, true, true><<<wgs3, 64 * kBpcDecWgWaves, 0, s>>>(a);
         else bpc_decode_kernel<false, kDecSmallPlanes, true><<<wgs3, 64 * kBpcDecWgWaves, 0, s>>>(a);
     } else {

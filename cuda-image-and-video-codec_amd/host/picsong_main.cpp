@@ -236,7 +236,7 @@ int run_encode_rgb(const Options &o, size_t file_base, long nframes)
     for (int c = 0; c < 3; c++) { HIPCK(hipMalloc(&d_in[c], P)); HIPCK(hipMalloc(&d_c[c], P * 4)); }
     // the three components of a frame through ONE launch per stage (picsong_encode_rgb_frame) wherever the library
     // offers it: -cp 2, k = 0; otherwise plane by plane
-    const bool batched = o.k <= 0.0f && o.cp != 3;
+    const bool batched = o.cp != 3;
     HIPCK(hipHostMalloc(&h_out, max_shorts * 2));
     HIPCK(hipMalloc(&d_out, max_shorts * 2 * (batched ? 3 : 1)));
     std::vector<uint8_t> raw((size_t)o.x * o.y);
@@ -587,7 +587,7 @@ int run_decode_rgb(const Options &o, const picsong_params &p, picsong_ctx *ctx, 
     uint16_t *h_in, *d_in;
     uint8_t *h_pix, *d_pix[3];
     char *d_plane[3];
-    const bool batched = p.k <= 0.0f && p.cp != 3;      // (picsong_decode_rgb_frame: one launch per stage for the three components)
+    const bool batched = p.cp != 3;      // (picsong_decode_rgb_frame: one launch per stage for the three components)
     HIPCK(hipHostMalloc(&h_in, max_shorts * 2));
     HIPCK(hipMalloc(&d_in, max_shorts * 2 * (batched ? 3 : 1)));
     HIPCK(hipHostMalloc(&h_pix, P));

@@ -241,10 +241,11 @@ int picsong_decode_plane(picsong_ctx *ctx, const uint16_t *d_stream, int compone
  * codestream lands at d_streams + c * stream_stride (shorts, >= picsong_max_stream_shorts); header_mask bit c = that
  * component carries the populated header (image: 1 -- component 0 only, iter = component; video frame 0: 7; else 0).
  * Lengths: picsong_last_totals(ctx, stream, 3, ..) / picsong_copy_last_totals.  Byte-identical to the plane-by-plane
- * calls; -cp 2, k = 0 RGB contexts whose three tables share one geometry.  The planes need 4-byte alignment; the
- * lossless form's fused head (the colour transform in the transform's load stage) runs when all three are 16-byte
+ * calls; -cp 2 RGB contexts (any -k) whose three tables share one geometry.  The planes need 4-byte alignment; the
+ * fused head (the colour transform, RCT or ICT, in the transform's load stage) runs when all three are 16-byte
  * aligned, the separate colour-transform kernel otherwise (same streams).  The decoder's mirror takes the three
- * codestreams (same stride) to the three padded u8 planes (Engines/DecodingEngine.cu:599-701, 736-769). */
+ * codestreams (same stride) to the three padded u8 planes (Engines/DecodingEngine.cu:599-701, 736-769); its 5/3 form
+ * runs the inverse colour transform inside the finest synthesis level. */
 int picsong_encode_rgb_frame(picsong_ctx *ctx, const uint8_t *d_r, const uint8_t *d_g, const uint8_t *d_b, int header_mask,
                              uint16_t *d_streams, size_t stream_stride, void *stream);
 int picsong_decode_rgb_frame(picsong_ctx *ctx, const uint16_t *d_streams, size_t stream_stride, uint8_t *d_r, uint8_t *d_g,

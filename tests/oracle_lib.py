@@ -226,23 +226,24 @@ def rgb_inverse(c0, c1, c2):
     return outs
 
 
-def lut_for_component(lossy, wl, component, fill=0):
-    """component 0/1/2 -> the R/G/B table files of the fixture folder."""
-    return Lut(os.path.join(LUT_DIR, "n1_lossy" if lossy else "n1_lossless"), wl, component + 1, fill)
+def lut_for_component(lossy, wl, component, fill=0, k=0.0):
+    """component 0/1/2 -> the R/G/B table files of the fixture folder (k > 0: every bit-plane file of the component)."""
+    return Lut(os.path.join(LUT_DIR, "n1_lossy" if lossy else "n1_lossless"), wl, component + 1, fill,
+               n_tables=0 if k > 0 else 1)
 
 
-def encode_plane(plane, wl, lossy, qs, lut, header):
+def encode_plane(plane, wl, lossy, qs, lut, header, k=0.0):
     """One component: DWT + BPC + pack of an already transformed / shifted padded plane."""
     AH, AW = plane.shape
     f = dwt_forward(np.ascontiguousarray(plane), wl, qs)
-    st, sz = bpc_encode(f[:AW * AH].reshape(AH, AW), wl, lut)
+    st, sz = bpc_encode(f[:AW * AH].reshape(AH, AW), wl, lut, k=k)
     return bitstream_pack(st, sz, header)
 
 
-def decode_plane(stream, AW, AH, wl, lossy, qs, lut):
+def decode_plane(stream, AW, AH, wl, lossy, qs, lut, k=0.0):
     """Inverse of encode_plane up to (not including) clamping: returns the (AH, AW) component."""
     st, sz = bitstream_unpack(stream, (AW // 64) * (AH // 64))
-    coef = bpc_decode(st, sz, AW, AH, wl, lut)
+    coef = bpc_decode(st, sz, AW, AH, wl, lut, k=k)
     out, extra = dwt_inverse(coef, wl, lossy, qs)
     return out[extra:].reshape(AH, AW)
 

@@ -182,11 +182,11 @@ def test_4k_video_file_equals_oracle_frame_by_frame(oracle, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lossy,video", [(False, False), (True, True)])
-def test_rgb_files_roundtrip_and_oracle_parity(oracle, tmp_path, lossy, video):
+@pytest.mark.parametrize("lossy,video,k", [(False, False, 0.0), (True, True, 0.0), (False, True, 0.5), (True, False, 1.5)])
+def test_rgb_files_roundtrip_and_oracle_parity(oracle, tmp_path, lossy, video, k):
     """-isRGB 1 -components 3: planar R,G,B planes; every component stream equals the oracle's
     (RCT/ICT + per-component LUT), header on component 0 (image) / on frame 0's three components
-    (video), decode returns planar planes."""
+    (video), decode returns planar planes.  With -k > 0 too (every component with its own bit-plane tables)."""
     W, H, wl, qs, F = 256, 192, 2, (0.5 if lossy else 1.0), (2 if video else 1)
     lutdir = os.path.join(oracle.LUT_DIR, "n1_lossy" if lossy else "n1_lossless")
     planes = [[oracle.gen_frame(W, H, 10 * f + c) for c in range(3)] for f in range(F)]
@@ -194,20 +194,22 @@ def test_rgb_files_roundtrip_and_oracle_parity(oracle, tmp_path, lossy, video):
     np.concatenate([p.ravel() for fr in planes for p in fr]).tofile(raw)
     args = ["-cd", 0, "-i", raw, "-o", enc, "-xSize", W, "-ySize", H, "-wl", wl, "-type", int(lossy), "-qs", qs,
             "-isRGB", 1, "-components", 3, "-LUTFolder", lutdir]
+    if k > 0:
+        args += ["-k", k]
     if video:
         args += ["-video", 1, "-frames", F]
     r = _run(*args)
     assert r.returncode == 0, r.stdout + r.stderr
     hdr = oracle.header_pack(n_samples=W * H * 3, cp=2, cb_height=18, cb_width=64, wl=wl, bit_depth=8, lossy=int(lossy),
                              qs_1e4=int(qs * 10000), components=3, is_rgb=1, height=H, endianess=0, bps=8,
-                             is_signed=0, frames=F if video else 0, k_1e3=0)
+                             is_signed=0, frames=F if video else 0, k_1e3=int(round(k * 1000)))
     ref = []
     for f in range(F):
         comps = oracle.rgb_forward(*[oracle.pad_frame(p) for p in planes[f]], lossy)
         for c in range(3):
             with_hdr = (f == 0) if video else (c == 0)
-            ref.append(oracle.encode_plane(comps[c], wl, lossy, qs, oracle.lut_for_component(lossy, wl, c),
-                                           hdr if with_hdr else None))
+            ref.append(oracle.encode_plane(comps[c], wl, lossy, qs, oracle.lut_for_component(lossy, wl, c, k=k),
+                                           hdr if with_hdr else None, k=k))
     assert np.array_equal(np.fromfile(enc, np.uint16), np.concatenate(ref))
     assert open(str(enc) + "_SIZE").read() == ",".join(str(x.size) for x in ref)
     args = ["-cd", 1, "-i", enc, "-o", dec, "-LUTFolder", lutdir] + (["-video", 1] if video else [])

@@ -701,14 +701,18 @@ def test_unaligned_frame_pointer_and_late_novec_fall_back_to_the_32_bit_form(ora
     c.close()
 
 
-@pytest.mark.parametrize("W,H,wl,lossy,qs,mask", [(320, 192, 3, False, 1.0, 1), (704, 448, 4, True, 0.5, 7), (1000, 300, 3, False, 1.0, 0)])
-def test_rgb_frame_through_the_batched_grid_equals_oracle(oracle, pa, torch, W, H, wl, lossy, qs, mask):
+@pytest.mark.parametrize("W,H,wl,lossy,qs,mask,kk,hint", [(320, 192, 3, False, 1.0, 1, 0.0, False), (704, 448, 4, True, 0.5, 7, 0.0, False),
+                                                          (1000, 300, 3, False, 1.0, 0, 0.0, False), (704, 448, 4, False, 1.0, 1, 0.6, False),
+                                                          (512, 512, 5, True, 0.5, 7, 1.5, True), (1000, 300, 3, False, 1.0, 2, 0.4, True)])
+def test_rgb_frame_through_the_batched_grid_equals_oracle(oracle, pa, torch, W, H, wl, lossy, qs, mask, kk, hint):
     """picsong_encode_rgb_frame / picsong_decode_rgb_frame: the three components of an RGB frame as the three frames
-    of ONE launch per stage (component c with table c) -- every component's codestream equals the oracle's and the
-    plane-by-plane calls', the header lands on the components of the mask, and the decode returns the planes."""
+    of ONE launch per stage (component c with table c; the colour transform inside the transform's first and last
+    launches) -- every component's codestream equals the oracle's and the plane-by-plane calls', the header lands on the
+    components of the mask, and the decode returns the planes.  -k > 0 too (the BULK coder instantiations over the
+    three components, both of the encoder's, the decoder's int16 form)."""
     planes = [oracle.pad_frame(oracle.gen_frame(W, H, 60 + c)) for c in range(3)]
     AH, AW = planes[0].shape
-    c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=_lutdir(oracle, lossy), rgb=True)
+    c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=_lutdir(oracle, lossy), rgb=True, k=kk, pipelined=hint)
     d = [_dev(torch, p) for p in planes]
     hdr = pa.header_pack(c.params)
     got = [g.clone() for g in c.encode_rgb_frame(*d, header_mask=mask)]
@@ -716,7 +720,7 @@ def test_rgb_frame_through_the_batched_grid_equals_oracle(oracle, pa, torch, W, 
     comps = c.rgb_forward(*d)
     for k in range(3):
         with_hdr = (mask >> k) & 1
-        ref = oracle.encode_plane(ref_comps[k], wl, lossy, qs, oracle.lut_for_component(lossy, wl, k), hdr if with_hdr else None)
+        ref = oracle.encode_plane(ref_comps[k], wl, lossy, qs, oracle.lut_for_component(lossy, wl, k, k=kk), hdr if with_hdr else None, k=kk)
         assert np.array_equal(got[k].cpu().numpy().view(np.uint16), ref), f"component {k}"
         assert torch.equal(got[k], c.encode_plane(comps[k], k, bool(with_hdr)))
     streams = torch.zeros((3, c.max_stream_shorts()), dtype=torch.int16, device="cuda")
@@ -729,6 +733,11 @@ def test_rgb_frame_through_the_batched_grid_equals_oracle(oracle, pa, torch, W, 
         assert torch.equal(back[k].view(-1), ref_back[k].view(-1))
         if not lossy:
             assert np.array_equal(back[k].cpu().numpy(), planes[k])
+    # ... and the oracle's own decode of the three streams, through its inverse colour transform
+    ob = oracle.rgb_inverse(*[oracle.decode_plane(got[k].cpu().numpy().view(np.uint16), AW, AH, wl, lossy, qs,
+                                                  oracle.lut_for_component(lossy, wl, k, k=kk), k=kk) for k in range(3)])
+    for k in range(3):
+        assert np.array_equal(back[k].cpu().numpy().reshape(AH, AW), ob[k]), f"plane {k} against the oracle's decode"
     # a grey context refuses the call
     g = pa.Codec(W, H, wl=wl, lut_folder=_lutdir(oracle, False))
     with pytest.raises(pa.PicsongError):
