@@ -1215,6 +1215,32 @@ static int ensure_coef_i(picsong_ctx *c, int n)
     return PICSONG_OK;
 }
 
+// -k > 0 over the frames (or the three components) of a batched call: the BULK coder instantiations, one-wave
+// workgroups -- a frame is exactly its codeblock pairs, no padding waves --, chosen as bpc_encode_impl / bpc_decode_impl
+// choose them for one frame (`cmp`: every table the launch uses takes the compact LDS copies)
+static void launch_bulk_encode_frames(picsong_ctx *c, BpcArgs &a, unsigned frames, bool cmp, hipStream_t s)
+{
+    a.waves_per_frame = (c->ncb + 1) / 2;
+    const unsigned wgs = frames * (unsigned)a.waves_per_frame;
+    if (cmp && c->pipelined) bpc_encode_kernel<true, true><<<wgs, 64, 0, s>>>(a);
+    else bpc_encode_kernel<true><<<wgs, 64, 0, s>>>(a);
+}
+static void launch_bulk_decode_frames(picsong_ctx *c, BpcArgs &a, unsigned frames, bool cmp, bool direct, bool c16, hipStream_t s)
+{
+    a.waves_per_frame = (c->ncb + 1) / 2;
+    const unsigned wgs = frames * (unsigned)a.waves_per_frame;
+    if (direct && c16) {
+        if (cmp) bpc_decode_kernel<true, kDecSmallPlanes, true, true, true><<<wgs, 64, 0, s>>>(a);
+        else bpc_decode_kernel<true, kDecSmallPlanes, true, true><<<wgs, 64, 0, s>>>(a);
+    } else if (direct) {
+        if (cmp) bpc_decode_kernel<true, kDecSmallPlanes, true, false, true><<<wgs, 64, 0, s>>>(a);
+        else bpc_decode_kernel<true, kDecSmallPlanes, true><<<wgs, 64, 0, s>>>(a);
+    } else {
+        if (cmp) bpc_decode_kernel<true, kDecSmallPlanes, false, false, true><<<wgs, 64, 0, s>>>(a);
+        else bpc_decode_kernel<true, kDecSmallPlanes><<<wgs, 64, 0, s>>>(a);
+    }
+}
+
 int picsong_encode_frames(picsong_ctx *c, int n, const uint8_t *d_frames, size_t frame_stride, int first_iter,
                           uint16_t *d_streams, size_t stream_stride, void *stream)
 {
@@ -1222,9 +1248,9 @@ int picsong_encode_frames(picsong_ctx *c, int n, const uint8_t *d_frames, size_t
     if (n < 1 || n > 64) return fail(PICSONG_ERR_ARG, "encode_frames: %d frames outside 1..64", n);
     if (n > 1 && (frame_stride < c->P || stream_stride < picsong_max_stream_shorts(c->aw, c->ah)))
         return fail(PICSONG_ERR_ARG, "encode_frames: strides smaller than a padded frame / a worst-case codestream");
-    if (c->p.k > 0.0f || c->p.cp == 3 || c->p.is_rgb)
-        return fail(PICSONG_ERR_ARG, "encode_frames: grey -cp 2 contexts with k = 0 only (-k > 0, -cp 3 and RGB components "
-                                     "are coded frame by frame: picsong_encode_frame / picsong_encode_plane)");
+    if (c->p.cp == 3 || c->p.is_rgb)
+        return fail(PICSONG_ERR_ARG, "encode_frames: grey -cp 2 contexts only (-cp 3 is coded frame by frame: picsong_encode_frame; "
+                                     "an RGB frame's components: picsong_encode_rgb_frame)");
     if (((uintptr_t)d_frames | frame_stride) & 15u) return fail(PICSONG_ERR_ARG, "encode_frames: frames must be 16-byte aligned");
     HIP_TRY(hipSetDevice(c->device));                       // (a caller with several devices may be on another one)
     BpcArgs a;
@@ -1261,7 +1287,8 @@ int picsong_encode_frames(picsong_ctx *c, int n, const uint8_t *d_frames, size_t
     a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch;
     a.frames = n; a.waves_per_frame = wpf; a.coef_z = coef_z;
     const size_t waves = (size_t)n * (size_t)wpf;
-    bpc_encode_kernel<false><<<(unsigned)((waves + kBpcEncWgWaves - 1) / kBpcEncWgWaves), 64 * kBpcEncWgWaves, 0, s>>>(a);
+    if (a.k > 0.0f) launch_bulk_encode_frames(c, a, (unsigned)n, bulk_compact(c, 0), s);
+    else bpc_encode_kernel<false><<<(unsigned)((waves + kBpcEncWgWaves - 1) / kBpcEncWgWaves), 64 * kBpcEncWgWaves, 0, s>>>(a);
     HIP_TRY(hipGetLastError());
 
     if (ev) HIP_TRY(hipEventRecord(ev[2], s));
@@ -1303,8 +1330,8 @@ int picsong_decode_frames(picsong_ctx *c, int n, const uint16_t *d_streams, size
 {
     if (!c || !d_streams || !d_frames_out) return fail(PICSONG_ERR_ARG, "decode_frames: null argument");
     if (n < 1 || n > 64) return fail(PICSONG_ERR_ARG, "decode_frames: n = %d outside 1..64", n);
-    if (c->p.k > 0.0f || c->p.cp == 3 || c->p.is_rgb)
-        return fail(PICSONG_ERR_ARG, "decode_frames: grey -cp 2 contexts with k = 0 only (decode those frame by frame)");
+    if (c->p.cp == 3 || c->p.is_rgb)
+        return fail(PICSONG_ERR_ARG, "decode_frames: grey -cp 2 contexts only (-cp 3: frame by frame; RGB: picsong_decode_rgb_frame)");
     if (n > 1 && (stream_stride < picsong_max_stream_shorts(c->aw, c->ah) || frame_stride < c->P))
         return fail(PICSONG_ERR_ARG, "decode_frames: strides %zu shorts / %zu bytes too small", stream_stride, frame_stride);
     if (n == 1) return picsong_decode_frame(c, d_streams, d_frames_out, stream);
@@ -1345,6 +1372,9 @@ int picsong_decode_frames(picsong_ctx *c, int n, const uint16_t *d_streams, size
     if (direct) {
         a.cw16 = d_streams; a.cw16_offsets = c->b_offsets; a.cw16_total = c->b_total; a.cw16_stride = stream_stride;
         a.cw16_max = (uint32_t)picsong_max_stream_shorts(c->aw, c->ah);
+    }
+    if (a.k > 0.0f) launch_bulk_decode_frames(c, a, (unsigned)n, bulk_compact(c, 0), direct, c16, s);
+    else if (direct) {
         if (c16) bpc_decode_kernel<false, kDecSmallPlanes, true, true><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
         else bpc_decode_kernel<false, kDecSmallPlanes, true><<<wgs, 64 * kBpcDecWgWaves, 0, s>>>(a);
     } else {
@@ -1514,12 +1544,7 @@ int picsong_encode_rgb_frame(picsong_ctx *c, const uint8_t *d_r, const uint8_t *
     a.staging16 = reinterpret_cast<uint16_t *>(c->b_staging);
     a.sizes = c->b_sizes; a.plane_scratch = c->b_plane_scratch; a.coef_z = coef_z;
     if (a.k > 0.0f) {
-        // -k > 0: the BULK instantiations (one-wave workgroups: a frame is exactly its codeblock pairs), the hint's
-        // choice between them as in bpc_encode_impl
-        a.waves_per_frame = (c->ncb + 1) / 2;
-        const unsigned wgs = 3u * (unsigned)a.waves_per_frame;
-        if (bulk_compact(c, 0) && bulk_compact(c, 1) && bulk_compact(c, 2) && c->pipelined) bpc_encode_kernel<true, true><<<wgs, 64, 0, s>>>(a);
-        else bpc_encode_kernel<true><<<wgs, 64, 0, s>>>(a);
+        launch_bulk_encode_frames(c, a, 3u, bulk_compact(c, 0) && bulk_compact(c, 1) && bulk_compact(c, 2), s);
     } else {
         bpc_encode_kernel<false><<<(unsigned)(3 * a.waves_per_frame / kBpcEncWgWaves), 64 * kBpcEncWgWaves, 0, s>>>(a);
     }
@@ -1581,20 +1606,7 @@ int picsong_decode_rgb_frame(picsong_ctx *c, const uint16_t *d_streams, size_t s
         a.cw16_max = (uint32_t)picsong_max_stream_shorts(c->aw, c->ah);
     }
     if (a.k > 0.0f) {
-        // -k > 0: the BULK instantiations over the three components (one-wave workgroups), as bpc_decode_impl picks them
-        a.waves_per_frame = (c->ncb + 1) / 2;
-        const unsigned wgs = 3u * (unsigned)a.waves_per_frame;
-        const bool cmp = bulk_compact(c, 0) && bulk_compact(c, 1) && bulk_compact(c, 2);
-        if (direct && c16) {
-            if (cmp) bpc_decode_kernel<true, kDecSmallPlanes, true, true, true><<<wgs, 64, 0, s>>>(a);
-            else bpc_decode_kernel<true, kDecSmallPlanes, true, true><<<wgs, 64, 0, s>>>(a);
-        } else if (direct) {
-            if (cmp) bpc_decode_kernel<true, kDecSmallPlanes, true, false, true><<<wgs, 64, 0, s>>>(a);
-            else bpc_decode_kernel<true, kDecSmallPlanes, true><<<wgs, 64, 0, s>>>(a);
-        } else {
-            if (cmp) bpc_decode_kernel<true, kDecSmallPlanes, false, false, true><<<wgs, 64, 0, s>>>(a);
-            else bpc_decode_kernel<true, kDecSmallPlanes><<<wgs, 64, 0, s>>>(a);
-        }
+        launch_bulk_decode_frames(c, a, 3u, bulk_compact(c, 0) && bulk_compact(c, 1) && bulk_compact(c, 2), direct, c16, s);
     } else if (direct) {
         if (c16) bpc_decode_kernel<false, kDecSmallPlanes, true, true><<<wgs3, 64 * kBpcDecWgWaves, 0, s>>>(a);
         else bpc_decode_kernel<false, kDecSmallPlanes, true><<<wgs3, 64 * kBpcDecWgWaves, 0, s>>>(a);

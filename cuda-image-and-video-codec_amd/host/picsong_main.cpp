@@ -329,7 +329,7 @@ int run_encode(Options o)
     const size_t P = (size_t)aw * ah, max_shorts = picsong_max_stream_shorts(aw, ah);
     // frames per launch: a 4K frame is 1020 coder waves, one per SIMD; four of them fill the GPU like an 8K frame
     int B = o.frames_per_launch > 0 ? o.frames_per_launch : (P <= (size_t)3840 * 2176 ? 4 : 1);
-    if (!o.video || o.k > 0.0f || o.cp == 3) B = 1;
+    if (!o.video || o.cp == 3) B = 1;
     if (B > 16) B = 16;
     if ((long)B > nframes) B = (int)nframes;
     const long ngroups = (nframes + B - 1) / B;
@@ -646,7 +646,7 @@ int run_decode_video(const Options &o, const picsong_params &p, const std::vecto
     // groups of B consecutive frames per launch (picsong_decode_frames), as the encoder's video engine codes them:
     // a 4K frame alone is one decoder wave per SIMD
     int B = o.frames_per_launch > 0 ? o.frames_per_launch : (P <= (size_t)3840 * 2176 ? 4 : 1);
-    if (p.k > 0.0f || p.cp == 3) B = 1;
+    if (p.cp == 3) B = 1;
     if (B > 16) B = 16;
     if ((long)B > nframes) B = (int)nframes;
     const long ngroups = (nframes + B - 1) / B;

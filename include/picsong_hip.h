@@ -181,8 +181,8 @@ int picsong_last_total(picsong_ctx *ctx, void *stream, int *h_total);
  *      (Engines/DecodingEngine.cu:770-794).  d_frame: padded u8[AW*AH] (caller pads as
  *      IOManager::loadFrameCAdaptedSizes does, or uses picsong_pad_frame_host).  iter == 0
  *      writes the populated header.  Asynchronous; length via picsong_last_total().
- *      picsong_decode_frame reads the stream's own shorts and nothing beyond them (k = 0, -cp 2: the coder
- *      takes its codewords from d_stream itself; otherwise through the staging, as
+ *      picsong_decode_frame reads the stream's own shorts and nothing beyond them (-cp 2: the coder
+ *      takes its codewords from d_stream itself; -cp 3 through the staging, as
  *      picsong_bitstream_unpack does); lengths outside 1..4096 are clamped and raise the range flag.  A
  *      DAMAGED length table can still claim more codewords than the stream holds: reads then reach up to
  *      picsong_max_stream_shorts() shorts, so an untrusted stream belongs in a buffer of that size (as with
@@ -203,14 +203,15 @@ int picsong_decode_frame(picsong_ctx *ctx, const uint16_t *d_stream, uint8_t *d_
  *      (first_iter + f == 0) carries the populated header.  n = 1..64; the context grows its workspace to
  *      the largest n seen (about 10 bytes per pixel per frame).  Asynchronous; picsong_last_totals
  *      synchronises `stream` and returns the n lengths in shorts.  Byte-identical to n calls of
- *      picsong_encode_frame.  k > 0 contexts are refused (code those frame by frame). ---- */
+ *      picsong_encode_frame.  Grey -cp 2 contexts, any -k (k > 0: the BULK coder instantiations over the
+ *      n frames of the launch); -cp 3 is coded frame by frame. ---- */
 int picsong_encode_frames(picsong_ctx *ctx, int n, const uint8_t *d_frames, size_t frame_stride, int first_iter,
                           uint16_t *d_streams, size_t stream_stride, void *stream);
 int picsong_last_totals(picsong_ctx *ctx, void *stream, int n, int *h_totals);
 /* The mirror for decoding: n codestreams (stream f at d_streams + f * stream_stride shorts) to n padded u8 frames (frame f
  * at d_frames_out + f * frame_stride bytes, 4-byte aligned strides) through one launch per stage -- DecodingEngine's
  * video loop (Engines/DecodingEngine.cu:734-1141) for n consecutive frames.  Byte-identical to n calls of
- * picsong_decode_frame; grey -cp 2 contexts with k = 0. */
+ * picsong_decode_frame; grey -cp 2 contexts, any -k. */
 int picsong_decode_frames(picsong_ctx *ctx, int n, const uint16_t *d_streams, size_t stream_stride, uint8_t *d_frames_out,
                           size_t frame_stride, void *stream);
 /* The same lengths without a wait: copies the totals of the most recent picsong_encode_frame (n = 1) or

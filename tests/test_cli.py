@@ -90,6 +90,7 @@ def test_video_files_roundtrip(oracle, tmp_path):
     ["-framesPerLaunch", 3],                                   # groups of 3 frames per launch, 11 = 3+3+3+2
     ["-framesPerLaunch", 2, "--devices", "0,0"],               # two worker sets (the -gpus sharding, on one GPU)
     ["-framesPerLaunch", 1, "--devices", "0,0,0", "-numberOfStreams", 4],
+    ["-framesPerLaunch", 3, "-k", 0.5],                        # -k > 0 video: groups of frames per launch too (round 4)
 ])
 def test_video_sharded_and_batched_equals_oracle(oracle, tmp_path, extra):
     """The video engine with groups of frames per launch and with the groups sharded round-robin over several
@@ -104,8 +105,9 @@ def test_video_sharded_and_batched_equals_oracle(oracle, tmp_path, extra):
     r = _run("-cd", 0, "-i", raw, "-o", enc, "-xSize", W, "-ySize", H, "-wl", wl, "-type", 0,
              "-video", 1, "-frames", F, "-LUTFolder", lutdir, *extra)
     assert r.returncode == 0, r.stdout + r.stderr
-    lut = oracle.lut_for(False, wl)
-    ref = [oracle.encode_frame(frames[f], wl, False, 1.0, lut, 0 if f == 0 else 1, F) for f in range(F)]
+    k = float(extra[extra.index("-k") + 1]) if "-k" in extra else 0.0
+    lut = oracle.lut_for_k(False, wl) if k > 0 else oracle.lut_for(False, wl)
+    ref = [oracle.encode_frame(frames[f], wl, False, 1.0, lut, 0 if f == 0 else 1, F, k=k) for f in range(F)]
     assert np.array_equal(np.fromfile(enc, np.uint16), np.concatenate(ref))
     assert open(str(enc) + "_SIZE").read() == ",".join(str(x.size) for x in ref)
     r = _run("-cd", 1, "-i", enc, "-o", dec, "-video", 1, "-LUTFolder", lutdir)

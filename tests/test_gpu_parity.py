@@ -375,6 +375,36 @@ def test_copy_last_totals_matches_the_waited_for_lengths(oracle, pa, torch):
     c.close()
 
 
+@pytest.mark.parametrize("W,H,wl,lossy,qs,k,n,hint", [(576, 320, 3, False, 1.0, 0.5, 3, False), (512, 512, 5, False, 1.0, 1.5, 2, True),
+                                                      (640, 384, 3, True, 0.5, 0.7, 4, True)])
+def test_batched_frames_of_a_complexity_scalable_context(oracle, pa, torch, W, H, wl, lossy, qs, k, n, hint):
+    """picsong_encode_frames / picsong_decode_frames of a -k > 0 context: the BULK coder instantiations over the n frames
+    of one launch (both of the encoder's; 45 codeblocks: the last wave of a frame half empty) -- the oracle's streams
+    frame by frame, header on the video's frame 0 only, and the decode the single-frame decode's and the oracle's."""
+    oracle.set_threads(oracle.usable_threads())
+    try:
+        lut = oracle.lut_for_k(lossy, wl)
+        imgs = [oracle.gen_frame(W, H, 70 + i) for i in range(n)]
+        c = pa.Codec(W, H, wl=wl, lossy=lossy, qs=qs, lut_folder=_lutdir(oracle, lossy), k=k, pipelined=hint)
+        frames = _dev(torch, np.stack([oracle.pad_frame(im).reshape(-1) for im in imgs]))
+        streams = torch.full((n, c.max_stream_shorts()), -1, dtype=torch.int16, device="cuda")
+        c.encode_frames_async(frames, streams, 0)
+        totals = c.last_totals(n)
+        assert c.range_flag() == 0
+        refs = [oracle.encode_frame(imgs[i], wl, lossy, qs, lut, 0 if i == 0 else 1, 0, k=k) for i in range(n)]
+        for i in range(n):
+            g = streams[i, :totals[i]].cpu().numpy().view(np.uint16)
+            assert g.size == refs[i].size and np.array_equal(g, refs[i]), f"frame {i} of the batch differs from the oracle"
+        got = c.decode_frames(streams)
+        for i in range(n):
+            assert torch.equal(got[i], c.decode_frame(streams[i, :totals[i]].clone())), f"frame {i}: batched decode"
+            ref = oracle.decode_frame(refs[i], W, H, wl, lossy, qs, lut, k=k)
+            assert np.array_equal(got[i].cpu().numpy()[:H, :W], ref)
+        c.close()
+    finally:
+        oracle.set_threads(1)
+
+
 def test_batched_frames_argument_checks(oracle, pa, torch):
     c = pa.Codec(256, 256, wl=2, lut_folder=_lutdir(oracle, False))
     frames = torch.zeros((2, c.P), dtype=torch.uint8, device="cuda")

@@ -56,7 +56,7 @@ for case in range(n_cases):
         ok_dec = np.array_equal(got, refpix[:H, :W]) and (lossy or np.array_equal(got, img))
         # batched: three copies of the frame through encode_frames / decode_frames
         ok_b = True
-        if c.ncb <= 4096 and k == 0.0 and cp == 2:     # (the batched call is the two-pass k = 0 path only)
+        if c.ncb <= 4096 and cp == 2:                  # (the batched calls: -cp 2, any k)
             frames = torch.stack([frame.view(-1)] * 3)
             out = torch.empty((3, c.max_stream_shorts()), dtype=torch.int16, device="cuda")
             c.encode_frames_async(frames, out, 1)
