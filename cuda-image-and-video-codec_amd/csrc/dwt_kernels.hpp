@@ -1557,10 +1557,32 @@ __device__ __forceinline__ void convert97(const DwtInvArgs &a, const Inv97Steps 
     }
 }
 
+// RGB (dwt_inv97_rgb_kernel): the wave is one of the three that run the finest level of an RGB frame's three components
+// over the same columns; a finished row pair is exchanged through LDS and the wave delivers ONE pixel plane -- row `comp`
+// of the inverse ICT (rgb_inverse_kernel<float>'s arithmetic), level shift and clamp included.
+struct Rgb97Out {
+    float4 *xb;             // [2 (iteration parity)][3 components][2 rows][64 lanes]
+    int comp;               // this wave's component in, pixel plane out (0 / 1 / 2: Y -> R, Cb -> G, Cr -> B)
+    uint8_t *plane;         // the pixel plane this wave writes, row stride W
+    float m0, m1, m2;       // row `comp` of the inverse matrix
+    int off;
+};
+__device__ __forceinline__ uint32_t ict_pixels(const float4 &y, const float4 &cb, const float4 &cr, const Rgb97Out &o)
+{
+    const float yv[4] = { y.x, y.y, y.z, y.w }, bv[4] = { cb.x, cb.y, cb.z, cb.w }, rv[4] = { cr.x, cr.y, cr.z, cr.w };
+    uint32_t w = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int v = (int)rintf(fmaf(o.m2, rv[i], fmaf(o.m1, bv[i], o.m0 * yv[i])) + 0.01f) + o.off;
+        w |= (uint32_t)(v > 255 ? 255 : (v < 0 ? 0 : v)) << (8 * i);
+    }
+    return w;
+}
+
 // returns (wave-uniform) whether some lane divided a value too small for the reciprocal form: the band must be
 // run again with EXACT
-template <int BAND, bool U8OUT, bool FIRST, bool ONE_DIV, bool EDGE, bool EXACT, bool C16 = false>
-__device__ __forceinline__ bool dwt_inv97_band(const DwtInvArgs &a, int strip, int lane)
+template <int BAND, bool U8OUT, bool FIRST, bool ONE_DIV, bool EDGE, bool EXACT, bool C16 = false, bool RGB = false>
+__device__ __forceinline__ bool dwt_inv97_band(const DwtInvArgs &a, int strip, int lane, const Rgb97Out *rgb = nullptr)
 {
     const int c0 = strip * kStripUseful - 4 * kEdgeLanes + 4 * lane;
     const int pc = c0 >> 1;                                  // arithmetic shift: -4 -> -2
@@ -1664,7 +1686,19 @@ __device__ __forceinline__ bool dwt_inv97_band(const DwtInvArgs &a, int strip, i
             // pair j - 2: stored when it is one of the band's (not a run-in pair, not past the image's last pair)
             if (it >= 4 && j - 2 < m1) {
                 const uint32_t y = (uint32_t)(2 * (j - 2));
-                if constexpr (U8OUT) {
+                if constexpr (RGB) {
+                    // (the three waves of the workgroup run the same strip and band: the same trips take this branch)
+                    float4 *const xb = rgb->xb + (size_t)(it & 1) * (3 * 2 * 64);
+                    xb[(rgb->comp * 2 + 0) * 64 + lane] = make_float4(ev[0], ev[1], ev[2], ev[3]);
+                    xb[(rgb->comp * 2 + 1) * 64 + lane] = make_float4(od[0], od[1], od[2], od[3]);
+                    __syncthreads();
+                    const uint32_t we = ict_pixels(xb[0 * 64 + lane], xb[2 * 64 + lane], xb[4 * 64 + lane], *rgb);
+                    const uint32_t wo = ict_pixels(xb[1 * 64 + lane], xb[3 * 64 + lane], xb[5 * 64 + lane], *rgb);
+                    if (wr) {
+                        *reinterpret_cast<uint32_t *>(rgb->plane + (size_t)y * (size_t)a.W + (uint32_t)c0) = we;
+                        *reinterpret_cast<uint32_t *>(rgb->plane + (size_t)(y + 1u) * (size_t)a.W + (uint32_t)c0) = wo;
+                    }
+                } else if constexpr (U8OUT) {
                     rb_store32(out, vo, y * ow, pack_pixels(ev, foff));
                     rb_store32(out, vo, (y + 1u) * ow, pack_pixels(od, foff));
                 } else {
@@ -1694,6 +1728,39 @@ __global__ __launch_bounds__(256, PICSONG_DWT_INV97_WAVES) void dwt_inv97_kernel
     else again = dwt_inv97_band<BAND, U8OUT, FIRST, ONE_DIV, false, false, C16>(a, strip, lane);
     // (a.exact_replay: PICSONG_DWT_EXACT_REPLAY=1, the tests' way into the second pass)
     if (__builtin_expect(again || a.exact_replay, 0)) dwt_inv97_band<BAND, U8OUT, FIRST, ONE_DIV, true, true, C16>(a, strip, lane);
+}
+
+// RGB frames, 9/7: the finest synthesis level of the three components as the three waves of a workgroup (same strip,
+// same band), the inverse ICT, level shift and clamp at the stores -- the three 134 MB float planes the separate launches
+// wrote and rgb_inverse_kernel read back are never made.  (Three copies of the lean kernel's state do not fit ONE wave, as
+// dwt_inv_rgb_kernel does it for 5/3; here a finished row pair crosses LDS, 12 KB a workgroup, one barrier a row pair.)
+// A wave that must run its band again with true divisions takes the workgroup with it.
+// a: the finest level's arguments of a three-frame plan (component c at mallat + c * mallat_z, LL at ll + c * ll_z).
+template <int BAND, bool ONE_DIV>
+__global__ __launch_bounds__(192, PICSONG_DWT_INV97_WAVES) void dwt_inv97_rgb_kernel(DwtInvArgs a, uint8_t *dr, uint8_t *dg, uint8_t *db)
+{
+    __shared__ float4 xb[2 * 3 * 2 * 64];
+    __shared__ int again_any;
+    const int lane = threadIdx.x & 63, comp = threadIdx.x >> 6;
+    const int strip = blockIdx.x;
+    if (strip * kStripUseful >= a.W) return;                 // (the whole workgroup: one strip)
+    if (threadIdx.x == 0) again_any = 0;
+    a.mallat = (const int32_t *)((const char *)a.mallat + (unsigned long long)comp * a.mallat_z);
+    a.ll = (const char *)a.ll + (unsigned long long)comp * a.ll_z;
+    Rgb97Out o;
+    o.xb = xb; o.comp = comp; o.plane = comp == 0 ? dr : (comp == 1 ? dg : db); o.off = a.off;
+    // rgb_inverse_kernel<float>'s matrix, row = the plane
+    o.m0 = in_vgpr(1.0f);
+    o.m1 = in_vgpr(comp == 0 ? 0.0f : (comp == 1 ? -0.344136f : 1.772f));
+    o.m2 = in_vgpr(comp == 0 ? 1.402f : (comp == 1 ? -0.714136f : 0.0f));
+    __syncthreads();
+    const int first = strip * kStripUseful - 4 * kEdgeLanes;
+    bool again;
+    if (first <= 0 || first + kStripCols >= a.W) again = dwt_inv97_band<BAND, false, false, ONE_DIV, true, false, true, true>(a, strip, lane, &o);
+    else again = dwt_inv97_band<BAND, false, false, ONE_DIV, false, false, true, true>(a, strip, lane, &o);
+    if (again && lane == 0) atomicOr(&again_any, 1);
+    __syncthreads();
+    if (__builtin_expect(again_any != 0 || a.exact_replay, 0)) dwt_inv97_band<BAND, false, false, ONE_DIV, true, true, true, true>(a, strip, lane, &o);
 }
 
 // ---- synthesis levels 1 and 0 in one launch (the decode frame paths' tail; round 4) ----------------------------

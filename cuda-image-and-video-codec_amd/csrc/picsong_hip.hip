@@ -1633,6 +1633,29 @@ int picsong_decode_rgb_frame(picsong_ctx *c, const uint16_t *d_streams, size_t s
         HIP_TRY(hipGetLastError());
         return PICSONG_OK;
     }
+    // 9/7 with 16-bit coefficients (the lean kernel's domain): the finest level of the three components as the three
+    // waves of a workgroup, a row pair exchanged through LDS, the inverse ICT at the stores (dwt_inv97_rgb_kernel)
+    if (c->p.lossy && c16 && plan.size() >= 2 && plan.back().vec && plan.back().fast && px_aligned && !getenv("PICSONG_RGB_NOFUSE") &&
+        !(getenv("PICSONG_DWT_INV97") && atoi(getenv("PICSONG_DWT_INV97")) == 0)) {
+        std::vector<InvLaunch> head(plan.begin(), plan.end() - 1);
+        if ((rc = run_inverse(c, head, s, 3u))) return rc;
+        const InvLaunch &f = plan.back();
+        DwtInvArgs fa = f.a;
+        fa.off = 1 << (c->p.bit_depth - 1);
+        const dim3 grid((unsigned)((fa.W + kStripUseful - 1) / kStripUseful), f.gy, 1);
+#define PS_INV97_RGB(B)                                                                              \
+        do { if (fa.one_div) dwt_inv97_rgb_kernel<B, true><<<grid, 192, 0, s>>>(fa, d_r, d_g, d_b);   \
+             else dwt_inv97_rgb_kernel<B, false><<<grid, 192, 0, s>>>(fa, d_r, d_g, d_b); } while (0)
+        switch (f.band) {
+        case 32: PS_INV97_RGB(32); break;
+        case 16: PS_INV97_RGB(16); break;
+        case 8: PS_INV97_RGB(8); break;
+        default: PS_INV97_RGB(4); break;
+        }
+#undef PS_INV97_RGB
+        HIP_TRY(hipGetLastError());
+        return PICSONG_OK;
+    }
     if ((rc = run_inverse(c, plan, s, 3u))) return rc;
     const char *img = (const char *)c->b_coef + c->extra * 4;
     const size_t z = (c->P + c->extra) * 4;

@@ -155,7 +155,7 @@ def dwt_inverse_u8_c16(coef16, wl, lossy, qs=1.0, extra=0):
     return pix.reshape(AH, AW), int(flags)
 
 
-def dwt_inverse_rgb(coefs16, wl, extra):
+def dwt_inverse_rgb(coefs16, wl, extra, lossy=False, qs=1.0):
     """picsong_decode_rgb_frame's lossless synthesis: `coefs16` three int16 (AH, AW) Mallat arrays (Y, Cb, Cr); the
     finest level of the three components and the inverse colour transform run as one launch.  Returns the three pixel
     planes, or None when the form does not apply."""
@@ -164,10 +164,10 @@ def dwt_inverse_rgb(coefs16, wl, extra):
     inp = aligned_zeros(3 * P, np.int16)
     for c in range(3):
         inp[c * P:(c + 1) * P] = np.ascontiguousarray(coefs16[c], np.int16).ravel()
-    scratch = aligned_zeros(3 * (P + extra), np.int32)
+    scratch = aligned_zeros(3 * (P + extra), np.float32 if lossy else np.int32)
     out = [aligned_zeros(P, np.uint8) for _ in range(3)]
     ok = lib().emu_dwt_inverse_rgb(_p(inp), C.c_size_t(P * 2), _p(scratch), C.c_size_t((P + extra) * 4), _p(out[0]), _p(out[1]),
-                                   _p(out[2]), AW, AH, wl)
+                                   _p(out[2]), AW, AH, wl, int(lossy), C.c_float(qs))
     return [o.reshape(AH, AW) for o in out] if ok else None
 
 

@@ -281,26 +281,27 @@ int emu_dwt_inverse_u8_c16(const int16_t *in16, void *scratch, uint8_t *pixels, 
     return res;
 }
 
-// picsong_decode_rgb_frame's lossless synthesis with 16-bit coefficients: the levels above the finest per component,
+// picsong_decode_rgb_frame's synthesis with 16-bit coefficients (5/3: dwt_inv_rgb_kernel; 9/7: dwt_inv97_rgb_kernel): the levels above the finest per component,
 // then the finest level of all three components + the inverse colour transform as ONE launch (dwt_inv_rgb_kernel).
 // in16: three int16 Mallat arrays in_z BYTES apart; scratch: three work buffers wrk_z bytes apart.  Returns 1 when the
 // form applies.
 int emu_dwt_inverse_rgb(const int16_t *in16, size_t in_z, void *scratch, size_t wrk_z, uint8_t *r, uint8_t *g, uint8_t *b,
-                        int aw, int ah, int wl)
+                        int aw, int ah, int wl, int lossy, float qs)
 {
-    if (!dec_c16_ok(false, wl, 1.0f, 255, aw, ah, false)) return 0;
+    const bool fast = emu_fast_div(lossy, qs, wl);
+    if (!dec_c16_ok(lossy != 0, wl, qs, 255, aw, ah, fast)) return 0;
     std::vector<InvLaunch> plan0;
     for (int c = 0; c < 3; c++) {
         std::vector<InvLaunch> plan = plan_dwt_inverse((const int32_t *)((const char *)in16 + c * in_z), (char *)scratch + c * wrk_z,
-                                                       aw, ah, wl, 1.0f, false, true);
+                                                       aw, ah, wl, qs, fast, true);
         if (!plan_inv_is_c16(plan) || plan.size() < 2 || !plan.back().vec) return 0;
         for (size_t l = 0; l + 1 < plan.size(); l++) {
             const InvLaunch &f = plan[l];
             switch (f.band) {
-            case 32: emu_inv<32>(f, 0); break;
-            case 16: emu_inv<16>(f, 0); break;
-            case 8: emu_inv<8>(f, 0); break;
-            default: emu_inv<4>(f, 0); break;
+            case 32: emu_inv<32>(f, lossy); break;
+            case 16: emu_inv<16>(f, lossy); break;
+            case 8: emu_inv<8>(f, lossy); break;
+            default: emu_inv<4>(f, lossy); break;
             }
         }
         if (c == 0) plan0 = plan;
@@ -308,6 +309,21 @@ int emu_dwt_inverse_rgb(const int16_t *in16, size_t in_z, void *scratch, size_t 
     const InvLaunch &f = plan0.back();
     DwtInvArgs fa = f.a;
     fa.mallat_z = in_z; fa.ll_z = wrk_z; fa.off = 128;
+    if (lossy) {
+        // 9/7: the three components as the three waves of a workgroup (dwt_inv97_rgb_kernel)
+        const dim3 grid((unsigned)((fa.W + kStripUseful - 1) / kStripUseful), f.gy);
+#define EMU_INV97_RGB(B)                                                                                          \
+        do { if (fa.one_div) emu::launch(grid, dim3(192), [&] { dwt_inv97_rgb_kernel<B, true>(fa, r, g, b); });    \
+             else emu::launch(grid, dim3(192), [&] { dwt_inv97_rgb_kernel<B, false>(fa, r, g, b); }); } while (0)
+        switch (f.band) {
+        case 32: EMU_INV97_RGB(32); break;
+        case 16: EMU_INV97_RGB(16); break;
+        case 8: EMU_INV97_RGB(8); break;
+        default: EMU_INV97_RGB(4); break;
+        }
+#undef EMU_INV97_RGB
+        return 1;
+    }
     const dim3 grid(f.gx, f.gy);
     switch (f.band) {
     case 32: emu::launch(grid, dim3(256), [&] { dwt_inv_rgb_kernel<32>(fa, r, g, b); }); break;

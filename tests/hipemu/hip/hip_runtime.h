@@ -31,6 +31,8 @@ struct int2 { int x, y; };
 struct uint2 { unsigned x, y; };
 struct float2 { float x, y; };
 struct uint4 { unsigned x, y, z, w; };
+struct float4 { float x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { float4 r = { x, y, z, w }; return r; }
 static inline int2 make_int2(int a, int b) { int2 r = { a, b }; return r; }
 
 namespace emu {

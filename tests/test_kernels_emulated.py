@@ -369,6 +369,30 @@ def test_rgb_inverse_colour_transform_in_the_finest_synthesis_level(oracle, E, W
     assert (got[0] == 0).any() and (got[0] == 255).any()
 
 
+@pytest.mark.parametrize("W,H,wl,qs,replay", [(320, 192, 3, 0.5, "0"), (512, 320, 5, 1.0, "0"), (256, 128, 2, 0.3, "0"), (320, 192, 3, 0.5, "1")])
+def test_rgb_inverse_ict_across_the_three_waves_of_a_workgroup(oracle, E, monkeypatch, W, H, wl, qs, replay):
+    """dwt_inv97_rgb_kernel: the finest 9/7 synthesis level of the three components as the three waves of a workgroup, a
+    finished row pair exchanged through LDS, each wave delivering one pixel plane of the inverse ICT -- the oracle's
+    pixels (its synthesis of every component, then its inverse colour transform), the clamp at both ends included, and
+    through the pass with true divisions the whole workgroup repeats (PICSONG_DWT_EXACT_REPLAY=1)."""
+    monkeypatch.setenv("PICSONG_DWT_EXACT_REPLAY", replay)
+    planes = [oracle.pad_frame(oracle.gen_frame(W, H, 95 + c)) for c in range(3)]
+    planes[0][:11, :7] = 255; planes[1][:11, :7] = 0; planes[2][-9:, -6:] = 255; planes[0][-9:, -6:] = 0
+    AH, AW = planes[0].shape
+    comps = oracle.rgb_forward(*planes, True)
+    coefs = [np.trunc(oracle.dwt_forward(comps[k], wl, qs)[:AW * AH].reshape(AH, AW)).astype(np.int16) for k in range(3)]
+    got = E.dwt_inverse_rgb(coefs, wl, oracle.dwt_extra(W, H, wl), True, qs)
+    assert got is not None
+    back = []
+    for k in range(3):
+        inv, extra = oracle.dwt_inverse(coefs[k].astype(np.int32), wl, True, qs)
+        back.append(inv[extra:].reshape(AH, AW))
+    ref = oracle.rgb_inverse(*back)
+    for k in range(3):
+        assert np.array_equal(got[k], ref[k]), f"plane {k}"
+    assert (got[0] == 0).any() and (got[0] == 255).any()
+
+
 def test_16_bit_coefficient_bound(E):
     """coef16_ok: the 16-bit form only where magnitudes are bounded below 2^15 (8-bit samples; 9/7: times the
     quantisation weights): BASELINE's configurations qualify, a fine qs or a geometry off the vector kernels does not."""
