@@ -55,5 +55,6 @@ echo "decode done"
 python3 tools/modes_time.py > $out/modes_time.txt 2>&1 || true
 python3 tools/lone_frame_time.py > $out/lone_frame.txt 2>&1 || true
 python3 tools/rgb_probe.py > $out/rgb_probe.txt 2>&1 || true
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_rgb -- python3 tools/rgb_probe.py > $out/prof_rgb.log 2>&1 || true
 python3 tools/fuzz_parity.py 120 4 > $out/fuzz_parity.txt 2>&1 || true
 echo "modes done"

@@ -96,6 +96,7 @@ def main():
     A(f"| `r04_decode.txt` | `tools/decode_bench.py --streams=3`: 8K 5/3 lone **{num(dec[0]):.1f}** / three calls in flight **{num(dec[1]):.1f} Gpixel/s**; 9/7 {num(dec[2]):.1f} / **{num(dec[3]):.1f}**; 4K {num(dec[4]):.1f} alone, {num(dec[5]):.1f} over three streams, **{num(dec[6]):.1f}** four to a `picsong_decode_frames` call |")
     A("| `r04_modes_time.txt` | `tools/modes_time.py`: a lone 8K frame and three hinted calls in flight, encode and decode, for k = 0, `-k 0.5`, `-k 1.5`, `-cp 3` (DESIGN 4.5 / 4.6) |")
     A("| `r04_lone_frame.txt`, `r04_rgb_probe.txt`, `r04_fuzz_parity.txt` | `tools/lone_frame_time.py` (single-frame calls timed from Python, launch overhead included); `tools/rgb_probe.py` (an 8K RGB frame through one launch per stage against three grey frames: DESIGN 4.7's table); `tools/fuzz_parity.py 120 4` (120 random geometries / contents / transforms / coder modes — 39 with -k > 0, 19 with -cp 3 — through the frame paths against the oracle: 0 mismatches) |")
+    A("| `r04_kernel_stats_rgb.csv` | `rocprofv3 --kernel-trace --stats -- python3 tools/rgb_probe.py`: the RGB frame paths' kernels (DESIGN 4.7): the fused heads `dwt_fwd2_kernel<..., RGB>`, `dwt_inv_rgb_kernel`, `dwt_inv97_rgb_kernel`, next to the grey heads over the same three planes |")
     A("| `r04_video_k_time.txt` | `tools/video_k_time.py 0.5 6`: 4K frames on three streams, one and six to a `picsong_encode_frames` / `picsong_decode_frames` call, k = 0 and k = 0.5 (the -k > 0 contexts' batched launches) |")
     A("| `r04_valu_probe.txt` / `.json` | `tools/valu_probe`: issue rates per instruction class (DESIGN 4) |")
     A("| `r04_library.sha256` | line 1: sha256 of the `libpicsong_hip.so` all of the above belong to; line 2: `bench.py: source_hash()` of the kernel sources it was built from -- what `bench.py` compares before it quotes an offline counter (`roofline.source`) |")

@@ -5,7 +5,7 @@
 set -e
 src=gpurun_out/$1; tag=$2; dst=profiles
 ks() { ls $src/$1/*/*kernel_stats.csv 2>/dev/null | head -1; }
-for n in pipelined b3 lone lossy_pipelined lossy_b6 lossy_lone 4k_pipelined 4k_b6 4k_lone 16k decode decode_lossy; do
+for n in pipelined b3 lone lossy_pipelined lossy_b6 lossy_lone 4k_pipelined 4k_b6 4k_lone 16k decode decode_lossy rgb; do
   f=$(ks prof_$n); [ -n "$f" ] && cp $f $dst/${tag}_kernel_stats_$n.csv
   [ -f $src/prof_$n.json ] && cp $src/prof_$n.json $dst/${tag}_kernel_stats_$n.line.json
 done
