@@ -1945,6 +1945,7 @@ void bpc_decode_kernel(BpcArgs a)
     if (t == 0u) lds_cnt[(threadIdx.x >> 6) * 2u + half] = 0u;        // (barrier: below, with the table copy)
     sign_table2_fill(sign_tab, lane);                       // (the LUT copy below ends with the barrier)
     const int gwave = BULK ? (int)blockIdx.x : (int)blockIdx.x * kBpcDecWgWaves + (int)(threadIdx.x >> 6);
+    PS_BPC_TRACE(0, __builtin_amdgcn_s_memrealtime());     // (trace builds only, tools/bpc_trace.py dec)
     int wave = gwave;                                       // wave within its frame
     if (a.frames > 1) {                                     // batched launch (picsong_decode_frames), as in the encoder
         const int f = gwave / a.waves_per_frame;            // wave-uniform
@@ -2038,6 +2039,7 @@ void bpc_decode_kernel(BpcArgs a)
     { int o = __shfl_xor(msbw, 32); msbw = msbw > o ? msbw : o; }
     msbw = (int)__builtin_amdgcn_readfirstlane((uint32_t)msbw);
     prio_by_planes(np);
+    PS_BPC_TRACE(1, __builtin_amdgcn_s_memrealtime() * 256ull + (unsigned long long)np);
 
     for (int p = 0; p < np; p++) {
         const int bp = msb - p;
@@ -2118,6 +2120,7 @@ void bpc_decode_kernel(BpcArgs a)
             q[0] = PLlo[0]; q[64] = PLhi[0]; q[128] = PRlo[0]; q[192] = PRhi[0];
         }
     }
+    PS_BPC_TRACE(2, __builtin_amdgcn_s_memrealtime());
     // the signs back as X-form row masks (the all-significant marks of an idle half sit on the even bits)
     const M64 sgnL = { cform_signs(CL0, CL1, CL2), cform_signs(CL2, CL3, CL4) };
     const M64 sgnR = { cform_signs(CR0, CR1, CR2), cform_signs(CR2, CR3, CR4) };
@@ -2157,6 +2160,7 @@ void bpc_decode_kernel(BpcArgs a)
             }
         }
     }
+    PS_BPC_TRACE(3, __builtin_amdgcn_s_memrealtime());
     if constexpr (BULK) {
         // ---- bulk scan (decodeBulkMode :1653-1662): the planes below cbp, row by row; a row's two coefficients as the
         // epilogue left them (magnitude bits of the two-pass planes, sign) are read back two rows ahead, the scan's low bits

@@ -18,6 +18,7 @@ import oracle_lib as orc
 import picsong_amd as pa
 
 lossy = "lossy" in sys.argv[1:]
+DEC = "dec" in sys.argv[1:]                     # the decoder's waves: start, plane loop, epilogue
 W, H = (3840, 2160) if "4k" in sys.argv[1:] else (7680, 4320)
 wl, qs = (6, 0.5) if lossy else (5, 1.0)
 lut = os.path.join(orc.LUT_DIR, "n1_lossy" if lossy else "n1_lossless")
@@ -36,6 +37,46 @@ nw = c.ncb                                      # (a variant with one codeblock 
 buf = torch.zeros(4 * (nw + 8), dtype=torch.int64, device="cuda")
 c.L.picsong_debug_set_bpc_trace.argtypes = [C.c_void_p]
 assert c.L.picsong_debug_set_bpc_trace(C.c_void_p(buf.data_ptr())) == 0
+if DEC:
+    torch.cuda.synchronize()
+    assert c.L.picsong_debug_set_bpc_trace(C.c_void_p(0)) == 0
+    for _ in range(3):
+        c.decode_frame(s_)
+    torch.cuda.synchronize()
+    t_0 = time.perf_counter()
+    for _ in range(50):
+        c.decode_frame(s_)
+    torch.cuda.synchronize()
+    print(f"lone-frame decode: {(time.perf_counter() - t_0) / 50 * 1e3:.3f} ms")
+    buf.zero_()
+    assert c.L.picsong_debug_set_bpc_trace(C.c_void_p(buf.data_ptr())) == 0
+    c.decode_frame(s_)
+    torch.cuda.synchronize()
+    assert c.L.picsong_debug_set_bpc_trace(C.c_void_p(0)) == 0
+    t = buf.cpu().numpy().reshape(-1, 4)[:nw]
+    t = t[t[:, 0] != 0]
+    npl = (t[:, 1] & 255).astype(np.float64)
+    t = t.astype(np.float64)
+    t[:, 1] = np.floor(t[:, 1] / 256.0)
+    t0 = t[:, 0].min()
+    start, loop0, loop1, end = [(t[:, k] - t0) / 100 for k in range(4)]
+    print(f"decoder, {W}x{H} {'9/7 wl 6' if lossy else '5/3 wl 5'}: {len(t)} waves; the launch's last wave is done at {end.max():.1f} us")
+    q = lambda v: " / ".join(f"{x:7.1f}" for x in np.percentile(v, [0, 10, 50, 90, 99, 100]))
+    print("us, min / p10 / median / p90 / p99 / max")
+    print("  start          ", q(start))
+    print("  prologue       ", q(loop0 - start))
+    print("  plane loop     ", q(loop1 - loop0))
+    print("  epilogue       ", q(end - loop1))
+    print("  whole wave     ", q(end - start))
+    for k in sorted(set(npl.astype(int))):
+        m = npl == k
+        print(f"  waves with {k:2d} planes: {int(m.sum()):5d}, plane loop median {np.median((loop1 - loop0)[m]):6.1f} max {(loop1 - loop0)[m].max():6.1f}; "
+              f"prologue median {np.median((loop0 - start)[m]):5.1f}; epilogue median {np.median((end - loop1)[m]):5.1f}; wave done median {np.median(end[m]):6.1f} max {end[m].max():6.1f} us")
+    slow = np.argsort(-end)[:8]
+    print("the last eight waves (wave, planes, start, prologue, loop, epilogue, done):")
+    for w in slow:
+        print(f"  {w:5d}  {int(npl[w]):2d}  {start[w]:6.1f}  {(loop0 - start)[w]:6.1f}  {(loop1 - loop0)[w]:6.1f}  {(end - loop1)[w]:6.1f}  {end[w]:6.1f}")
+    sys.exit(0)
 c.encode_frame(frame)
 torch.cuda.synchronize()
 assert c.L.picsong_debug_set_bpc_trace(C.c_void_p(0)) == 0
