@@ -1110,9 +1110,11 @@ __device__ __forceinline__ int bulk_setup(const BpcArgs &a, bool coded, int msb,
 #define PICSONG_BPC_ENC_WAVES 7
 #endif
 // the -k > 0 instantiations (one wave a workgroup): resident waves per SIMD asked for -- what they get is also bounded by
-// their LDS (two table copies a wave: whole tables 4, compact copies 6 and more)
+// their LDS (two table copies a wave: whole tables 4, compact copies 7 and more).  8K, three hinted calls in flight,
+// encode / decode Gpixel/s at k = 0.5 | 1.5: 5 waves 144 / 109, 6 waves 146 / 113 | 147 / 110, 7 waves (72 registers) 154 / 117
+// | 154 / 112, 8 waves 151 / 102 | 154 / 98; a lone frame the same at 6, 7, 8 (0.37 / 0.475 ms), 0.41 ms at 5.
 #ifndef PICSONG_BPC_BULK_WAVES
-#define PICSONG_BPC_BULK_WAVES 6
+#define PICSONG_BPC_BULK_WAVES 7
 #endif
 
 // one row (two coefficients of the lane) of the coefficient array as magnitudes and sign bits
