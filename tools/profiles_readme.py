@@ -97,6 +97,7 @@ def main():
     A("| `r04_modes_time.txt` | `tools/modes_time.py`: a lone 8K frame and three hinted calls in flight, encode and decode, for k = 0, `-k 0.5`, `-k 1.5`, `-cp 3` (DESIGN 4.5 / 4.6) |")
     A("| `r04_lone_frame.txt`, `r04_rgb_probe.txt`, `r04_fuzz_parity.txt` | `tools/lone_frame_time.py` (single-frame calls timed from Python, launch overhead included); `tools/rgb_probe.py` (an 8K RGB frame through one launch per stage against three grey frames: DESIGN 4.7's table); `tools/fuzz_parity.py 120 4` (120 random geometries / contents / transforms / coder modes — 39 with -k > 0, 19 with -cp 3 — through the frame paths against the oracle: 0 mismatches) |")
     A("| `r04_kernel_stats_rgb.csv` | `rocprofv3 --kernel-trace --stats -- python3 tools/rgb_probe.py`: the RGB frame paths' kernels (DESIGN 4.7): the fused heads `dwt_fwd2_kernel<..., RGB>`, `dwt_inv_rgb_kernel`, `dwt_inv97_rgb_kernel`, next to the grey heads over the same three planes |")
+    A("| `r04_bench_exchange_w1.json` | `python bench.py --force-exchange --steps 6 --no-cpu-baseline`: the frame-sharded path's per-step exchange (`picsong_dist.gather_step`: one all-gather of lengths + one grouped point-to-point batch) through RCCL at world = 1 -- the only form a one-GPU box can run; `exchange.ranks_seen` 1 |")
     A("| `r04_pmc_kmode.txt` | `tools/kmode_prof.sh`: the -k 0.5 kernels over lone 8K frames: encoder (the lone frame's register-rich instantiation) 314.5 us, 136.0 M vector + 70.9 M scalar instructions; decoder (compact table copies, int16 coefficients out) 446.1 us, 169.2 M + 95.5 M |")
     A("| `r04_video_k_time.txt` | `tools/video_k_time.py 0.5 6`: 4K frames on three streams, one and six to a `picsong_encode_frames` / `picsong_decode_frames` call, k = 0 and k = 0.5 (the -k > 0 contexts' batched launches) |")
     A("| `r04_valu_probe.txt` / `.json` | `tools/valu_probe`: issue rates per instruction class (DESIGN 4) |")

@@ -25,5 +25,5 @@ for w in 8k_lossless 8k_lossy 4k_lossless; do
 done
 summ $dst/${tag}_pmc_sq_pipelined.csv sq_pipe sq_pipe2
 for f in valu_probe.txt valu_probe.json decode.txt pmc_decode.txt modes_time.txt lone_frame.txt rgb_probe.txt fuzz_parity.txt; do [ -f $src/$f ] && cp $src/$f $dst/${tag}_$f; done
-for f in bench bench_4k bench_8k_lossy bench_16k_intra bench_16k_intra_banded_w1; do [ -s $src/$f.json ] && cp $src/$f.json $dst/${tag}_$f.json; done
+for f in bench bench_4k bench_8k_lossy bench_16k_intra bench_16k_intra_banded_w1 bench_exchange_w1; do [ -s $src/$f.json ] && cp $src/$f.json $dst/${tag}_$f.json; done
 ls $dst | grep $tag
